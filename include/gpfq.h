@@ -1,0 +1,140 @@
+/*
+ * gpfq.h -- C ABI of the MI355X (gfx950) greedy path-following quantizer (GPFQ) hot path.
+ *
+ * The reference (elybrand/quantized_neural_networks) is pure Python and has no FFI; the boundary
+ * this library replaces is its process-pool task signature
+ *
+ *     executor.submit(_quantize_neuron_parallel, W[:, j], hf_filename, layer_alphabet)
+ *                                               scripts/quantized_network.py:553-556
+ *     executor.submit(_quantize_filter2D_parallel_jit, channel_filters[:,:,f], channel_idx,
+ *                     channel_hf_filename, alphabet)
+ *                                               scripts/quantized_network.py:707-712
+ *
+ * i.e. "one weight vector + the two activation matrices + the scaled alphabet -> one quantized
+ * weight vector".  Here one call quantizes ALL neurons of a layer shard (or all filters of one
+ * input channel) on the GPU.  INTEGRATION.md shows the ctypes binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - plain C, no C++/torch/HIP types in signatures; `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream).  All launches are asynchronous on that stream.
+ *   - every pointer marked [device] must be device-accessible memory owned by the caller; the
+ *     library never allocates, frees or retains caller memory.  Scratch is caller-provided and
+ *     sized by gpfq_workspace_bytes().
+ *   - [host] pointers are read during the call only (copied into kernel arguments).
+ *   - return value: GPFQ_OK (0) or a negative GPFQ_ERR_* code; gpfq_last_error() returns a
+ *     thread-local human-readable message for the last failing call.  Nothing throws.
+ *   - re-entrant per stream: calls on different streams with disjoint outputs/workspaces may
+ *     overlap.
+ *
+ * Data layout (all row-major, "feature-major" as the reference's transposed HDF5 datasets,
+ * scripts/quantized_network.py:467-470, :789-797):
+ *   X, Xq   f32 [N][ld]   row t = direction t of the analog / quantized network's walk over the m
+ *                         calibration samples (wX[t,:], qX[t,:]); ld >= m is the row pitch in elements
+ *   Wt      f32 [C][ldw]  neuron-major weights: row j = W[:, j] (ldw >= N)
+ *   qidx    i8  [C][N]    alphabet index chosen for weight t of neuron j; `zero_idx` semantics below
+ *   Qt      f32 [C][N]    the quantized weights, (float)alphabet[qidx] (Keras stores float32)
+ *   resid   f64 [C]       ||u_final||_2 per neuron (the reference discards u, :121; emitted for parity checks)
+ *   u_out   f64 [C][m]    optional final residual vectors (NULL to skip)
+ */
+#ifndef GPFQ_H
+#define GPFQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPFQ_OK                 0
+#define GPFQ_ERR_INVALID_ARG   (-1)   /* NULL pointer, negative size, bad pitch ...            */
+#define GPFQ_ERR_UNSUPPORTED   (-2)   /* e.g. alphabet larger than GPFQ_MAX_ALPHABET           */
+#define GPFQ_ERR_WORKSPACE     (-3)   /* workspace missing or smaller than gpfq_workspace_bytes */
+#define GPFQ_ERR_LAUNCH        (-4)   /* HIP reported an error; text in gpfq_last_error()      */
+#define GPFQ_ERR_NO_DEVICE     (-5)   /* no gfx950 device visible                              */
+
+#define GPFQ_MAX_ALPHABET 64          /* alphabet members per call (bits <= 6)                 */
+
+/* gpfq_quantize_neurons `path` selector */
+#define GPFQ_PATH_AUTO      0   /* on-chip residual when m fits a wavefront's registers, else streaming */
+#define GPFQ_PATH_ONCHIP    1   /* residual u lives in VGPRs, rows staged through LDS (m <= GPFQ_ONCHIP_MAX_M) */
+#define GPFQ_PATH_STREAM    2   /* residual u lives in HBM (any m; conv patch matrices)          */
+
+#define GPFQ_ONCHIP_MAX_M 2048
+
+int         gpfq_version(void);
+const char *gpfq_last_error(void);
+/* number of visible HIP devices whose architecture is gfx950 (0 if none / no driver) */
+int         gpfq_device_count(void);
+
+/*
+ * Pre-pass over the quantized-network activations: nrm32[t] = (float)sqrt(sum_i (double)Xq[t][i]^2).
+ * Replaces the two scipy.linalg.norm(X_tilde, 2) calls made per weight at
+ * scripts/quantized_network.py:83 and :89 (BLAS snrm2 -> float32-rounded norm); the value only
+ * depends on t, so it is computed once per layer instead of 2*C times.
+ *   Xq [device] f32 [N][ld], nrm32 [device] f32 [N].
+ */
+int gpfq_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, float *nrm32, void *stream);
+
+/* Bytes of scratch gpfq_quantize_neurons needs for this shape on this path (0 for on-chip). */
+size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path);
+
+/*
+ * The hot path: run the greedy recurrence for C independent neurons.
+ * Replaces C calls of _quantize_neuron_parallel (scripts/quantized_network.py:91-121) -- or, with
+ * N = kh*kw and C = number of filters, of _quantize_filter2D_parallel_jit (:185-233) -- including
+ * _quantize_weight_parallel (:59-89) and _bit_round_parallel (:40-57) per weight:
+ *
+ *   u = 0 (f64[m]);  for t in 0..N-1:
+ *     if nrm32[t] < 1e-16:            q = 0 (literal; index zero_idx)            (:83-84)
+ *     elif |<Xq_t, u>| < 1e-10:       q = nearest(alphabet, (double)w_t)          (:86-87)
+ *     else:                           q = nearest(alphabet, <Xq_t, u + w_t*X_t> / nrm32[t]^2)   (:89)
+ *     u += (double)( f32(w_t*X_t) - f32((float)q * Xq_t) )                        (:119)
+ *
+ * with the reference's float32/float64 flow reproduced per element (DESIGN.md "numerics").
+ * nearest() = first index of min |alphabet[k] - t| (np.argmin tie rule).
+ *
+ *   alphabet [host] f64 [M], 1 <= M <= GPFQ_MAX_ALPHABET  (the layer alphabet rad*linspace(-1,1,M), :545)
+ *   zero_idx : index written to qidx for the literal 0 of rule (i); pass the index of an exact
+ *              0.0 alphabet member, or -1 if there is none (even M).
+ *   nrm32    [device] from gpfq_row_norms.
+ *   qidx, Qt, resid [device] outputs; any of them may be NULL.  u_out [device] optional.
+ *   workspace [device], workspace_bytes >= gpfq_workspace_bytes(N, m, C, path).
+ */
+int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const float *nrm32,
+                          const float *Wt, int64_t ldw,
+                          const double *alphabet, int M, int zero_idx,
+                          int64_t N, int64_t m, int64_t C,
+                          int8_t *qidx, float *Qt, double *resid, double *u_out,
+                          void *workspace, size_t workspace_bytes, int path, void *stream);
+
+/*
+ * Memoryless scalar quantization of n weights: Q[i] = (float)alphabet[nearest((double)W[i])].
+ * Replaces the per-weight Python loop `[_bit_round_parallel(w, layer_alphabet) for w in W.flatten()]`
+ * of the drivers' MSQ baseline (scripts/quantize_pretrained_mlp.py:109, _cnn.py:114, _imagenet.py:219).
+ *   W [device] f32 [n]; Q [device] f32 [n] (may be NULL); qidx [device] i8 [n] (may be NULL).
+ */
+int gpfq_msq_round(const float *W, int64_t n, const double *alphabet, int M,
+                   float *Q, int8_t *qidx, void *stream);
+
+/*
+ * Per-channel im2col: the patch matrices of ONE input channel for the analog and quantized
+ * activations, transposed to feature-major [kh*kw][n*oh*ow].  Replaces _build_patch_array
+ * (scripts/quantized_network.py:729-809) + _segment_data2D (:123-183), i.e.
+ * tf.image.extract_patches(images[B,H,W,1], sizes=[1,kh,kw,1], strides=[1,sh,sw,1],
+ * rates=[1,rh,rw,1], padding) reshaped to (B*oh*ow, kh*kw) and stored transposed.
+ *   act  [device] f32 NHWC [n][H][W][Cin]; channel c is gathered.
+ *   same_padding: 1 = TF "SAME" (pad_before = floor(total/2)), 0 = "VALID".
+ *   P    [device] f32 [kh*kw][ldp], ldp >= n*oh*ow; column order (image, oy, ox) row-major.
+ * oh/ow as TF defines them; query with gpfq_patch_out_dim.
+ */
+int64_t gpfq_patch_out_dim(int64_t in, int64_t k, int64_t stride, int64_t rate, int same_padding);
+int gpfq_extract_patches(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t c,
+                         int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
+                         float *P, int64_t ldp, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPFQ_H */

@@ -1,0 +1,188 @@
+// extern "C" boundary of libgpfq_hip.so (declared in include/gpfq.h).  Argument validation,
+// path selection and error reporting; no allocation, no synchronisation.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/gpfq.h"
+#include "gpfq_launch.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    return fail(GPFQ_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+
+// Copies the host alphabet into the by-value kernel argument and classifies it.
+int make_alphabet(const double *alphabet, int M, int zero_idx, gpfq::AlphabetArg *A)
+{
+    if (!alphabet) return fail(GPFQ_ERR_INVALID_ARG, "alphabet is NULL");
+    if (M < 1) return fail(GPFQ_ERR_INVALID_ARG, "alphabet size M=%d must be >= 1", M);
+    if (M > GPFQ_MAX_ALPHABET)
+        return fail(GPFQ_ERR_UNSUPPORTED, "alphabet size M=%d exceeds GPFQ_MAX_ALPHABET=%d", M, GPFQ_MAX_ALPHABET);
+    if (zero_idx < -1 || zero_idx >= M) return fail(GPFQ_ERR_INVALID_ARG, "zero_idx=%d out of range", zero_idx);
+    std::memset(A, 0, sizeof(*A));
+    bool asc = true;
+    for (int k = 0; k < M; ++k) {
+        A->a[k] = alphabet[k];
+        if (std::isnan(alphabet[k])) asc = false;
+        if (k > 0 && !(alphabet[k - 1] <= alphabet[k])) asc = false;
+    }
+    A->M = M;
+    A->zero_idx = zero_idx;
+    A->ascending = asc ? 1 : 0;
+    return GPFQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpfq_version(void) { return 100; }
+
+const char *gpfq_last_error(void) { return g_err; }
+
+int gpfq_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, d) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+int gpfq_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, float *nrm32, void *stream)
+{
+    if (N < 0 || m < 0) return fail(GPFQ_ERR_INVALID_ARG, "negative size N=%lld m=%lld", (long long)N, (long long)m);
+    if (N == 0) return GPFQ_OK;
+    if (!nrm32 || (!Xq && m > 0)) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    if (ld < m) return fail(GPFQ_ERR_INVALID_ARG, "row pitch ld=%lld < m=%lld", (long long)ld, (long long)m);
+    hipError_t e = gpfq::launch_row_norms(Xq, N, m, ld, nrm32, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_row_norms");
+}
+
+static int resolve_path(int64_t m, int path)
+{
+    if (path == GPFQ_PATH_AUTO) return m <= GPFQ_ONCHIP_MAX_M ? GPFQ_PATH_ONCHIP : GPFQ_PATH_STREAM;
+    return path;
+}
+
+size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path)
+{
+    if (N < 0 || m < 0 || C < 0) return 0;
+    if (resolve_path(m, path) == GPFQ_PATH_ONCHIP) return 0;
+    return gpfq::stream_workspace_bytes(N, m, C, /*need_u=*/true);
+}
+
+int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const float *nrm32,
+                          const float *Wt, int64_t ldw,
+                          const double *alphabet, int M, int zero_idx,
+                          int64_t N, int64_t m, int64_t C,
+                          int8_t *qidx, float *Qt, double *resid, double *u_out,
+                          void *workspace, size_t workspace_bytes, int path, void *stream)
+{
+    if (N < 0 || m < 0 || C < 0)
+        return fail(GPFQ_ERR_INVALID_ARG, "negative size N=%lld m=%lld C=%lld", (long long)N, (long long)m, (long long)C);
+    gpfq::AlphabetArg A;
+    int rc = make_alphabet(alphabet, M, zero_idx, &A);
+    if (rc != GPFQ_OK) return rc;
+    if (C == 0) return GPFQ_OK;
+    if (N > 0 && (!Wt || !nrm32)) return fail(GPFQ_ERR_INVALID_ARG, "Wt/nrm32 is NULL");
+    if (N > 0 && m > 0 && (!X || !Xq)) return fail(GPFQ_ERR_INVALID_ARG, "X/Xq is NULL");
+    if (ld < m) return fail(GPFQ_ERR_INVALID_ARG, "row pitch ld=%lld < m=%lld", (long long)ld, (long long)m);
+    if (ldw < N) return fail(GPFQ_ERR_INVALID_ARG, "weight pitch ldw=%lld < N=%lld", (long long)ldw, (long long)N);
+    if (path != GPFQ_PATH_AUTO && path != GPFQ_PATH_ONCHIP && path != GPFQ_PATH_STREAM)
+        return fail(GPFQ_ERR_INVALID_ARG, "unknown path %d", path);
+    const int p = resolve_path(m, path);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    if (p == GPFQ_PATH_ONCHIP) {
+        if (m > GPFQ_ONCHIP_MAX_M)
+            return fail(GPFQ_ERR_UNSUPPORTED, "on-chip path needs m <= %d (got %lld)", GPFQ_ONCHIP_MAX_M, (long long)m);
+        gpfq::OnchipArgs a;
+        a.X = X; a.Xq = Xq; a.ld = ld; a.nrm32 = nrm32; a.Wt = Wt; a.ldw = ldw; a.A = A;
+        a.N = N; a.m = m; a.C = C; a.qidx = qidx; a.Qt = Qt; a.resid = resid; a.u_out = u_out;
+        hipError_t e = gpfq::launch_onchip(a, s);
+        return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_neurons(on-chip)");
+    }
+
+    const size_t need = gpfq::stream_workspace_bytes(N, m, C, u_out == nullptr);
+    if (!workspace || workspace_bytes < need)
+        return fail(GPFQ_ERR_WORKSPACE, "streaming path needs %zu workspace bytes, got %zu", need, workspace ? workspace_bytes : (size_t)0);
+    if ((uintptr_t)workspace % 16 != 0) return fail(GPFQ_ERR_INVALID_ARG, "workspace must be 16-byte aligned");
+    gpfq::StreamArgs a;
+    a.X = X; a.Xq = Xq; a.ld = ld; a.nrm32 = nrm32; a.Wt = Wt; a.ldw = ldw; a.A = A;
+    a.N = N; a.m = m; a.C = C; a.qidx = qidx; a.Qt = Qt; a.resid = resid; a.u_out = u_out;
+    a.workspace = workspace; a.workspace_bytes = workspace_bytes;
+    hipError_t e = gpfq::launch_stream(a, s);
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_neurons(stream)");
+}
+
+int gpfq_msq_round(const float *W, int64_t n, const double *alphabet, int M, float *Q, int8_t *qidx, void *stream)
+{
+    if (n < 0) return fail(GPFQ_ERR_INVALID_ARG, "negative n");
+    gpfq::AlphabetArg A;
+    int rc = make_alphabet(alphabet, M, -1, &A);
+    if (rc != GPFQ_OK) return rc;
+    if (n == 0) return GPFQ_OK;
+    if (!W) return fail(GPFQ_ERR_INVALID_ARG, "W is NULL");
+    hipError_t e = gpfq::launch_msq(W, n, A, Q, qidx, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_msq_round");
+}
+
+int64_t gpfq_patch_out_dim(int64_t in, int64_t k, int64_t stride, int64_t rate, int same_padding)
+{
+    if (in <= 0 || k <= 0 || stride <= 0 || rate <= 0) return 0;
+    if (same_padding) return (in + stride - 1) / stride;                 // ceil(in / stride)
+    const int64_t keff = k + (k - 1) * (rate - 1);
+    const int64_t span = in - keff + 1;
+    return span <= 0 ? 0 : (span + stride - 1) / stride;                 // ceil((in - k_eff + 1) / stride)
+}
+
+int gpfq_extract_patches(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t c,
+                         int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
+                         float *P, int64_t ldp, void *stream)
+{
+    if (n < 0 || H <= 0 || W <= 0 || Cin <= 0 || c < 0 || c >= Cin)
+        return fail(GPFQ_ERR_INVALID_ARG, "bad activation shape/channel");
+    if (kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || rh <= 0 || rw <= 0)
+        return fail(GPFQ_ERR_INVALID_ARG, "bad kernel/stride/rate");
+    const int64_t oh = gpfq_patch_out_dim(H, kh, sh, rh, same_padding);
+    const int64_t ow = gpfq_patch_out_dim(W, kw, sw, rw, same_padding);
+    const int64_t cols = n * oh * ow;
+    if (cols == 0) return GPFQ_OK;
+    if (!act || !P) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    if (ldp < cols) return fail(GPFQ_ERR_INVALID_ARG, "patch pitch ldp=%lld < n*oh*ow=%lld", (long long)ldp, (long long)cols);
+    int pad_top = 0, pad_left = 0;
+    if (same_padding) {
+        // TF SAME: total = max((out-1)*stride + k_eff - in, 0), before = total / 2 (floor)
+        const int64_t keh = kh + (int64_t)(kh - 1) * (rh - 1), kew = kw + (int64_t)(kw - 1) * (rw - 1);
+        int64_t th = (oh - 1) * sh + keh - H; if (th < 0) th = 0;
+        int64_t tw = (ow - 1) * sw + kew - W; if (tw < 0) tw = 0;
+        pad_top = (int)(th / 2);
+        pad_left = (int)(tw / 2);
+    }
+    hipError_t e = gpfq::launch_extract_patches(act, n, H, W, Cin, c, kh, kw, sh, sw, rh, rw, pad_top, pad_left,
+                                                oh, ow, P, ldp, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_extract_patches");
+}
+
+}  // extern "C"

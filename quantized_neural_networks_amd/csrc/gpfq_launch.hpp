@@ -1,0 +1,56 @@
+// Host-side launch interfaces between the C ABI (gpfq_capi.hip) and the kernel files.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "gpfq_device.hpp"
+
+namespace gpfq {
+
+struct OnchipArgs {
+    const float *X, *Xq;
+    int64_t ld;
+    const float *nrm32;
+    const float *Wt;
+    int64_t ldw;
+    AlphabetArg A;
+    int64_t N, m, C;
+    int8_t *qidx;
+    float *Qt;
+    double *resid;
+    double *u_out;
+    int ts_override = 0;   // tuning hooks (bench/tests); 0 = heuristic
+    int nw_override = 0;
+    int variant = 0;
+};
+
+struct StreamArgs {
+    const float *X, *Xq;
+    int64_t ld;
+    const float *nrm32;
+    const float *Wt;
+    int64_t ldw;
+    AlphabetArg A;
+    int64_t N, m, C;
+    int8_t *qidx;
+    float *Qt;
+    double *resid;
+    double *u_out;      // may be NULL: then the residual lives in the workspace
+    void *workspace;
+    size_t workspace_bytes;
+};
+
+hipError_t launch_onchip(const OnchipArgs &a, hipStream_t stream);
+
+size_t stream_workspace_bytes(int64_t N, int64_t m, int64_t C, bool need_u);
+hipError_t launch_stream(const StreamArgs &a, hipStream_t stream);
+
+hipError_t launch_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, float *nrm32, hipStream_t stream);
+hipError_t launch_msq(const float *W, int64_t n, const AlphabetArg &A, float *Q, int8_t *qidx, hipStream_t stream);
+hipError_t launch_extract_patches(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t c,
+                                  int kh, int kw, int sh, int sw, int rh, int rw, int pad_top, int pad_left,
+                                  int64_t oh, int64_t ow, float *P, int64_t ldp, hipStream_t stream);
+
+}  // namespace gpfq

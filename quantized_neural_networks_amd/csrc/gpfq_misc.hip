@@ -1,0 +1,114 @@
+// Small kernels around the hot loop: the per-row norm pre-pass, memoryless scalar quantization,
+// and the per-channel im2col that lays conv activations out as feature-major patch matrices.
+#include "gpfq_device.hpp"
+#include "gpfq_launch.hpp"
+
+namespace gpfq {
+
+// ---- row norms -----------------------------------------------------------------------------
+// nrm32[t] = (float)sqrt(sum_i (double)Xq[t][i]^2): scipy.linalg.norm(X_tilde, 2) on float32 data
+// (scripts/quantized_network.py:83, :89) = BLAS snrm2, a float32-rounded norm.
+// One workgroup per row; lanes stride the row with 16-B loads; fixed-order reduction.
+__global__ void __launch_bounds__(256)
+gpfq_row_norms_kernel(const float *__restrict__ Xq, int64_t m, int64_t ld, int vec, float *__restrict__ nrm32)
+{
+    __shared__ double sm[4];
+    const float *row = Xq + (int64_t)blockIdx.x * ld;
+    double s = 0.0;
+    if (vec) {
+        const int64_t m4 = m / 4;
+        const float4 *r4 = reinterpret_cast<const float4 *>(row);
+        for (int64_t i = threadIdx.x; i < m4; i += 256) {
+            const float4 v = r4[i];
+            s = fma((double)v.x, (double)v.x, s);
+            s = fma((double)v.y, (double)v.y, s);
+            s = fma((double)v.z, (double)v.z, s);
+            s = fma((double)v.w, (double)v.w, s);
+        }
+        for (int64_t i = m4 * 4 + threadIdx.x; i < m; i += 256) s = fma((double)row[i], (double)row[i], s);
+    } else {
+        for (int64_t i = threadIdx.x; i < m; i += 256) s = fma((double)row[i], (double)row[i], s);
+    }
+    s = wave_sum(s);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sm[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) nrm32[blockIdx.x] = (float)sqrt(sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+hipError_t launch_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, float *nrm32, hipStream_t stream)
+{
+    if (N == 0) return hipSuccess;
+    const int vec = (ld % 4 == 0) && ((uintptr_t)Xq % 16 == 0);
+    hipLaunchKernelGGL(gpfq_row_norms_kernel, dim3((unsigned)N), dim3(256), 0, stream, Xq, m, ld, vec, nrm32);
+    return hipGetLastError();
+}
+
+// ---- MSQ -----------------------------------------------------------------------------------
+// Q[i] = alphabet[argmin |alphabet - (double)W[i]|], first index on ties
+// (_bit_round_parallel applied per weight, scripts/quantize_pretrained_mlp.py:109).
+__global__ void __launch_bounds__(256)
+gpfq_msq_kernel(const float *__restrict__ W, int64_t n, AlphabetArg A, float *__restrict__ Q, int8_t *__restrict__ qidx)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double t = (double)W[i];
+        int best = 0;
+        double dbest = fabs(A.a[0] - t);
+        for (int k = 1; k < A.M; ++k) {
+            const double d = fabs(A.a[k] - t);
+            if (d < dbest) { dbest = d; best = k; }
+        }
+        if (Q) Q[i] = (float)A.a[best];
+        if (qidx) qidx[i] = (int8_t)best;
+    }
+}
+
+hipError_t launch_msq(const float *W, int64_t n, const AlphabetArg &A, float *Q, int8_t *qidx, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gpfq_msq_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, W, n, A, Q, qidx);
+    return hipGetLastError();
+}
+
+// ---- per-channel im2col ----------------------------------------------------------------------
+// P[ky*kw + kx][(b*oh + oy)*ow + ox] = act[b][oy*sh + ky*rh - pad_top][ox*sw + kx*rw - pad_left][c]
+// (zero outside the image): tf.image.extract_patches on one channel, reshaped to
+// (B*oh*ow, kh*kw) and stored transposed (scripts/quantized_network.py:158-179, :789-797).
+__global__ void __launch_bounds__(256)
+gpfq_patches_kernel(const float *__restrict__ act, int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t c,
+                    int kh, int kw, int sh, int sw, int rh, int rw, int pad_top, int pad_left,
+                    int64_t oh, int64_t ow, float *__restrict__ P, int64_t ldp)
+{
+    const int64_t cols = n * oh * ow;
+    const int r = blockIdx.y;                    // patch row = ky*kw + kx
+    const int ky = r / kw, kx = r - ky * kw;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; col < cols; col += stride) {
+        const int64_t ox = col % ow;
+        const int64_t oy = (col / ow) % oh;
+        const int64_t b  = col / (ow * oh);
+        const int64_t iy = oy * sh + (int64_t)ky * rh - pad_top;
+        const int64_t ix = ox * sw + (int64_t)kx * rw - pad_left;
+        float v = 0.f;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = act[((b * H + iy) * W + ix) * Cin + c];
+        P[(int64_t)r * ldp + col] = v;
+    }
+}
+
+hipError_t launch_extract_patches(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t c,
+                                  int kh, int kw, int sh, int sw, int rh, int rw, int pad_top, int pad_left,
+                                  int64_t oh, int64_t ow, float *P, int64_t ldp, hipStream_t stream)
+{
+    const int64_t cols = n * oh * ow;
+    if (cols == 0 || kh * kw == 0) return hipSuccess;
+    int64_t bx = (cols + 255) / 256;
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(gpfq_patches_kernel, dim3((unsigned)bx, (unsigned)(kh * kw)), dim3(256), 0, stream,
+                       act, n, H, W, Cin, c, kh, kw, sh, sw, rh, rw, pad_top, pad_left, oh, ow, P, ldp);
+    return hipGetLastError();
+}
+
+}  // namespace gpfq

@@ -1,0 +1,215 @@
+// On-chip GPFQ kernel: one wavefront per neuron, the float64 residual u lives in VGPRs for the
+// whole N-step walk, activation rows are staged through LDS once per workgroup and shared by
+// all its neurons.
+//
+// Replaces _quantize_neuron_parallel / _quantize_filter2D_parallel_jit
+// (scripts/quantized_network.py:91-121, :185-233) for m <= 64*EPL <= 2048.
+//
+// Work decomposition (cfg2: N = C = 4096, m = 1024):
+//   grid  = C / NW workgroups, NW wavefronts (= neurons) each; 256 workgroups of 16 waves fill the
+//           256 CUs with 4 waves per SIMD, so every neuron of the layer is resident at once and the
+//           kernel is one pass of N sequential steps.
+//   lane l of a wave owns elements {256c + 4l + e} of u (EPL = m/64 float64 values = 2*EPL VGPRs).
+//   per tile of TS steps the workgroup copies rows X[t0..t0+TS), Xq[t0..t0+TS) (2*TS*m*4 B) from
+//   global/L2 into LDS with 16-B loads; each wave then reads its 16-B slices with ds_read_b128.
+//   HBM traffic is therefore (2*N*m*4 B) per workgroup-pass from L2/MALL and compulsory once from
+//   HBM -- the kernel is bound by FP64 VALU issue and the per-step reduction latency, not by HBM.
+#include "gpfq_device.hpp"
+#include "gpfq_launch.hpp"
+
+namespace gpfq {
+
+template <int EPL>
+struct Lanes {
+    static constexpr int VW  = EPL >= 4 ? 4 : EPL;   // contiguous elements per lane per chunk
+    static constexpr int NCH = EPL / VW;             // chunks of 64*VW elements
+    static constexpr int MP  = 64 * EPL;             // padded row length held by one wave
+    __device__ static __forceinline__ int elem(int lane, int c, int e) { return 64 * VW * c + VW * lane + e; }
+};
+
+template <int EPL>
+__device__ __forceinline__ void lds_read_row(const float *row, int lane, float (&dst)[EPL])
+{
+    using L = Lanes<EPL>;
+#pragma unroll
+    for (int c = 0; c < L::NCH; ++c) {
+        const float *p = row + L::elem(lane, c, 0);
+        if constexpr (L::VW == 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(p);
+            dst[4 * c + 0] = v.x; dst[4 * c + 1] = v.y; dst[4 * c + 2] = v.z; dst[4 * c + 3] = v.w;
+        } else if constexpr (L::VW == 2) {
+            const float2 v = *reinterpret_cast<const float2 *>(p);
+            dst[2 * c + 0] = v.x; dst[2 * c + 1] = v.y;
+        } else {
+            dst[c] = *p;
+        }
+    }
+}
+
+// Copy rows [t0, t0+ts) of a [N][ld] f32 matrix into LDS rows of pitch MP, zero-filling i >= m.
+template <int MP>
+__device__ __forceinline__ void stage_rows(const float *__restrict__ G, int64_t ld, int64_t t0, int ts,
+                                           int64_t N, int m, bool vec4, float *lds, int tid, int nthreads)
+{
+    if (vec4) {
+        constexpr int Q = MP / 4;
+        for (int idx = tid; idx < ts * Q; idx += nthreads) {
+            const int s = idx / Q, i4 = (idx - s * Q) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t0 + s < N && i4 < m) v = *reinterpret_cast<const float4 *>(G + (t0 + s) * ld + i4);
+            *reinterpret_cast<float4 *>(lds + s * MP + i4) = v;
+        }
+    } else {
+        for (int idx = tid; idx < ts * MP; idx += nthreads) {
+            const int s = idx / MP, i = idx - s * MP;
+            float v = 0.f;
+            if (t0 + s < N && i < m) v = G[(t0 + s) * ld + i];
+            lds[s * MP + i] = v;
+        }
+    }
+}
+
+// EPL = 32 needs ~200 VGPRs: cap the workgroup at 8 waves so the allocator may use 256.
+template <int EPL>
+__global__ void __launch_bounds__(EPL >= 32 ? 512 : 1024)
+gpfq_onchip_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld,
+                                   const float *__restrict__ nrm32, const float *__restrict__ Wt, int64_t ldw,
+                                   AlphabetArg A, int64_t N, int m, int64_t C, int TS, int vec4,
+                                   int8_t *__restrict__ qidx, float *__restrict__ Qt,
+                                   double *__restrict__ resid, double *__restrict__ u_out)
+{
+    using L = Lanes<EPL>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *ldsX  = lds;                  // [TS][MP]
+    float *ldsXq = lds + TS * L::MP;     // [TS][MP]
+
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t j = (int64_t)blockIdx.x * (nthreads >> 6) + wave;   // this wave's neuron
+    const bool active = j < C;
+
+    const double a_lane = alphabet_lane(A, lane);
+    const bool ascending = A.ascending != 0;
+
+    double u[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) u[e] = 0.0;   // zeros(m), :115
+
+    int   my_idx = 0;      // lane (t & 63) keeps step t's outputs until the 64-step flush
+    float my_q   = 0.f;
+
+    for (int64_t t0 = 0; t0 < N; t0 += TS) {
+        __syncthreads();   // previous tile fully consumed
+        stage_rows<L::MP>(X,  ld, t0, TS, N, m, vec4, ldsX,  tid, nthreads);
+        stage_rows<L::MP>(Xq, ld, t0, TS, N, m, vec4, ldsXq, tid, nthreads);
+        // this tile's weights and norms: lane s holds step t0+s
+        float wv = 0.f, nv = 0.f;
+        if (active && lane < TS && t0 + lane < N) {
+            wv = Wt[j * ldw + t0 + lane];
+            nv = nrm32[t0 + lane];
+        }
+        __syncthreads();
+        if (!active) continue;
+
+        const int ts = (int)((N - t0) < TS ? (N - t0) : TS);
+        for (int s = 0; s < ts; ++s) {
+            const int64_t t = t0 + s;
+            const float w   = readlane_f32(wv, s);
+            const float nrm = readlane_f32(nv, s);
+
+            float x[EPL], xq[EPL], p[EPL];
+            lds_read_row<EPL>(ldsX  + s * L::MP, lane, x);
+            lds_read_row<EPL>(ldsXq + s * L::MP, lane, xq);
+
+            // <Xq_t, u> (:86) and <Xq_t, u + w*X_t> (:89); two accumulators per sum break the
+            // dependent-FMA chain.
+            double d0a = 0.0, d0b = 0.0, d1a = 0.0, d1b = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                p[e] = __fmul_rn(w, x[e]);                     // f32 product
+                const double xd = (double)xq[e];
+                const double v  = u[e] + (double)p[e];         // f64 add
+                if (e & 1) { d0b = fma(xd, u[e], d0b); d1b = fma(xd, v, d1b); }
+                else       { d0a = fma(xd, u[e], d0a); d1a = fma(xd, v, d1a); }
+            }
+            const double dot_u  = wave_sum(d0a + d0b);
+            const double dot_uw = wave_sum(d1a + d1b);
+
+            const Decision dec = decide(w, nrm, dot_u, dot_uw, a_lane, A.M, A.zero_idx, ascending);
+
+            // u += w*X_t - q*Xq_t  (:119): f32 products, f32 subtraction, f64 accumulate
+            const float q32 = (float)dec.q;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const float r = __fmul_rn(q32, xq[e]);
+                const float d = __fsub_rn(p[e], r);
+                u[e] += (double)d;
+            }
+
+            if (lane == (int)(t & 63)) { my_idx = dec.idx; my_q = q32; }
+            if (((t + 1) & 63) == 0 || t + 1 == N) {
+                const int64_t base = t & ~(int64_t)63;
+                if (lane <= (int)(t & 63)) {
+                    if (qidx) qidx[j * N + base + lane] = (int8_t)my_idx;
+                    if (Qt)   Qt[j * N + base + lane]   = my_q;
+                }
+            }
+        }
+    }
+
+    if (!active) return;
+    if (resid) {
+        double ss = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) ss = fma(u[e], u[e], ss);
+        ss = wave_sum(ss);
+        if (lane == 0) resid[j] = sqrt(ss);
+    }
+    if (u_out) {
+#pragma unroll
+        for (int c = 0; c < L::NCH; ++c)
+#pragma unroll
+            for (int e = 0; e < L::VW; ++e) {
+                const int i = L::elem(lane, c, e);
+                if (i < m) u_out[j * (int64_t)m + i] = u[c * L::VW + e];
+            }
+    }
+}
+
+template <int EPL>
+static hipError_t launch_epl(const OnchipArgs &a, hipStream_t stream)
+{
+    constexpr int MP = 64 * EPL;
+    // neurons (waves) per workgroup: enough workgroups to cover the 256 CUs, at most 16 waves
+    int nw = 16;
+    if (EPL >= 32) nw = 8;                       // ~200 VGPRs -> 2 waves/SIMD
+    while (nw > 1 && (a.C + nw - 1) / nw < 256) nw >>= 1;
+    // tile: as many steps as fit ~64 KiB of LDS for both matrices, a divisor of 64
+    int ts = 64;
+    while (ts > 1 && (size_t)2 * ts * MP * sizeof(float) > 64 * 1024) ts >>= 1;
+    if (a.ts_override > 0) ts = a.ts_override;
+    if (a.nw_override > 0) nw = a.nw_override;
+    const size_t lds_bytes = (size_t)2 * ts * MP * sizeof(float);
+    const bool vec4 = (a.ld % 4 == 0) && (a.m % 4 == 0) && ((uintptr_t)a.X % 16 == 0) && ((uintptr_t)a.Xq % 16 == 0);
+    const unsigned grid = (unsigned)((a.C + nw - 1) / nw);
+    hipError_t e = hipFuncSetAttribute((const void *)gpfq_onchip_kernel<EPL>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gpfq_onchip_kernel<EPL>, dim3(grid), dim3(nw * 64), lds_bytes, stream,
+                       a.X, a.Xq, a.ld, a.nrm32, a.Wt, a.ldw, a.A, a.N, (int)a.m, a.C, ts, vec4 ? 1 : 0,
+                       a.qidx, a.Qt, a.resid, a.u_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_onchip(const OnchipArgs &a, hipStream_t stream)
+{
+    if (a.m <= 64)   return launch_epl<1>(a, stream);
+    if (a.m <= 128)  return launch_epl<2>(a, stream);
+    if (a.m <= 256)  return launch_epl<4>(a, stream);
+    if (a.m <= 512)  return launch_epl<8>(a, stream);
+    if (a.m <= 1024) return launch_epl<16>(a, stream);
+    return launch_epl<32>(a, stream);
+}
+
+}  // namespace gpfq

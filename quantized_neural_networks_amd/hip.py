@@ -1,0 +1,183 @@
+"""ctypes binding of libgpfq_hip.so (the C ABI of include/gpfq.h) on PyTorch-ROCm tensors.
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every compute call goes
+through the C ABI with raw device pointers.  There is NO CPU fallback: if the library cannot be
+loaded, or a tensor is not on a GPU, the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import build as _build
+
+GPFQ_PATH_AUTO, GPFQ_PATH_ONCHIP, GPFQ_PATH_STREAM = 0, 1, 2
+GPFQ_MAX_ALPHABET = 64
+GPFQ_ONCHIP_MAX_M = 2048
+
+# every symbol include/gpfq.h declares: (restype, argtypes)
+_i64, _int, _vp, _sz = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+_dp = ctypes.POINTER(ctypes.c_double)
+SYMBOLS = {
+    "gpfq_version": (_int, []),
+    "gpfq_last_error": (ctypes.c_char_p, []),
+    "gpfq_device_count": (_int, []),
+    "gpfq_row_norms": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "gpfq_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
+    "gpfq_quantize_neurons": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _int, _int, _i64, _i64, _i64,
+                                     _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp]),
+    "gpfq_msq_round": (_int, [_vp, _i64, _dp, _int, _vp, _vp, _vp]),
+    "gpfq_patch_out_dim": (_i64, [_i64, _i64, _i64, _i64, _int]),
+    "gpfq_extract_patches": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int,
+                                    _vp, _i64, _vp]),
+}
+
+_lib = None
+
+
+class GpfqError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load libgpfq_hip.so (must already be built in-tree: __graft_entry__.build() / build.py)."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise GpfqError(f"{path} is missing: run `python -m quantized_neural_networks_amd.build` "
+                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)      # AttributeError if the ABI and the header disagree
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise GpfqError(f"{what} failed ({rc}): {load().gpfq_last_error().decode()}")
+
+
+def _dev(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise GpfqError(f"{name} must be a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise GpfqError(f"{name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def _rows(t, name):
+    """2-D tensor with unit inner stride -> (ptr, rows, cols, pitch)."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise GpfqError(f"{name} must be 2-D with contiguous rows")
+    pitch = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+    return t.data_ptr(), t.shape[0], t.shape[1], max(pitch, t.shape[1])
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _alphabet(alphabet):
+    a = [float(v) for v in alphabet]
+    if not 1 <= len(a) <= GPFQ_MAX_ALPHABET:
+        raise GpfqError(f"alphabet size {len(a)} not in [1, {GPFQ_MAX_ALPHABET}]")
+    arr = (ctypes.c_double * len(a))(*a)
+    zero_idx = -1
+    for k, v in enumerate(a):
+        if v == 0.0:
+            zero_idx = k
+    return arr, len(a), zero_idx
+
+
+def row_norms(Xq):
+    """float32-rounded Euclidean norm of every row of Xq (f32 [N][m]) -> f32 [N]."""
+    _dev(Xq, torch.float32, "Xq")
+    ptr, N, m, ld = _rows(Xq, "Xq")
+    out = torch.empty(N, dtype=torch.float32, device=Xq.device)
+    with torch.cuda.device(Xq.device):
+        _check(load().gpfq_row_norms(ptr, N, m, ld, out.data_ptr(), _stream()), "gpfq_row_norms")
+    return out
+
+
+def quantize_neurons(X, Xq, Wt, alphabet, nrm32=None, want_u=False, path=GPFQ_PATH_AUTO, want_values=True):
+    """Greedy recurrence for all C neurons (rows of Wt [C][N]) against X, Xq [N][m].
+
+    Returns dict(idx=i8 [C][N], Q=f32 [C][N], resid=f64 [C], u=f64 [C][m] or None).
+    """
+    _dev(X, torch.float32, "X"); _dev(Xq, torch.float32, "Xq"); _dev(Wt, torch.float32, "Wt")
+    xp, N, m, ld = _rows(X, "X")
+    xqp, N2, m2, ld2 = _rows(Xq, "Xq")
+    wp, C, Nw, ldw = _rows(Wt, "Wt")
+    if (N2, m2) != (N, m) or Nw != N:
+        raise GpfqError(f"shape mismatch: X {tuple(X.shape)}, Xq {tuple(Xq.shape)}, Wt {tuple(Wt.shape)}")
+    if ld2 != ld:
+        raise GpfqError("X and Xq must share one row pitch")
+    arr, M, zero_idx = _alphabet(alphabet)
+    dev = X.device
+    if nrm32 is None:
+        nrm32 = row_norms(Xq)
+    _dev(nrm32, torch.float32, "nrm32")
+    idx = torch.empty((C, N), dtype=torch.int8, device=dev)
+    Q = torch.empty((C, N), dtype=torch.float32, device=dev) if want_values else None
+    resid = torch.empty(C, dtype=torch.float64, device=dev)
+    lib = load()
+    nbytes = lib.gpfq_workspace_bytes(N, m, C, path)
+    streaming = nbytes > 0
+    u = torch.empty((C, m), dtype=torch.float64, device=dev) if (want_u or streaming) else None
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev) if streaming else None
+    with torch.cuda.device(dev):
+        rc = lib.gpfq_quantize_neurons(xp, xqp, ld, nrm32.data_ptr(), wp, ldw, arr, M, zero_idx, N, m, C,
+                                       idx.data_ptr(), Q.data_ptr() if Q is not None else None, resid.data_ptr(),
+                                       u.data_ptr() if u is not None else None,
+                                       ws.data_ptr() if ws is not None else None, nbytes, path, _stream())
+    _check(rc, "gpfq_quantize_neurons")
+    return dict(idx=idx, Q=Q, resid=resid, u=u if want_u else None)
+
+
+def msq_round(W, alphabet):
+    """Nearest alphabet member of every weight (first index on ties) -> (Q f32, idx i8), W's shape."""
+    _dev(W, torch.float32, "W")
+    Wc = W.contiguous()
+    arr, M, _ = _alphabet(alphabet)
+    Q = torch.empty_like(Wc)
+    idx = torch.empty(Wc.shape, dtype=torch.int8, device=W.device)
+    with torch.cuda.device(W.device):
+        _check(load().gpfq_msq_round(Wc.data_ptr(), Wc.numel(), arr, M, Q.data_ptr(), idx.data_ptr(), _stream()),
+               "gpfq_msq_round")
+    return Q, idx
+
+
+def patch_out_dim(size, k, stride, rate, same):
+    return int(load().gpfq_patch_out_dim(size, k, stride, rate, 1 if same else 0))
+
+
+def extract_patches(act, channel, kernel_size, strides, rate, padding, out=None):
+    """Patch matrix [kh*kw][n*oh*ow] of one channel of NHWC activations (TF extract_patches order)."""
+    _dev(act, torch.float32, "act")
+    if act.dim() != 4 or not act.is_contiguous():
+        raise GpfqError("act must be a contiguous NHWC tensor")
+    n, H, W, Cin = act.shape
+    kh, kw = kernel_size
+    sh, sw = strides
+    rh, rw = rate if rate else (1, 1)
+    same = str(padding).upper() == "SAME"
+    if not same and str(padding).upper() != "VALID":
+        raise GpfqError(f"unknown padding {padding!r}")
+    oh, ow = patch_out_dim(H, kh, sh, rh, same), patch_out_dim(W, kw, sw, rw, same)
+    cols = n * oh * ow
+    if out is None:
+        out = torch.empty((kh * kw, cols), dtype=torch.float32, device=act.device)
+    ptr, r, c, ldp = _rows(out, "out")
+    if r != kh * kw or c != cols:
+        raise GpfqError("out has the wrong shape")
+    with torch.cuda.device(act.device):
+        _check(load().gpfq_extract_patches(act.data_ptr(), n, H, W, Cin, channel, kh, kw, sh, sw, rh, rw,
+                                           1 if same else 0, out.data_ptr(), ldp, _stream()), "gpfq_extract_patches")
+    return out
