@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: weights quantized per second for a whole Dense layer (BASELINE.json).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY 8d "cfg2"): one Dense(4096 -> 4096) layer, 1024
+calibration samples, ternary alphabet (M = 3), alphabet_scalar = 3, synthetic ReLU-like activations.
+One "step" = the whole layer driver on inputs already resident in HBM: alphabet radius (median of
+|W|), the row-norm pre-pass, the greedy kernel for every neuron, the all-gather (N > 1) and the
+transposes back to the Keras kernel layout.
+
+N > 1: one process per GPU.  Default "weak" scaling: every rank quantizes its own 4096-neuron shard
+of a Dense(4096 -> 4096*N) layer and one RCCL all-gather reassembles Q; `--scaling strong` splits
+the fixed 4096x4096 layer instead.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` (dominant kernel,
+live HIP-event timing, algorithmic bytes (8m+8) per weight) and `cpu_baseline` (the C oracle port on
+all host cores over a bounded sample of the same layer).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+
+
+def synthetic_layer(N, m, C, c_lo, c_hi, seed=0):
+    """SURVEY 8d recipe.  W columns [c_lo, c_hi) are generated per 4096-column block so a shard
+    does not need the whole kernel on the host; block 0 is exactly rng(0) of the 1-GPU case."""
+    rng_g = np.random.default_rng(seed + 1)
+    G = rng_g.standard_normal((N, m))
+    X = np.maximum(G, 0).astype(np.float32)
+    Xq = np.maximum(G + 0.1 * np.random.default_rng(seed + 2).standard_normal((N, m)), 0).astype(np.float32)
+    return X, Xq
+
+
+def weight_block(N, block, width, seed=0):
+    return (np.random.default_rng(seed + 1000003 * block).standard_normal((N, width)) / np.sqrt(N)).astype(np.float32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--n", type=int, default=4096, help="fan-in N (rows of W)")
+    ap.add_argument("--c", type=int, default=4096, help="neurons per GPU (weak) / total (strong)")
+    ap.add_argument("--m", type=int, default=1024, help="calibration samples")
+    ap.add_argument("--bits", type=float, default=float(np.log2(3)))
+    ap.add_argument("--alphabet-scalar", type=float, default=3.0)
+    ap.add_argument("--cpu-sample", type=int, default=512, help="neurons timed on the host cores (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from quantized_neural_networks_amd import hip, layer
+
+    N, m = args.n, args.m
+    C_total = args.c * world if args.scaling == "weak" else args.c
+    M = int(round(2 ** args.bits))
+    unit_alphabet = np.linspace(-1, 1, num=M)
+
+    # ---- synthetic inputs, resident in HBM before the timed region -------------------------
+    X, Xq = synthetic_layer(N, m, C_total, 0, 0)
+    nblocks = -(-C_total // args.c)
+    W = np.concatenate([weight_block(N, b, min(args.c, C_total - b * args.c)) for b in range(nblocks)], axis=1)
+    Xd, Xqd = torch.from_numpy(X).to(dev), torch.from_numpy(Xq).to(dev)
+    Wd = torch.from_numpy(W).to(dev)
+
+    kernel_ms = []
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i_timed=None):
+        alphabet, _ = layer.layer_alphabet(Wd, unit_alphabet, args.alphabet_scalar)
+        lo, hi = layer.shard_bounds(C_total, world, rank)
+        Wt = Wd[:, lo:hi].t().contiguous()
+        nrm = hip.row_norms(Xqd)
+        if i_timed is not None:
+            ev[i_timed][0].record()          # same stream the kernel is launched on (torch current stream)
+        r = hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm)
+        if i_timed is not None:
+            ev[i_timed][1].record()
+        Qt = layer.all_gather_units(r["Q"], C_total, group)
+        It = layer.all_gather_units(r["idx"], C_total, group)
+        Q = Qt.t().contiguous()
+        idx = It.t().contiguous()
+        return Q, idx, r
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        Q, idx, last = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+
+    weights_per_step = N * C_total
+    value = weights_per_step * args.steps / elapsed
+    lo, hi = layer.shard_bounds(C_total, world, rank)
+    k_avg_s = float(np.mean(kernel_ms)) / 1e3
+    alg_bytes = (8 * m + 8) * N * (hi - lo)          # per launch on this rank
+    achieved = alg_bytes / k_avg_s / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "weights_quantized_per_sec", "value": value, "unit": "weights/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"Dense({N}->{C_total}) whole-layer GPFQ, m={m} calibration samples, "
+                            f"M={M} alphabet, alphabet_scalar={args.alphabet_scalar:g} (BASELINE cfg2 per GPU)",
+                "N": N, "C": C_total, "m": m, "M": M, "neurons_per_gpu": hi - lo,
+                "sharding": "neurons (columns of W) contiguous over ranks; one all-gather per layer" if world > 1 else "none",
+                "arithmetic": "f32 products / f64 residual and dot products (reference's mixed flow)",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "gpfq_onchip_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": _recorded_traffic(N, m, hi - lo),
+                "kernel_ms_avg": k_avg_s * 1e3, "kernel_ms_min": float(np.min(kernel_ms)),
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "algorithmic bytes = (8m+8) per weight; rows are shared by the 16 neurons of a workgroup "
+                        "through LDS, so achieved/peak may exceed 1 -- see DESIGN.md for the FP64-VALU bound",
+            },
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"], out["parity_sample"] = _cpu_baseline(W, X, Xq, unit_alphabet, args, idx, last)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _recorded_traffic(N, m, C_local):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*.json), if one was
+    recorded for this exact shape; else null."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        for r in rec.get("records", []):
+            if (r["N"], r["m"], r["C"]) == (N, m, C_local):
+                return r["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
+def _cpu_baseline(W, X, Xq, unit_alphabet, args, idx_gpu, last):
+    """The C oracle port (oracle/gpfq_oracle.c, OpenMP over neurons) on this box's host cores over a
+    bounded sample of the same layer; also the parity check of the GPU result on that sample."""
+    import oracle
+    oracle.build()
+    alphabet, _ = oracle.layer_alphabet(W, unit_alphabet, args.alphabet_scalar)
+    n = min(args.cpu_sample, W.shape[1])
+    threads = oracle.num_threads()
+    t0 = time.perf_counter()
+    Qo, io, ro = oracle.layer(W, X, Xq, alphabet, 0, n, threads=threads)
+    dt = time.perf_counter() - t0
+    ig = idx_gpu[:, :n].t().cpu().numpy()
+    rg = last["resid"][:n].cpu().numpy()
+    bad = int((ig != io).any(axis=1).sum())
+    rel = float(np.max(np.abs(rg - ro) / np.maximum(ro, 1e-300)))
+    cpu = {"value": n * W.shape[0] / dt, "unit": "weights/s", "cores": threads, "kind": "port",
+           "sample": f"{n} of {W.shape[1]} neurons of the same layer (independent, equal cost), "
+                     f"{dt:.2f} s wall on {threads} threads, in-memory arrays (no HDF5)"}
+    parity = {"neurons_checked": n, "neurons_with_index_mismatch": bad, "max_resid_rel_err": rel}
+    return cpu, parity
+
+
+if __name__ == "__main__":
+    main()

@@ -119,6 +119,16 @@ int gpfq_msq_round(const float *W, int64_t n, const double *alphabet, int M,
                    float *Q, int8_t *qidx, void *stream);
 
 /*
+ * median(|W|) of n float32 weights with NumPy's semantics (float32 result; even n -> float32 mean of
+ * the two middle values).  Replaces `median(abs(W.flatten()))` of the alphabet radius
+ * (scripts/quantized_network.py:544, :831).  Exact radix select, no sort.
+ *   W [device] f32 [n]; median_out [device] f32 [1]; workspace [device] >= gpfq_median_abs_workspace_bytes().
+ */
+size_t gpfq_median_abs_workspace_bytes(void);
+int gpfq_median_abs(const float *W, int64_t n, float *median_out, void *workspace, size_t workspace_bytes,
+                    void *stream);
+
+/*
  * Per-channel im2col: the patch matrices of ONE input channel for the analog and quantized
  * activations, transposed to feature-major [kh*kw][n*oh*ow].  Replaces _build_patch_array
  * (scripts/quantized_network.py:729-809) + _segment_data2D (:123-183), i.e.

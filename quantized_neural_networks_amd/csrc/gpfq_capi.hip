@@ -148,6 +148,18 @@ int gpfq_msq_round(const float *W, int64_t n, const double *alphabet, int M, flo
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_msq_round");
 }
 
+size_t gpfq_median_abs_workspace_bytes(void) { return gpfq::median_workspace_bytes(); }
+
+int gpfq_median_abs(const float *W, int64_t n, float *median_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (n <= 0) return fail(GPFQ_ERR_INVALID_ARG, "median of %lld elements", (long long)n);
+    if (!W || !median_out) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    if (!workspace || workspace_bytes < gpfq::median_workspace_bytes() || (uintptr_t)workspace % 16 != 0)
+        return fail(GPFQ_ERR_WORKSPACE, "median needs %zu aligned workspace bytes", gpfq::median_workspace_bytes());
+    hipError_t e = gpfq::launch_median_abs(W, n, median_out, workspace, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_median_abs");
+}
+
 int64_t gpfq_patch_out_dim(int64_t in, int64_t k, int64_t stride, int64_t rate, int same_padding)
 {
     if (in <= 0 || k <= 0 || stride <= 0 || rate <= 0) return 0;

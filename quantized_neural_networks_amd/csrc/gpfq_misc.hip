@@ -111,4 +111,96 @@ hipError_t launch_extract_patches(const float *act, int64_t n, int64_t H, int64_
     return hipGetLastError();
 }
 
+// ---- median of |W| ---------------------------------------------------------------------------
+// np.median(np.abs(W.flatten())) on float32 data (scripts/quantized_network.py:544, :831) without a
+// sort: exact radix select on the bit patterns of |w| (monotone as unsigned integers), three
+// histogram passes of 11 + 11 + 10 bits per order statistic.  For an even count NumPy returns the
+// float32 mean of the two middle values, so both are selected.
+struct SelState {
+    unsigned prefix;            // bits of the answer fixed so far
+    unsigned pad;
+    unsigned long long k;       // rank still to be resolved inside the prefix class
+};
+
+constexpr int kSelBins = 2048;
+
+__global__ void __launch_bounds__(256)
+gpfq_select_hist_kernel(const float *__restrict__ W, int64_t n, const SelState *__restrict__ st,
+                        int shift, int nbits, unsigned *__restrict__ hist)
+{
+    __shared__ unsigned h[kSelBins];
+    for (int b = threadIdx.x; b < kSelBins; b += 256) h[b] = 0;
+    __syncthreads();
+    const unsigned prefix = st->prefix;
+    const unsigned hi_mask = (shift + nbits >= 32) ? 0u : ~((1u << (shift + nbits)) - 1u);
+    const unsigned bin_mask = (1u << nbits) - 1u;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const unsigned key = __float_as_uint(W[i]) & 0x7fffffffu;
+        if ((key & hi_mask) == prefix) atomicAdd(&h[(key >> shift) & bin_mask], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < kSelBins; b += 256)
+        if (h[b]) atomicAdd(&hist[b], h[b]);
+}
+
+__global__ void __launch_bounds__(256)
+gpfq_select_pick_kernel(unsigned *__restrict__ hist, SelState *__restrict__ st, int shift, int nbits)
+{
+    __shared__ unsigned h[kSelBins];
+    const int bins = 1 << nbits;
+    for (int b = threadIdx.x; b < kSelBins; b += 256) { h[b] = b < bins ? hist[b] : 0u; hist[b] = 0u; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long k = st->k, acc = 0;
+        int b = 0;
+        for (; b < bins - 1; ++b) {
+            if (acc + h[b] > k) break;
+            acc += h[b];
+        }
+        st->k = k - acc;
+        st->prefix |= (unsigned)b << shift;
+    }
+}
+
+__global__ void gpfq_select_init_kernel(SelState *st, unsigned long long k0, unsigned long long k1)
+{
+    st[0].prefix = 0; st[0].pad = 0; st[0].k = k0;
+    st[1].prefix = 0; st[1].pad = 0; st[1].k = k1;
+}
+
+__global__ void gpfq_select_finish_kernel(const SelState *st, int even, float *out)
+{
+    const float a = __uint_as_float(st[0].prefix);
+    if (!even) { *out = a; return; }
+    const float b = __uint_as_float(st[1].prefix);
+    *out = __fdiv_rn(__fadd_rn(a, b), 2.0f);          // float32 mean of the two middle values
+}
+
+size_t median_workspace_bytes() { return 2 * sizeof(SelState) + 2 * kSelBins * sizeof(unsigned) + 64; }
+
+hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream)
+{
+    SelState *st = static_cast<SelState *>(workspace);
+    unsigned *hist = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + 64);
+    hipError_t e = hipMemsetAsync(hist, 0, 2 * kSelBins * sizeof(unsigned), stream);
+    if (e != hipSuccess) return e;
+    const bool even = (n % 2) == 0;
+    const unsigned long long k0 = even ? (unsigned long long)(n / 2 - 1) : (unsigned long long)(n / 2);
+    hipLaunchKernelGGL(gpfq_select_init_kernel, dim3(1), dim3(1), 0, stream, st, k0, (unsigned long long)(n / 2));
+    int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+    for (int sel = 0; sel < (even ? 2 : 1); ++sel)
+        for (int p = 0; p < 3; ++p) {
+            hipLaunchKernelGGL(gpfq_select_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                               W, n, st + sel, shifts[p], widths[p], hist + sel * kSelBins);
+            hipLaunchKernelGGL(gpfq_select_pick_kernel, dim3(1), dim3(256), 0, stream,
+                               hist + sel * kSelBins, st + sel, shifts[p], widths[p]);
+        }
+    hipLaunchKernelGGL(gpfq_select_finish_kernel, dim3(1), dim3(1), 0, stream, st, even ? 1 : 0, out);
+    return hipGetLastError();
+}
+
 }  // namespace gpfq

@@ -27,6 +27,8 @@ SYMBOLS = {
     "gpfq_quantize_neurons": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _int, _int, _i64, _i64, _i64,
                                      _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp]),
     "gpfq_msq_round": (_int, [_vp, _i64, _dp, _int, _vp, _vp, _vp]),
+    "gpfq_median_abs_workspace_bytes": (_sz, []),
+    "gpfq_median_abs": (_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
     "gpfq_patch_out_dim": (_i64, [_i64, _i64, _i64, _i64, _int]),
     "gpfq_extract_patches": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int,
                                     _vp, _i64, _vp]),
@@ -152,6 +154,21 @@ def msq_round(W, alphabet):
         _check(load().gpfq_msq_round(Wc.data_ptr(), Wc.numel(), arr, M, Q.data_ptr(), idx.data_ptr(), _stream()),
                "gpfq_msq_round")
     return Q, idx
+
+
+def median_abs(W):
+    """np.median(np.abs(W.flatten())) of a float32 GPU tensor as a numpy float32 (exact select)."""
+    import numpy as np
+    _dev(W, torch.float32, "W")
+    Wc = W.contiguous()
+    lib = load()
+    nbytes = lib.gpfq_median_abs_workspace_bytes()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=W.device)
+    out = torch.empty(1, dtype=torch.float32, device=W.device)
+    with torch.cuda.device(W.device):
+        _check(lib.gpfq_median_abs(Wc.data_ptr(), Wc.numel(), out.data_ptr(), ws.data_ptr(), nbytes, _stream()),
+               "gpfq_median_abs")
+    return np.float32(out.item())
 
 
 def patch_out_dim(size, k, stride, rate, same):

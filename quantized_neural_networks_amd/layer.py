@@ -1,0 +1,152 @@
+"""Device-side layer drivers: what the reference's ``_quantize_layer_parallel``
+(scripts/quantized_network.py:523-574) and ``_quantize_conv2D_layer_parallel_jit`` (:815-867) do
+between "activations and weights are available" and "Q is handed to set_weights", on GPU tensors.
+
+Multi-GPU: the independent units -- neurons of a Dense layer, (input-channel, filter)
+pairs of a conv layer -- are partitioned contiguously over the ranks of a ``torch.distributed``
+process group (one process per GPU, backend "nccl" = RCCL over xGMI).  Every rank holds the full
+activation matrices and the full analog kernel, quantizes its shard, and ONE all-gather per layer
+reassembles the quantized kernel; there is no other communication.
+"""
+import numpy as np
+import torch
+
+from . import hip
+
+
+# ------------------------------------------------------------------------------------------
+# alphabet radius
+# ------------------------------------------------------------------------------------------
+def median_abs(W):
+    """np.median(np.abs(W.flatten())) for float32 W (:544, :831) as a float32 value: the middle
+    element, or for an even count the float32 mean of the two middle elements (NumPy semantics;
+    torch.median would return the lower one)."""
+    if W.numel() == 0:
+        return np.float32(np.nan)
+    return hip.median_abs(W.detach().reshape(-1))
+
+
+def layer_alphabet(W, alphabet, alphabet_scalar):
+    """(rad * alphabet, rad) with the reference's legacy-NumPy typing (:544-545): the python
+    scalar times the float32 median is a float64 product."""
+    rad = np.float64(alphabet_scalar) * np.float64(median_abs(W))
+    return rad * np.asarray(alphabet, dtype=np.float64), rad
+
+
+# ------------------------------------------------------------------------------------------
+# sharding helpers
+# ------------------------------------------------------------------------------------------
+def shard_bounds(n_units, world_size, rank):
+    """Contiguous partition of n_units over world_size ranks: [lo, hi) of `rank`."""
+    per = -(-n_units // world_size)
+    lo = min(rank * per, n_units)
+    return lo, min(lo + per, n_units)
+
+
+def _group_info(group):
+    import torch.distributed as dist
+    if group is None and not (dist.is_available() and dist.is_initialized()):
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+def all_gather_units(local, n_units, group=None):
+    """Reassemble a [units_local, ...] shard into [n_units, ...] on every rank with one all-gather.
+    Shards are padded to the common size ceil(n_units / world) so a single
+    all_gather_into_tensor (ncclAllGather on RCCL) moves them."""
+    import torch.distributed as dist
+    world, rank = _group_info(group)
+    if world == 1:
+        return local
+    per = -(-n_units // world)
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return out[:n_units]
+
+
+# The local worker.  Tests of the collective plumbing (gloo, CPU) substitute a stand-in here; the
+# product never does -- there is no CPU fallback.
+_local_quantize = hip.quantize_neurons
+
+
+# ------------------------------------------------------------------------------------------
+# Dense layer
+# ------------------------------------------------------------------------------------------
+def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True):
+    """Quantize every neuron (column) of a Dense kernel.
+
+    W        f32 [N][C]  Keras kernel layout (row = input feature), on the GPU
+    X, Xq    f32 [N][m]  feature-major analog / quantized activations (the transposed wX, qX)
+    alphabet f64 [M]     the layer alphabet rad * linspace(-1, 1, M)
+
+    Returns dict(Q f32 [N][C], idx i8 [N][C], resid f64 [C]) on every rank.
+    """
+    N, C = W.shape
+    world, rank = _group_info(group)
+    lo, hi = shard_bounds(C, world, rank)
+    Wt = W[:, lo:hi].t().contiguous()                        # neuron-major shard [C_local][N]
+    if hi > lo:
+        r = _local_quantize(X, Xq, Wt, alphabet)
+        q_loc, i_loc, res_loc = r["Q"], r["idx"], r["resid"]
+    else:
+        q_loc = torch.empty((0, N), dtype=torch.float32, device=W.device)
+        i_loc = torch.empty((0, N), dtype=torch.int8, device=W.device)
+        res_loc = torch.empty((0,), dtype=torch.float64, device=W.device)
+    Qt = all_gather_units(q_loc, C, group)
+    idx = all_gather_units(i_loc, C, group)
+    out = dict(Q=Qt.t().contiguous(), idx=idx.t().contiguous())
+    if want_resid:
+        out["resid"] = all_gather_units(res_loc, C, group)
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# Conv2D layer
+# ------------------------------------------------------------------------------------------
+def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=None):
+    """Quantize a Conv2D / DepthwiseConv2D kernel channel by channel.
+
+    W          f32 [kh][kw][Cin][F]   Keras kernel layout
+    act_w/q    f32 NHWC [n][H][W][Cin] analog / quantized layer inputs
+    Each (input channel c, filter f) pair is an independent neuron of kh*kw weights whose data are
+    the rows of channel c's patch matrix (:652-727); channels are partitioned over the ranks
+    (when Cin < world, the filters of each channel are partitioned instead).
+
+    Returns dict(Q f32 [kh][kw][Cin][F], idx i8 same shape, resid f64 [Cin][F]).
+    """
+    kh, kw, Cin, F = W.shape
+    K = kh * kw
+    dev = W.device
+    world, rank = _group_info(group)
+    by_channel = Cin >= world
+    Qc = torch.zeros((Cin, F, K), dtype=torch.float32, device=dev)
+    Ic = torch.zeros((Cin, F, K), dtype=torch.int8, device=dev)
+    Rc = torch.zeros((Cin, F), dtype=torch.float64, device=dev)
+    c_lo, c_hi = shard_bounds(Cin, world, rank) if by_channel else (0, Cin)
+    f_lo, f_hi = (0, F) if by_channel else shard_bounds(F, world, rank)
+    Pw = Pq = None
+    for c in range(c_lo, c_hi):
+        if f_hi <= f_lo:
+            break
+        Pw = hip.extract_patches(act_w, c, (kh, kw), strides, rate, padding, out=Pw)
+        Pq = hip.extract_patches(act_q, c, (kh, kw), strides, rate, padding, out=Pq)
+        # row-major flattening of the kh x kw filter (:215): weight t = (ky, kx) = divmod(t, kw)
+        Wt = W[:, :, c, f_lo:f_hi].reshape(K, f_hi - f_lo).t().contiguous()
+        r = _local_quantize(Pw, Pq, Wt, alphabet)
+        Qc[c, f_lo:f_hi] = r["Q"]
+        Ic[c, f_lo:f_hi] = r["idx"]
+        Rc[c, f_lo:f_hi] = r["resid"]
+    if world > 1:
+        if by_channel:
+            Qc = all_gather_units(Qc[c_lo:c_hi], Cin, group)
+            Ic = all_gather_units(Ic[c_lo:c_hi], Cin, group)
+            Rc = all_gather_units(Rc[c_lo:c_hi], Cin, group)
+        else:
+            Qc = all_gather_units(Qc[:, f_lo:f_hi].transpose(0, 1).contiguous(), F, group).transpose(0, 1)
+            Ic = all_gather_units(Ic[:, f_lo:f_hi].transpose(0, 1).contiguous(), F, group).transpose(0, 1)
+            Rc = all_gather_units(Rc[:, f_lo:f_hi].transpose(0, 1).contiguous(), F, group).transpose(0, 1)
+    Q = Qc.reshape(Cin, F, kh, kw).permute(2, 3, 0, 1).contiguous()
+    idx = Ic.reshape(Cin, F, kh, kw).permute(2, 3, 0, 1).contiguous()
+    return dict(Q=Q, idx=idx, resid=Rc.contiguous())
