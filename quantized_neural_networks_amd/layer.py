@@ -69,6 +69,7 @@ def all_gather_units(local, n_units, group=None):
 # The local worker.  Tests of the collective plumbing (gloo, CPU) substitute a stand-in here; the
 # product never does -- there is no CPU fallback.
 _local_quantize = hip.quantize_neurons
+_extract_patches = hip.extract_patches
 
 
 # ------------------------------------------------------------------------------------------
@@ -130,8 +131,8 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
     for c in range(c_lo, c_hi):
         if f_hi <= f_lo:
             break
-        Pw = hip.extract_patches(act_w, c, (kh, kw), strides, rate, padding, out=Pw)
-        Pq = hip.extract_patches(act_q, c, (kh, kw), strides, rate, padding, out=Pq)
+        Pw = _extract_patches(act_w, c, (kh, kw), strides, rate, padding, out=Pw)
+        Pq = _extract_patches(act_q, c, (kh, kw), strides, rate, padding, out=Pq)
         # row-major flattening of the kh x kw filter (:215): weight t = (ky, kx) = divmod(t, kw)
         Wt = W[:, :, c, f_lo:f_hi].reshape(K, f_hi - f_lo).t().contiguous()
         r = _local_quantize(Pw, Pq, Wt, alphabet)

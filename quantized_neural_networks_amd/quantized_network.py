@@ -1,0 +1,319 @@
+"""Drop-in for the reference's ``scripts/quantized_network.py`` module surface.
+
+Same public names, constructor signatures, attributes and log lines as the reference
+(``QuantizedNeuralNetwork`` :331-590, ``QuantizedCNN`` :592-883, the three ``Sequence`` feeders
+:235-329, ``_bit_round_parallel`` :40-57), so ``quantize_pretrained_{mlp,cnn,imagenet}.py`` can do
+``from quantized_network import ...`` unchanged.  What differs is where the work
+happens: calibration activations are captured straight into GPU tensors (no HDF5 files), and each
+layer's greedy per-neuron loop is one call into the HIP kernels behind ``include/gpfq.h`` instead
+of a process pool of Python workers.
+
+The network object is only touched through the Keras attribute set of SURVEY A.4, so a real
+``tf.keras`` model works when TensorFlow is installed; otherwise the torch-backed
+``keras_shim`` supplies ``Model`` / ``clone_model``.
+
+Extra keyword-only constructor arguments (not in the reference): ``device`` (torch device of this
+process' GPU) and ``process_group`` (a ``torch.distributed`` group over which the neurons of every
+layer are sharded), and ``fix_partial_batch`` to opt out of the reference's
+partial-last-batch layout quirk (:491-495).
+"""
+from collections import namedtuple
+from math import ceil
+from time import time
+
+import numpy as np
+import torch
+
+from . import hip, layer as _layer
+
+try:  # real Keras when present (never on the MI355X image)
+    from tensorflow.keras.models import Model, clone_model   # type: ignore
+    from tensorflow.keras.utils import Sequence as _SequenceBase   # type: ignore
+    HAVE_TF = True
+except Exception:  # pragma: no cover - exercised on every box without TensorFlow
+    from .keras_shim import Model, clone_model
+    _SequenceBase = object
+    HAVE_TF = False
+
+SegmentedData = namedtuple("SegmentedData", ["wX_seg", "qX_seg"])
+
+
+def _bit_round_parallel(t, alphabet):
+    """Nearest member of the (scaled) alphabet to ``t``; the first one on ties (reference :40-57).
+    Host-side scalar helper the drivers call per weight for their MSQ baseline; ``msq_quantize``
+    below is the vectorised GPU form."""
+    alphabet = np.asarray(alphabet)
+    return alphabet[np.argmin(np.abs(alphabet - t))]
+
+
+def msq_quantize(W, alphabet, device=None):
+    """Whole-kernel MSQ on the GPU: equals ``[_bit_round_parallel(w, alphabet) for w in W.flatten()]``
+    reshaped to ``W.shape`` (as float32, what Keras stores)."""
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    Wd = torch.from_numpy(np.ascontiguousarray(W, dtype=np.float32)).to(dev)
+    Q, _ = hip.msq_round(Wd, np.asarray(alphabet, dtype=np.float64))
+    return Q.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------
+# data feeders (reference :235-329) -- same names and behaviour
+# ------------------------------------------------------------------------------------------
+class _SliceSequence(_SequenceBase):
+    def __init__(self, x_set, y_set, batch_size):
+        self.x, self.y = x_set, y_set
+        self.batch_size = batch_size
+
+    def __len__(self):
+        return ceil(len(self.x) / self.batch_size)
+
+    def _slice(self, idx):
+        lo, hi = idx * self.batch_size, (idx + 1) * self.batch_size
+        return self.x[lo:hi], self.y[lo:hi]
+
+    def __getitem__(self, idx):
+        bx, by = self._slice(idx)
+        return np.array(bx), np.array(by)
+
+
+class MNISTSequence(_SliceSequence):
+    pass
+
+
+class CIFAR10Sequence(_SliceSequence):
+    pass
+
+
+class ImageNetSequence(_SliceSequence):
+    """x_set holds paths of ``.npy`` images; each is loaded and run through ``preprocess_func``."""
+
+    def __init__(self, x_set, y_set, batch_size, preprocess_func):
+        super().__init__(x_set, y_set, batch_size)
+        self.preprocess_func = preprocess_func
+
+    def __getitem__(self, idx):
+        bx, by = self._slice(idx)
+        return np.array([self.preprocess_func(np.load(f)) for f in bx]), np.array(by)
+
+
+# ------------------------------------------------------------------------------------------
+class QuantizedNeuralNetwork:
+    """Wrapper around a Keras-style model that quantizes its Dense layers (reference :331-590)."""
+
+    def __init__(self, network, batch_size, get_data, mini_batch_size=32, logger=None, ignore_layers=[],
+                 bits=np.log2(3), alphabet_scalar=1, *, device=None, process_group=None, fix_partial_batch=False):
+        # batch_size and mini_batch_size are accepted and ignored, as in the reference (:371-400):
+        # the sample count comes from get_data alone.
+        self.get_data = get_data
+        self.trained_net = network
+        self.quantized_net = clone_model(network)
+        self.quantized_net.set_weights(network.get_weights())
+        self.alphabet_scalar = alphabet_scalar
+        self.layer_dims = {
+            layer_idx: layer.get_weights()[0].shape
+            for layer_idx, layer in enumerate(network.layers)
+            if layer.__class__.__name__ == "Dense"
+        }
+        self.bits = bits
+        self.alphabet = np.linspace(-1, 1, num=int(round(2 ** (bits))))
+        self.logger = logger
+        self.ignore_layers = ignore_layers
+        self._init_device(device, process_group, fix_partial_batch)
+
+    # -- MI355X plumbing ------------------------------------------------------------------
+    def _init_device(self, device, process_group, fix_partial_batch):
+        if device is None:
+            if not torch.cuda.is_available():
+                raise hip.GpfqError("no GPU visible: the quantizer's hot path is HIP-only (no CPU fallback)")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        self.process_group = process_group
+        self.fix_partial_batch = fix_partial_batch
+        self.last_layer_stats = {}          # layer_idx -> dict(rad, alphabet, resid) for inspection/tests
+
+    def _log(self, msg):
+        if self.logger:
+            self.logger.info(msg)
+        else:
+            print(msg)
+
+    def _to_device(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=torch.float32)
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=np.float32)).to(self.device)
+
+    # -- activation capture (reference :408-502) --------------------------------------------
+    def _get_layer_data_generator(self, layer_idx, transpose=False):
+        """Inputs of layer ``layer_idx`` in the analog (wX) and quantized (qX) networks for all
+        calibration batches, as two GPU tensors ``(wX, qX)`` -- the reference's HDF5 datasets
+        without the file.  Shape ``(len(get_data)*batch_size, *layer_input_shape)``, reversed when
+        ``transpose`` (feature-major for Dense).  Batch b is written at offset b*(its own size), as
+        in the reference (:491-495): with a partial last batch that overwrites earlier columns and
+        leaves a zero tail.  ``fix_partial_batch=True`` writes batches back to back instead."""
+        if layer_idx == 0:
+            inbound_analog = inbound_quant = None
+        else:
+            nodes_a = self.trained_net.layers[layer_idx].inbound_nodes
+            nodes_q = self.quantized_net.layers[layer_idx].inbound_nodes
+            if len(nodes_a) > 1 or len(nodes_q) > 1:
+                raise NotImplementedError(f"layer {layer_idx} has several inbound nodes")
+            inbound_analog, inbound_quant = nodes_a[0].inbound_layers, nodes_q[0].inbound_layers
+            if not isinstance(inbound_analog, (list, tuple)):
+                inbound_analog, inbound_quant = [inbound_analog], [inbound_quant]
+            if len(inbound_analog) != 1 or len(inbound_quant) != 1:
+                raise NotImplementedError(f"layer {layer_idx} has {len(inbound_analog)} inbound layers")
+
+        layer = self.trained_net.layers[layer_idx]
+        in_shape = layer.input_shape
+        data_shape = tuple(in_shape[1:]) if in_shape[0] is None else tuple(in_shape)
+        if layer_idx > 0:
+            prev_trained = Model(inputs=self.trained_net.layers[0].input,
+                                 outputs=[l.output for l in inbound_analog])
+            prev_quant = Model(inputs=self.quantized_net.layers[0].input,
+                               outputs=[l.output for l in inbound_quant])
+
+        n_batches = self.get_data.__len__()
+        num_images = n_batches * self.get_data.batch_size
+        shape = (num_images,) + data_shape
+        if transpose:
+            shape = shape[::-1]
+        wX_all = torch.zeros(shape, dtype=torch.float32, device=self.device)
+        qX_all = wX_all if layer_idx == 0 else torch.zeros(shape, dtype=torch.float32, device=self.device)
+        written = 0
+        for b in range(n_batches):
+            mini_batch = self.get_data.__getitem__(b)[0]
+            if layer_idx == 0:
+                wX = qX = self._to_device(mini_batch)
+            else:
+                wX = self._to_device(prev_trained.predict_on_batch(mini_batch))
+                qX = self._to_device(prev_quant.predict_on_batch(mini_batch))
+            k = wX.shape[0]
+            lo = written if self.fix_partial_batch else b * k
+            if transpose:
+                perm = tuple(range(wX.dim() - 1, -1, -1))
+                wX_all[..., lo:lo + k] = wX.permute(perm)
+                if layer_idx != 0:
+                    qX_all[..., lo:lo + k] = qX.permute(perm)
+            else:
+                wX_all[lo:lo + k] = wX
+                if layer_idx != 0:
+                    qX_all[lo:lo + k] = qX
+            written += k
+        return wX_all, qX_all
+
+    def _update_weights(self, layer_idx, Q):
+        """Install Q in the quantized network; the bias is carried over from the analog one (:504-521)."""
+        if self.trained_net.layers[layer_idx].use_bias:
+            bias = self.trained_net.layers[layer_idx].get_weights()[1]
+            self.quantized_net.layers[layer_idx].set_weights([Q, bias])
+        else:
+            self.quantized_net.layers[layer_idx].set_weights([Q])
+
+    def _layer_alphabet(self, Wd):
+        return _layer.layer_alphabet(Wd, self.alphabet, self.alphabet_scalar)      # (:544-545)
+
+    # -- Dense layer (reference :523-574) ---------------------------------------------------
+    def _quantize_layer_parallel(self, layer_idx):
+        W = self.trained_net.layers[layer_idx].get_weights()[0]
+        N_ell, N_ell_plus_1 = W.shape
+        self._log("\tFeeding input data through hidden layers...")
+        tic = time()
+        wX, qX = self._get_layer_data_generator(layer_idx, transpose=True)
+        self._log(f"\tdone. {time()-tic:2f} seconds.")
+
+        Wd = self._to_device(W)
+        layer_alphabet, rad = self._layer_alphabet(Wd)
+
+        self._log("\tQuantizing neurons (in parallel)...")
+        tic = time()
+        try:
+            out = _layer.quantize_dense(Wd, wX, qX, layer_alphabet, group=self.process_group)
+            Q = out["Q"].cpu().numpy()
+        except Exception as exc:
+            self._log(f"\t\tLayer {layer_idx} generated an exception: {exc}")
+            raise exc
+        for neuron_idx in range(N_ell_plus_1):
+            self._log(f"\t\tNeuron {neuron_idx} of {N_ell_plus_1} quantized successfully.")
+        self._update_weights(layer_idx, Q)
+        self._log(f"\tdone. {time()-tic:.2f} seconds.")
+        self.last_layer_stats[layer_idx] = dict(rad=rad, alphabet=layer_alphabet,
+                                                resid=out["resid"].cpu().numpy(), idx=out["idx"].cpu().numpy())
+
+    def quantize_network(self):
+        """Quantizes all Dense layers that are not in ``ignore_layers``, in order (:576-590)."""
+        num_layers = len(self.trained_net.layers)
+        for layer_idx, layer in enumerate(self.trained_net.layers):
+            if layer.__class__.__name__ == "Dense" and layer_idx not in self.ignore_layers:
+                tic = time()
+                self._log(f"Quantizing layer {layer_idx} (in parallel) of {num_layers}...")
+                self._quantize_layer_parallel(layer_idx)
+                self._log(f"Layer {layer_idx} of {num_layers} quantized successfully in {time() - tic:.2f} seconds.")
+
+
+class QuantizedCNN(QuantizedNeuralNetwork):
+    """Adds Conv2D / DepthwiseConv2D quantization (reference :592-883).  As in the reference the
+    constructor does not chain to the parent's: there is no ``ignore_layers`` and no ``layer_dims``."""
+
+    def __init__(self, network, batch_size, get_data, mini_batch_size=32, logger=None, bits=np.log2(3),
+                 alphabet_scalar=1, patch_mini_batch_size=5000, is_quantize_conv2d=True, *,
+                 device=None, process_group=None, fix_partial_batch=False):
+        self.get_data = get_data
+        self.trained_net = network
+        self.quantized_net = clone_model(network)
+        self.quantized_net.set_weights(network.get_weights())
+        self.patch_mini_batch_size = patch_mini_batch_size      # kept for drop-in; patches are built on the GPU
+        self.is_quantize_conv2d = is_quantize_conv2d
+        self.alphabet_scalar = alphabet_scalar
+        self.bits = bits
+        self.alphabet = np.linspace(-1, 1, num=int(round(2 ** (bits))))
+        self.logger = logger
+        self._init_device(device, process_group, fix_partial_batch)
+
+    def _quantize_dense_layer(self, layer_idx):
+        super()._quantize_layer_parallel(layer_idx)
+
+    def _quantize_conv2D_layer_parallel_jit(self, layer_idx):
+        """Every (input channel, filter) pair of the kernel is quantized as an independent neuron of
+        kh*kw weights against that channel's patch matrix (:815-867, :652-727).  The reference's
+        (1,1)-filter shortcut is dead code (:835-842), so 1x1 kernels take the general path too."""
+        self._log("\tFeeding input data through hidden layers...")
+        tic = time()
+        wX, qX = self._get_layer_data_generator(layer_idx)
+        self._log(f"\tdone. {time()-tic:.2f} seconds.")
+
+        layer = self.trained_net.layers[layer_idx]
+        try:
+            rate = layer.dilation_rate
+        except Exception:
+            rate = None
+        W = layer.get_weights()[0]
+        Wd = self._to_device(W)
+        alphabet, rad = self._layer_alphabet(Wd)                                   # (:831-832)
+        num_channels = W.shape[-2]
+        tic = time()
+        self._log(f"\t\tBuilding patch arrays and quantizing channel filters for {num_channels} channels...")
+        try:
+            out = _layer.quantize_conv2d(Wd, wX, qX, alphabet, strides=tuple(layer.strides),
+                                         padding=layer.padding.upper(), rate=tuple(rate) if rate else None,
+                                         group=self.process_group)
+            Q = out["Q"].cpu().numpy()
+        except Exception as exc:
+            self._log(f"\t\t\tLayer {layer_idx} generated an exception: {exc}")
+            raise Exception
+        self._log(f"\t\tdone. {time()-tic:.2f} seconds.")
+        self._update_weights(layer_idx, Q)
+        self.last_layer_stats[layer_idx] = dict(rad=rad, alphabet=alphabet, resid=out["resid"].cpu().numpy(),
+                                                idx=out["idx"].cpu().numpy())
+
+    def quantize_network(self):
+        num_layers = len(self.trained_net.layers)
+        for layer_idx, layer in enumerate(self.trained_net.layers):
+            if layer.__class__.__name__ == "Dense":
+                self._log(f"Quantizing (Dense) layer {layer_idx} of {num_layers}...")
+                tic = time()
+                self._quantize_dense_layer(layer_idx)
+                self._log(f"done. {time() - tic:.2f} seconds.")
+            if layer.__class__.__name__ in {"Conv2D", "DepthwiseConv2D"} and self.is_quantize_conv2d:
+                self._log(f"Quantizing ({layer.__class__.__name__}) layer {layer_idx} of {num_layers}...")
+                tic = time()
+                self._quantize_conv2D_layer_parallel_jit(layer_idx)
+                self._log(f"done. {time() - tic:.2f} seconds.")

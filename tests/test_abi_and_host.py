@@ -1,0 +1,142 @@
+"""CPU: the C-ABI library builds for gfx950, loads, exports every symbol include/gpfq.h declares
+(no compute calls without a GPU), and the host-side logic around it behaves."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from quantized_neural_networks_amd import build, hip
+    build.build()
+    return hip.load()
+
+
+def test_header_symbols_exported(lib):
+    from quantized_neural_networks_amd import hip
+    header = open(os.path.join(ROOT, "include", "gpfq.h")).read()
+    declared = set(re.findall(r"\b(gpfq_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    assert declared == set(hip.SYMBOLS), declared ^ set(hip.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_version_and_errors_without_gpu(lib):
+    assert lib.gpfq_version() >= 100
+    # argument validation happens before any launch: safe without a device
+    a = (ctypes.c_double * 3)(-1.0, 0.0, 1.0)
+    rc = lib.gpfq_quantize_neurons(None, None, 4, None, None, 4, a, 3, 1, 4, 8, 2, None, None, None, None, None, 0, 0, None)
+    assert rc == -1 and b"NULL" in lib.gpfq_last_error()
+    big = (ctypes.c_double * 65)(*range(65))
+    rc = lib.gpfq_quantize_neurons(None, None, 4, None, None, 4, big, 65, -1, 4, 8, 2, None, None, None, None, None, 0, 0, None)
+    assert rc == -2 and b"GPFQ_MAX_ALPHABET" in lib.gpfq_last_error()
+    rc = lib.gpfq_quantize_neurons(None, None, 2, None, None, 4, a, 3, 1, 4, 8, 2, None, None, None, None, None, 0, 0, None)
+    assert rc == -1
+    assert lib.gpfq_quantize_neurons(None, None, 8, None, None, 4, a, 3, 1, 4, 8, 0, None, None, None, None, None, 0, 0, None) == 0
+    assert lib.gpfq_workspace_bytes(9, 1024, 8, 0) == 0
+    assert lib.gpfq_workspace_bytes(9, 100000, 8, 0) >= 8 * 100000 * 8
+    assert lib.gpfq_workspace_bytes(9, 1024, 8, 2) > 0
+
+
+def test_patch_out_dim(lib):
+    f = lib.gpfq_patch_out_dim
+    assert f(32, 3, 1, 1, 1) == 32 and f(32, 3, 1, 1, 0) == 30
+    assert f(224, 7, 2, 1, 0) == 109 and f(230, 7, 2, 1, 0) == 112 and f(224, 3, 2, 1, 1) == 112
+    assert f(10, 3, 1, 2, 0) == 6 and f(2, 3, 1, 1, 0) == 0
+
+
+def test_no_cpu_fallback():
+    import torch
+    from quantized_neural_networks_amd import hip
+    X = torch.zeros((4, 8))
+    with pytest.raises(hip.GpfqError):
+        hip.quantize_neurons(X, X, torch.zeros((2, 4)), [-1.0, 0.0, 1.0])
+    with pytest.raises(hip.GpfqError):
+        hip.row_norms(X)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "quantized_neural_networks_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, re.M), f
+                assert "gpfq_oracle" not in src, f
+
+
+def test_shard_bounds():
+    from quantized_neural_networks_amd.layer import shard_bounds
+    for n, w in [(4096, 8), (1000, 8), (3, 8), (10, 4), (0, 2)]:
+        cover = []
+        for r in range(w):
+            lo, hi = shard_bounds(n, w, r)
+            assert 0 <= lo <= hi <= n
+            cover += list(range(lo, hi))
+        assert cover == list(range(n))
+
+
+def test_bit_round_host(golden):
+    from quantized_neural_networks_amd.quantized_network import _bit_round_parallel
+    g = golden("bit_round")
+    for M in (3, 4, 8, 16):
+        a = g[f"alphabet_M{M}"]
+        got = np.array([_bit_round_parallel(t, a) for t in g[f"t64_M{M}"]])
+        assert np.array_equal(got, g[f"round64_M{M}"])
+        got = np.array([_bit_round_parallel(t, a) for t in g[f"t32_M{M}"]])
+        assert np.array_equal(got, g[f"round32_M{M}"])
+
+
+def test_sequences():
+    from quantized_neural_networks_amd.quantized_network import CIFAR10Sequence, MNISTSequence
+    x, y = np.arange(40).reshape(10, 4), np.arange(10)
+    s = MNISTSequence(x, y, 4)
+    assert len(s) == 3 and s.batch_size == 4
+    assert np.array_equal(s[2][0], x[8:10]) and np.array_equal(s[0][1], y[0:4])
+    assert len(CIFAR10Sequence(x, y, 5)) == 2
+
+
+def test_module_surface():
+    import quantized_network as qn
+    for name in ["QuantizedNeuralNetwork", "QuantizedCNN", "MNISTSequence", "CIFAR10Sequence", "ImageNetSequence",
+                 "_bit_round_parallel"]:
+        assert hasattr(qn, name)
+    import inspect
+    sig = inspect.signature(qn.QuantizedNeuralNetwork.__init__)
+    assert list(sig.parameters)[:9] == ["self", "network", "batch_size", "get_data", "mini_batch_size", "logger",
+                                        "ignore_layers", "bits", "alphabet_scalar"]
+    sig = inspect.signature(qn.QuantizedCNN.__init__)
+    assert list(sig.parameters)[:10] == ["self", "network", "batch_size", "get_data", "mini_batch_size", "logger",
+                                         "bits", "alphabet_scalar", "patch_mini_batch_size", "is_quantize_conv2d"]
+
+
+def test_keras_shim_cpu():
+    """The shim's layers against plain torch/numpy references (CPU tensors)."""
+    import torch
+    from quantized_neural_networks_amd import keras_shim as ks
+    net = ks.Sequential([ks.Conv2D(4, 3, padding="same", activation="relu", input_shape=(8, 8, 3)),
+                         ks.MaxPooling2D(), ks.Conv2D(5, 3, strides=2, padding="same"), ks.Flatten(),
+                         ks.Dense(7, activation="relu"), ks.Dense(3, activation="softmax")], device="cpu")
+    assert [l.__class__.__name__ for l in net.layers] == ["Conv2D", "MaxPooling2D", "Conv2D", "Flatten", "Dense", "Dense"]
+    assert net.layers[4].input_shape == (None, 2 * 2 * 5) and net.layers[0].input_shape == (None, 8, 8, 3)
+    x = np.random.default_rng(0).random((6, 8, 8, 3)).astype(np.float32)
+    y = net.predict_on_batch(x)
+    assert tuple(y.shape) == (6, 3) and torch.allclose(y.sum(1), torch.ones(6), atol=1e-5)
+    clone = ks.clone_model(net)
+    assert not np.array_equal(clone.get_weights()[0], net.get_weights()[0])
+    clone.set_weights(net.get_weights())
+    assert torch.equal(clone.predict_on_batch(x), y)
+    trunc = ks.Model(inputs=net.layers[0].input, outputs=[net.layers[3].output])
+    assert tuple(trunc.predict_on_batch(x).shape) == (6, 20)
+    assert net.layers[5].inbound_nodes[0].inbound_layers is net.layers[4]
+    # Dense against numpy
+    d = ks.Sequential([ks.Dense(3, use_bias=False, input_shape=(2,))], device="cpu")
+    d.layers[0].set_weights([np.ones((2, 3))])
+    assert np.array_equal(d.predict_on_batch(np.array([[1, 0], [0, 2]], dtype=np.float32)).numpy(),
+                          np.array([[1, 1, 1], [2, 2, 2]], dtype=np.float32))

@@ -1,0 +1,266 @@
+"""GPU: the drop-in class surface (QuantizedNeuralNetwork / QuantizedCNN) end to end on the HIP
+path, against the reference's whole-network golden runs, its tests/settings.py known answer, and
+the CPU oracle for conv layers (whose TF dependency makes a reference run impossible here)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _im2col_ref import patches as ref_patches  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+class ListLogger:
+    def __init__(self):
+        self.lines = []
+
+    def info(self, msg):
+        self.lines.append(msg)
+
+
+@pytest.fixture(scope="module")
+def qn():
+    from quantized_neural_networks_amd import quantized_network
+    return quantized_network
+
+
+@pytest.fixture(scope="module")
+def ks():
+    from quantized_neural_networks_amd import keras_shim
+    return keras_shim
+
+
+def _mlp_from_golden(ks, g):
+    dims = g["dims"]
+    layers = []
+    use_bias = bool(g["use_bias"])
+    for k, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+        kw = dict(input_shape=(int(a),)) if k == 0 else {}
+        layers.append(ks.Dense(int(b), activation="relu" if b != dims[-1] else None, use_bias=use_bias, **kw))
+    net = ks.Sequential(layers)
+    for k, layer in enumerate(net.layers):
+        layer.set_weights([g[f"W{k}"]] + ([g[f"b{k}"]] if use_bias else []))
+    return net
+
+
+def _record_captures(q):
+    rec = {}
+    orig = q._get_layer_data_generator
+
+    def wrapped(layer_idx, transpose=False):
+        wX, qX = orig(layer_idx, transpose)
+        rec[layer_idx] = (wX.cpu().numpy(), qX.cpu().numpy())
+        return wX, qX
+
+    q._get_layer_data_generator = wrapped
+    return rec
+
+
+def test_settings_known_answer(qn, ks, golden):
+    """The fixture the reference's empty test was written for (tests/settings.py:30-48)."""
+    g = golden("settings_known_answer")
+    net = ks.Sequential([ks.Dense(3, use_bias=False, input_shape=(2,)), ks.Dense(2, use_bias=False)])
+    net.layers[0].set_weights([np.ones((2, 3))])
+    net.layers[1].set_weights([np.ones((3, 2))])
+    q = qn.QuantizedNeuralNetwork(network=net, batch_size=1, get_data=qn.MNISTSequence(g["data"], g["labels"], 1),
+                                  logger=ListLogger())
+    wX0, _ = q._get_layer_data_generator(0, transpose=True)
+    wX1, qX1 = q._get_layer_data_generator(1, transpose=True)
+    assert np.array_equal(wX0.cpu().numpy(), g["wX0"])
+    assert np.array_equal(wX1.cpu().numpy(), g["wX1"]) and np.array_equal(qX1.cpu().numpy(), g["qX1"])
+    assert np.array_equal(net.predict_on_batch(g["data"]).cpu().numpy(), g["out"])
+
+
+@pytest.mark.parametrize("case", ["net_mlp_full", "net_mlp_partial", "net_mlp_nobias_ignore"])
+def test_mlp_network_golden(qn, ks, golden, oracle_mod, case):
+    g = golden("network")[case]
+    net = _mlp_from_golden(ks, g)
+    logger = ListLogger()
+    batch = int(g["batch"])
+    y = np.zeros((len(g["x"]), 1), dtype=np.float32)
+    q = qn.QuantizedNeuralNetwork(network=net, batch_size=batch, get_data=qn.MNISTSequence(g["x"], y, batch),
+                                  logger=logger, ignore_layers=g["ignore"].tolist(), bits=float(g["bits"]),
+                                  alphabet_scalar=float(g["scalar"]))
+    assert np.array_equal(q.alphabet, g["alphabet"])
+    rec = _record_captures(q)
+    q.quantize_network()
+    ignore = set(g["ignore"].tolist())
+    nlayers = len(g["dims"]) - 1
+    exact_inputs = True
+    for k in range(nlayers):
+        Qk = q.quantized_net.layers[k].get_weights()[0]
+        if k in ignore:
+            assert np.array_equal(Qk, g[f"W{k}"])
+            continue
+        wX, qX = rec[k]
+        # layout (incl. the partial-last-batch quirk) is exact; values may differ in the last bits
+        # because the forward pass is a GPU matmul, not the golden run's CPU BLAS
+        assert wX.shape == g[f"wX{k}"].shape
+        assert np.array_equal(wX == 0, g[f"wX{k}"] == 0) or k > 0
+        np.testing.assert_allclose(wX, g[f"wX{k}"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(qX, g[f"qX{k}"], rtol=1e-4, atol=1e-5)
+        # exact: the class's result equals the oracle's on the activations the class captured
+        st = q.last_layer_stats[k]
+        alphabet, rad = oracle_mod.layer_alphabet(g[f"W{k}"], g["alphabet"], float(g["scalar"]))
+        assert rad == st["rad"] and np.array_equal(alphabet, st["alphabet"])
+        Qo, io, ro = oracle_mod.layer(g[f"W{k}"], wX, qX, alphabet)
+        assert np.array_equal(Qk, Qo.T.astype(np.float32))
+        assert np.array_equal(st["idx"], io.T)
+        np.testing.assert_allclose(st["resid"], ro, rtol=1e-5)
+        if bool(g["use_bias"]):
+            assert np.array_equal(q.quantized_net.layers[k].get_weights()[1], g[f"b{k}"])
+        exact_inputs &= np.array_equal(wX, g[f"wX{k}"]) and np.array_equal(qX, g[f"qX{k}"])
+        # against the reference run itself: identical when the captured activations are identical,
+        # otherwise only a few decisions may move
+        agree = np.mean(Qk == g[f"Q{k}"])
+        assert agree == 1.0 if exact_inputs else agree > 0.9, (k, agree)
+    n_neuron_lines = sum("quantized successfully." in l and "Neuron" in l for l in logger.lines)
+    assert n_neuron_lines == int(g["n_log_neuron_lines"])
+    assert any(l.startswith("Quantizing layer") for l in logger.lines)
+
+
+def test_first_layer_matches_reference_run_exactly(qn, ks, golden):
+    """Layer 0's inputs are the raw calibration data, so no forward pass is involved and the
+    class must reproduce the reference's Q for that layer bit for bit."""
+    for case in ["net_mlp_full", "net_mlp_partial", "net_mlp_nobias_ignore"]:
+        g = golden("network")[case]
+        net = _mlp_from_golden(ks, g)
+        batch = int(g["batch"])
+        y = np.zeros((len(g["x"]), 1), dtype=np.float32)
+        q = qn.QuantizedNeuralNetwork(network=net, batch_size=batch, get_data=qn.MNISTSequence(g["x"], y, batch),
+                                      logger=ListLogger(), bits=float(g["bits"]), alphabet_scalar=float(g["scalar"]))
+        rec = _record_captures(q)
+        q._quantize_layer_parallel(0)
+        assert np.array_equal(rec[0][0], g["wX0"]) and np.array_equal(rec[0][1], g["qX0"])
+        assert np.array_equal(q.quantized_net.layers[0].get_weights()[0], g["Q0"])
+
+
+def test_fix_partial_batch_flag(qn, ks, golden):
+    g = golden("network")["net_mlp_partial"]
+    net = _mlp_from_golden(ks, g)
+    y = np.zeros((len(g["x"]), 1), dtype=np.float32)
+    q = qn.QuantizedNeuralNetwork(network=net, batch_size=16, get_data=qn.MNISTSequence(g["x"], y, 16),
+                                  logger=ListLogger(), fix_partial_batch=True)
+    wX, _ = q._get_layer_data_generator(0, transpose=True)
+    wX = wX.cpu().numpy()
+    assert np.array_equal(wX[:, :40], g["x"].T) and (wX[:, 40:] == 0).all()
+
+
+@pytest.mark.parametrize("kh,kw,sh,sw,rh,rw,padding", [
+    (3, 3, 1, 1, 1, 1, "SAME"), (3, 3, 1, 1, 1, 1, "VALID"), (3, 3, 2, 2, 1, 1, "SAME"), (7, 7, 2, 2, 1, 1, "VALID"),
+    (1, 1, 1, 1, 1, 1, "SAME"), (3, 2, 2, 1, 1, 1, "SAME"), (3, 3, 1, 1, 2, 2, "SAME"), (2, 2, 2, 2, 1, 1, "SAME"),
+])
+def test_extract_patches(kh, kw, sh, sw, rh, rw, padding):
+    from quantized_neural_networks_amd import hip
+    r = np.random.default_rng(kh * 100 + sh * 10 + rh)
+    act = r.random((3, 9, 8, 4)).astype(np.float32)
+    for c in (0, 3):
+        got = hip.extract_patches(torch.from_numpy(act).cuda(), c, (kh, kw), (sh, sw), (rh, rw), padding).cpu().numpy()
+        want = ref_patches(act, c, kh, kw, sh, sw, rh, rw, padding)
+        assert got.shape == want.shape and np.array_equal(got, want)
+    if padding == "VALID" and (rh, rw) == (1, 1):
+        # second opinion: torch's unfold (symmetric / no padding only)
+        x = torch.from_numpy(act[..., 1]).unsqueeze(1)                    # [n][1][H][W]
+        unf = torch.nn.functional.unfold(x, (kh, kw), stride=(sh, sw))    # [n][kh*kw][L]
+        want2 = unf.permute(1, 0, 2).reshape(kh * kw, -1).numpy()
+        got = hip.extract_patches(torch.from_numpy(act).cuda(), 1, (kh, kw), (sh, sw), (1, 1), padding).cpu().numpy()
+        assert np.array_equal(got, want2)
+
+
+def _cnn(ks):
+    return ks.Sequential([
+        ks.Conv2D(4, 3, padding="same", activation="relu", input_shape=(16, 16, 3)),
+        ks.Conv2D(5, 3, strides=2, padding="same", activation="relu"),
+        ks.MaxPooling2D(),
+        ks.DepthwiseConv2D(3, padding="valid", depth_multiplier=2, use_bias=False),
+        ks.Conv2D(3, 1, padding="valid"),
+        ks.Flatten(),
+        ks.Dense(6, activation="softmax"),
+    ], seed=3)
+
+
+def test_cnn_against_oracle(qn, ks, oracle_mod):
+    """QuantizedCNN layer by layer: every (channel, filter) pair equals the oracle's recurrence on the
+    independently built patch matrix of the activations the class captured."""
+    net = _cnn(ks)
+    r = np.random.default_rng(11)
+    x = r.random((20, 16, 16, 3)).astype(np.float32)
+    y = np.zeros((20, 6), dtype=np.float32)
+    logger = ListLogger()
+    q = qn.QuantizedCNN(network=net, batch_size=8, get_data=qn.CIFAR10Sequence(x, y, 8), logger=logger,
+                        bits=3, alphabet_scalar=4)                        # 20 % 8 != 0 -> quirk, 24 rows
+    assert not hasattr(q, "ignore_layers") and not hasattr(q, "layer_dims")
+    rec = _record_captures(q)
+    analog = [l.get_weights() for l in net.layers]
+    q.quantize_network()
+    for k, layer in enumerate(net.layers):
+        name = layer.__class__.__name__
+        if name not in ("Conv2D", "DepthwiseConv2D", "Dense"):
+            continue
+        W = analog[k][0]
+        Qk = q.quantized_net.layers[k].get_weights()[0]
+        wX, qX = rec[k]
+        alphabet, rad = oracle_mod.layer_alphabet(W, q.alphabet, 4)
+        assert rad == q.last_layer_stats[k]["rad"]
+        if name == "Dense":
+            assert wX.shape == (W.shape[0], 24)
+            Qo, _, _ = oracle_mod.layer(W, wX, qX, alphabet)
+            assert np.array_equal(Qk, Qo.T.astype(np.float32))
+            continue
+        assert wX.shape[0] == 24 and (wX[20:] == 0).all()                 # zero tail of the quirk
+        kh, kw, Cin, F = W.shape
+        sh, sw = layer.strides
+        rh, rw = layer.dilation_rate
+        for c in range(Cin):
+            Pw = ref_patches(wX, c, kh, kw, sh, sw, rh, rw, layer.padding)
+            Pq = ref_patches(qX, c, kh, kw, sh, sw, rh, rw, layer.padding)
+            for f in range(F):
+                qo, _, _ = oracle_mod.neuron(W[:, :, c, f].reshape(-1), Pw, Pq, alphabet)
+                assert np.array_equal(Qk[:, :, c, f], qo.reshape(kh, kw).astype(np.float32)), (k, c, f)
+        if layer.use_bias:
+            assert np.array_equal(q.quantized_net.layers[k].get_weights()[1], analog[k][1])
+    assert any("(Conv2D)" in l for l in logger.lines) and any("(DepthwiseConv2D)" in l for l in logger.lines)
+
+
+def test_cnn_dense_only(qn, ks):
+    net = _cnn(ks)
+    x = np.random.default_rng(1).random((8, 16, 16, 3)).astype(np.float32)
+    q = qn.QuantizedCNN(network=net, batch_size=8, get_data=qn.CIFAR10Sequence(x, np.zeros((8, 6)), 8),
+                        logger=ListLogger(), is_quantize_conv2d=False)
+    q.quantize_network()
+    assert np.array_equal(q.quantized_net.layers[0].get_weights()[0], net.layers[0].get_weights()[0])
+    assert not np.array_equal(q.quantized_net.layers[6].get_weights()[0], net.layers[6].get_weights()[0])
+    assert len(np.unique(q.quantized_net.layers[6].get_weights()[0])) <= 3
+
+
+def test_msq_quantize(qn):
+    r = np.random.default_rng(2)
+    W = (r.standard_normal((37, 11)) * 0.2).astype(np.float32)
+    alphabet = 0.3 * np.linspace(-1, 1, 8)
+    want = np.array([qn._bit_round_parallel(w, alphabet) for w in W.flatten()]).reshape(W.shape)
+    assert np.array_equal(qn.msq_quantize(W, alphabet), want.astype(np.float32))
+
+
+def test_quantization_reduces_error_vs_msq(qn, ks):
+    """Sanity of the algorithm itself: on the calibration data GPFQ's layer output error is well
+    below MSQ's (the point of the paper)."""
+    r = np.random.default_rng(5)
+    net = ks.Sequential([ks.Dense(64, activation="relu", input_shape=(128,)), ks.Dense(10)], seed=9)
+    x = r.random((256, 128)).astype(np.float32)
+    q = qn.QuantizedNeuralNetwork(network=net, batch_size=256, get_data=qn.MNISTSequence(x, np.zeros((256, 1)), 256),
+                                  logger=ListLogger(), bits=np.log2(3), alphabet_scalar=2)
+    q.quantize_network()
+    ref_out = net.predict_on_batch(x)
+    gpfq_err = float(torch.linalg.norm(q.quantized_net.predict_on_batch(x) - ref_out))
+    msq = ks.clone_model(net)
+    msq.set_weights(net.get_weights())
+    for k in (0, 1):
+        W, b = net.layers[k].get_weights()
+        rad = 2 * np.median(np.abs(W))
+        msq.layers[k].set_weights([qn.msq_quantize(W, rad * q.alphabet), b])
+    msq_err = float(torch.linalg.norm(msq.predict_on_batch(x) - ref_out))
+    assert gpfq_err < 0.5 * msq_err, (gpfq_err, msq_err)

@@ -1,0 +1,98 @@
+"""CPU, world_size 2, gloo: the neuron/channel sharding and the single all-gather per layer
+reassemble exactly the unsharded result.  The local worker is replaced by an oracle-backed stand-in
+(the collective plumbing is what is under test; the HIP kernels are covered by the -m gpu tests)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _standin_quantize(X, Xq, Wt, alphabet, **kw):
+    import oracle
+    W = Wt.numpy().T.copy()
+    Q, idx, resid = oracle.layer(W, X.numpy(), Xq.numpy(), np.asarray(alphabet))
+    return dict(Q=torch.from_numpy(Q.astype(np.float32)), idx=torch.from_numpy(idx), resid=torch.from_numpy(resid), u=None)
+
+
+def _standin_patches(act, channel, kernel_size, strides, rate, padding, out=None):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _im2col_ref import patches
+    rh, rw = rate if rate else (1, 1)
+    return torch.from_numpy(patches(act.numpy(), channel, kernel_size[0], kernel_size[1], strides[0], strides[1], rh, rw, padding))
+
+
+def _worker(rank, world, port, case, result_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from quantized_neural_networks_amd import layer
+    layer._local_quantize = _standin_quantize
+    layer._extract_patches = _standin_patches
+    r = np.random.default_rng(7)
+    if case == "dense":
+        N, m, C = 24, 40, 7                                  # 7 neurons over 2 ranks: uneven shards
+        W = (r.standard_normal((N, C)) / np.sqrt(N)).astype(np.float32)
+        G = r.standard_normal((N, m))
+        X = np.maximum(G, 0).astype(np.float32)
+        Xq = np.maximum(G + 0.1 * r.standard_normal((N, m)), 0).astype(np.float32)
+        alphabet = 0.3 * np.linspace(-1, 1, 4)
+        out = layer.quantize_dense(torch.from_numpy(W), torch.from_numpy(X), torch.from_numpy(Xq), alphabet)
+    else:
+        Cin = 3 if case == "conv_channels" else 1            # Cin < world -> filters are sharded instead
+        act = r.random((4, 6, 6, Cin)).astype(np.float32)
+        actq = (act + 0.05 * r.random(act.shape)).astype(np.float32)
+        W = (r.standard_normal((3, 3, Cin, 5)) / 3).astype(np.float32)
+        alphabet = 0.25 * np.linspace(-1, 1, 3)
+        out = layer.quantize_conv2d(torch.from_numpy(W), torch.from_numpy(act), torch.from_numpy(actq), alphabet,
+                                    strides=(1, 1), padding="SAME", rate=(1, 1))
+    np.savez(os.path.join(result_dir, f"{case}_{rank}.npz"), **{k: v.numpy() for k, v in out.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["dense", "conv_channels", "conv_filters"])
+def test_sharded_equals_unsharded(case, tmp_path, oracle_mod):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(tmp_path / f"{case}_{r}.npz") for r in range(world)]
+    for k in res[0].files:
+        assert np.array_equal(res[0][k], res[1][k]), f"ranks disagree on {k}"
+    # unsharded reference: same stand-ins, no process group
+    sys.path.insert(0, ROOT)
+    from quantized_neural_networks_amd import layer
+    keep = layer._local_quantize, layer._extract_patches
+    layer._local_quantize, layer._extract_patches = _standin_quantize, _standin_patches
+    try:
+        r = np.random.default_rng(7)
+        if case == "dense":
+            N, m, C = 24, 40, 7
+            W = (r.standard_normal((N, C)) / np.sqrt(N)).astype(np.float32)
+            G = r.standard_normal((N, m))
+            X = np.maximum(G, 0).astype(np.float32)
+            Xq = np.maximum(G + 0.1 * r.standard_normal((N, m)), 0).astype(np.float32)
+            out = layer.quantize_dense(torch.from_numpy(W), torch.from_numpy(X), torch.from_numpy(Xq), 0.3 * np.linspace(-1, 1, 4))
+        else:
+            Cin = 3 if case == "conv_channels" else 1
+            act = r.random((4, 6, 6, Cin)).astype(np.float32)
+            actq = (act + 0.05 * r.random(act.shape)).astype(np.float32)
+            W = (r.standard_normal((3, 3, Cin, 5)) / 3).astype(np.float32)
+            out = layer.quantize_conv2d(torch.from_numpy(W), torch.from_numpy(act), torch.from_numpy(actq),
+                                        0.25 * np.linspace(-1, 1, 3), strides=(1, 1), padding="SAME", rate=(1, 1))
+    finally:
+        layer._local_quantize, layer._extract_patches = keep
+    for k, v in out.items():
+        assert np.array_equal(res[0][k], v.numpy()), k

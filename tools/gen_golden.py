@@ -409,13 +409,27 @@ def network_cases(workdir):
             logger = ListLogger()
             qn = ref.QuantizedNeuralNetwork(network=net, batch_size=batch, get_data=ArraySequence(x, y, batch),
                                             logger=logger, ignore_layers=ignore, bits=bits, alphabet_scalar=scalar)
+            recorded = {}
+            orig_capture = qn._get_layer_data_generator
+
+            def capture(layer_idx, transpose=False, _orig=orig_capture, _rec=recorded):
+                # record the exact HDF5 contents each layer was quantized against
+                fn = _orig(layer_idx, transpose)
+                with h5py.File(fn, "r") as hf:
+                    _rec[layer_idx] = (hf["wX"][...], hf["qX"][...])
+                return fn
+
+            qn._get_layer_data_generator = capture
             qn.quantize_network()
+            qn._get_layer_data_generator = orig_capture
             case = dict(x=x, batch=np.int64(batch), bits=np.float64(bits), scalar=np.float64(scalar),
                         dims=np.array(dims), use_bias=np.bool_(use_bias), ignore=np.array(ignore, dtype=np.int64),
                         alphabet=qn.alphabet)
             for k, (la, lq) in enumerate(zip(net.layers, qn.quantized_net.layers)):
                 case[f"W{k}"] = la.kernel
                 case[f"Q{k}"] = lq.kernel                # float32 after Keras' cast
+                if k in recorded:
+                    case[f"wX{k}"], case[f"qX{k}"] = recorded[k]
                 if use_bias:
                     case[f"b{k}"] = la.bias
                     case[f"qb{k}"] = lq.bias
