@@ -77,8 +77,19 @@ int         gpfq_device_count(void);
  */
 int gpfq_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, float *nrm32, void *stream);
 
-/* Bytes of scratch gpfq_quantize_neurons needs for this shape on this path (0 for on-chip). */
+/* Bytes of scratch gpfq_quantize_neurons needs for this shape on this path.  The on-chip path
+ * keeps per-row statistics there (32*N + 64 bytes; after the call the first 8 bytes hold, as a
+ * uint64, how many decisions were re-derived with the exact dot product -- diagnostics only);
+ * without a workspace it still runs, in the reference's verbatim flow (same results, slower). */
 size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path);
+
+/*
+ * Process-wide tuning/test hooks; results never depend on them.
+ *   "onchip_mode"  1 (default) certified-prediction mode, 0 verbatim reference flow
+ *   "tile_steps"   LDS tile height in steps (power of two <= 64), 0 = heuristic
+ *   "group_waves"  neurons (wavefronts) per workgroup 1..16, 0 = heuristic
+ */
+int gpfq_set_option(const char *key, int value);
 
 /*
  * The hot path: run the greedy recurrence for C independent neurons.

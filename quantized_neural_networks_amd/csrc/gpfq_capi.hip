@@ -85,11 +85,34 @@ static int resolve_path(int64_t m, int path)
     return path;
 }
 
+// on-chip workspace: [fallback counter, 64 B][RowStats x N]
+static size_t onchip_workspace_bytes(int64_t N) { return 64 + (size_t)N * sizeof(gpfq::RowStats); }
+
 size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path)
 {
     if (N < 0 || m < 0 || C < 0) return 0;
-    if (resolve_path(m, path) == GPFQ_PATH_ONCHIP) return 0;
+    if (resolve_path(m, path) == GPFQ_PATH_ONCHIP) return onchip_workspace_bytes(N);
     return gpfq::stream_workspace_bytes(N, m, C, /*need_u=*/true);
+}
+
+// Tuning / test hooks (process-wide).  Results never depend on them.
+static int g_onchip_mode = 1;      // 1 = certified (default), 0 = exact flow
+static int g_tile_steps = 0;       // 0 = heuristic
+static int g_group_waves = 0;      // 0 = heuristic
+
+int gpfq_set_option(const char *key, int value)
+{
+    if (!key) return fail(GPFQ_ERR_INVALID_ARG, "option key is NULL");
+    if (!std::strcmp(key, "onchip_mode")) { g_onchip_mode = value ? 1 : 0; return GPFQ_OK; }
+    if (!std::strcmp(key, "tile_steps")) {
+        if (value < 0 || value > 64 || (value & (value - 1))) return fail(GPFQ_ERR_INVALID_ARG, "tile_steps must be 0 or a power of two <= 64");
+        g_tile_steps = value; return GPFQ_OK;
+    }
+    if (!std::strcmp(key, "group_waves")) {
+        if (value < 0 || value > 16) return fail(GPFQ_ERR_INVALID_ARG, "group_waves must be in [0, 16]");
+        g_group_waves = value; return GPFQ_OK;
+    }
+    return fail(GPFQ_ERR_INVALID_ARG, "unknown option '%s'", key);
 }
 
 int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const float *nrm32,
@@ -120,6 +143,23 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
         gpfq::OnchipArgs a;
         a.X = X; a.Xq = Xq; a.ld = ld; a.nrm32 = nrm32; a.Wt = Wt; a.ldw = ldw; a.A = A;
         a.N = N; a.m = m; a.C = C; a.qidx = qidx; a.Qt = Qt; a.resid = resid; a.u_out = u_out;
+        a.ts_override = g_tile_steps; a.nw_override = g_group_waves;
+        a.mode = g_onchip_mode;
+        // certified mode needs the per-row statistics in the workspace; without one, run the exact flow
+        const bool have_ws = workspace && workspace_bytes >= onchip_workspace_bytes(N) && (uintptr_t)workspace % 16 == 0;
+        if (have_ws) {
+            hipError_t e0 = hipMemsetAsync(workspace, 0, 64, s);       // exact-fallback counter
+            if (e0 != hipSuccess) return hip_fail(e0, "gpfq_quantize_neurons(workspace)");
+        }
+        if (a.mode == 1 && N > 0 && have_ws) {
+            auto *stats = reinterpret_cast<gpfq::RowStats *>(static_cast<char *>(workspace) + 64);
+            a.fallback_count = static_cast<unsigned long long *>(workspace);
+            hipError_t e0 = gpfq::launch_row_stats(X, Xq, N, m, ld, nrm32, stats, s);
+            if (e0 != hipSuccess) return hip_fail(e0, "gpfq_quantize_neurons(row stats)");
+            a.stats = stats;
+        } else {
+            a.mode = 0;
+        }
         hipError_t e = gpfq::launch_onchip(a, s);
         return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_neurons(on-chip)");
     }

@@ -20,16 +20,15 @@ namespace gpfq {
 
 constexpr int kWave = 64;
 
-// ---- DPP plumbing -------------------------------------------------------------------------
-// dpp_ctrl encodings (CDNA ISA): row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_fetch(double x)
+// ---- cross-lane plumbing -------------------------------------------------------------------
+// dpp_ctrl encodings (CDNA ISA): row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+// bound_ctrl:1 makes lanes without a source read 0, so no "old" operand has to be initialised.
+template <int CTRL>
+__device__ __forceinline__ double dpp_fetch0(double x)
 {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    // lanes whose source is outside the row / masked rows receive `old` = 0
-    int rlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
-    int rhi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
-    return __hiloint2double(rhi, rlo);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
 }
 
 __device__ __forceinline__ double readlane_f64(double x, int lane)
@@ -44,17 +43,38 @@ __device__ __forceinline__ float readlane_f32(float x, int lane)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
 }
 
+// Inclusive scan inside each row of 16 lanes: lane 15 of a row ends with the row total.
+__device__ __forceinline__ double row_scan(double x)
+{
+    x += dpp_fetch0<0x111>(x);   // row_shr:1
+    x += dpp_fetch0<0x112>(x);   // row_shr:2
+    x += dpp_fetch0<0x114>(x);   // row_shr:4
+    x += dpp_fetch0<0x118>(x);   // row_shr:8
+    return x;
+}
+
 // Sum of x over the 64 lanes of the wavefront, returned wave-uniform (read from lane 63).
-// 4 in-row scan steps + 2 row broadcasts; deterministic order.
+// 4 in-row scan steps + 2 row broadcasts; fixed order, so results are run-to-run identical.
 __device__ __forceinline__ double wave_sum(double x)
 {
-    x += dpp_fetch<0x111, 0xF>(x);   // row_shr:1
-    x += dpp_fetch<0x112, 0xF>(x);   // row_shr:2
-    x += dpp_fetch<0x114, 0xF>(x);   // row_shr:4
-    x += dpp_fetch<0x118, 0xF>(x);   // row_shr:8   -> lane 15 of each row = row total
-    x += dpp_fetch<0x142, 0xA>(x);   // row_bcast:15 into rows 1,3
-    x += dpp_fetch<0x143, 0xC>(x);   // row_bcast:31 into rows 2,3 -> lane 63 = wave total
+    x = row_scan(x);
+    x += dpp_fetch0<0x142>(x);   // row_bcast:15 -> lane 31 = r0+r1, lane 63 = r2+r3 (+ unused others)
+    x += dpp_fetch0<0x143>(x);   // row_bcast:31 -> lane 63 = r0+r1+r2+r3
     return readlane_f64(x, 63);
+}
+
+// Two sums for the price of one: v_permlane32_swap folds the upper half-wave of `a` onto its lower
+// half and the lower half-wave of `b` onto its upper half, after which lanes 0-31 hold a's 32
+// pair-sums and lanes 32-63 hold b's; one row scan + one row_bcast:15 finishes both.
+__device__ __forceinline__ void wave_sum2(double a, double b, double &sum_a, double &sum_b)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    double x = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    x = row_scan(x);
+    x += dpp_fetch0<0x142>(x);   // lane 31 = rows 0+1 (a), lane 63 = rows 2+3 (b)
+    sum_a = readlane_f64(x, 31);
+    sum_b = readlane_f64(x, 63);
 }
 
 // ---- alphabet rounding -------------------------------------------------------------------
@@ -88,6 +108,34 @@ __device__ __forceinline__ int nearest(double t, double a_lane, int M, bool asce
         if (dk < dbest) { dbest = dk; best = k; }
     }
     return best;
+}
+
+// nearest() plus the distance of t from the closest decision boundary (the midpoint between the
+// chosen member and the runner-up), used to certify decisions taken from an approximated t.
+// margin < 0 means "cannot certify" (non-ascending alphabet, ties/plateaus).
+__device__ __forceinline__ int nearest_margin(double t, double a_lane, int M, bool ascending, double &margin)
+{
+    margin = -1.0;
+    if (!ascending) return nearest(t, a_lane, M, false);
+    const double d = fabs(a_lane - t);
+    const unsigned long long lt = __ballot(a_lane < t);
+    const int p = __popcll(lt);
+    const int lo = p > 0 ? p - 1 : 0;
+    const int hi = p < M ? p : M - 1;
+    const double dlo = readlane_f64(d, lo);
+    const double dhi = readlane_f64(d, hi);
+    const double dmin = dlo <= dhi ? dlo : dhi;
+    const unsigned long long eq = __ballot(d == dmin);
+    const int idx = eq ? (int)__ffsll((long long)eq) - 1 : 0;
+    if (lo != hi) {
+        if (idx == lo || idx == hi) margin = 0.5 * fabs(dlo - dhi);
+    } else if (M == 1) {
+        margin = __longlong_as_double(0x7ff0000000000000LL);
+    } else if (idx == lo) {
+        const double dn = readlane_f64(d, lo == 0 ? 1 : M - 2);      // t lies outside the alphabet's range
+        margin = 0.5 * (dn - dmin);
+    }
+    return idx;
 }
 
 struct Decision {

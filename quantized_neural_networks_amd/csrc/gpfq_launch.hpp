@@ -9,10 +9,22 @@
 
 namespace gpfq {
 
+// Per-row quantities of the certified mode (gpfq_onchip.hip), produced by launch_row_stats:
+//   G      = <Xq_t, X_t>                         (f64)
+//   rden   = 1 / (f32-rounded ||Xq_t||)^2        (0 for rows that take rule (i))
+//   cbound = 2^-23 * sum_i |Xq_ti X_ti| * rden   bound on the f32 product roundings, per unit |w|
+//   cabs   = 2^-149 * sum_i |Xq_ti| * rden       the same for products that round in the subnormal range
+struct RowStats {
+    double G, rden, cbound, cabs;
+};
+
 struct OnchipArgs {
     const float *X, *Xq;
     int64_t ld;
     const float *nrm32;
+    const RowStats *stats = nullptr;
+    unsigned long long *fallback_count = nullptr;
+    int mode = 0;          // 0 = exact flow, 1 = certified (needs stats)
     const float *Wt;
     int64_t ldw;
     AlphabetArg A;
@@ -47,6 +59,8 @@ hipError_t launch_onchip(const OnchipArgs &a, hipStream_t stream);
 size_t stream_workspace_bytes(int64_t N, int64_t m, int64_t C, bool need_u);
 hipError_t launch_stream(const StreamArgs &a, hipStream_t stream);
 
+hipError_t launch_row_stats(const float *X, const float *Xq, int64_t N, int64_t m, int64_t ld, const float *nrm32,
+                            RowStats *stats, hipStream_t stream);
 hipError_t launch_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, float *nrm32, hipStream_t stream);
 hipError_t launch_msq(const float *W, int64_t n, const AlphabetArg &A, float *Q, int8_t *qidx, hipStream_t stream);
 size_t median_workspace_bytes();

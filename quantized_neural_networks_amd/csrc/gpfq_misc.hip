@@ -44,6 +44,44 @@ hipError_t launch_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, f
     return hipGetLastError();
 }
 
+// ---- row statistics of the certified mode (see RowStats) -----------------------------------
+__global__ void __launch_bounds__(256)
+gpfq_row_stats_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t m, int64_t ld,
+                      const float *__restrict__ nrm32, RowStats *__restrict__ stats)
+{
+    __shared__ double sm[3][4];
+    const float *rx = X + (int64_t)blockIdx.x * ld, *rq = Xq + (int64_t)blockIdx.x * ld;
+    double g = 0.0, a = 0.0, s1 = 0.0;
+    for (int64_t i = threadIdx.x; i < m; i += 256) {
+        const double xq = (double)rq[i], pr = xq * (double)rx[i];     // exact product of two f32
+        g += pr; a += fabs(pr); s1 += fabs(xq);
+    }
+    g = wave_sum(g); a = wave_sum(a); s1 = wave_sum(s1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sm[0][wave] = g; sm[1][wave] = a; sm[2][wave] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        g  = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3];
+        a  = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
+        s1 = sm[2][0] + sm[2][1] + sm[2][2] + sm[2][3];
+        const double nrm = (double)nrm32[blockIdx.x];
+        RowStats st;
+        st.G = g;
+        st.rden = nrm < 1e-16 ? 0.0 : 1.0 / (nrm * nrm);
+        st.cbound = 0x1p-23 * a * st.rden * (1.0 + 0x1p-20);
+        st.cabs = 0x1p-149 * s1 * st.rden * (1.0 + 0x1p-20);
+        stats[blockIdx.x] = st;
+    }
+}
+
+hipError_t launch_row_stats(const float *X, const float *Xq, int64_t N, int64_t m, int64_t ld, const float *nrm32,
+                            RowStats *stats, hipStream_t stream)
+{
+    if (N == 0) return hipSuccess;
+    hipLaunchKernelGGL(gpfq_row_stats_kernel, dim3((unsigned)N), dim3(256), 0, stream, X, Xq, m, ld, nrm32, stats);
+    return hipGetLastError();
+}
+
 // ---- MSQ -----------------------------------------------------------------------------------
 // Q[i] = alphabet[argmin |alphabet - (double)W[i]|], first index on ties
 // (_bit_round_parallel applied per weight, scripts/quantize_pretrained_mlp.py:109).

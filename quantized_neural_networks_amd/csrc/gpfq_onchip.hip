@@ -12,8 +12,20 @@
 //   lane l of a wave owns elements {256c + 4l + e} of u (EPL = m/64 float64 values = 2*EPL VGPRs).
 //   per tile of TS steps the workgroup copies rows X[t0..t0+TS), Xq[t0..t0+TS) (2*TS*m*4 B) from
 //   global/L2 into LDS with 16-B loads; each wave then reads its 16-B slices with ds_read_b128.
-//   HBM traffic is therefore (2*N*m*4 B) per workgroup-pass from L2/MALL and compulsory once from
-//   HBM -- the kernel is bound by FP64 VALU issue and the per-step reduction latency, not by HBM.
+//   HBM sees each row once per XCD; the kernel is bound by FP64-rate VALU issue and the per-step
+//   wave-uniform work (reduction, decision), not by HBM.
+//
+// Two arithmetic modes, identical results:
+//   MODE_EXACT      the reference's flow verbatim: <Xq_t, u> and <Xq_t, u + f32(w*X_t)> are both
+//                   accumulated element by element (:86, :89).
+//   MODE_CERTIFIED  only <Xq_t, u> is accumulated.  The second dot product is predicted as
+//                   <Xq_t, u> + w * G_t with G_t = <Xq_t, X_t> from the pre-pass; it differs from the
+//                   exact one only by the float32 rounding of the products w*X_ti, which is bounded by
+//                   2^-24 |w| A_t, A_t = sum_i |Xq_ti X_ti|.  If the predicted quotient is farther from
+//                   every decision boundary of the alphabet than that bound (plus float64 slack), the
+//                   decision is provably the exact flow's; otherwise (about once per 10^7 weights) the
+//                   wave recomputes the exact dot product.  The residual update is always the exact
+//                   element-wise flow, so u is bit-identical in both modes.
 #include "gpfq_device.hpp"
 #include "gpfq_launch.hpp"
 
@@ -69,14 +81,18 @@ __device__ __forceinline__ void stage_rows(const float *__restrict__ G, int64_t 
     }
 }
 
+enum { MODE_EXACT = 0, MODE_CERTIFIED = 1 };
+
 // EPL = 32 needs ~200 VGPRs: cap the workgroup at 8 waves so the allocator may use 256.
-template <int EPL>
+template <int EPL, int MODE>
 __global__ void __launch_bounds__(EPL >= 32 ? 512 : 1024)
 gpfq_onchip_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld,
-                                   const float *__restrict__ nrm32, const float *__restrict__ Wt, int64_t ldw,
-                                   AlphabetArg A, int64_t N, int m, int64_t C, int TS, int vec4,
-                                   int8_t *__restrict__ qidx, float *__restrict__ Qt,
-                                   double *__restrict__ resid, double *__restrict__ u_out)
+                   const float *__restrict__ nrm32, const RowStats *__restrict__ stats,
+                   const float *__restrict__ Wt, int64_t ldw,
+                   AlphabetArg A, int64_t N, int m, int64_t C, int TS, int vec4,
+                   int8_t *__restrict__ qidx, float *__restrict__ Qt,
+                   double *__restrict__ resid, double *__restrict__ u_out,
+                   unsigned long long *__restrict__ fallback_count)
 {
     using L = Lanes<EPL>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -98,53 +114,113 @@ gpfq_onchip_kernel(const float *__restrict__ X, const float *__restrict__ Xq, in
 
     int   my_idx = 0;      // lane (t & 63) keeps step t's outputs until the 64-step flush
     float my_q   = 0.f;
+    unsigned n_fallback = 0;
+
+    // Per-step wave-uniform operands (w_t, ||Xq_t||, row statistics) travel through the scalar
+    // cache and are fetched one step ahead, so they cost SGPRs instead of VGPRs and their latency
+    // hides behind the previous step.
+    const int64_t jw = active ? j : 0;
+    const float *__restrict__ wrow = Wt + jw * ldw;
+    float w_next = 0.f, nrm_next = 0.f;
+    RowStats st_next = {0.0, 0.0, 0.0, 0.0};
+    if (N > 0) {
+        w_next = wrow[0];
+        nrm_next = nrm32[0];
+        if (MODE == MODE_CERTIFIED) st_next = stats[0];
+    }
 
     for (int64_t t0 = 0; t0 < N; t0 += TS) {
         __syncthreads();   // previous tile fully consumed
         stage_rows<L::MP>(X,  ld, t0, TS, N, m, vec4, ldsX,  tid, nthreads);
         stage_rows<L::MP>(Xq, ld, t0, TS, N, m, vec4, ldsXq, tid, nthreads);
-        // this tile's weights and norms: lane s holds step t0+s
-        float wv = 0.f, nv = 0.f;
-        if (active && lane < TS && t0 + lane < N) {
-            wv = Wt[j * ldw + t0 + lane];
-            nv = nrm32[t0 + lane];
-        }
         __syncthreads();
         if (!active) continue;
 
         const int ts = (int)((N - t0) < TS ? (N - t0) : TS);
         for (int s = 0; s < ts; ++s) {
             const int64_t t = t0 + s;
-            const float w   = readlane_f32(wv, s);
-            const float nrm = readlane_f32(nv, s);
+            const float w = w_next, nrm = nrm_next;
+            const RowStats st = st_next;
+            if (t + 1 < N) {
+                w_next = wrow[t + 1];
+                nrm_next = nrm32[t + 1];
+                if (MODE == MODE_CERTIFIED) st_next = stats[t + 1];
+            }
 
-            float x[EPL], xq[EPL], p[EPL];
-            lds_read_row<EPL>(ldsX  + s * L::MP, lane, x);
+            float x[EPL], xq[EPL];
             lds_read_row<EPL>(ldsXq + s * L::MP, lane, xq);
 
-            // <Xq_t, u> (:86) and <Xq_t, u + w*X_t> (:89); two accumulators per sum break the
-            // dependent-FMA chain.
-            double d0a = 0.0, d0b = 0.0, d1a = 0.0, d1b = 0.0;
+            Decision dec;
+            if (MODE == MODE_EXACT) {
+                lds_read_row<EPL>(ldsX + s * L::MP, lane, x);
+                // <Xq_t, u> (:86) and <Xq_t, u + w*X_t> (:89); two accumulators per sum break the
+                // dependent-FMA chain.
+                double d0a = 0.0, d0b = 0.0, d1a = 0.0, d1b = 0.0;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                p[e] = __fmul_rn(w, x[e]);                     // f32 product
-                const double xd = (double)xq[e];
-                const double v  = u[e] + (double)p[e];         // f64 add
-                if (e & 1) { d0b = fma(xd, u[e], d0b); d1b = fma(xd, v, d1b); }
-                else       { d0a = fma(xd, u[e], d0a); d1a = fma(xd, v, d1a); }
+                for (int e = 0; e < EPL; ++e) {
+                    const float p = __fmul_rn(w, x[e]);            // f32 product
+                    const double xd = (double)xq[e];
+                    const double v  = u[e] + (double)p;            // f64 add
+                    if (e & 1) { d0b = fma(xd, u[e], d0b); d1b = fma(xd, v, d1b); }
+                    else       { d0a = fma(xd, u[e], d0a); d1a = fma(xd, v, d1a); }
+                }
+                double dot_u, dot_uw;
+                wave_sum2(d0a + d0b, d1a + d1b, dot_u, dot_uw);
+                dec = decide(w, nrm, dot_u, dot_uw, a_lane, A.M, A.zero_idx, ascending);
+            } else {
+                double d0a = 0.0, d0b = 0.0;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    if (e & 1) d0b = fma((double)xq[e], u[e], d0b);
+                    else       d0a = fma((double)xq[e], u[e], d0a);
+                }
+                // X_t is only needed by the update (and the rare exact fallback): issue its LDS
+                // reads now so they complete under the reduction and the decision
+                lds_read_row<EPL>(ldsX + s * L::MP, lane, x);
+                const double dot_u = wave_sum(d0a + d0b);
+                if ((double)nrm < 1e-16) {                                     // :83-84
+                    dec.idx = A.zero_idx; dec.q = 0.0;
+                } else {
+                    if (fabs(dot_u) < 1e-10) {                                 // :86-87
+                        dec.idx = nearest((double)w, a_lane, A.M, ascending);
+                    } else {
+                        const double wd = (double)w;
+                        const double wg = wd * st.G;
+                        const double tq = (dot_u + wg) * st.rden;              // predicted quotient (:89)
+                        // modelling error of the prediction (in quotient units) + float64 slack
+                        const double delta = fabs(wd) * st.cbound + st.cabs + 0x1p-44 * (fabs(dot_u) + fabs(wg)) * st.rden;
+                        double margin;
+                        dec.idx = nearest_margin(tq, a_lane, A.M, ascending, margin);
+                        if (!(margin > delta)) {                               // rare: exact :89
+                            ++n_fallback;
+                            double a = 0.0, b = 0.0;
+#pragma unroll
+                            for (int e = 0; e < EPL; ++e) {
+                                const double v = u[e] + (double)__fmul_rn(w, x[e]);
+                                if (e & 1) b = fma((double)xq[e], v, b);
+                                else       a = fma((double)xq[e], v, a);
+                            }
+                            const double te = wave_sum(a + b) / ((double)nrm * (double)nrm);
+                            dec.idx = nearest(te, a_lane, A.M, ascending);
+                        }
+                    }
+                    dec.q = readlane_f64(a_lane, dec.idx);
+                }
             }
-            const double dot_u  = wave_sum(d0a + d0b);
-            const double dot_uw = wave_sum(d1a + d1b);
-
-            const Decision dec = decide(w, nrm, dot_u, dot_uw, a_lane, A.M, A.zero_idx, ascending);
 
             // u += w*X_t - q*Xq_t  (:119): f32 products, f32 subtraction, f64 accumulate
             const float q32 = (float)dec.q;
+            if (q32 == 0.0f) {
+                // f32(0 * xq) = +-0 and p - (+-0) = p: the increment is the product itself
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const float r = __fmul_rn(q32, xq[e]);
-                const float d = __fsub_rn(p[e], r);
-                u[e] += (double)d;
+                for (int e = 0; e < EPL; ++e) u[e] += (double)__fmul_rn(w, x[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const float p = __fmul_rn(w, x[e]);
+                    const float r = __fmul_rn(q32, xq[e]);
+                    u[e] += (double)__fsub_rn(p, r);
+                }
             }
 
             if (lane == (int)(t & 63)) { my_idx = dec.idx; my_q = q32; }
@@ -159,6 +235,8 @@ gpfq_onchip_kernel(const float *__restrict__ X, const float *__restrict__ Xq, in
     }
 
     if (!active) return;
+    if (MODE == MODE_CERTIFIED && fallback_count && n_fallback && lane == 0)
+        atomicAdd(fallback_count, (unsigned long long)n_fallback);
     if (resid) {
         double ss = 0.0;
 #pragma unroll
@@ -177,7 +255,7 @@ gpfq_onchip_kernel(const float *__restrict__ X, const float *__restrict__ Xq, in
     }
 }
 
-template <int EPL>
+template <int EPL, int MODE>
 static hipError_t launch_epl(const OnchipArgs &a, hipStream_t stream)
 {
     constexpr int MP = 64 * EPL;
@@ -193,23 +271,30 @@ static hipError_t launch_epl(const OnchipArgs &a, hipStream_t stream)
     const size_t lds_bytes = (size_t)2 * ts * MP * sizeof(float);
     const bool vec4 = (a.ld % 4 == 0) && (a.m % 4 == 0) && ((uintptr_t)a.X % 16 == 0) && ((uintptr_t)a.Xq % 16 == 0);
     const unsigned grid = (unsigned)((a.C + nw - 1) / nw);
-    hipError_t e = hipFuncSetAttribute((const void *)gpfq_onchip_kernel<EPL>,
+    hipError_t e = hipFuncSetAttribute((const void *)gpfq_onchip_kernel<EPL, MODE>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(gpfq_onchip_kernel<EPL>, dim3(grid), dim3(nw * 64), lds_bytes, stream,
-                       a.X, a.Xq, a.ld, a.nrm32, a.Wt, a.ldw, a.A, a.N, (int)a.m, a.C, ts, vec4 ? 1 : 0,
-                       a.qidx, a.Qt, a.resid, a.u_out);
+    hipLaunchKernelGGL((gpfq_onchip_kernel<EPL, MODE>), dim3(grid), dim3(nw * 64), lds_bytes, stream,
+                       a.X, a.Xq, a.ld, a.nrm32, a.stats, a.Wt, a.ldw, a.A, a.N, (int)a.m, a.C, ts, vec4 ? 1 : 0,
+                       a.qidx, a.Qt, a.resid, a.u_out, a.fallback_count);
     return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_mode(const OnchipArgs &a, hipStream_t stream)
+{
+    if (a.m <= 64)   return launch_epl<1, MODE>(a, stream);
+    if (a.m <= 128)  return launch_epl<2, MODE>(a, stream);
+    if (a.m <= 256)  return launch_epl<4, MODE>(a, stream);
+    if (a.m <= 512)  return launch_epl<8, MODE>(a, stream);
+    if (a.m <= 1024) return launch_epl<16, MODE>(a, stream);
+    return launch_epl<32, MODE>(a, stream);
 }
 
 hipError_t launch_onchip(const OnchipArgs &a, hipStream_t stream)
 {
-    if (a.m <= 64)   return launch_epl<1>(a, stream);
-    if (a.m <= 128)  return launch_epl<2>(a, stream);
-    if (a.m <= 256)  return launch_epl<4>(a, stream);
-    if (a.m <= 512)  return launch_epl<8>(a, stream);
-    if (a.m <= 1024) return launch_epl<16>(a, stream);
-    return launch_epl<32>(a, stream);
+    if (a.mode == MODE_CERTIFIED && a.stats) return launch_mode<MODE_CERTIFIED>(a, stream);
+    return launch_mode<MODE_EXACT>(a, stream);
 }
 
 }  // namespace gpfq

@@ -24,6 +24,7 @@ SYMBOLS = {
     "gpfq_device_count": (_int, []),
     "gpfq_row_norms": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "gpfq_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
+    "gpfq_set_option": (_int, [ctypes.c_char_p, _int]),
     "gpfq_quantize_neurons": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _int, _int, _i64, _i64, _i64,
                                      _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp]),
     "gpfq_msq_round": (_int, [_vp, _i64, _dp, _int, _vp, _vp, _vp]),
@@ -131,16 +132,28 @@ def quantize_neurons(X, Xq, Wt, alphabet, nrm32=None, want_u=False, path=GPFQ_PA
     resid = torch.empty(C, dtype=torch.float64, device=dev)
     lib = load()
     nbytes = lib.gpfq_workspace_bytes(N, m, C, path)
-    streaming = nbytes > 0
+    streaming = path == GPFQ_PATH_STREAM or (path == GPFQ_PATH_AUTO and m > GPFQ_ONCHIP_MAX_M)
     u = torch.empty((C, m), dtype=torch.float64, device=dev) if (want_u or streaming) else None
-    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev) if streaming else None
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = lib.gpfq_quantize_neurons(xp, xqp, ld, nrm32.data_ptr(), wp, ldw, arr, M, zero_idx, N, m, C,
                                        idx.data_ptr(), Q.data_ptr() if Q is not None else None, resid.data_ptr(),
                                        u.data_ptr() if u is not None else None,
-                                       ws.data_ptr() if ws is not None else None, nbytes, path, _stream())
+                                       ws.data_ptr(), nbytes, path, _stream())
     _check(rc, "gpfq_quantize_neurons")
-    return dict(idx=idx, Q=Q, resid=resid, u=u if want_u else None)
+    # on-chip path: the first 8 workspace bytes count decisions re-derived exactly (diagnostics)
+    return dict(idx=idx, Q=Q, resid=resid, u=u if want_u else None, workspace=None if streaming else ws)
+
+
+def exact_fallbacks(result):
+    """How many decisions of an on-chip quantize_neurons() call were re-derived with the exact dot
+    product (forces a device sync; diagnostics only)."""
+    ws = result.get("workspace")
+    return 0 if ws is None or ws.numel() < 8 else int(ws[:8].view(torch.int64).item())
+
+
+def set_option(key, value):
+    _check(load().gpfq_set_option(key.encode(), int(value)), f"gpfq_set_option({key})")
 
 
 def msq_round(W, alphabet):

@@ -39,7 +39,7 @@ def test_version_and_errors_without_gpu(lib):
     rc = lib.gpfq_quantize_neurons(None, None, 2, None, None, 4, a, 3, 1, 4, 8, 2, None, None, None, None, None, 0, 0, None)
     assert rc == -1
     assert lib.gpfq_quantize_neurons(None, None, 8, None, None, 4, a, 3, 1, 4, 8, 0, None, None, None, None, None, 0, 0, None) == 0
-    assert lib.gpfq_workspace_bytes(9, 1024, 8, 0) == 0
+    assert lib.gpfq_workspace_bytes(9, 1024, 8, 0) == 64 + 9 * 32
     assert lib.gpfq_workspace_bytes(9, 100000, 8, 0) >= 8 * 100000 * 8
     assert lib.gpfq_workspace_bytes(9, 1024, 8, 2) > 0
 
