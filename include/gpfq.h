@@ -87,7 +87,10 @@ size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path);
  * Process-wide tuning/test hooks; results never depend on them.
  *   "onchip_mode"  1 (default) certified-prediction mode, 0 verbatim reference flow
  *   "tile_steps"   LDS tile height in steps (power of two <= 64), 0 = heuristic
- *   "group_waves"  neurons (wavefronts) per workgroup 1..16, 0 = heuristic
+ *   "group_waves"  neurons (wavefronts) per workgroup 1..16 of the wave-per-neuron kernel, 0 = heuristic
+ *   "lanes_per_neuron"  0 = heuristic, 16/32/64 = row-group kernel with that many lanes per neuron,
+ *                  1 = wave-per-neuron kernel
+ *   "variant"      bit 0: row-group kernel without the float64 copy of Xq in LDS
  */
 int gpfq_set_option(const char *key, int value);
 

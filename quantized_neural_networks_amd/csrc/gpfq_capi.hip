@@ -99,6 +99,8 @@ size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path)
 static int g_onchip_mode = 1;      // 1 = certified (default), 0 = exact flow
 static int g_tile_steps = 0;       // 0 = heuristic
 static int g_group_waves = 0;      // 0 = heuristic
+static int g_lpn = 0;              // 0 = heuristic, 1 = wave-per-neuron kernel, 16/32/64 = row-group kernel
+static int g_variant = 0;          // bit 0: row-group kernel without the float64 copy of Xq in LDS
 
 int gpfq_set_option(const char *key, int value)
 {
@@ -111,6 +113,12 @@ int gpfq_set_option(const char *key, int value)
     if (!std::strcmp(key, "group_waves")) {
         if (value < 0 || value > 16) return fail(GPFQ_ERR_INVALID_ARG, "group_waves must be in [0, 16]");
         g_group_waves = value; return GPFQ_OK;
+    }
+    if (!std::strcmp(key, "variant")) { g_variant = value; return GPFQ_OK; }
+    if (!std::strcmp(key, "lanes_per_neuron")) {
+        if (value != 0 && value != 1 && value != 16 && value != 32 && value != 64)
+            return fail(GPFQ_ERR_INVALID_ARG, "lanes_per_neuron must be 0, 1, 16, 32 or 64");
+        g_lpn = value; return GPFQ_OK;
     }
     return fail(GPFQ_ERR_INVALID_ARG, "unknown option '%s'", key);
 }
@@ -145,6 +153,8 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
         a.N = N; a.m = m; a.C = C; a.qidx = qidx; a.Qt = Qt; a.resid = resid; a.u_out = u_out;
         a.ts_override = g_tile_steps; a.nw_override = g_group_waves;
         a.mode = g_onchip_mode;
+        a.lpn = g_lpn;
+        a.variant = g_variant;
         // certified mode needs the per-row statistics in the workspace; without one, run the exact flow
         const bool have_ws = workspace && workspace_bytes >= onchip_workspace_bytes(N) && (uintptr_t)workspace % 16 == 0;
         if (have_ws) {

@@ -293,7 +293,13 @@ static hipError_t launch_mode(const OnchipArgs &a, hipStream_t stream)
 
 hipError_t launch_onchip(const OnchipArgs &a, hipStream_t stream)
 {
-    if (a.mode == MODE_CERTIFIED && a.stats) return launch_mode<MODE_CERTIFIED>(a, stream);
+    if (a.mode == MODE_CERTIFIED && a.stats) {
+        int lpn = a.lpn;
+        if (lpn == 0) lpn = 32;                      // measured best on cfg2/cfg3-like layers (tools/sweep_shapes.py)
+        while (lpn >= 16 && lpn <= 64 && !rows_supported(a, lpn)) lpn *= 2;
+        if (lpn >= 16 && lpn <= 64) return launch_rows(a, lpn, stream);
+        return launch_mode<MODE_CERTIFIED>(a, stream);
+    }
     return launch_mode<MODE_EXACT>(a, stream);
 }
 
