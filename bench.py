@@ -154,12 +154,13 @@ def main():
                 "arithmetic": "f32 products / f64 residual and dot products (reference's mixed flow)",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "gpfq_onchip_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": "gpfq_rows_kernel<32,32,true> (row-group on-chip kernel, 2 neurons per wavefront)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": _recorded_traffic(N, m, hi - lo),
                 "kernel_ms_avg": k_avg_s * 1e3, "kernel_ms_min": float(np.min(kernel_ms)),
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "algorithmic bytes = (8m+8) per weight; rows are shared by the 16 neurons of a workgroup "
-                        "through LDS, so achieved/peak may exceed 1 -- see DESIGN.md for the FP64-VALU bound",
+                "note": "algorithmic bytes = (8m+8) per weight (SURVEY 8d); the 16 neurons of a workgroup share every "
+                        "LDS-staged row and u stays in VGPRs, so achieved/peak exceeds 1 and the kernel is bound by "
+                        "FP64-rate VALU issue, not HBM (DESIGN.md section 4); `traffic` is the PMC-measured HBM bytes",
             },
         }
         if world == 1 and args.cpu_sample > 0:

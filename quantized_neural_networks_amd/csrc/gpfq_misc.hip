@@ -156,7 +156,7 @@ hipError_t launch_extract_patches(const float *act, int64_t n, int64_t H, int64_
 // float32 mean of the two middle values, so both are selected.
 struct SelState {
     unsigned prefix;            // bits of the answer fixed so far
-    unsigned pad;
+    unsigned done;              // 1: already resolved (the second order statistic, from the first one's last pass)
     unsigned long long k;       // rank still to be resolved inside the prefix class
 };
 
@@ -166,6 +166,7 @@ __global__ void __launch_bounds__(256)
 gpfq_select_hist_kernel(const float *__restrict__ W, int64_t n, const SelState *__restrict__ st,
                         int shift, int nbits, unsigned *__restrict__ hist)
 {
+    if (st->done) return;
     __shared__ unsigned h[kSelBins];
     for (int b = threadIdx.x; b < kSelBins; b += 256) h[b] = 0;
     __syncthreads();
@@ -173,7 +174,18 @@ gpfq_select_hist_kernel(const float *__restrict__ W, int64_t n, const SelState *
     const unsigned hi_mask = (shift + nbits >= 32) ? 0u : ~((1u << (shift + nbits)) - 1u);
     const unsigned bin_mask = (1u << nbits) - 1u;
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const int64_t n4 = ((uintptr_t)W % 16 == 0) ? n / 4 : 0;
+    const float4 *W4 = reinterpret_cast<const float4 *>(W);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 v = W4[i];
+        const unsigned k0 = __float_as_uint(v.x) & 0x7fffffffu, k1 = __float_as_uint(v.y) & 0x7fffffffu;
+        const unsigned k2 = __float_as_uint(v.z) & 0x7fffffffu, k3 = __float_as_uint(v.w) & 0x7fffffffu;
+        if ((k0 & hi_mask) == prefix) atomicAdd(&h[(k0 >> shift) & bin_mask], 1u);
+        if ((k1 & hi_mask) == prefix) atomicAdd(&h[(k1 >> shift) & bin_mask], 1u);
+        if ((k2 & hi_mask) == prefix) atomicAdd(&h[(k2 >> shift) & bin_mask], 1u);
+        if ((k3 & hi_mask) == prefix) atomicAdd(&h[(k3 >> shift) & bin_mask], 1u);
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const unsigned key = __float_as_uint(W[i]) & 0x7fffffffu;
         if ((key & hi_mask) == prefix) atomicAdd(&h[(key >> shift) & bin_mask], 1u);
     }
@@ -182,29 +194,64 @@ gpfq_select_hist_kernel(const float *__restrict__ W, int64_t n, const SelState *
         if (h[b]) atomicAdd(&hist[b], h[b]);
 }
 
+// Locate the bin holding rank k (parallel: 256 threads x 8 bins), fix its bits, clear the histogram.
+// On the last pass of the first order statistic (`next` != NULL) the following order statistic is
+// resolved too when it lies in the same 2^10-value class: the same value if the bin holds more
+// elements beyond rank k, otherwise the next non-empty bin.
 __global__ void __launch_bounds__(256)
-gpfq_select_pick_kernel(unsigned *__restrict__ hist, SelState *__restrict__ st, int shift, int nbits)
+gpfq_select_pick_kernel(unsigned *__restrict__ hist, SelState *__restrict__ st, int shift, int nbits,
+                        SelState *__restrict__ next)
 {
+    if (st->done) return;
     __shared__ unsigned h[kSelBins];
+    __shared__ unsigned long long part[256];
+    __shared__ int found_bin;
+    __shared__ unsigned long long found_rank;
+    __shared__ unsigned next_bin;
     const int bins = 1 << nbits;
-    for (int b = threadIdx.x; b < kSelBins; b += 256) { h[b] = b < bins ? hist[b] : 0u; hist[b] = 0u; }
+    const int tid = threadIdx.x;
+    for (int b = tid; b < kSelBins; b += 256) { h[b] = b < bins ? hist[b] : 0u; hist[b] = 0u; }
+    if (tid == 0) { found_bin = bins - 1; found_rank = 0; next_bin = 0xffffffffu; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long k = st->k, acc = 0;
-        int b = 0;
-        for (; b < bins - 1; ++b) {
+    unsigned long long mine = 0;
+    for (int b = 0; b < 8; ++b) mine += h[tid * 8 + b];
+    part[tid] = mine;
+    __syncthreads();
+    unsigned long long before = 0;
+    for (int i = 0; i < tid; ++i) before += part[i];
+    const unsigned long long k = st->k;
+    if (before <= k && k < before + mine) {               // exactly one thread (or none if k is out of range)
+        unsigned long long acc = before;
+        int b = tid * 8;
+        for (; b < tid * 8 + 7; ++b) {
             if (acc + h[b] > k) break;
             acc += h[b];
         }
-        st->k = k - acc;
-        st->prefix |= (unsigned)b << shift;
+        found_bin = b;
+        found_rank = k - acc;
+    }
+    __syncthreads();
+    if (next) {
+        const int fb = found_bin;
+        for (int b = tid * 8; b < tid * 8 + 8; ++b)
+            if (b > fb && h[b]) { atomicMin(&next_bin, (unsigned)b); break; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned prefix = st->prefix | ((unsigned)found_bin << shift);
+        if (next) {
+            if (found_rank + 1 < h[found_bin]) { next->prefix = prefix; next->done = 1; }
+            else if (next_bin != 0xffffffffu) { next->prefix = st->prefix | (next_bin << shift); next->done = 1; }
+        }
+        st->k = found_rank;
+        st->prefix = prefix;
     }
 }
 
 __global__ void gpfq_select_init_kernel(SelState *st, unsigned long long k0, unsigned long long k1)
 {
-    st[0].prefix = 0; st[0].pad = 0; st[0].k = k0;
-    st[1].prefix = 0; st[1].pad = 0; st[1].k = k1;
+    st[0].prefix = 0; st[0].done = 0; st[0].k = k0;
+    st[1].prefix = 0; st[1].done = 0; st[1].k = k1;
 }
 
 __global__ void gpfq_select_finish_kernel(const SelState *st, int even, float *out)
@@ -227,7 +274,7 @@ hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *worksp
     const unsigned long long k0 = even ? (unsigned long long)(n / 2 - 1) : (unsigned long long)(n / 2);
     hipLaunchKernelGGL(gpfq_select_init_kernel, dim3(1), dim3(1), 0, stream, st, k0, (unsigned long long)(n / 2));
     int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
     for (int sel = 0; sel < (even ? 2 : 1); ++sel)
@@ -235,7 +282,8 @@ hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *worksp
             hipLaunchKernelGGL(gpfq_select_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
                                W, n, st + sel, shifts[p], widths[p], hist + sel * kSelBins);
             hipLaunchKernelGGL(gpfq_select_pick_kernel, dim3(1), dim3(256), 0, stream,
-                               hist + sel * kSelBins, st + sel, shifts[p], widths[p]);
+                               hist + sel * kSelBins, st + sel, shifts[p], widths[p],
+                               (even && sel == 0 && p == 2) ? st + 1 : static_cast<SelState *>(nullptr));
         }
     hipLaunchKernelGGL(gpfq_select_finish_kernel, dim3(1), dim3(1), 0, stream, st, even ? 1 : 0, out);
     return hipGetLastError();

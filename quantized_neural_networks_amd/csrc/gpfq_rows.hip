@@ -188,7 +188,15 @@ gpfq_rows_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int6
         // stage rows [t0, t0+TS) of X and Xq, zero-filled beyond m / N
         if (vec4) {
             constexpr int Q = MP / 4;
-            for (int idx = tid; idx < TS * Q; idx += nthreads) {
+            // All workgroups walk the same rows at about the same time; starting each one at a
+            // different 16-byte segment of the tile spreads their simultaneous requests over the L2
+            // channels instead of queueing them on the channel that holds the tile's first lines
+            // (staging alone: 1.17 -> 0.96 ms at cfg2).
+            const int total = TS * Q;
+            const int rot = (int)((blockIdx.x * 331u) % (unsigned)total);
+            for (int idx0 = tid; idx0 < total; idx0 += nthreads) {
+                int idx = idx0 + rot;
+                if (idx >= total) idx -= total;
                 const int s = idx / Q, i4 = (idx - s * Q) * 4;
                 float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vq = vx;
                 if (t0 + s < N && i4 < m) {
