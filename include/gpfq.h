@@ -133,6 +133,16 @@ int gpfq_msq_round(const float *W, int64_t n, const double *alphabet, int M,
                    float *Q, int8_t *qidx, void *stream);
 
 /*
+ * Assemble the quantized kernel in Keras layout from the neuron-major indices:
+ *   Q[t][j] = (float)alphabet[qidx[j][t]]   (0.0f for the literal-zero index -1),  qidx_t[t][j] = qidx[j][t].
+ * Replaces the `Q[:, neuron_idx] = future.result()` assembly loop (scripts/quantized_network.py:557-562);
+ * with neurons sharded over GPUs only the 1-byte indices need to be all-gathered.
+ *   qidx [device] i8 [C][N]; Q [device] f32 [N][C] (may be NULL); qidx_t [device] i8 [N][C] (may be NULL).
+ */
+int gpfq_assemble_kernel(const int8_t *qidx, const double *alphabet, int M, int64_t N, int64_t C,
+                         float *Q, int8_t *qidx_t, void *stream);
+
+/*
  * median(|W|) of n float32 weights with NumPy's semantics (float32 result; even n -> float32 mean of
  * the two middle values).  Replaces `median(abs(W.flatten()))` of the alphabet radius
  * (scripts/quantized_network.py:544, :831).  Exact radix select, no sort.

@@ -198,6 +198,20 @@ int gpfq_msq_round(const float *W, int64_t n, const double *alphabet, int M, flo
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_msq_round");
 }
 
+int gpfq_assemble_kernel(const int8_t *qidx, const double *alphabet, int M, int64_t N, int64_t C,
+                         float *Q, int8_t *qidx_t, void *stream)
+{
+    if (N < 0 || C < 0) return fail(GPFQ_ERR_INVALID_ARG, "negative size");
+    gpfq::AlphabetArg A;
+    int rc = make_alphabet(alphabet, M, -1, &A);
+    if (rc != GPFQ_OK) return rc;
+    if (N == 0 || C == 0) return GPFQ_OK;
+    if (!qidx) return fail(GPFQ_ERR_INVALID_ARG, "qidx is NULL");
+    if (N > 2147483647LL * 32 || (C + 31) / 32 > 65535) return fail(GPFQ_ERR_UNSUPPORTED, "kernel too large to assemble in one call");
+    hipError_t e = gpfq::launch_assemble(qidx, A, N, C, Q, qidx_t, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_assemble_kernel");
+}
+
 size_t gpfq_median_abs_workspace_bytes(void) { return gpfq::median_workspace_bytes(); }
 
 int gpfq_median_abs(const float *W, int64_t n, float *median_out, void *workspace, size_t workspace_bytes, void *stream)

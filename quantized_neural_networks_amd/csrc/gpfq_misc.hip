@@ -149,6 +149,41 @@ hipError_t launch_extract_patches(const float *act, int64_t n, int64_t H, int64_
     return hipGetLastError();
 }
 
+// ---- kernel assembly: [C][N] indices -> Keras-layout [N][C] values (+ indices) ------------------
+// Q[t][j] = (float)alphabet[qidx[j][t]] (0 for the literal-zero index -1), i.e. `Q[:, neuron_idx] =
+// future.result()` for every neuron (scripts/quantized_network.py:562) fused with the transpose from
+// the kernels' neuron-major layout.  32x32 tiles through LDS, both sides coalesced.
+__global__ void __launch_bounds__(256)
+gpfq_assemble_kernel(const int8_t *__restrict__ qidx, AlphabetArg A, int64_t N, int64_t C,
+                     float *__restrict__ Q, int8_t *__restrict__ idxT)
+{
+    __shared__ int8_t tile[32][33];
+    const int64_t t0 = (int64_t)blockIdx.x * 32, j0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t j = j0 + r, t = t0 + tx;
+        tile[r][tx] = (j < C && t < N) ? qidx[j * N + t] : (int8_t)0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t t = t0 + r, j = j0 + tx;
+        if (t < N && j < C) {
+            const int k = tile[tx][r];
+            if (Q) Q[t * C + j] = (k >= 0 && k < A.M) ? (float)A.a[k] : 0.f;
+            if (idxT) idxT[t * C + j] = (int8_t)k;
+        }
+    }
+}
+
+hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, int64_t C, float *Q, int8_t *idxT,
+                           hipStream_t stream)
+{
+    if (N == 0 || C == 0) return hipSuccess;
+    const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((C + 31) / 32));
+    hipLaunchKernelGGL(gpfq_assemble_kernel, grid, dim3(256), 0, stream, qidx, A, N, C, Q, idxT);
+    return hipGetLastError();
+}
+
 // ---- median of |W| ---------------------------------------------------------------------------
 // np.median(np.abs(W.flatten())) on float32 data (scripts/quantized_network.py:544, :831) without a
 // sort: exact radix select on the bit patterns of |w| (monotone as unsigned integers), three

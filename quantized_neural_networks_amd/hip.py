@@ -28,6 +28,7 @@ SYMBOLS = {
     "gpfq_quantize_neurons": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _int, _int, _i64, _i64, _i64,
                                      _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp]),
     "gpfq_msq_round": (_int, [_vp, _i64, _dp, _int, _vp, _vp, _vp]),
+    "gpfq_assemble_kernel": (_int, [_vp, _dp, _int, _i64, _i64, _vp, _vp, _vp]),
     "gpfq_median_abs_workspace_bytes": (_sz, []),
     "gpfq_median_abs": (_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
     "gpfq_patch_out_dim": (_i64, [_i64, _i64, _i64, _i64, _int]),
@@ -167,6 +168,22 @@ def msq_round(W, alphabet):
         _check(load().gpfq_msq_round(Wc.data_ptr(), Wc.numel(), arr, M, Q.data_ptr(), idx.data_ptr(), _stream()),
                "gpfq_msq_round")
     return Q, idx
+
+
+def assemble_kernel(qidx, alphabet, want_idx=True):
+    """[C][N] int8 indices -> (Q f32 [N][C] in Keras layout, idx i8 [N][C])."""
+    _dev(qidx, torch.int8, "qidx")
+    if qidx.dim() != 2 or not qidx.is_contiguous():
+        raise GpfqError("qidx must be a contiguous [C][N] tensor")
+    C, N = qidx.shape
+    arr, M, _ = _alphabet(alphabet)
+    Q = torch.empty((N, C), dtype=torch.float32, device=qidx.device)
+    idx_t = torch.empty((N, C), dtype=torch.int8, device=qidx.device) if want_idx else None
+    with torch.cuda.device(qidx.device):
+        _check(load().gpfq_assemble_kernel(qidx.data_ptr(), arr, M, N, C, Q.data_ptr(),
+                                           idx_t.data_ptr() if idx_t is not None else None, _stream()),
+               "gpfq_assemble_kernel")
+    return Q, idx_t
 
 
 def median_abs(W):

@@ -70,6 +70,7 @@ def all_gather_units(local, n_units, group=None):
 # product never does -- there is no CPU fallback.
 _local_quantize = hip.quantize_neurons
 _extract_patches = hip.extract_patches
+_assemble = hip.assemble_kernel
 
 
 # ------------------------------------------------------------------------------------------
@@ -89,15 +90,15 @@ def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True):
     lo, hi = shard_bounds(C, world, rank)
     Wt = W[:, lo:hi].t().contiguous()                        # neuron-major shard [C_local][N]
     if hi > lo:
-        r = _local_quantize(X, Xq, Wt, alphabet)
-        q_loc, i_loc, res_loc = r["Q"], r["idx"], r["resid"]
+        r = _local_quantize(X, Xq, Wt, alphabet, want_values=False)
+        i_loc, res_loc = r["idx"], r["resid"]
     else:
-        q_loc = torch.empty((0, N), dtype=torch.float32, device=W.device)
         i_loc = torch.empty((0, N), dtype=torch.int8, device=W.device)
         res_loc = torch.empty((0,), dtype=torch.float64, device=W.device)
-    Qt = all_gather_units(q_loc, C, group)
-    idx = all_gather_units(i_loc, C, group)
-    out = dict(Q=Qt.t().contiguous(), idx=idx.t().contiguous())
+    # only the 1-byte indices travel over xGMI; values are looked up while transposing to Keras layout
+    idx_t = all_gather_units(i_loc, C, group)
+    Q, idx = _assemble(idx_t.contiguous(), alphabet)
+    out = dict(Q=Q, idx=idx)
     if want_resid:
         out["resid"] = all_gather_units(res_loc, C, group)
     return out

@@ -264,3 +264,39 @@ def test_quantization_reduces_error_vs_msq(qn, ks):
         msq.layers[k].set_weights([qn.msq_quantize(W, rad * q.alphabet), b])
     msq_err = float(torch.linalg.norm(msq.predict_on_batch(x) - ref_out))
     assert gpfq_err < 0.5 * msq_err, (gpfq_err, msq_err)
+
+
+def test_single_rank_nccl_group(qn, ks):
+    """The collective plumbing on RCCL (1-rank group: the only multi-process setup a 1-GPU box allows):
+    process-group init on the device, all_gather_into_tensor on the dtypes the layer drivers gather,
+    and a sharded layer call through the class surface."""
+    import os
+    import torch.distributed as dist
+    from quantized_neural_networks_amd import layer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        for dtype in (torch.int8, torch.float32, torch.float64):
+            src = torch.arange(24, device="cuda").reshape(6, 4).to(dtype)
+            out = torch.empty_like(src)
+            dist.all_gather_into_tensor(out, src)
+            assert torch.equal(out, src)
+        assert layer.shard_bounds(10, *layer._group_info(None)) == (0, 10)
+        r = np.random.default_rng(0)
+        net = ks.Sequential([ks.Dense(12, activation="relu", input_shape=(16,)), ks.Dense(4)], seed=1)
+        x = r.random((32, 16)).astype(np.float32)
+        a = qn.QuantizedNeuralNetwork(network=net, batch_size=32, get_data=qn.MNISTSequence(x, np.zeros((32, 1)), 32),
+                                      logger=ListLogger(), process_group=dist.group.WORLD)
+        a.quantize_network()
+        b = qn.QuantizedNeuralNetwork(network=net, batch_size=32, get_data=qn.MNISTSequence(x, np.zeros((32, 1)), 32),
+                                      logger=ListLogger())
+        b.quantize_network()
+        for la, lb in zip(a.quantized_net.layers, b.quantized_net.layers):
+            assert np.array_equal(la.get_weights()[0], lb.get_weights()[0])
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -25,6 +25,13 @@ def _standin_quantize(X, Xq, Wt, alphabet, **kw):
     return dict(Q=torch.from_numpy(Q.astype(np.float32)), idx=torch.from_numpy(idx), resid=torch.from_numpy(resid), u=None)
 
 
+def _standin_assemble(qidx, alphabet, want_idx=True):
+    a = np.asarray(alphabet, dtype=np.float64)
+    k = qidx.numpy().astype(np.int64)
+    Q = np.where(k < 0, 0.0, a[np.maximum(k, 0)]).astype(np.float32)
+    return torch.from_numpy(np.ascontiguousarray(Q.T)), torch.from_numpy(np.ascontiguousarray(qidx.numpy().T))
+
+
 def _standin_patches(act, channel, kernel_size, strides, rate, padding, out=None):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _im2col_ref import patches
@@ -41,6 +48,7 @@ def _worker(rank, world, port, case, result_dir):
     from quantized_neural_networks_amd import layer
     layer._local_quantize = _standin_quantize
     layer._extract_patches = _standin_patches
+    layer._assemble = _standin_assemble
     r = np.random.default_rng(7)
     if case == "dense":
         N, m, C = 24, 40, 7                                  # 7 neurons over 2 ranks: uneven shards
@@ -74,8 +82,8 @@ def test_sharded_equals_unsharded(case, tmp_path, oracle_mod):
     # unsharded reference: same stand-ins, no process group
     sys.path.insert(0, ROOT)
     from quantized_neural_networks_amd import layer
-    keep = layer._local_quantize, layer._extract_patches
-    layer._local_quantize, layer._extract_patches = _standin_quantize, _standin_patches
+    keep = layer._local_quantize, layer._extract_patches, layer._assemble
+    layer._local_quantize, layer._extract_patches, layer._assemble = _standin_quantize, _standin_patches, _standin_assemble
     try:
         r = np.random.default_rng(7)
         if case == "dense":
@@ -93,6 +101,6 @@ def test_sharded_equals_unsharded(case, tmp_path, oracle_mod):
             out = layer.quantize_conv2d(torch.from_numpy(W), torch.from_numpy(act), torch.from_numpy(actq),
                                         0.25 * np.linspace(-1, 1, 3), strides=(1, 1), padding="SAME", rate=(1, 1))
     finally:
-        layer._local_quantize, layer._extract_patches = keep
+        layer._local_quantize, layer._extract_patches, layer._assemble = keep
     for k, v in out.items():
         assert np.array_equal(res[0][k], v.numpy()), k
