@@ -124,6 +124,29 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
                           void *workspace, size_t workspace_bytes, int path, void *stream);
 
 /*
+ * The same recurrence for SHORT walks over LONG rows (conv: N = kh*kw steps against patch matrices of
+ * m = n_img*oh*ow columns, _quantize_filter2D_parallel_jit, scripts/quantized_network.py:185-233), done on
+ * N x N Gram matrices of the rows instead of on the rows: the patch data are read once per call instead of
+ * once per neuron and step.  Every decision is certified against a rigorous bound on the float32 roundings
+ * the Gram formulation skips; neurons whose chain cannot be certified (about 1 in 10^5) are flagged in
+ * `uncertified` and MUST be rerun by the caller through gpfq_quantize_neurons -- the outputs of flagged
+ * neurons are undefined, those of unflagged neurons equal the exact flow's.
+ *   N <= GPFQ_GRAM_MAX_N, m < 2^30.  Arguments as gpfq_quantize_neurons; uncertified [device] i32 [C].
+ *   resid (optional) is produced by an exact element-wise replay of the residual with the chosen q.
+ *   compute_norms != 0: nrm32 is an OUTPUT, filled with (float)sqrt(<Xq_t,Xq_t>) from the Gram diagonal (the
+ *   row norms come for free here; pass the same array on to the rerun of flagged neurons); else an input.
+ *   Option "gram_slack_log2" (gpfq_set_option) multiplies the error bounds by 2^value (tests).
+ */
+#define GPFQ_GRAM_MAX_N 256
+size_t gpfq_gram_workspace_bytes(int64_t N, int64_t m, int64_t C);
+int gpfq_quantize_neurons_gram(const float *X, const float *Xq, int64_t ld, float *nrm32, int compute_norms,
+                               const float *Wt, int64_t ldw,
+                               const double *alphabet, int M, int zero_idx,
+                               int64_t N, int64_t m, int64_t C,
+                               int8_t *qidx, float *Qt, double *resid, int32_t *uncertified,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Memoryless scalar quantization of n weights: Q[i] = (float)alphabet[nearest((double)W[i])].
  * Replaces the per-weight Python loop `[_bit_round_parallel(w, layer_alphabet) for w in W.flatten()]`
  * of the drivers' MSQ baseline (scripts/quantize_pretrained_mlp.py:109, _cnn.py:114, _imagenet.py:219).

@@ -100,6 +100,7 @@ static int g_onchip_mode = 1;      // 1 = certified (default), 0 = exact flow
 static int g_tile_steps = 0;       // 0 = heuristic
 static int g_group_waves = 0;      // 0 = heuristic
 static int g_lpn = 0;              // 0 = heuristic, 1 = wave-per-neuron kernel, 16/32/64 = row-group kernel
+static int g_gram_slack_log2 = 0;  // Gram path: error bounds multiplied by 2^this (tests force the uncertified branch)
 static int g_variant = 0;          // bit 0: row-group kernel without the float64 copy of Xq in LDS
 
 int gpfq_set_option(const char *key, int value)
@@ -115,6 +116,7 @@ int gpfq_set_option(const char *key, int value)
         g_group_waves = value; return GPFQ_OK;
     }
     if (!std::strcmp(key, "variant")) { g_variant = value; return GPFQ_OK; }
+    if (!std::strcmp(key, "gram_slack_log2")) { g_gram_slack_log2 = value; return GPFQ_OK; }
     if (!std::strcmp(key, "lanes_per_neuron")) {
         if (value != 0 && value != 1 && value != 16 && value != 32 && value != 64)
             return fail(GPFQ_ERR_INVALID_ARG, "lanes_per_neuron must be 0, 1, 16, 32 or 64");
@@ -184,6 +186,45 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
     a.workspace = workspace; a.workspace_bytes = workspace_bytes;
     hipError_t e = gpfq::launch_stream(a, s);
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_neurons(stream)");
+}
+
+size_t gpfq_gram_workspace_bytes(int64_t N, int64_t m, int64_t C)
+{
+    if (N < 0 || m < 0 || C < 0) return 0;
+    return gpfq::gram_workspace_bytes(N, m, C);
+}
+
+int gpfq_quantize_neurons_gram(const float *X, const float *Xq, int64_t ld, float *nrm32, int compute_norms,
+                               const float *Wt, int64_t ldw,
+                               const double *alphabet, int M, int zero_idx,
+                               int64_t N, int64_t m, int64_t C,
+                               int8_t *qidx, float *Qt, double *resid, int32_t *uncertified,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (N < 0 || m < 0 || C < 0)
+        return fail(GPFQ_ERR_INVALID_ARG, "negative size N=%lld m=%lld C=%lld", (long long)N, (long long)m, (long long)C);
+    gpfq::AlphabetArg A;
+    int rc = make_alphabet(alphabet, M, zero_idx, &A);
+    if (rc != GPFQ_OK) return rc;
+    if (C == 0) return GPFQ_OK;
+    if (N > GPFQ_GRAM_MAX_N) return fail(GPFQ_ERR_UNSUPPORTED, "Gram path needs N <= %d (got %lld)", GPFQ_GRAM_MAX_N, (long long)N);
+    if (m >= (1LL << 30)) return fail(GPFQ_ERR_UNSUPPORTED, "Gram path needs m < 2^30 (error-bound derivation)");
+    if (!uncertified) return fail(GPFQ_ERR_INVALID_ARG, "uncertified is NULL");
+    if (N > 0 && (!Wt || !nrm32)) return fail(GPFQ_ERR_INVALID_ARG, "Wt/nrm32 is NULL");
+    if (N > 0 && m > 0 && (!X || !Xq)) return fail(GPFQ_ERR_INVALID_ARG, "X/Xq is NULL");
+    if (ld < m) return fail(GPFQ_ERR_INVALID_ARG, "row pitch ld=%lld < m=%lld", (long long)ld, (long long)m);
+    if (ldw < N) return fail(GPFQ_ERR_INVALID_ARG, "weight pitch ldw=%lld < N=%lld", (long long)ldw, (long long)N);
+    const size_t need = gpfq::gram_workspace_bytes(N, m, C);
+    if (!workspace || workspace_bytes < need || (uintptr_t)workspace % 16 != 0)
+        return fail(GPFQ_ERR_WORKSPACE, "Gram path needs %zu aligned workspace bytes", need);
+    gpfq::GramArgs a;
+    a.X = X; a.Xq = Xq; a.ld = ld; a.nrm32 = nrm32; a.Wt = Wt; a.ldw = ldw; a.A = A;
+    a.N = N; a.m = m; a.C = C; a.qidx = qidx; a.Qt = Qt; a.resid = resid; a.uncertified = uncertified;
+    a.workspace = workspace;
+    a.nrm32_out = compute_norms ? nrm32 : nullptr;
+    a.slack = std::ldexp(1.0, g_gram_slack_log2);
+    hipError_t e = gpfq::launch_gram(a, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_neurons_gram");
 }
 
 int gpfq_msq_round(const float *W, int64_t n, const double *alphabet, int M, float *Q, int8_t *qidx, void *stream)

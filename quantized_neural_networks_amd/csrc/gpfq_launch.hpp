@@ -62,6 +62,26 @@ hipError_t launch_rows(const OnchipArgs &a, int lpn, hipStream_t stream);
 size_t stream_workspace_bytes(int64_t N, int64_t m, int64_t C, bool need_u);
 hipError_t launch_stream(const StreamArgs &a, hipStream_t stream);
 
+struct GramArgs {
+    const float *X, *Xq;
+    int64_t ld;
+    const float *nrm32;
+    float *nrm32_out = nullptr;   // non-NULL: fill the row norms from the Gram diagonal first (nrm32 == nrm32_out)
+    const float *Wt;
+    int64_t ldw;
+    AlphabetArg A;
+    int64_t N, m, C;
+    int8_t *qidx;
+    float *Qt;
+    double *resid;          // may be NULL (skips the exact replay of the residual)
+    int32_t *uncertified;   // [C]: 1 = decision chain not certified, rerun through the exact path
+    void *workspace;
+    double slack = 1.0;     // multiplies the error bounds (tests)
+};
+
+size_t gram_workspace_bytes(int64_t N, int64_t m, int64_t C);
+hipError_t launch_gram(const GramArgs &a, hipStream_t stream);
+
 hipError_t launch_row_stats(const float *X, const float *Xq, int64_t N, int64_t m, int64_t ld, const float *nrm32,
                             RowStats *stats, hipStream_t stream);
 hipError_t launch_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, float *nrm32, hipStream_t stream);

@@ -12,6 +12,8 @@ import torch
 from . import build as _build
 
 GPFQ_PATH_AUTO, GPFQ_PATH_ONCHIP, GPFQ_PATH_STREAM = 0, 1, 2
+GPFQ_PATH_GRAM = 3                 # binding-level selector: gpfq_quantize_neurons_gram + exact rerun of flagged neurons
+GPFQ_GRAM_AUTO_MAX_N = 64          # AUTO takes the Gram path for walks this short over rows longer than GPFQ_ONCHIP_MAX_M
 GPFQ_MAX_ALPHABET = 64
 GPFQ_ONCHIP_MAX_M = 2048
 
@@ -27,6 +29,9 @@ SYMBOLS = {
     "gpfq_set_option": (_int, [ctypes.c_char_p, _int]),
     "gpfq_quantize_neurons": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _int, _int, _i64, _i64, _i64,
                                      _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp]),
+    "gpfq_gram_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "gpfq_quantize_neurons_gram": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _i64, _dp, _int, _int, _i64, _i64, _i64,
+                                          _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpfq_msq_round": (_int, [_vp, _i64, _dp, _int, _vp, _vp, _vp]),
     "gpfq_assemble_kernel": (_int, [_vp, _dp, _int, _i64, _i64, _vp, _vp, _vp]),
     "gpfq_median_abs_workspace_bytes": (_sz, []),
@@ -125,6 +130,9 @@ def quantize_neurons(X, Xq, Wt, alphabet, nrm32=None, want_u=False, path=GPFQ_PA
         raise GpfqError("X and Xq must share one row pitch")
     arr, M, zero_idx = _alphabet(alphabet)
     dev = X.device
+    if path == GPFQ_PATH_GRAM or (path == GPFQ_PATH_AUTO and not want_u and m > GPFQ_ONCHIP_MAX_M
+                                  and N <= GPFQ_GRAM_AUTO_MAX_N):
+        return _quantize_neurons_gram(X, Xq, Wt, alphabet, nrm32, want_values)
     if nrm32 is None:
         nrm32 = row_norms(Xq)
     _dev(nrm32, torch.float32, "nrm32")
@@ -144,6 +152,37 @@ def quantize_neurons(X, Xq, Wt, alphabet, nrm32=None, want_u=False, path=GPFQ_PA
     _check(rc, "gpfq_quantize_neurons")
     # on-chip path: the first 8 workspace bytes count decisions re-derived exactly (diagnostics)
     return dict(idx=idx, Q=Q, resid=resid, u=u if want_u else None, workspace=None if streaming else ws)
+
+
+def _quantize_neurons_gram(X, Xq, Wt, alphabet, nrm32, want_values=True):
+    """Gram-matrix path (short walks over long rows) + exact rerun of the uncertified neurons."""
+    xp, N, m, ld = _rows(X, "X")
+    xqp, _, _, _ = _rows(Xq, "Xq")
+    wp, C, _, ldw = _rows(Wt, "Wt")
+    arr, M, zero_idx = _alphabet(alphabet)
+    dev = X.device
+    lib = load()
+    idx = torch.empty((C, N), dtype=torch.int8, device=dev)
+    Q = torch.empty((C, N), dtype=torch.float32, device=dev)
+    resid = torch.empty(C, dtype=torch.float64, device=dev)
+    unc = torch.empty(C, dtype=torch.int32, device=dev)
+    compute_norms = nrm32 is None            # the row norms are the Gram diagonal: no separate pass
+    if compute_norms:
+        nrm32 = torch.empty(N, dtype=torch.float32, device=dev)
+    _dev(nrm32, torch.float32, "nrm32")
+    nbytes = lib.gpfq_gram_workspace_bytes(N, m, C)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gpfq_quantize_neurons_gram(xp, xqp, ld, nrm32.data_ptr(), 1 if compute_norms else 0, wp, ldw, arr, M, zero_idx, N, m, C,
+                                            idx.data_ptr(), Q.data_ptr(), resid.data_ptr(), unc.data_ptr(),
+                                            ws.data_ptr(), nbytes, _stream())
+    _check(rc, "gpfq_quantize_neurons_gram")
+    bad = torch.nonzero(unc).flatten()                    # one sync per call
+    if bad.numel():
+        r2 = quantize_neurons(X, Xq, Wt[bad].contiguous(), alphabet, nrm32=nrm32, path=GPFQ_PATH_STREAM)
+        idx[bad], Q[bad], resid[bad] = r2["idx"], r2["Q"], r2["resid"]
+    return dict(idx=idx, Q=Q if want_values else None, resid=resid, u=None, workspace=None,
+                uncertified=int(bad.numel()))
 
 
 def exact_fallbacks(result):

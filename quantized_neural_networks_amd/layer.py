@@ -129,11 +129,16 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
     c_lo, c_hi = shard_bounds(Cin, world, rank) if by_channel else (0, Cin)
     f_lo, f_hi = (0, F) if by_channel else shard_bounds(F, world, rank)
     Pw = Pq = None
+    # channel-major copies [Cin][n][H][W] of this rank's channels: the per-channel gather then reads
+    # contiguous planes instead of one float out of every Cin (one transposing pass per layer)
+    same = act_q is act_w
+    cm_w = act_w[..., c_lo:c_hi].permute(3, 0, 1, 2).contiguous()
+    cm_q = cm_w if same else act_q[..., c_lo:c_hi].permute(3, 0, 1, 2).contiguous()
     for c in range(c_lo, c_hi):
         if f_hi <= f_lo:
             break
-        Pw = _extract_patches(act_w, c, (kh, kw), strides, rate, padding, out=Pw)
-        Pq = _extract_patches(act_q, c, (kh, kw), strides, rate, padding, out=Pq)
+        Pw = _extract_patches(cm_w[c - c_lo].unsqueeze(-1), 0, (kh, kw), strides, rate, padding, out=Pw)
+        Pq = Pw if same else _extract_patches(cm_q[c - c_lo].unsqueeze(-1), 0, (kh, kw), strides, rate, padding, out=Pq)
         # row-major flattening of the kh x kw filter (:215): weight t = (ky, kx) = divmod(t, kw)
         Wt = W[:, :, c, f_lo:f_hi].reshape(K, f_hi - f_lo).t().contiguous()
         r = _local_quantize(Pw, Pq, Wt, alphabet)
