@@ -1,0 +1,97 @@
+"""Single-GPU timings of the BASELINE.json configs other than the headline (parity-test cases, not
+bench lines): cfg1 MNIST MLP layer, cfg3 VGG16 fc2/fc1, cfg4 CIFAR10 CNN conv + dense layers, with
+synthetic activations of the right shapes.  Writes profiles/r01/configs.json.
+
+    python tools/bench_configs.py [--skip-fc1]
+"""
+import json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from quantized_neural_networks_amd import hip, layer
+import oracle
+
+
+def synthetic(N, m, C, dev):
+    W = (np.random.default_rng(0).standard_normal((N, C)) / np.sqrt(N)).astype(np.float32)
+    g = torch.Generator(device=dev).manual_seed(1)
+    G = torch.randn((N, m), device=dev, generator=g)
+    X = torch.relu(G)
+    Xq = torch.relu(G + 0.1 * torch.randn((N, m), device=dev, generator=g))
+    return W, X, Xq
+
+
+def time_dense(name, N, m, C, bits, scalar, dev, check=8):
+    W, X, Xq = synthetic(N, m, C, dev)
+    Wd = torch.from_numpy(W).to(dev)
+    unit = np.linspace(-1, 1, int(round(2 ** bits)))
+    best = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        alphabet, rad = layer.layer_alphabet(Wd, unit, scalar)
+        out = layer.quantize_dense(Wd, X, Xq, alphabet)
+        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+    # parity of a few neurons against the oracle on the same tensors
+    Xh, Xqh = X.cpu().numpy(), Xq.cpu().numpy()
+    _, io, ro = oracle.layer(W, Xh, Xqh, alphabet, 0, check)
+    bad = int((out["idx"][:, :check].t().cpu().numpy() != io).any(axis=1).sum())
+    rel = float(np.max(np.abs(out["resid"][:check].cpu().numpy() - ro) / ro))
+    rec = dict(config=name, kind="dense", N=N, m=m, C=C, M=len(unit), ms=best * 1e3, weights_per_s=N * C / best,
+               algorithmic_GBps=N * C * (8 * m + 8) / best / 1e9, neurons_checked=check,
+               neurons_with_index_mismatch=bad, max_resid_rel_err=rel)
+    print(json.dumps(rec), flush=True)
+    return rec
+
+
+def time_conv(name, cin, cout, hw, n, bits, scalar, dev, check=2):
+    g = torch.Generator(device=dev).manual_seed(2)
+    act_w = torch.rand((n, hw, hw, cin), device=dev, generator=g)
+    act_q = torch.relu(act_w + 0.05 * torch.randn((n, hw, hw, cin), device=dev, generator=g))
+    W = torch.randn((3, 3, cin, cout), device=dev, generator=g) / 3
+    unit = np.linspace(-1, 1, int(round(2 ** bits)))
+    best = 1e9
+    for _ in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        alphabet, rad = layer.layer_alphabet(W, unit, scalar)
+        out = layer.quantize_conv2d(W, act_w, act_q, alphabet, strides=(1, 1), padding="SAME", rate=(1, 1))
+        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+    # parity: channel 0, first `check` filters, oracle on the GPU-built patch matrices
+    Pw = hip.extract_patches(act_w, 0, (3, 3), (1, 1), (1, 1), "SAME").cpu().numpy()
+    Pq = hip.extract_patches(act_q, 0, (3, 3), (1, 1), (1, 1), "SAME").cpu().numpy()
+    Wh = W.cpu().numpy()
+    bad = 0
+    for f in range(check):
+        q, _, _ = oracle.neuron(Wh[:, :, 0, f].reshape(-1), Pw, Pq, alphabet)
+        bad += int(not np.array_equal(out["Q"][:, :, 0, f].cpu().numpy().reshape(-1), q.astype(np.float32)))
+    m = n * hw * hw
+    rec = dict(config=name, kind="conv3x3", Cin=cin, Cout=cout, m=m, M=len(unit), ms=best * 1e3,
+               weights_per_s=9 * cin * cout / best, filters_checked=check, filters_with_mismatch=bad)
+    print(json.dumps(rec), flush=True)
+    return rec
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    recs = []
+    recs.append(time_dense("cfg1 MNIST MLP Dense(784->128), m=512, 4-bit, scalar 5", 784, 512, 128, 4, 5, dev))
+    recs.append(time_dense("cfg2 Dense(4096->4096), m=1024, ternary, scalar 3 (layer driver incl. median/assemble)", 4096, 1024, 4096, np.log2(3), 3, dev))
+    recs.append(time_dense("cfg3 VGG16 fc2 Dense(4096->4096), m=2048, 4-bit, scalar 5", 4096, 2048, 4096, 4, 5, dev))
+    if "--skip-fc1" not in sys.argv:
+        recs.append(time_dense("cfg3 VGG16 fc1 Dense(25088->4096), m=2048, 4-bit, scalar 5", 25088, 2048, 4096, 4, 5, dev, check=4))
+    recs.append(time_dense("cfg3 VGG16 predictions Dense(4096->1000), m=2048, 4-bit, scalar 5", 4096, 2048, 1000, 4, 5, dev))
+    total = 0.0
+    for idx, (cin, cout, hw) in {0: (3, 32, 32), 2: (32, 32, 32), 6: (32, 64, 16), 8: (64, 64, 16), 12: (64, 128, 8), 14: (128, 128, 8)}.items():
+        r = time_conv(f"cfg4 CIFAR10 CNN conv layer {idx} ({cin}->{cout} @{hw}x{hw}), 5008 images, 3-bit, scalar 4", cin, cout, hw, 5008, 3, 4, dev)
+        total += r["ms"]; recs.append(r)
+    for name, N, C in [("cfg4 CIFAR10 CNN Dense(2048->128), m=5008", 2048, 128), ("cfg4 CIFAR10 CNN Dense(128->10), m=5008", 128, 10)]:
+        r = time_dense(name + ", 3-bit, scalar 4", N, 5008, C, 3, 4, dev, check=4)
+        total += r["ms"]; recs.append(r)
+    recs.append(dict(config="cfg4 CIFAR10 CNN, all 6 conv + 2 dense layers (quantization only, synthetic activations)", ms=total))
+    print(json.dumps(recs[-1]))
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(dict(note="tools/bench_configs.py on one MI355X; best of 2-3 runs per layer; whole layer driver "
+                        "(median, norms, kernel, assemble) with inputs resident in HBM", records=recs),
+              open("gpurun_out/configs.json", "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
