@@ -229,6 +229,13 @@ class DepthwiseConv2D(Conv2D):
 
 
 class Flatten(Layer):
+    def __init__(self, input_shape=None, name=None):
+        super().__init__(name)
+        self._decl = tuple(input_shape) if input_shape is not None else None
+
+    def config(self):
+        return dict(input_shape=self._decl)
+
     def compute_output_shape(self, s):
         return (s[0], int(np.prod(s[1:])))
 
