@@ -58,10 +58,10 @@ extern "C" {
 
 /* gpfq_quantize_neurons `path` selector */
 #define GPFQ_PATH_AUTO      0   /* on-chip residual when m fits a wavefront's registers, else streaming */
-#define GPFQ_PATH_ONCHIP    1   /* residual u lives in VGPRs, rows staged through LDS (m <= GPFQ_ONCHIP_MAX_M) */
+#define GPFQ_PATH_ONCHIP    1   /* residual u lives in VGPRs (of up to 16 wavefronts per neuron), rows staged through LDS (m <= GPFQ_ONCHIP_MAX_M) */
 #define GPFQ_PATH_STREAM    2   /* residual u lives in HBM (any m; conv patch matrices)          */
 
-#define GPFQ_ONCHIP_MAX_M 2048
+#define GPFQ_ONCHIP_MAX_M 16384
 
 int         gpfq_version(void);
 const char *gpfq_last_error(void);
@@ -91,6 +91,7 @@ size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path);
  *   "lanes_per_neuron"  0 = heuristic, 16/32/64 = row-group kernel with that many lanes per neuron,
  *                  1 = wave-per-neuron kernel
  *   "variant"      bit 0: row-group kernel without the float64 copy of Xq in LDS
+ *   "waves_per_neuron"  2..16: force the wide kernel (one neuron over that many wavefronts), 0 = only for m > 2048
  */
 int gpfq_set_option(const char *key, int value);
 

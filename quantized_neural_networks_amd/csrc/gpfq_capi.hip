@@ -101,6 +101,7 @@ static int g_tile_steps = 0;       // 0 = heuristic
 static int g_group_waves = 0;      // 0 = heuristic
 static int g_lpn = 0;              // 0 = heuristic, 1 = wave-per-neuron kernel, 16/32/64 = row-group kernel
 static int g_gram_slack_log2 = 0;  // Gram path: error bounds multiplied by 2^this (tests force the uncertified branch)
+static int g_wpn = 0;              // wide kernel: wavefronts per neuron (0 = heuristic: only for rows > 2048)
 static int g_variant = 0;          // bit 0: row-group kernel without the float64 copy of Xq in LDS
 
 int gpfq_set_option(const char *key, int value)
@@ -116,6 +117,10 @@ int gpfq_set_option(const char *key, int value)
         g_group_waves = value; return GPFQ_OK;
     }
     if (!std::strcmp(key, "variant")) { g_variant = value; return GPFQ_OK; }
+    if (!std::strcmp(key, "waves_per_neuron")) {
+        if (value < 0 || value > 16) return fail(GPFQ_ERR_INVALID_ARG, "waves_per_neuron must be in [0, 16]");
+        g_wpn = value; return GPFQ_OK;
+    }
     if (!std::strcmp(key, "gram_slack_log2")) { g_gram_slack_log2 = value; return GPFQ_OK; }
     if (!std::strcmp(key, "lanes_per_neuron")) {
         if (value != 0 && value != 1 && value != 16 && value != 32 && value != 64)
@@ -156,6 +161,7 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
         a.ts_override = g_tile_steps; a.nw_override = g_group_waves;
         a.mode = g_onchip_mode;
         a.lpn = g_lpn;
+        a.wpn = g_wpn;
         a.variant = g_variant;
         // certified mode needs the per-row statistics in the workspace; without one, run the exact flow
         const bool have_ws = workspace && workspace_bytes >= onchip_workspace_bytes(N) && (uintptr_t)workspace % 16 == 0;

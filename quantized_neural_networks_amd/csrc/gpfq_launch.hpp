@@ -26,6 +26,7 @@ struct OnchipArgs {
     unsigned long long *fallback_count = nullptr;
     int mode = 0;          // 0 = exact flow, 1 = certified (needs stats)
     int lpn = 0;           // lanes per neuron of the row-group kernel: 16/32/64, 1 = wave kernel, 0 = heuristic
+    int wpn = 0;           // wavefronts per neuron of the wide kernel (forced split), 0 = heuristic
     const float *Wt;
     int64_t ldw;
     AlphabetArg A;
@@ -58,6 +59,7 @@ struct StreamArgs {
 hipError_t launch_onchip(const OnchipArgs &a, hipStream_t stream);
 bool rows_supported(const OnchipArgs &a, int lpn);
 hipError_t launch_rows(const OnchipArgs &a, int lpn, hipStream_t stream);
+hipError_t launch_wide(const OnchipArgs &a, int W, hipStream_t stream);
 
 size_t stream_workspace_bytes(int64_t N, int64_t m, int64_t C, bool need_u);
 hipError_t launch_stream(const StreamArgs &a, hipStream_t stream);

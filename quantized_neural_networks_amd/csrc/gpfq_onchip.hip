@@ -293,6 +293,17 @@ static hipError_t launch_mode(const OnchipArgs &a, hipStream_t stream)
 
 hipError_t launch_onchip(const OnchipArgs &a, hipStream_t stream)
 {
+    // rows too long for one wavefront (or a forced split): one neuron over several wavefronts
+    // ... or a layer too narrow to fill the chip with one or two neurons per wavefront: its steps are
+    // latency-bound, and splitting a neuron over 2-4 wavefronts shortens them (tools/sweep_wide.py:
+    // C = 512, m = 1024: 1.41 -> 1.11 ms per 1024 steps; m = 2048: 2.57 -> 1.45 ms)
+    const bool narrow = a.wpn == 0 && a.lpn == 0 && a.m >= 512 && a.C <= 1024;
+    if (a.wpn > 1 || a.m > 2048 || narrow) {
+        int W = a.wpn > 1 ? a.wpn : (int)((a.m + 1023) / 1024);
+        if (narrow && a.m <= 2048) W = a.C > 512 ? 2 : 4;
+        while ((a.m + 64 * (int64_t)W - 1) / (64 * (int64_t)W) > 16) ++W;
+        return launch_wide(a, W, stream);
+    }
     if (a.mode == MODE_CERTIFIED && a.stats) {
         int lpn = a.lpn;
         if (lpn == 0) lpn = 32;                      // measured best on cfg2/cfg3-like layers (tools/sweep_shapes.py)

@@ -1,0 +1,217 @@
+// "Wide" on-chip GPFQ kernel: one neuron spread over W wavefronts of a workgroup.
+//
+// Same recurrence and numerics as gpfq_onchip_kernel<EPL, MODE_EXACT> (the reference's verbatim
+// flow, scripts/quantized_network.py:59-121), for the two situations the one-wave-per-neuron layouts
+// handle badly:
+//   * rows longer than one wavefront's registers (2048 < m <= 16384): the residual still never
+//     leaves the chip, instead of streaming u through HBM with two launches per step;
+//   * narrow layers / small shards (C of a few hundred): the element sweeps of one step are split
+//     over W waves, so the per-step latency -- which is all that matters when the chip is not full --
+//     shrinks.
+// Each wave owns 64*EPL consecutive elements of u, forms its share of the two dot products, and the
+// W partial pairs meet in LDS with ONE workgroup barrier per step (slots alternate by step parity);
+// every wave then takes the (identical) decision itself and updates its own elements.
+#include "gpfq_device.hpp"
+#include "gpfq_launch.hpp"
+
+namespace gpfq {
+
+template <int EPL>
+__device__ __forceinline__ void wide_read_row(const float *row, int lane, float (&dst)[EPL])
+{
+    constexpr int VW = EPL >= 4 ? 4 : EPL;
+#pragma unroll
+    for (int c = 0; c < EPL / VW; ++c) {
+        const float *p = row + 64 * VW * c + VW * lane;
+        if constexpr (VW == 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(p);
+            dst[4 * c + 0] = v.x; dst[4 * c + 1] = v.y; dst[4 * c + 2] = v.z; dst[4 * c + 3] = v.w;
+        } else if constexpr (VW == 2) {
+            const float2 v = *reinterpret_cast<const float2 *>(p);
+            dst[2 * c + 0] = v.x; dst[2 * c + 1] = v.y;
+        } else {
+            dst[c] = *p;
+        }
+    }
+}
+
+template <int EPL>
+__global__ void __launch_bounds__(1024)
+gpfq_wide_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld,
+                 const float *__restrict__ nrm32, const float *__restrict__ Wt, int64_t ldw,
+                 AlphabetArg A, int64_t N, int m, int64_t C, int TS, int W, int G, int vec4,
+                 int8_t *__restrict__ qidx, float *__restrict__ Qt,
+                 double *__restrict__ resid, double *__restrict__ u_out)
+{
+    constexpr int VW = EPL >= 4 ? 4 : EPL;
+    const int MP = 64 * EPL * W;                        // padded row length covered by a neuron's W waves
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *ldsX  = lds;                                  // [TS][MP]
+    float *ldsXq = lds + (size_t)TS * MP;                // [TS][MP]
+    double *red  = reinterpret_cast<double *>(lds + (size_t)2 * TS * MP);   // [2][G][W][2]
+
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave / W, part = wave - g * W;         // neuron within the workgroup, slice of the row
+    const int64_t j = (int64_t)blockIdx.x * G + g;
+    const bool active = j < C;                            // inactive waves still walk (barriers) but write nothing
+    const float *__restrict__ wrow = Wt + (active ? j : 0) * ldw;
+
+    const double a_lane = alphabet_lane(A, lane);
+    const bool ascending = A.ascending != 0;
+
+    double u[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) u[e] = 0.0;            // zeros(m), :115
+    int   my_idx = 0;
+    float my_q   = 0.f;
+
+    float w_next = 0.f, nrm_next = 0.f;
+    if (N > 0) { w_next = wrow[0]; nrm_next = nrm32[0]; }
+
+    const int total4 = TS * (MP / 4);
+    const int rot = (int)((blockIdx.x * 331u) % (unsigned)(total4 > 0 ? total4 : 1));   // see gpfq_rows.hip
+
+    for (int64_t t0 = 0; t0 < N; t0 += TS) {
+        __syncthreads();                                  // previous tile fully consumed
+        if (vec4) {
+            const int Q = MP / 4;
+            for (int idx0 = tid; idx0 < total4; idx0 += nthreads) {
+                int idx = idx0 + rot;
+                if (idx >= total4) idx -= total4;
+                const int s = idx / Q, i4 = (idx - s * Q) * 4;
+                float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vq = vx;
+                if (t0 + s < N && i4 < m) {
+                    vx = *reinterpret_cast<const float4 *>(X  + (t0 + s) * ld + i4);
+                    vq = *reinterpret_cast<const float4 *>(Xq + (t0 + s) * ld + i4);
+                }
+                *reinterpret_cast<float4 *>(ldsX  + (size_t)s * MP + i4) = vx;
+                *reinterpret_cast<float4 *>(ldsXq + (size_t)s * MP + i4) = vq;
+            }
+        } else {
+            for (int idx = tid; idx < TS * MP; idx += nthreads) {
+                const int s = idx / MP, i = idx - s * MP;
+                float vx = 0.f, vq = 0.f;
+                if (t0 + s < N && i < m) { vx = X[(t0 + s) * ld + i]; vq = Xq[(t0 + s) * ld + i]; }
+                ldsX[idx] = vx;
+                ldsXq[idx] = vq;
+            }
+        }
+        __syncthreads();
+
+        const int ts = (int)((N - t0) < TS ? (N - t0) : TS);
+        for (int s = 0; s < ts; ++s) {
+            const int64_t t = t0 + s;
+            const float w = w_next, nrm = nrm_next;
+            if (t + 1 < N) { w_next = wrow[t + 1]; nrm_next = nrm32[t + 1]; }
+
+            float x[EPL], xq[EPL];
+            const size_t off = (size_t)s * MP + (size_t)part * 64 * EPL;
+            wide_read_row<EPL>(ldsXq + off, lane, xq);
+            wide_read_row<EPL>(ldsX + off, lane, x);
+
+            // this wave's share of <Xq_t, u> (:86) and <Xq_t, u + f32(w*X_t)> (:89)
+            double d0a = 0.0, d0b = 0.0, d1a = 0.0, d1b = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const float p = __fmul_rn(w, x[e]);
+                const double xd = (double)xq[e];
+                const double v  = u[e] + (double)p;
+                if (e & 1) { d0b = fma(xd, u[e], d0b); d1b = fma(xd, v, d1b); }
+                else       { d0a = fma(xd, u[e], d0a); d1a = fma(xd, v, d1a); }
+            }
+            double dot_u, dot_uw;
+            wave_sum2(d0a + d0b, d1a + d1b, dot_u, dot_uw);
+            // the W shares meet in LDS; slots alternate with the step parity so one barrier suffices
+            double *slot = red + ((size_t)(t & 1) * G + g) * W * 2;
+            if (lane == 0) { slot[2 * part] = dot_u; slot[2 * part + 1] = dot_uw; }
+            __syncthreads();
+            dot_u = 0.0; dot_uw = 0.0;
+            for (int p2 = 0; p2 < W; ++p2) { dot_u += slot[2 * p2]; dot_uw += slot[2 * p2 + 1]; }   // fixed order
+
+            const Decision dec = decide(w, nrm, dot_u, dot_uw, a_lane, A.M, A.zero_idx, ascending);
+
+            // u += w*X_t - q*Xq_t  (:119)
+            const float q32 = (float)dec.q;
+            if (q32 == 0.0f) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) u[e] += (double)__fmul_rn(w, x[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e)
+                    u[e] += (double)__fsub_rn(__fmul_rn(w, x[e]), __fmul_rn(q32, xq[e]));
+            }
+
+            if (lane == (int)(t & 63)) { my_idx = dec.idx; my_q = q32; }
+            if (((t + 1) & 63) == 0 || t + 1 == N) {
+                const int64_t base = t & ~(int64_t)63;
+                if (active && part == 0 && lane <= (int)(t & 63)) {
+                    if (qidx) qidx[j * N + base + lane] = (int8_t)my_idx;
+                    if (Qt)   Qt[j * N + base + lane]   = my_q;
+                }
+            }
+        }
+    }
+
+    if (resid) {
+        double ss = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) ss = fma(u[e], u[e], ss);
+        ss = wave_sum(ss);
+        __syncthreads();                                  // all step slots consumed
+        if (lane == 0) red[(size_t)g * W + part] = ss;
+        __syncthreads();
+        if (active && part == 0 && lane == 0) {
+            double s2 = 0.0;
+            for (int p2 = 0; p2 < W; ++p2) s2 += red[(size_t)g * W + p2];
+            resid[j] = sqrt(s2);
+        }
+    }
+    if (u_out && active) {
+#pragma unroll
+        for (int c = 0; c < EPL / VW; ++c)
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                const int i = part * 64 * EPL + 64 * VW * c + VW * lane + e;
+                if (i < m) u_out[j * (int64_t)m + i] = u[c * VW + e];
+            }
+    }
+}
+
+template <int EPL>
+static hipError_t launch_wide_epl(const OnchipArgs &a, int W, hipStream_t stream)
+{
+    const int MP = 64 * EPL * W;
+    int G = 16 / W;                                       // neurons per workgroup (<= 16 wavefronts)
+    if (G < 1) G = 1;
+    while (G > 1 && (a.C + G - 1) / G < 256) G >>= 1;     // narrow layers: spread the neurons over the CUs
+    int ts = 16;
+    while (ts > 1 && (size_t)2 * ts * MP * sizeof(float) > 96 * 1024) ts >>= 1;
+    if (a.ts_override > 0 && (size_t)2 * a.ts_override * MP * sizeof(float) <= 150 * 1024) ts = a.ts_override;
+    const size_t lds_bytes = (size_t)2 * ts * MP * sizeof(float) + (size_t)2 * G * W * 2 * sizeof(double);
+    const bool vec4 = (a.ld % 4 == 0) && (a.m % 4 == 0) && ((uintptr_t)a.X % 16 == 0) && ((uintptr_t)a.Xq % 16 == 0);
+    const unsigned grid = (unsigned)((a.C + G - 1) / G);
+    hipError_t e = hipFuncSetAttribute((const void *)gpfq_wide_kernel<EPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((gpfq_wide_kernel<EPL>), dim3(grid), dim3(64 * W * G), lds_bytes, stream,
+                       a.X, a.Xq, a.ld, a.nrm32, a.Wt, a.ldw, a.A, a.N, (int)a.m, a.C, ts, W, G, vec4 ? 1 : 0,
+                       a.qidx, a.Qt, a.resid, a.u_out);
+    return hipGetLastError();
+}
+
+// W = wavefronts per neuron (2..16); elements per lane follow from m.
+hipError_t launch_wide(const OnchipArgs &a, int W, hipStream_t stream)
+{
+    if (W < 1) W = 1;
+    if (W > 16) W = 16;
+    const int64_t per_lane = (a.m + 64 * (int64_t)W - 1) / (64 * (int64_t)W);
+    if (per_lane <= 1)  return launch_wide_epl<1>(a, W, stream);
+    if (per_lane <= 2)  return launch_wide_epl<2>(a, W, stream);
+    if (per_lane <= 4)  return launch_wide_epl<4>(a, W, stream);
+    if (per_lane <= 8)  return launch_wide_epl<8>(a, W, stream);
+    if (per_lane <= 16) return launch_wide_epl<16>(a, W, stream);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace gpfq

@@ -15,7 +15,7 @@ GPFQ_PATH_AUTO, GPFQ_PATH_ONCHIP, GPFQ_PATH_STREAM = 0, 1, 2
 GPFQ_PATH_GRAM = 3                 # binding-level selector: gpfq_quantize_neurons_gram + exact rerun of flagged neurons
 GPFQ_GRAM_AUTO_MAX_N = 64          # AUTO takes the Gram path for walks this short over rows longer than GPFQ_ONCHIP_MAX_M
 GPFQ_MAX_ALPHABET = 64
-GPFQ_ONCHIP_MAX_M = 2048
+GPFQ_ONCHIP_MAX_M = 16384
 
 # every symbol include/gpfq.h declares: (restype, argtypes)
 _i64, _int, _vp, _sz = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
