@@ -229,6 +229,7 @@ int gpfq_quantize_neurons_gram(const float *X, const float *Xq, int64_t ld, floa
     a.workspace = workspace;
     a.nrm32_out = compute_norms ? nrm32 : nullptr;
     a.slack = std::ldexp(1.0, g_gram_slack_log2);
+    a.variant = g_variant;
     hipError_t e = gpfq::launch_gram(a, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_neurons_gram");
 }

@@ -36,11 +36,12 @@ __global__ void __launch_bounds__(kGramThreads)
 gpfq_gram_tile_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int N, int64_t m,
                       int64_t nchunks, double *__restrict__ part)
 {
-    __shared__ float lqt[4 * TB][kGramCH];
-    __shared__ float lxs[SB][kGramCH];
-    __shared__ float lqs[SB][kGramCH];
+    __shared__ __attribute__((aligned(16))) float lqt[4 * TB][kGramCH];
+    __shared__ __attribute__((aligned(16))) float lxs[SB][kGramCH];
+    __shared__ __attribute__((aligned(16))) float lqs[SB][kGramCH];
     const int t0 = blockIdx.y * 4 * TB, s0 = blockIdx.z * SB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = (ld % 4 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)Xq % 16 == 0);
     double acc[TB][SB][4];
 #pragma unroll
     for (int a = 0; a < TB; ++a)
@@ -52,39 +53,51 @@ gpfq_gram_tile_kernel(const float *__restrict__ X, const float *__restrict__ Xq,
     for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
         const int64_t c0 = ch * kGramCH;
         __syncthreads();
-        for (int idx = threadIdx.x; idx < (4 * TB + 2 * SB) * kGramCH; idx += kGramThreads) {
-            const int r = idx / kGramCH, c = idx - r * kGramCH;
+        // stage the 4*TB + 2*SB row segments as 16-byte pieces (zero beyond N / m)
+        for (int idx = threadIdx.x; idx < (4 * TB + 2 * SB) * (kGramCH / 4); idx += kGramThreads) {
+            const int r = idx / (kGramCH / 4), c = (idx - r * (kGramCH / 4)) * 4;
             const int64_t col = c0 + c;
-            float v = 0.f;
-            if (r < 4 * TB) {
-                const int t = t0 + r;
-                if (t < N && col < m) v = Xq[(int64_t)t * ld + col];
-                lqt[r][c] = v;
-            } else if (r < 4 * TB + SB) {
-                const int sidx = s0 + r - 4 * TB;
-                if (sidx < N && col < m) v = X[(int64_t)sidx * ld + col];
-                lxs[r - 4 * TB][c] = v;
-            } else {
-                const int sidx = s0 + r - 4 * TB - SB;
-                if (sidx < N && col < m) v = Xq[(int64_t)sidx * ld + col];
-                lqs[r - 4 * TB - SB][c] = v;
+            const float *src;
+            float *dst;
+            int row;
+            if (r < 4 * TB)           { row = t0 + r;               src = Xq; dst = &lqt[r][c]; }
+            else if (r < 4 * TB + SB) { row = s0 + r - 4 * TB;      src = X;  dst = &lxs[r - 4 * TB][c]; }
+            else                      { row = s0 + r - 4 * TB - SB; src = Xq; dst = &lqs[r - 4 * TB - SB][c]; }
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < N && col < m) {
+                const float *g = src + (int64_t)row * ld + col;
+                if (vec && col + 4 <= m) v = *reinterpret_cast<const float4 *>(g);
+                else {
+                    v.x = g[0];
+                    if (col + 1 < m) v.y = g[1];
+                    if (col + 2 < m) v.z = g[2];
+                    if (col + 3 < m) v.w = g[3];
+                }
             }
+            *reinterpret_cast<float4 *>(dst) = v;
         }
         __syncthreads();
-        for (int c = lane; c < kGramCH; c += 64) {
-            double qt[TB], qta[TB];
+        // lane l feeds columns 4l..4l+3 of the chunk: one 16-byte LDS read per row
+        float4 qt4[TB];
 #pragma unroll
-            for (int a = 0; a < TB; ++a) { qt[a] = (double)lqt[wave * TB + a][c]; qta[a] = fabs(qt[a]); }
+        for (int a = 0; a < TB; ++a) qt4[a] = *reinterpret_cast<const float4 *>(&lqt[wave * TB + a][4 * lane]);
 #pragma unroll
-            for (int s = 0; s < SB; ++s) {
-                const double xs = (double)lxs[s][c], qs = (double)lqs[s][c];
+        for (int s = 0; s < SB; ++s) {
+            const float4 xs4 = *reinterpret_cast<const float4 *>(&lxs[s][4 * lane]);
+            const float4 qs4 = *reinterpret_cast<const float4 *>(&lqs[s][4 * lane]);
+            const float xsv[4] = {xs4.x, xs4.y, xs4.z, xs4.w}, qsv[4] = {qs4.x, qs4.y, qs4.z, qs4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double xs = (double)xsv[e], qs = (double)qsv[e];
                 const double xsa = fabs(xs), qsa = fabs(qs);
 #pragma unroll
                 for (int a = 0; a < TB; ++a) {
-                    acc[a][s][0] = fma(qt[a], xs, acc[a][s][0]);
-                    acc[a][s][1] = fma(qt[a], qs, acc[a][s][1]);
-                    acc[a][s][2] = fma(qta[a], xsa, acc[a][s][2]);
-                    acc[a][s][3] = fma(qta[a], qsa, acc[a][s][3]);
+                    const float qtf = e == 0 ? qt4[a].x : e == 1 ? qt4[a].y : e == 2 ? qt4[a].z : qt4[a].w;
+                    const double qt = (double)qtf, qta = fabs(qt);
+                    acc[a][s][0] = fma(qt, xs, acc[a][s][0]);
+                    acc[a][s][1] = fma(qt, qs, acc[a][s][1]);
+                    acc[a][s][2] = fma(qta, xsa, acc[a][s][2]);
+                    acc[a][s][3] = fma(qta, qsa, acc[a][s][3]);
                 }
             }
         }
@@ -281,7 +294,13 @@ hipError_t launch_gram(const GramArgs &a, hipStream_t stream)
 
     const int N = (int)a.N;
     if (a.m > 0 && N > 0) {
-        if (N <= 9) {
+        if (N <= 9 && a.variant == 1) {
+            hipLaunchKernelGGL((gpfq_gram_tile_kernel<1, 9>), dim3((unsigned)nparts, (unsigned)((N + 3) / 4), 1), dim3(kGramThreads), 0, stream,
+                               a.X, a.Xq, a.ld, N, a.m, nchunks, part);
+        } else if (N <= 9 && a.variant == 2) {
+            hipLaunchKernelGGL((gpfq_gram_tile_kernel<2, 9>), dim3((unsigned)nparts, (unsigned)((N + 7) / 8), 1), dim3(kGramThreads), 0, stream,
+                               a.X, a.Xq, a.ld, N, a.m, nchunks, part);
+        } else if (N <= 9) {
             hipLaunchKernelGGL((gpfq_gram_tile_kernel<3, 9>), dim3((unsigned)nparts, 1, 1), dim3(kGramThreads), 0, stream,
                                a.X, a.Xq, a.ld, N, a.m, nchunks, part);
         } else {

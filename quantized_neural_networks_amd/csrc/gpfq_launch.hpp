@@ -79,6 +79,7 @@ struct GramArgs {
     int32_t *uncertified;   // [C]: 1 = decision chain not certified, rerun through the exact path
     void *workspace;
     double slack = 1.0;     // multiplies the error bounds (tests)
+    int variant = 0;        // tuning hook: Gram tile shape
 };
 
 size_t gram_workspace_bytes(int64_t N, int64_t m, int64_t C);

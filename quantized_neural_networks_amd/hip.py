@@ -185,6 +185,37 @@ def _quantize_neurons_gram(X, Xq, Wt, alphabet, nrm32, want_values=True):
                 uncertified=int(bad.numel()))
 
 
+class GramPlan:
+    """Repeated gpfq_quantize_neurons_gram calls of one shape (the channels of a conv layer) without
+    per-call allocation or synchronisation: scratch, the row-norm buffer and the alphabet are set up
+    once; run() writes into caller-provided (views of) output tensors and flags uncertified neurons."""
+
+    def __init__(self, N, m, C, alphabet, device):
+        self.N, self.m, self.C, self.dev = int(N), int(m), int(C), device
+        self.arr, self.M, self.zero_idx = _alphabet(alphabet)
+        self.lib = load()
+        self.nbytes = self.lib.gpfq_gram_workspace_bytes(self.N, self.m, self.C)
+        self.ws = torch.empty(max(self.nbytes, 16), dtype=torch.uint8, device=device)
+        self.nrm = torch.empty(max(self.N, 1), dtype=torch.float32, device=device)
+
+    def run(self, X, Xq, Wt, idx, Q, resid, unc):
+        xp, N, m, ld = _rows(X, "X")
+        xqp, _, _, ld2 = _rows(Xq, "Xq")
+        wp, C, Nw, ldw = _rows(Wt, "Wt")
+        if (N, m, C, Nw) != (self.N, self.m, self.C, self.N) or ld2 != ld:
+            raise GpfqError("GramPlan.run: shape differs from the plan")
+        for t, dt, shape in ((idx, torch.int8, (C, N)), (Q, torch.float32, (C, N)), (resid, torch.float64, (C,)),
+                             (unc, torch.int32, (C,))):
+            if t.dtype != dt or tuple(t.shape) != shape or not t.is_contiguous() or not t.is_cuda:
+                raise GpfqError("GramPlan.run: outputs must be contiguous GPU tensors of the planned shape")
+        with torch.cuda.device(self.dev):
+            rc = self.lib.gpfq_quantize_neurons_gram(xp, xqp, ld, self.nrm.data_ptr(), 1, wp, ldw, self.arr, self.M,
+                                                     self.zero_idx, N, m, C, idx.data_ptr(), Q.data_ptr(),
+                                                     resid.data_ptr(), unc.data_ptr(), self.ws.data_ptr(), self.nbytes,
+                                                     _stream())
+        _check(rc, "gpfq_quantize_neurons_gram")
+
+
 def exact_fallbacks(result):
     """How many decisions of an on-chip quantize_neurons() call were re-derived with the exact dot
     product (forces a device sync; diagnostics only)."""

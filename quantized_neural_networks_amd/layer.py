@@ -134,17 +134,41 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
     same = act_q is act_w
     cm_w = act_w[..., c_lo:c_hi].permute(3, 0, 1, 2).contiguous()
     cm_q = cm_w if same else act_q[..., c_lo:c_hi].permute(3, 0, 1, 2).contiguous()
-    for c in range(c_lo, c_hi):
-        if f_hi <= f_lo:
-            break
+    def patches(c):
+        nonlocal Pw, Pq
         Pw = _extract_patches(cm_w[c - c_lo].unsqueeze(-1), 0, (kh, kw), strides, rate, padding, out=Pw)
         Pq = Pw if same else _extract_patches(cm_q[c - c_lo].unsqueeze(-1), 0, (kh, kw), strides, rate, padding, out=Pq)
-        # row-major flattening of the kh x kw filter (:215): weight t = (ky, kx) = divmod(t, kw)
-        Wt = W[:, :, c, f_lo:f_hi].reshape(K, f_hi - f_lo).t().contiguous()
-        r = _local_quantize(Pw, Pq, Wt, alphabet)
-        Qc[c, f_lo:f_hi] = r["Q"]
-        Ic[c, f_lo:f_hi] = r["idx"]
-        Rc[c, f_lo:f_hi] = r["resid"]
+
+    # neuron-major filters [Cin][F][K]: row-major flattening of each kh x kw filter (:215), t = ky*kw + kx
+    Wt_all = W.permute(2, 3, 0, 1).reshape(Cin, F, K).contiguous()
+    plan = None
+    if _local_quantize is hip.quantize_neurons and _extract_patches is hip.extract_patches and f_hi > f_lo:
+        rh, rw = rate if rate else (1, 1)
+        same_pad = str(padding).upper() == "SAME"
+        cols = (act_w.shape[0] * hip.patch_out_dim(act_w.shape[1], kh, strides[0], rh, same_pad)
+                * hip.patch_out_dim(act_w.shape[2], kw, strides[1], rw, same_pad))
+        if K <= hip.GPFQ_GRAM_AUTO_MAX_N and cols > hip.GPFQ_ONCHIP_MAX_M:
+            plan = hip.GramPlan(K, cols, f_hi - f_lo, alphabet, dev)
+    if plan is not None:
+        # Gram path without per-channel allocations or syncs: results land in the layer-level tensors,
+        # the filters whose decision chain could not be certified are collected once per layer
+        Unc = torch.zeros((Cin, F), dtype=torch.int32, device=dev)
+        for c in range(c_lo, c_hi):
+            patches(c)
+            plan.run(Pw, Pq, Wt_all[c, f_lo:f_hi], Ic[c, f_lo:f_hi], Qc[c, f_lo:f_hi], Rc[c, f_lo:f_hi], Unc[c, f_lo:f_hi])
+        for c, f in torch.nonzero(Unc).tolist():                      # one sync per layer; ~1 filter in 10^5
+            patches(c)
+            r = hip.quantize_neurons(Pw, Pq, Wt_all[c, f:f + 1], alphabet, path=hip.GPFQ_PATH_STREAM)
+            Qc[c, f], Ic[c, f], Rc[c, f] = r["Q"][0], r["idx"][0], r["resid"][0]
+    else:
+        for c in range(c_lo, c_hi):
+            if f_hi <= f_lo:
+                break
+            patches(c)
+            r = _local_quantize(Pw, Pq, Wt_all[c, f_lo:f_hi], alphabet)
+            Qc[c, f_lo:f_hi] = r["Q"]
+            Ic[c, f_lo:f_hi] = r["idx"]
+            Rc[c, f_lo:f_hi] = r["resid"]
     if world > 1:
         if by_channel:
             Qc = all_gather_units(Qc[c_lo:c_hi], Cin, group)

@@ -300,3 +300,31 @@ def test_single_rank_nccl_group(qn, ks):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("slack", [0, 60])
+def test_conv_layer_gram_fast_path(oracle_mod, slack):
+    """layer.quantize_conv2d on patch matrices long enough for the Gram plan (no per-channel sync);
+    slack=60 makes every filter uncertified, exercising the once-per-layer exact rerun."""
+    from quantized_neural_networks_amd import hip, layer
+    r = np.random.default_rng(21)
+    act_w = r.random((36, 24, 24, 2)).astype(np.float32)
+    act_q = np.maximum(act_w + 0.05 * r.standard_normal(act_w.shape), 0).astype(np.float32)
+    W = (r.standard_normal((3, 3, 2, 3)) / 3).astype(np.float32)
+    Wd = torch.from_numpy(W).cuda()
+    alphabet, _ = layer.layer_alphabet(Wd, np.linspace(-1, 1, 8), 4)
+    assert 36 * 24 * 24 > hip.GPFQ_ONCHIP_MAX_M
+    try:
+        hip.set_option("gram_slack_log2", slack)
+        out = layer.quantize_conv2d(Wd, torch.from_numpy(act_w).cuda(), torch.from_numpy(act_q).cuda(), alphabet,
+                                    strides=(1, 1), padding="SAME", rate=(1, 1))
+    finally:
+        hip.set_option("gram_slack_log2", 0)
+    Q = out["Q"].cpu().numpy()
+    for c in range(2):
+        Pw = ref_patches(act_w, c, 3, 3, 1, 1, 1, 1, "SAME")
+        Pq = ref_patches(act_q, c, 3, 3, 1, 1, 1, 1, "SAME")
+        for f in range(3):
+            qo, _, uo = oracle_mod.neuron(W[:, :, c, f].reshape(-1), Pw, Pq, alphabet)
+            assert np.array_equal(Q[:, :, c, f].reshape(-1), qo.astype(np.float32)), (c, f)
+            np.testing.assert_allclose(out["resid"][c, f].item(), np.linalg.norm(uo), rtol=1e-5)
