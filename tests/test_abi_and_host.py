@@ -140,3 +140,11 @@ def test_keras_shim_cpu():
     d.layers[0].set_weights([np.ones((2, 3))])
     assert np.array_equal(d.predict_on_batch(np.array([[1, 0], [0, 2]], dtype=np.float32)).numpy(),
                           np.array([[1, 1, 1], [2, 2, 2]], dtype=np.float32))
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/gpfq.h is a C header: it must compile as C99 without any HIP/C++ context."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "gpfq.h"\nint main(void) { int (*f)(const char *, int) = gpfq_set_option; return f ? GPFQ_MAX_ALPHABET - 64 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
