@@ -108,9 +108,13 @@ def main():
         r = hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm, want_values=False)
         if i_timed is not None:
             ev[i_timed][1].record()
-        # one all-gather of the 1-byte indices, then values + transpose to the Keras layout in one pass
-        It = layer.all_gather_units(r["idx"], C_total, group)
-        Q, idx = hip.assemble_kernel(It.contiguous(), alphabet)
+        # one all-gather of the indices (packed to 2 bits per weight for the ternary alphabet when N > 1),
+        # then values + transpose to the Keras layout in one pass
+        if world > 1:
+            packed, bits = hip.pack_indices(r["idx"], M)
+            Q, idx = hip.assemble_kernel(layer.all_gather_units(packed, C_total, group).contiguous(), alphabet, bits=bits, N=N)
+        else:
+            Q, idx = hip.assemble_kernel(r["idx"], alphabet)
         return Q, idx, r
 
     def fence():

@@ -160,10 +160,16 @@ int gpfq_msq_round(const float *W, int64_t n, const double *alphabet, int M,
  * Assemble the quantized kernel in Keras layout from the neuron-major indices:
  *   Q[t][j] = (float)alphabet[qidx[j][t]]   (0.0f for the literal-zero index -1),  qidx_t[t][j] = qidx[j][t].
  * Replaces the `Q[:, neuron_idx] = future.result()` assembly loop (scripts/quantized_network.py:557-562);
- * with neurons sharded over GPUs only the 1-byte indices need to be all-gathered.
- *   qidx [device] i8 [C][N]; Q [device] f32 [N][C] (may be NULL); qidx_t [device] i8 [N][C] (may be NULL).
+ * with neurons sharded over GPUs only the indices need to be all-gathered -- packed to 2 or 4 bits per
+ * weight by gpfq_pack_indices when the alphabet allows (code = index + 1, 0 = the literal zero; every
+ * neuron row padded to whole bytes, ceil(N*bits/8) bytes per row, so shards stay row-aligned).
+ *   gpfq_index_bits(M): 2 for M <= 3, 4 for M <= 15, else 8 (plain int8 indices, no packing).
+ *   qidx [device] i8 [C][N] (bits = 8) or packed u8 [C][ceil(N*bits/8)];
+ *   Q [device] f32 [N][C] (may be NULL); qidx_t [device] i8 [N][C] (may be NULL).
  */
-int gpfq_assemble_kernel(const int8_t *qidx, const double *alphabet, int M, int64_t N, int64_t C,
+int gpfq_index_bits(int M);
+int gpfq_pack_indices(const int8_t *qidx, int64_t N, int64_t C, int bits, uint8_t *packed, void *stream);
+int gpfq_assemble_kernel(const void *qidx, int bits, const double *alphabet, int M, int64_t N, int64_t C,
                          float *Q, int8_t *qidx_t, void *stream);
 
 /*

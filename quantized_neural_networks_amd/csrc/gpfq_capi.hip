@@ -246,17 +246,35 @@ int gpfq_msq_round(const float *W, int64_t n, const double *alphabet, int M, flo
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_msq_round");
 }
 
-int gpfq_assemble_kernel(const int8_t *qidx, const double *alphabet, int M, int64_t N, int64_t C,
+int gpfq_index_bits(int M)
+{
+    if (M < 1 || M > GPFQ_MAX_ALPHABET) return 0;
+    return M <= 3 ? 2 : (M <= 15 ? 4 : 8);            // codes 0..M (0 = literal zero)
+}
+
+int gpfq_pack_indices(const int8_t *qidx, int64_t N, int64_t C, int bits, uint8_t *packed, void *stream)
+{
+    if (N < 0 || C < 0) return fail(GPFQ_ERR_INVALID_ARG, "negative size");
+    if (bits != 2 && bits != 4) return fail(GPFQ_ERR_INVALID_ARG, "bits must be 2 or 4 (8-bit indices need no packing)");
+    if (N == 0 || C == 0) return GPFQ_OK;
+    if (!qidx || !packed) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    hipError_t e = gpfq::launch_pack(qidx, N, C, bits, packed, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_pack_indices");
+}
+
+int gpfq_assemble_kernel(const void *qidx, int bits, const double *alphabet, int M, int64_t N, int64_t C,
                          float *Q, int8_t *qidx_t, void *stream)
 {
     if (N < 0 || C < 0) return fail(GPFQ_ERR_INVALID_ARG, "negative size");
+    if (bits != 2 && bits != 4 && bits != 8) return fail(GPFQ_ERR_INVALID_ARG, "bits must be 2, 4 or 8");
     gpfq::AlphabetArg A;
     int rc = make_alphabet(alphabet, M, -1, &A);
     if (rc != GPFQ_OK) return rc;
+    if (bits < 8 && M + 1 > (1 << bits)) return fail(GPFQ_ERR_INVALID_ARG, "%d-bit codes cannot hold an alphabet of %d", bits, M);
     if (N == 0 || C == 0) return GPFQ_OK;
     if (!qidx) return fail(GPFQ_ERR_INVALID_ARG, "qidx is NULL");
     if (N > 2147483647LL * 32 || (C + 31) / 32 > 65535) return fail(GPFQ_ERR_UNSUPPORTED, "kernel too large to assemble in one call");
-    hipError_t e = gpfq::launch_assemble(qidx, A, N, C, Q, qidx_t, static_cast<hipStream_t>(stream));
+    hipError_t e = gpfq::launch_assemble(static_cast<const int8_t *>(qidx), A, N, C, bits, Q, qidx_t, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_assemble_kernel");
 }
 

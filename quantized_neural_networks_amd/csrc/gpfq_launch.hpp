@@ -89,8 +89,9 @@ hipError_t launch_row_stats(const float *X, const float *Xq, int64_t N, int64_t 
                             RowStats *stats, hipStream_t stream);
 hipError_t launch_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, float *nrm32, hipStream_t stream);
 hipError_t launch_msq(const float *W, int64_t n, const AlphabetArg &A, float *Q, int8_t *qidx, hipStream_t stream);
-hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, int64_t C, float *Q, int8_t *idxT,
+hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, int64_t C, int bits, float *Q, int8_t *idxT,
                            hipStream_t stream);
+hipError_t launch_pack(const int8_t *qidx, int64_t N, int64_t C, int bits, uint8_t *packed, hipStream_t stream);
 size_t median_workspace_bytes();
 hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream);
 hipError_t launch_extract_patches(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t c,

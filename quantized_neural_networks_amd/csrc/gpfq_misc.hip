@@ -153,16 +153,27 @@ hipError_t launch_extract_patches(const float *act, int64_t n, int64_t H, int64_
 // Q[t][j] = (float)alphabet[qidx[j][t]] (0 for the literal-zero index -1), i.e. `Q[:, neuron_idx] =
 // future.result()` for every neuron (scripts/quantized_network.py:562) fused with the transpose from
 // the kernels' neuron-major layout.  32x32 tiles through LDS, both sides coalesced.
+// `bits` = 8: qidx holds one int8 index per weight; 2 or 4: rows packed by gpfq_pack_kernel
+// (code = index + 1, 0 = the literal zero), row pitch NB = ceil(N*bits/8) bytes.
 __global__ void __launch_bounds__(256)
-gpfq_assemble_kernel(const int8_t *__restrict__ qidx, AlphabetArg A, int64_t N, int64_t C,
+gpfq_assemble_kernel(const int8_t *__restrict__ qidx, AlphabetArg A, int64_t N, int64_t C, int bits,
                      float *__restrict__ Q, int8_t *__restrict__ idxT)
 {
     __shared__ int8_t tile[32][33];
     const int64_t t0 = (int64_t)blockIdx.x * 32, j0 = (int64_t)blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    const int64_t NB = (N * bits + 7) / 8;
     for (int r = ty; r < 32; r += 8) {
         const int64_t j = j0 + r, t = t0 + tx;
-        tile[r][tx] = (j < C && t < N) ? qidx[j * N + t] : (int8_t)0;
+        int8_t k = 0;
+        if (j < C && t < N) {
+            if (bits == 8) k = qidx[j * N + t];
+            else {
+                const unsigned byte = (unsigned char)qidx[j * NB + (t * bits) / 8];
+                k = (int8_t)((int)((byte >> ((t * bits) & 7)) & ((1u << bits) - 1u)) - 1);
+            }
+        }
+        tile[r][tx] = k;
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
@@ -175,12 +186,41 @@ gpfq_assemble_kernel(const int8_t *__restrict__ qidx, AlphabetArg A, int64_t N, 
     }
 }
 
-hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, int64_t C, float *Q, int8_t *idxT,
+hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, int64_t C, int bits, float *Q, int8_t *idxT,
                            hipStream_t stream)
 {
     if (N == 0 || C == 0) return hipSuccess;
     const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((C + 31) / 32));
-    hipLaunchKernelGGL(gpfq_assemble_kernel, grid, dim3(256), 0, stream, qidx, A, N, C, Q, idxT);
+    hipLaunchKernelGGL(gpfq_assemble_kernel, grid, dim3(256), 0, stream, qidx, A, N, C, bits, Q, idxT);
+    return hipGetLastError();
+}
+
+// Pack the indices of each neuron row into `bits`-wide codes (index + 1; 0 = literal zero) so that the
+// all-gather over xGMI moves 2 or 4 bits per weight instead of 8.  One thread per output byte.
+__global__ void __launch_bounds__(256)
+gpfq_pack_kernel(const int8_t *__restrict__ qidx, int64_t N, int64_t C, int bits, uint8_t *__restrict__ packed)
+{
+    const int64_t NB = (N * bits + 7) / 8;
+    const int per = 8 / bits;
+    const int64_t total = C * NB;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t j = o / NB, b = o - j * NB;
+        unsigned byte = 0;
+        for (int e = 0; e < per; ++e) {
+            const int64_t t = b * per + e;
+            if (t < N) byte |= (unsigned)((int)qidx[j * N + t] + 1) << (e * bits);
+        }
+        packed[o] = (uint8_t)byte;
+    }
+}
+
+hipError_t launch_pack(const int8_t *qidx, int64_t N, int64_t C, int bits, uint8_t *packed, hipStream_t stream)
+{
+    const int64_t total = C * ((N * bits + 7) / 8);
+    if (total == 0) return hipSuccess;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gpfq_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, qidx, N, C, bits, packed);
     return hipGetLastError();
 }
 

@@ -33,7 +33,9 @@ SYMBOLS = {
     "gpfq_quantize_neurons_gram": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _i64, _dp, _int, _int, _i64, _i64, _i64,
                                           _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpfq_msq_round": (_int, [_vp, _i64, _dp, _int, _vp, _vp, _vp]),
-    "gpfq_assemble_kernel": (_int, [_vp, _dp, _int, _i64, _i64, _vp, _vp, _vp]),
+    "gpfq_index_bits": (_int, [_int]),
+    "gpfq_pack_indices": (_int, [_vp, _i64, _i64, _int, _vp, _vp]),
+    "gpfq_assemble_kernel": (_int, [_vp, _int, _dp, _int, _i64, _i64, _vp, _vp, _vp]),
     "gpfq_median_abs_workspace_bytes": (_sz, []),
     "gpfq_median_abs": (_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
     "gpfq_patch_out_dim": (_i64, [_i64, _i64, _i64, _i64, _int]),
@@ -240,17 +242,42 @@ def msq_round(W, alphabet):
     return Q, idx
 
 
-def assemble_kernel(qidx, alphabet, want_idx=True):
-    """[C][N] int8 indices -> (Q f32 [N][C] in Keras layout, idx i8 [N][C])."""
+def index_bits(M):
+    """Bits per packed index for an alphabet of M members (8 = plain int8, no packing)."""
+    return int(load().gpfq_index_bits(int(M)))
+
+
+def pack_indices(qidx, M):
+    """[C][N] int8 indices -> (packed u8 [C][ceil(N*bits/8)], bits); bits == 8 returns qidx itself."""
     _dev(qidx, torch.int8, "qidx")
     if qidx.dim() != 2 or not qidx.is_contiguous():
         raise GpfqError("qidx must be a contiguous [C][N] tensor")
+    bits = index_bits(M)
+    if bits == 8:
+        return qidx, 8
     C, N = qidx.shape
+    packed = torch.empty((C, (N * bits + 7) // 8), dtype=torch.uint8, device=qidx.device)
+    with torch.cuda.device(qidx.device):
+        _check(load().gpfq_pack_indices(qidx.data_ptr(), N, C, bits, packed.data_ptr(), _stream()), "gpfq_pack_indices")
+    return packed, bits
+
+
+def assemble_kernel(qidx, alphabet, want_idx=True, bits=8, N=None):
+    """[C][N] int8 indices (bits = 8) or rows packed by pack_indices (bits = 2/4, pass N) ->
+    (Q f32 [N][C] in Keras layout, idx i8 [N][C])."""
+    _dev(qidx, torch.int8 if bits == 8 else torch.uint8, "qidx")
+    if qidx.dim() != 2 or not qidx.is_contiguous():
+        raise GpfqError("qidx must be a contiguous 2-D tensor")
+    C = qidx.shape[0]
+    if bits == 8:
+        N = qidx.shape[1]
+    elif N is None or qidx.shape[1] != (N * bits + 7) // 8:
+        raise GpfqError("packed indices need N, with ceil(N*bits/8) bytes per row")
     arr, M, _ = _alphabet(alphabet)
     Q = torch.empty((N, C), dtype=torch.float32, device=qidx.device)
     idx_t = torch.empty((N, C), dtype=torch.int8, device=qidx.device) if want_idx else None
     with torch.cuda.device(qidx.device):
-        _check(load().gpfq_assemble_kernel(qidx.data_ptr(), arr, M, N, C, Q.data_ptr(),
+        _check(load().gpfq_assemble_kernel(qidx.data_ptr(), bits, arr, M, N, C, Q.data_ptr(),
                                            idx_t.data_ptr() if idx_t is not None else None, _stream()),
                "gpfq_assemble_kernel")
     return Q, idx_t

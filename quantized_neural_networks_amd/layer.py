@@ -71,6 +71,7 @@ def all_gather_units(local, n_units, group=None):
 _local_quantize = hip.quantize_neurons
 _extract_patches = hip.extract_patches
 _assemble = hip.assemble_kernel
+_pack = hip.pack_indices
 
 
 # ------------------------------------------------------------------------------------------
@@ -95,9 +96,13 @@ def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True):
     else:
         i_loc = torch.empty((0, N), dtype=torch.int8, device=W.device)
         res_loc = torch.empty((0,), dtype=torch.float64, device=W.device)
-    # only the 1-byte indices travel over xGMI; values are looked up while transposing to Keras layout
-    idx_t = all_gather_units(i_loc, C, group)
-    Q, idx = _assemble(idx_t.contiguous(), alphabet)
+    # only the indices travel over xGMI -- packed to 2 or 4 bits per weight when the alphabet allows;
+    # values are looked up while transposing to the Keras layout
+    if world > 1 and _pack is not None:
+        packed, bits = _pack(i_loc, len(alphabet))
+        Q, idx = _assemble(all_gather_units(packed, C, group).contiguous(), alphabet, bits=bits, N=N)
+    else:
+        Q, idx = _assemble(all_gather_units(i_loc, C, group).contiguous(), alphabet)
     out = dict(Q=Q, idx=idx)
     if want_resid:
         out["resid"] = all_gather_units(res_loc, C, group)

@@ -49,6 +49,7 @@ def _worker(rank, world, port, case, result_dir):
     layer._local_quantize = _standin_quantize
     layer._extract_patches = _standin_patches
     layer._assemble = _standin_assemble
+    layer._pack = None                      # index packing is a HIP kernel; covered by the -m gpu tests
     r = np.random.default_rng(7)
     if case == "dense":
         N, m, C = 24, 40, 7                                  # 7 neurons over 2 ranks: uneven shards
