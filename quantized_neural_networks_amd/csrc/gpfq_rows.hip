@@ -85,15 +85,12 @@ __device__ __forceinline__ double dot_partial(const double (&u)[EPL], const floa
     return (a0 + a1) + (a2 + a3);
 }
 
-// u += f32(w*X_t) - f32(q*Xq_t)  (:119) and, fused into the same sweep over the elements, the
-// partial sums of the NEXT step's <Xq_{t+1}, u> on the updated residual (FUSE; measured slower than
-// the separate sweeps on gfx950 -- register pressure -- and currently unused).  ZERO: every lane's
-// q is 0, so the increment is the product itself (f32(0*xq) = +-0, p - (+-0) = p).
-template <int LPN, int EPL, bool XQD, bool ZERO, bool FUSE>
-__device__ __forceinline__ double update_and_dot(double (&u)[EPL], float w, float q32, const float *rowx, const float *rowq,
-                                                 const float *rowq_next, const double *rowd_next)
+// u += f32(w*X_t) - f32(q*Xq_t)  (:119): f32 products, f32 subtraction, f64 accumulate.  ZERO: every
+// lane's q is 0, so the increment is the product itself (f32(0*xq) = +-0, p - (+-0) = p).
+// (Fusing this sweep with the next step's dot product was measured slower: register pressure.)
+template <int LPN, int EPL, bool ZERO>
+__device__ __forceinline__ void update_residual(double (&u)[EPL], float w, float q32, const float *rowx, const float *rowq)
 {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
     for (int c = 0; c < EPL / 4; ++c) {
         const float4 x4 = *reinterpret_cast<const float4 *>(rowx + 4 * LPN * c);
@@ -109,20 +106,7 @@ __device__ __forceinline__ double update_and_dot(double (&u)[EPL], float w, floa
             u[4 * c + 2] += (double)__fsub_rn(__fmul_rn(w, x4.z), __fmul_rn(q32, q4.z));
             u[4 * c + 3] += (double)__fsub_rn(__fmul_rn(w, x4.w), __fmul_rn(q32, q4.w));
         }
-        if constexpr (FUSE) {
-            if constexpr (XQD) {
-                const double2 qa = *reinterpret_cast<const double2 *>(rowd_next + 4 * LPN * c);
-                const double2 qb = *reinterpret_cast<const double2 *>(rowd_next + 4 * LPN * c + 2 * LPN);
-                a0 = fma(qa.x, u[4 * c + 0], a0); a1 = fma(qa.y, u[4 * c + 1], a1);
-                a2 = fma(qb.x, u[4 * c + 2], a2); a3 = fma(qb.y, u[4 * c + 3], a3);
-            } else {
-                const float4 n4 = *reinterpret_cast<const float4 *>(rowq_next + 4 * LPN * c);
-                a0 = fma((double)n4.x, u[4 * c + 0], a0); a1 = fma((double)n4.y, u[4 * c + 1], a1);
-                a2 = fma((double)n4.z, u[4 * c + 2], a2); a3 = fma((double)n4.w, u[4 * c + 3], a3);
-            }
-        }
     }
-    return (a0 + a1) + (a2 + a3);
 }
 
 // XQD: additionally stage Xq converted to float64 (conversion done once per workgroup instead of
@@ -305,9 +289,9 @@ gpfq_rows_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int6
 
             // ---- u += w*X_t - q*Xq_t  (:119): f32 products, f32 subtraction, f64 accumulate -------
             if (__ballot(q32 != 0.0f) == 0ull)                    // every neuron of the wave chose 0
-                update_and_dot<LPN, EPL, XQD, true, false>(u, w, q32, rowx, rowq, rowq, ldsXqd);
+                update_residual<LPN, EPL, true>(u, w, q32, rowx, rowq);
             else
-                update_and_dot<LPN, EPL, XQD, false, false>(u, w, q32, rowx, rowq, rowq, ldsXqd);
+                update_residual<LPN, EPL, false>(u, w, q32, rowx, rowq);
 
             // ---- outputs: lane (t mod LPN) of the neuron keeps step t until the LPN-step flush -------
             const int slot = (int)(t & (LPN - 1));

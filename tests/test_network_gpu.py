@@ -280,7 +280,7 @@ def test_single_rank_nccl_group(qn, ks):
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         created = True
     try:
-        for dtype in (torch.int8, torch.float32, torch.float64):
+        for dtype in (torch.int8, torch.uint8, torch.float32, torch.float64):
             src = torch.arange(24, device="cuda").reshape(6, 4).to(dtype)
             out = torch.empty_like(src)
             dist.all_gather_into_tensor(out, src)
