@@ -42,30 +42,36 @@ def time_dense(name, N, m, C, bits, scalar, dev, check=8):
     return rec
 
 
-def time_conv(name, cin, cout, hw, n, bits, scalar, dev, check=2):
+def time_conv(name, cin, cout, hw, n, bits, scalar, dev, check=2, k=3, stride=1, padding="SAME", reps=2):
     g = torch.Generator(device=dev).manual_seed(2)
     act_w = torch.rand((n, hw, hw, cin), device=dev, generator=g)
     act_q = torch.relu(act_w + 0.05 * torch.randn((n, hw, hw, cin), device=dev, generator=g))
-    W = torch.randn((3, 3, cin, cout), device=dev, generator=g) / 3
+    W = torch.randn((k, k, cin, cout), device=dev, generator=g) / k
     unit = np.linspace(-1, 1, int(round(2 ** bits)))
     best = 1e9
-    for _ in range(2):
+    for _ in range(reps):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         alphabet, rad = layer.layer_alphabet(W, unit, scalar)
-        out = layer.quantize_conv2d(W, act_w, act_q, alphabet, strides=(1, 1), padding="SAME", rate=(1, 1))
+        out = layer.quantize_conv2d(W, act_w, act_q, alphabet, strides=(stride, stride), padding=padding, rate=(1, 1))
         torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
     # parity: channel 0, first `check` filters, oracle on the GPU-built patch matrices
-    Pw = hip.extract_patches(act_w, 0, (3, 3), (1, 1), (1, 1), "SAME").cpu().numpy()
-    Pq = hip.extract_patches(act_q, 0, (3, 3), (1, 1), (1, 1), "SAME").cpu().numpy()
+    Pw = hip.extract_patches(act_w, 0, (k, k), (stride, stride), (1, 1), padding)
+    Pq = hip.extract_patches(act_q, 0, (k, k), (stride, stride), (1, 1), padding)
+    m = Pw.shape[1]
     Wh = W.cpu().numpy()
     bad = 0
-    for f in range(check):
-        q, _, _ = oracle.neuron(Wh[:, :, 0, f].reshape(-1), Pw, Pq, alphabet)
-        bad += int(not np.array_equal(out["Q"][:, :, 0, f].cpu().numpy().reshape(-1), q.astype(np.float32)))
-    m = n * hw * hw
-    rec = dict(config=name, kind="conv3x3", Cin=cin, Cout=cout, m=m, M=len(unit), ms=best * 1e3,
-               weights_per_s=9 * cin * cout / best, filters_checked=check, filters_with_mismatch=bad)
+    if m * k * k <= 2_000_000_000:               # keep the host copy of the patch matrices reasonable
+        Pw, Pq = Pw.cpu().numpy(), Pq.cpu().numpy()
+        for f in range(check):
+            q, _, _ = oracle.neuron(Wh[:, :, 0, f].reshape(-1), Pw, Pq, alphabet)
+            bad += int(not np.array_equal(out["Q"][:, :, 0, f].cpu().numpy().reshape(-1), q.astype(np.float32)))
+    else:
+        check = 0
+    rec = dict(config=name, kind=f"conv{k}x{k}/{stride}", Cin=cin, Cout=cout, m=int(m), M=len(unit), ms=best * 1e3,
+               weights_per_s=k * k * cin * cout / best, filters_checked=check, filters_with_mismatch=bad)
     print(json.dumps(rec), flush=True)
+    del act_w, act_q, out
+    torch.cuda.empty_cache()
     return rec
 
 
@@ -87,6 +93,15 @@ def main():
         total += r["ms"]; recs.append(r)
     recs.append(dict(config="cfg4 CIFAR10 CNN, all 6 conv + 2 dense layers (quantization only, synthetic activations)", ms=total))
     print(json.dumps(recs[-1]))
+    if "--resnet" in sys.argv:
+        # cfg5: representative Keras-ResNet50 conv layers, 4096 synthetic calibration images, ternary;
+        # one layer of each spatial size (the net has 3/4/6/3 of the 3x3 ones) + conv1 (7x7/2 on the padded 230x230 input)
+        n = 4096
+        recs.append(time_conv("cfg5 ResNet50 conv1 7x7/2 VALID (3->64 @230x230 padded input), 4096 images, ternary, scalar 3",
+                              3, 64, 230, n, np.log2(3), 3, dev, k=7, stride=2, padding="VALID", reps=1))
+        for cin, hw in [(64, 56), (128, 28), (256, 14), (512, 7)]:
+            recs.append(time_conv(f"cfg5 ResNet50 3x3 conv ({cin}->{cin} @{hw}x{hw}), 4096 images, ternary, scalar 3",
+                                  cin, cin, hw, n, np.log2(3), 3, dev, reps=1))
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(dict(note="tools/bench_configs.py on one MI355X; best of 2-3 runs per layer; whole layer driver "
                         "(median, norms, kernel, assemble) with inputs resident in HBM", records=recs),
