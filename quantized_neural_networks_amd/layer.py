@@ -112,7 +112,30 @@ def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True):
 # ------------------------------------------------------------------------------------------
 # Conv2D layer
 # ------------------------------------------------------------------------------------------
-def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=None):
+def _quantize_conv1x1(W, act_q, alphabet, strides):
+    """1x1 kernels: every (channel, filter) pair is a ONE-step walk.  u = 0, hence <Xq_0, u> = 0 and rule
+    (ii) (:86-87) returns nearest(alphabet, w) -- plain MSQ -- unless the channel's (sub-sampled) quantized
+    activations are identically zero, where rule (i) (:83-84) returns the literal 0.  So the layer needs the
+    per-channel norms and one MSQ pass instead of Cin patch matrices; cheaper than any all-gather, so it is
+    not sharded.  (The reference reaches the same values through its general path: its (1,1) shortcut is
+    dead code, :835-842.)  The residual norms are not formed (NaN)."""
+    _, _, Cin, F = W.shape
+    sh, sw = strides
+    planes = act_q.permute(3, 0, 1, 2)[:, :, ::sh, ::sw].reshape(Cin, -1).contiguous()   # SAME == VALID for k = 1
+    nrm = hip.row_norms(planes)
+    Q, idx = hip.msq_round(W.reshape(Cin, F), alphabet)
+    dead = nrm.double() < 1e-16
+    zero_idx = -1
+    for k, a in enumerate(alphabet):
+        if float(a) == 0.0:
+            zero_idx = k
+    Q[dead] = 0.0
+    idx[dead] = zero_idx
+    resid = torch.full((Cin, F), float("nan"), dtype=torch.float64, device=W.device)
+    return dict(Q=Q.reshape(1, 1, Cin, F), idx=idx.reshape(1, 1, Cin, F), resid=resid)
+
+
+def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=None, want_resid=True):
     """Quantize a Conv2D / DepthwiseConv2D kernel channel by channel.
 
     W          f32 [kh][kw][Cin][F]   Keras kernel layout
@@ -126,6 +149,8 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
     kh, kw, Cin, F = W.shape
     K = kh * kw
     dev = W.device
+    if K == 1 and not want_resid and _local_quantize is hip.quantize_neurons:
+        return _quantize_conv1x1(W, act_q, alphabet, strides)
     world, rank = _group_info(group)
     by_channel = Cin >= world
     Qc = torch.zeros((Cin, F, K), dtype=torch.float32, device=dev)
