@@ -198,6 +198,26 @@ int gpfq_extract_patches(const float *act, int64_t n, int64_t H, int64_t W, int6
                          int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
                          float *P, int64_t ldp, void *stream);
 
+/*
+ * The channel loop of a conv layer in one call: for each of `nch` input channels build the two patch
+ * matrices and run gpfq_quantize_neurons_gram for that channel's F filters -- the body of
+ * `for channel_idx in range(num_channels)` in _quantize_conv2D_layer_parallel_jit
+ * (scripts/quantized_network.py:844-860) with _quantize_channel_parallel_jit (:652-727) inlined, all
+ * launches asynchronous on `stream`, patch buffers reused from channel to channel.
+ *   act_w, act_q [device] f32 CHANNEL-MAJOR [nch][n][H][W] (analog / quantized layer inputs of these channels;
+ *                the same pointer for a first layer);  Wt [device] f32 [nch][F][kh*kw], each filter flattened
+ *                row-major (:215);  outputs qidx/Qt [nch][F][kh*kw], resid [nch][F] (may be NULL),
+ *                uncertified i32 [nch][F] (see gpfq_quantize_neurons_gram: flagged pairs must be rerun).
+ *   Needs kh*kw <= GPFQ_GRAM_MAX_N and n*oh*ow < 2^30.
+ */
+size_t gpfq_conv_channels_workspace_bytes(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw,
+                                          int rh, int rw, int same_padding, int64_t F);
+int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,
+                                int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
+                                const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
+                                int8_t *qidx, float *Qt, double *resid, int32_t *uncertified,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

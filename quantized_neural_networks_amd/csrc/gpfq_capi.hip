@@ -327,4 +327,72 @@ int gpfq_extract_patches(const float *act, int64_t n, int64_t H, int64_t W, int6
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_extract_patches");
 }
 
+static size_t al256c(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t gpfq_conv_channels_workspace_bytes(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw,
+                                          int rh, int rw, int same_padding, int64_t F)
+{
+    const int64_t cols = n * gpfq_patch_out_dim(H, kh, sh, rh, same_padding) * gpfq_patch_out_dim(W, kw, sw, rw, same_padding);
+    const int64_t K = (int64_t)kh * kw;
+    if (cols <= 0 || K <= 0 || F < 0) return 0;
+    const int64_t ldp = (cols + 3) & ~(int64_t)3;
+    return 2 * al256c((size_t)K * ldp * sizeof(float)) + al256c((size_t)K * sizeof(float)) + gpfq::gram_workspace_bytes(K, cols, F);
+}
+
+int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,
+                                int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
+                                const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
+                                int8_t *qidx, float *Qt, double *resid, int32_t *uncertified,
+                                void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (n < 0 || H <= 0 || W <= 0 || nch < 0 || F < 0) return fail(GPFQ_ERR_INVALID_ARG, "bad shape");
+    if (kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || rh <= 0 || rw <= 0) return fail(GPFQ_ERR_INVALID_ARG, "bad kernel/stride/rate");
+    gpfq::AlphabetArg A;
+    int rc = make_alphabet(alphabet, M, zero_idx, &A);
+    if (rc != GPFQ_OK) return rc;
+    const int64_t oh = gpfq_patch_out_dim(H, kh, sh, rh, same_padding), ow = gpfq_patch_out_dim(W, kw, sw, rw, same_padding);
+    const int64_t cols = n * oh * ow, K = (int64_t)kh * kw;
+    if (nch == 0 || F == 0 || cols == 0) return GPFQ_OK;
+    if (K > GPFQ_GRAM_MAX_N || cols >= (1LL << 30)) return fail(GPFQ_ERR_UNSUPPORTED, "needs kh*kw <= %d and n*oh*ow < 2^30", GPFQ_GRAM_MAX_N);
+    if (!act_w || !act_q || !Wt || !qidx || !Qt || !uncertified) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    const size_t need = gpfq_conv_channels_workspace_bytes(n, H, W, kh, kw, sh, sw, rh, rw, same_padding, F);
+    if (!workspace || workspace_bytes < need || (uintptr_t)workspace % 16 != 0)
+        return fail(GPFQ_ERR_WORKSPACE, "conv channel loop needs %zu aligned workspace bytes", need);
+    int pad_top = 0, pad_left = 0;
+    if (same_padding) {
+        const int64_t keh = kh + (int64_t)(kh - 1) * (rh - 1), kew = kw + (int64_t)(kw - 1) * (rw - 1);
+        int64_t th = (oh - 1) * sh + keh - H; if (th < 0) th = 0;
+        int64_t tw = (ow - 1) * sw + kew - W; if (tw < 0) tw = 0;
+        pad_top = (int)(th / 2);
+        pad_left = (int)(tw / 2);
+    }
+    const int64_t ldp = (cols + 3) & ~(int64_t)3;
+    char *ws = static_cast<char *>(workspace);
+    float *Pw = reinterpret_cast<float *>(ws);   ws += al256c((size_t)K * ldp * sizeof(float));
+    float *Pq = reinterpret_cast<float *>(ws);   ws += al256c((size_t)K * ldp * sizeof(float));
+    float *nrm = reinterpret_cast<float *>(ws);  ws += al256c((size_t)K * sizeof(float));
+    const bool same_act = act_w == act_q;          // first layer: both networks see the raw data (:478-481)
+    const int64_t plane = n * H * W;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int64_t c = 0; c < nch; ++c) {
+        hipError_t e = gpfq::launch_extract_patches(act_w + c * plane, n, H, W, 1, 0, kh, kw, sh, sw, rh, rw, pad_top, pad_left,
+                                                    oh, ow, Pw, ldp, s);
+        if (e == hipSuccess && !same_act)
+            e = gpfq::launch_extract_patches(act_q + c * plane, n, H, W, 1, 0, kh, kw, sh, sw, rh, rw, pad_top, pad_left,
+                                             oh, ow, Pq, ldp, s);
+        if (e != hipSuccess) return hip_fail(e, "gpfq_quantize_conv_channels(patches)");
+        gpfq::GramArgs a;
+        a.X = Pw; a.Xq = same_act ? Pw : Pq; a.ld = ldp; a.nrm32 = nrm; a.nrm32_out = nrm;
+        a.Wt = Wt + c * F * K; a.ldw = K; a.A = A; a.N = K; a.m = cols; a.C = F;
+        a.qidx = qidx + c * F * K; a.Qt = Qt + c * F * K; a.resid = resid ? resid + c * F : nullptr;
+        a.uncertified = uncertified + c * F;
+        a.workspace = ws;
+        a.slack = std::ldexp(1.0, g_gram_slack_log2);
+        a.variant = g_variant;
+        e = gpfq::launch_gram(a, s);
+        if (e != hipSuccess) return hip_fail(e, "gpfq_quantize_conv_channels(gram)");
+    }
+    return GPFQ_OK;
+}
+
 }  // extern "C"

@@ -32,6 +32,9 @@ SYMBOLS = {
     "gpfq_gram_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "gpfq_quantize_neurons_gram": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _i64, _dp, _int, _int, _i64, _i64, _i64,
                                           _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gpfq_conv_channels_workspace_bytes": (_sz, [_i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _i64]),
+    "gpfq_quantize_conv_channels": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int,
+                                           _vp, _dp, _int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpfq_msq_round": (_int, [_vp, _i64, _dp, _int, _vp, _vp, _vp]),
     "gpfq_index_bits": (_int, [_int]),
     "gpfq_pack_indices": (_int, [_vp, _i64, _i64, _int, _vp, _vp]),
@@ -216,6 +219,40 @@ class GramPlan:
                                                      resid.data_ptr(), unc.data_ptr(), self.ws.data_ptr(), self.nbytes,
                                                      _stream())
         _check(rc, "gpfq_quantize_neurons_gram")
+
+
+def quantize_conv_channels(act_w_cm, act_q_cm, Wt_all, alphabet, kernel_size, strides, rate, padding,
+                           idx, Q, resid, unc):
+    """All channels of a conv layer shard in one library call (gpfq_quantize_conv_channels).
+    act_*_cm: channel-major f32 [nch][n][H][W]; Wt_all f32 [nch][F][K]; outputs are caller tensors
+    idx i8 / Q f32 [nch][F][K], resid f64 [nch][F], unc i32 [nch][F].  No sync; returns nothing."""
+    for t, dt in ((act_w_cm, torch.float32), (act_q_cm, torch.float32), (Wt_all, torch.float32), (idx, torch.int8),
+                  (Q, torch.float32), (resid, torch.float64), (unc, torch.int32)):
+        if t is None:
+            continue                                  # resid is optional (skips the exact replay)
+        _dev(t, dt, "tensor")
+        if not t.is_contiguous():
+            raise GpfqError("quantize_conv_channels needs contiguous tensors")
+    nch, n, H, W = act_w_cm.shape
+    kh, kw = kernel_size
+    sh, sw = strides
+    rh, rw = rate if rate else (1, 1)
+    same = 1 if str(padding).upper() == "SAME" else 0
+    F, K = Wt_all.shape[1], Wt_all.shape[2]
+    if (tuple(act_q_cm.shape) != (nch, n, H, W) or Wt_all.shape[0] != nch or K != kh * kw or tuple(idx.shape) != (nch, F, K)
+            or tuple(Q.shape) != (nch, F, K) or (resid is not None and tuple(resid.shape) != (nch, F))
+            or tuple(unc.shape) != (nch, F)):
+        raise GpfqError("quantize_conv_channels: shape mismatch")
+    arr, M, zero_idx = _alphabet(alphabet)
+    lib = load()
+    nbytes = lib.gpfq_conv_channels_workspace_bytes(n, H, W, kh, kw, sh, sw, rh, rw, same, F)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=act_w_cm.device)
+    with torch.cuda.device(act_w_cm.device):
+        rc = lib.gpfq_quantize_conv_channels(act_w_cm.data_ptr(), act_q_cm.data_ptr(), n, H, W, nch, kh, kw, sh, sw, rh, rw,
+                                             same, Wt_all.data_ptr(), arr, M, zero_idx, F, idx.data_ptr(), Q.data_ptr(),
+                                             resid.data_ptr() if resid is not None else None, unc.data_ptr(),
+                                             ws.data_ptr(), nbytes, _stream())
+    _check(rc, "gpfq_quantize_conv_channels")
 
 
 def exact_fallbacks(result):

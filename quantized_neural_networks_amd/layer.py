@@ -155,7 +155,7 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
     by_channel = Cin >= world
     Qc = torch.zeros((Cin, F, K), dtype=torch.float32, device=dev)
     Ic = torch.zeros((Cin, F, K), dtype=torch.int8, device=dev)
-    Rc = torch.zeros((Cin, F), dtype=torch.float64, device=dev)
+    Rc = torch.full((Cin, F), 0.0 if want_resid else float("nan"), dtype=torch.float64, device=dev)
     c_lo, c_hi = shard_bounds(Cin, world, rank) if by_channel else (0, Cin)
     f_lo, f_hi = (0, F) if by_channel else shard_bounds(F, world, rank)
     Pw = Pq = None
@@ -178,14 +178,23 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
         cols = (act_w.shape[0] * hip.patch_out_dim(act_w.shape[1], kh, strides[0], rh, same_pad)
                 * hip.patch_out_dim(act_w.shape[2], kw, strides[1], rw, same_pad))
         if K <= hip.GPFQ_GRAM_AUTO_MAX_N and cols > hip.GPFQ_ONCHIP_MAX_M:
-            plan = hip.GramPlan(K, cols, f_hi - f_lo, alphabet, dev)
+            plan = True
     if plan is not None:
-        # Gram path without per-channel allocations or syncs: results land in the layer-level tensors,
-        # the filters whose decision chain could not be certified are collected once per layer
+        # Gram path, the whole channel loop (:844-860) in one library call: no per-channel allocation,
+        # Python or sync; the filters whose decision chain could not be certified are collected once
         Unc = torch.zeros((Cin, F), dtype=torch.int32, device=dev)
-        for c in range(c_lo, c_hi):
-            patches(c)
-            plan.run(Pw, Pq, Wt_all[c, f_lo:f_hi], Ic[c, f_lo:f_hi], Qc[c, f_lo:f_hi], Rc[c, f_lo:f_hi], Unc[c, f_lo:f_hi])
+        if (f_lo, f_hi) == (0, F):
+            hip.quantize_conv_channels(cm_w, cm_q, Wt_all[c_lo:c_hi], alphabet, (kh, kw), strides, rate, padding,
+                                       Ic[c_lo:c_hi], Qc[c_lo:c_hi], Rc[c_lo:c_hi] if want_resid else None, Unc[c_lo:c_hi])
+        else:                                  # filters split over ranks (Cin < world): every rank walks all channels
+            Wt_f = Wt_all[:, f_lo:f_hi].contiguous()
+            i_f = torch.empty((Cin, f_hi - f_lo, K), dtype=torch.int8, device=dev)
+            q_f = torch.empty((Cin, f_hi - f_lo, K), dtype=torch.float32, device=dev)
+            r_f = torch.full((Cin, f_hi - f_lo), float("nan"), dtype=torch.float64, device=dev)
+            u_f = torch.empty((Cin, f_hi - f_lo), dtype=torch.int32, device=dev)
+            hip.quantize_conv_channels(cm_w, cm_q, Wt_f, alphabet, (kh, kw), strides, rate, padding, i_f, q_f,
+                                       r_f if want_resid else None, u_f)
+            Ic[:, f_lo:f_hi], Qc[:, f_lo:f_hi], Rc[:, f_lo:f_hi], Unc[:, f_lo:f_hi] = i_f, q_f, r_f, u_f
         for c, f in torch.nonzero(Unc).tolist():                      # one sync per layer; ~1 filter in 10^5
             patches(c)
             r = hip.quantize_neurons(Pw, Pq, Wt_all[c, f:f + 1], alphabet, path=hip.GPFQ_PATH_STREAM)

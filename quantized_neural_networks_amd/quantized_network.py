@@ -295,7 +295,7 @@ class QuantizedCNN(QuantizedNeuralNetwork):
             out = _layer.quantize_conv2d(Wd, wX, qX, alphabet, strides=tuple(layer.strides),
                                          padding=layer.padding.upper(), rate=tuple(rate) if rate else None,
                                          group=self.process_group,
-                                         want_resid=W.shape[0] * W.shape[1] > 1)   # 1x1 kernels: MSQ shortcut
+                                         want_resid=False)      # residual norms are diagnostics: skip their replay
             Q = out["Q"].cpu().numpy()
         except Exception as exc:
             self._log(f"\t\t\tLayer {layer_idx} generated an exception: {exc}")
