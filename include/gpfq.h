@@ -199,6 +199,13 @@ int gpfq_extract_patches(const float *act, int64_t n, int64_t H, int64_t W, int6
                          float *P, int64_t ldp, void *stream);
 
 /*
+ * Channel planes of NHWC activations: planes[c][p] = act[p][c_lo + c] for p < npos = n*H*W, c < nch -- the
+ * `[..., channel_idx]` slices of scripts/quantized_network.py:769-770 for a shard of channels in one pass
+ * (the input layout of gpfq_quantize_conv_channels).  act [device] f32 [npos][Cin]; planes [device] f32 [nch][npos].
+ */
+int gpfq_channel_planes(const float *act, int64_t npos, int64_t Cin, int64_t c_lo, int64_t nch, float *planes, void *stream);
+
+/*
  * The channel loop of a conv layer in one call: for each of `nch` input channels build the two patch
  * matrices and run gpfq_quantize_neurons_gram for that channel's F filters -- the body of
  * `for channel_idx in range(num_channels)` in _quantize_conv2D_layer_parallel_jit
@@ -209,9 +216,14 @@ int gpfq_extract_patches(const float *act, int64_t n, int64_t H, int64_t W, int6
  *                row-major (:215);  outputs qidx/Qt [nch][F][kh*kw], resid [nch][F] (may be NULL),
  *                uncertified i32 [nch][F] (see gpfq_quantize_neurons_gram: flagged pairs must be rerun).
  *   Needs kh*kw <= GPFQ_GRAM_MAX_N and n*oh*ow < 2^30.
+ * 3x3 kernels with stride 1 and rate 1 (when resid == NULL) never materialise the patch matrices: row
+ * t = (ky, kx) of a patch matrix is the channel plane shifted by (ky, kx), so the Gram matrices of all
+ * channels are accumulated straight from the planes in one launch, followed by one batched decide launch
+ * (option "conv_fused" = 0 switches back to the per-channel patch matrices; results are identical).
+ * The workspace size depends on whether resid is requested (want_resid = resid != NULL).
  */
-size_t gpfq_conv_channels_workspace_bytes(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw,
-                                          int rh, int rw, int same_padding, int64_t F);
+size_t gpfq_conv_channels_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t nch, int kh, int kw, int sh, int sw,
+                                          int rh, int rw, int same_padding, int64_t F, int want_resid);
 int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,
                                 int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
                                 const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,

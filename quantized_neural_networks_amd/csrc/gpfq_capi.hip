@@ -103,6 +103,8 @@ static int g_lpn = 0;              // 0 = heuristic, 1 = wave-per-neuron kernel,
 static int g_gram_slack_log2 = 0;  // Gram path: error bounds multiplied by 2^this (tests force the uncertified branch)
 static int g_wpn = 0;              // wide kernel: wavefronts per neuron (0 = heuristic: only for rows > 2048)
 static int g_variant = 0;          // bit 0: row-group kernel without the float64 copy of Xq in LDS
+static int g_conv_fused = 1;       // conv channel loop: 3x3/stride-1 Gram matrices straight from the planes
+static int g_conv_strip = 0;       // fused conv kernel: forced strip length (0 = heuristic)
 
 int gpfq_set_option(const char *key, int value)
 {
@@ -122,6 +124,12 @@ int gpfq_set_option(const char *key, int value)
         g_wpn = value; return GPFQ_OK;
     }
     if (!std::strcmp(key, "gram_slack_log2")) { g_gram_slack_log2 = value; return GPFQ_OK; }
+    if (!std::strcmp(key, "conv_fused")) { g_conv_fused = value ? 1 : 0; return GPFQ_OK; }
+    if (!std::strcmp(key, "conv_strip")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4)
+            return fail(GPFQ_ERR_INVALID_ARG, "conv_strip must be 0, 1, 2 or 4");
+        g_conv_strip = value; return GPFQ_OK;
+    }
     if (!std::strcmp(key, "lanes_per_neuron")) {
         if (value != 0 && value != 1 && value != 16 && value != 32 && value != 64)
             return fail(GPFQ_ERR_INVALID_ARG, "lanes_per_neuron must be 0, 1, 16, 32 or 64");
@@ -327,14 +335,26 @@ int gpfq_extract_patches(const float *act, int64_t n, int64_t H, int64_t W, int6
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_extract_patches");
 }
 
+int gpfq_channel_planes(const float *act, int64_t npos, int64_t Cin, int64_t c_lo, int64_t nch, float *planes, void *stream)
+{
+    if (npos < 0 || Cin <= 0 || c_lo < 0 || nch < 0 || c_lo + nch > Cin)
+        return fail(GPFQ_ERR_INVALID_ARG, "bad channel range [%lld, %lld) of %lld", (long long)c_lo, (long long)(c_lo + nch), (long long)Cin);
+    if (npos == 0 || nch == 0) return GPFQ_OK;
+    if (!act || !planes) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    hipError_t e = gpfq::launch_channel_planes(act, npos, Cin, c_lo, nch, planes, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_channel_planes");
+}
+
 static size_t al256c(size_t x) { return (x + 255) & ~(size_t)255; }
 
-size_t gpfq_conv_channels_workspace_bytes(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw,
-                                          int rh, int rw, int same_padding, int64_t F)
+size_t gpfq_conv_channels_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t nch, int kh, int kw, int sh, int sw,
+                                          int rh, int rw, int same_padding, int64_t F, int want_resid)
 {
     const int64_t cols = n * gpfq_patch_out_dim(H, kh, sh, rh, same_padding) * gpfq_patch_out_dim(W, kw, sw, rw, same_padding);
     const int64_t K = (int64_t)kh * kw;
-    if (cols <= 0 || K <= 0 || F < 0) return 0;
+    if (cols <= 0 || K <= 0 || F < 0 || nch < 0) return 0;
+    if (!want_resid && g_conv_fused && gpfq::gram_image_supported(n, H, W, kh, kw, sh, sw, rh, rw, same_padding))
+        return gpfq::gram_image_workspace_bytes(nch, F);
     const int64_t ldp = (cols + 3) & ~(int64_t)3;
     return 2 * al256c((size_t)K * ldp * sizeof(float)) + al256c((size_t)K * sizeof(float)) + gpfq::gram_workspace_bytes(K, cols, F);
 }
@@ -355,9 +375,20 @@ int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t 
     if (nch == 0 || F == 0 || cols == 0) return GPFQ_OK;
     if (K > GPFQ_GRAM_MAX_N || cols >= (1LL << 30)) return fail(GPFQ_ERR_UNSUPPORTED, "needs kh*kw <= %d and n*oh*ow < 2^30", GPFQ_GRAM_MAX_N);
     if (!act_w || !act_q || !Wt || !qidx || !Qt || !uncertified) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
-    const size_t need = gpfq_conv_channels_workspace_bytes(n, H, W, kh, kw, sh, sw, rh, rw, same_padding, F);
+    const size_t need = gpfq_conv_channels_workspace_bytes(n, H, W, nch, kh, kw, sh, sw, rh, rw, same_padding, F, resid != nullptr);
     if (!workspace || workspace_bytes < need || (uintptr_t)workspace % 16 != 0)
         return fail(GPFQ_ERR_WORKSPACE, "conv channel loop needs %zu aligned workspace bytes", need);
+    if (!resid && g_conv_fused && gpfq::gram_image_supported(n, H, W, kh, kw, sh, sw, rh, rw, same_padding)) {
+        // 3x3 / stride 1: Gram matrices of every channel straight from the planes, one batched decide launch
+        gpfq::ImageGramArgs g;
+        g.act_w = act_w; g.act_q = act_q; g.n = n; g.H = H; g.W = W; g.nch = nch; g.pad = same_padding ? 1 : 0;
+        g.Wt = Wt; g.A = A; g.F = F; g.qidx = qidx; g.Qt = Qt; g.uncertified = uncertified;
+        g.workspace = workspace;
+        g.slack = std::ldexp(1.0, g_gram_slack_log2);
+        g.variant = g_conv_strip;
+        hipError_t e = gpfq::launch_gram_image(g, static_cast<hipStream_t>(stream));
+        return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_conv_channels(fused)");
+    }
     int pad_top = 0, pad_left = 0;
     if (same_padding) {
         const int64_t keh = kh + (int64_t)(kh - 1) * (rh - 1), kew = kw + (int64_t)(kw - 1) * (rw - 1);

@@ -162,6 +162,36 @@ __device__ __forceinline__ Decision decide(float w, float nrm, double dot_u, dou
     return r;
 }
 
+// ---- Gram accumulators of the 3x3 conv case (gpfq_gram.hip, gpfq_gram_image.hip) -----------------
+// One column (sample) of the 9 patch rows: q[t] = Xq_t, x[s] = X_s in float64 (products of two float32
+// values are exact in float64).  Only what the decide step reads: the lower triangle s <= t of
+// <Xq_t,X_s> and <Xq_t,Xq_s> (packed index t(t+1)/2 + s), and the squared norms of the X rows.
+struct Gram9 {
+    double g[45][2];
+    double nx[9];
+};
+
+__device__ __forceinline__ void gram9_zero(Gram9 &a)
+{
+#pragma unroll
+    for (int i = 0; i < 45; ++i) { a.g[i][0] = 0.0; a.g[i][1] = 0.0; }
+#pragma unroll
+    for (int s = 0; s < 9; ++s) a.nx[s] = 0.0;
+}
+
+__device__ __forceinline__ void gram9_add(Gram9 &a, const double (&q)[9], const double (&x)[9])
+{
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        a.nx[s] = fma(x[s], x[s], a.nx[s]);
+#pragma unroll
+        for (int t = s; t < 9; ++t) {
+            a.g[t * (t + 1) / 2 + s][0] = fma(q[t], x[s], a.g[t * (t + 1) / 2 + s][0]);
+            a.g[t * (t + 1) / 2 + s][1] = fma(q[t], q[s], a.g[t * (t + 1) / 2 + s][1]);
+        }
+    }
+}
+
 struct AlphabetArg {
     double a[64];       // GPFQ_MAX_ALPHABET
     int    M;

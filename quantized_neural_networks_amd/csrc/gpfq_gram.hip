@@ -3,179 +3,280 @@
 // against patch matrices of m = n_img*oh*ow = 10^5..10^7 columns, shared by all C filters of a channel.
 //
 // The streaming kernel reads and writes every filter's residual u once per step (16 B per
-// filter*column*step of HBM traffic).  Here the patch rows are read ONCE per channel to form the N x N
-// Gram matrices
-//     G1[t][s] = <Xq_t, X_s>     G2[t][s] = <Xq_t, Xq_s>     (+ A1, A2: the same with absolute values)
+// filter*column*step of HBM traffic).  Here the patch rows are read ONCE per channel to form the lower
+// triangles (s <= t) of the N x N Gram matrices
+//     G1[t][s] = <Xq_t, X_s>     G2[t][s] = <Xq_t, Xq_s>     and the squared norms nx2[s] = <X_s, X_s>
 // and every filter then runs its N-step recurrence on scalars:
 //     <Xq_t, u_{t-1}>  ~  sum_{s<t} ( w_s G1[t][s] - q_s G2[t][s] ).
 // The reference forms u element-wise with three float32 roundings per step (:228) and accumulates it in
 // float64, so the identity above holds only up to
-//     |error| <= c * B_t,   B_t = sum_{s<t} ( |w_s| A1[t][s] + |q_s| A2[t][s] ),   c = 2^-21
-// (2^-24 each for the two products and the subtraction, float64 accumulation of u and of the dot
-// products, m < 2^30, and a factor ~2 of slack).  A decision is accepted only if the predicted
+//     |error| <= c * B_t,   B_t = sum_{s<t} ( |w_s| <|Xq_t|,|X_s|> + |q_s| <|Xq_t|,|Xq_s|> ),   c = 2^-22
+// (2^-24 for each product and 2^-24 of their sum for the subtraction: 2^-23 B_t; the float64 accumulation
+// of u and of the dot products with m < 2^30 is orders below that; a factor 2 of slack; products that
+// round in the subnormal range add at most 2^-128 ||Xq_t||).  The absolute inner products are bounded by
+// Cauchy-Schwarz, <|a|,|b|> <= ||a|| ||b||, so B_t <= ||Xq_t|| * sum_{s<t} ( |w_s| ||X_s|| + |q_s| ||Xq_s|| )
+// needs nothing beyond the diagonal of G2 and nx2.  A decision is accepted only if the predicted
 // quotient is farther from every decision boundary of the alphabet than that bound allows
 // (and the rule-(ii) test |<Xq_t,u>| < 1e-10 is decided the same way); otherwise the filter is
 // flagged `uncertified` and the caller reruns it through the exact element-wise path
 // (gpfq_quantize_neurons).  Accepted decisions are therefore provably the exact flow's.
+//
+// Layout of one Gram record (partials and totals): G[t][s][k] at (t*N + s)*2 + k, k = 0: G1, 1: G2,
+// then nx2[s] at N*N*2 + s.  Entries above the diagonal are never read (totals hold 0 there).
 #include "gpfq_device.hpp"
 #include "gpfq_launch.hpp"
 
 namespace gpfq {
 
 constexpr int kGramThreads = 256;
-constexpr int kGramCH = 256;               // columns staged per chunk
+constexpr int kGramCH = 256;               // columns staged per chunk (tile kernel)
 
-// Gram tiles with register accumulators.  Block (x, ty, sz) owns rows t in [t0, t0 + 4*TB), t0 = 4*TB*ty
-// (wave w: TB of them) against rows s in [s0, s0 + SB), s0 = SB*sz, and walks the column chunks
-// x, x + gridDim.x, ...: each chunk of 256 columns of the 4*TB + 2*SB rows it needs is staged in LDS once,
-// every lane then feeds 4 columns into its TB*SB*4 float64 accumulators (products of two f32 are exact in
-// f64).  Only at the end are the accumulators reduced across the wave and written as one partial per block:
-//     part[x][t][s][0..3] = <Xq_t,X_s>, <Xq_t,Xq_s>, <|Xq_t|,|X_s|>, <|Xq_t|,|Xq_s|>  over the block's columns.
+__host__ __device__ inline int64_t gram_record(int64_t N) { return N * N * 2 + N; }
+
+// ---- N > 9: register tiles over LDS-staged column chunks --------------------------------------------
+// Block (x, ty, sz) owns rows t in [t0, t0 + 4*TB), t0 = 4*TB*ty (wave w: TB of them) against rows s in
+// [s0, s0 + SB), s0 = SB*sz, and walks the column chunks x, x + gridDim.x, ...: each chunk of 256 columns of the
+// 4*TB + 2*SB rows it needs is staged in LDS once, every lane then feeds 4 columns into its TB*SB*2 float64
+// accumulators.  Tiles entirely above the diagonal exit at once.  The blocks of the last tile row (which
+// meets every column tile) also accumulate nx2 for their SB columns.
 template <int TB, int SB>
-__global__ void __launch_bounds__(kGramThreads)
+__global__ void __launch_bounds__(kGramThreads, 2)
 gpfq_gram_tile_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int N, int64_t m,
                       int64_t nchunks, double *__restrict__ part)
 {
-    __shared__ __attribute__((aligned(16))) float lqt[4 * TB][kGramCH];
-    __shared__ __attribute__((aligned(16))) float lxs[SB][kGramCH];
-    __shared__ __attribute__((aligned(16))) float lqs[SB][kGramCH];
+    constexpr int R = 4 * TB + 2 * SB;                 // staged rows: Xq_t | X_s | Xq_s
+    constexpr int J = (R + 3) / 4;                     // rows per wavefront
+    __shared__ __attribute__((aligned(16))) float lrow[R][kGramCH];
     const int t0 = blockIdx.y * 4 * TB, s0 = blockIdx.z * SB;
+    if (s0 > t0 + 4 * TB - 1) return;                  // tile above the diagonal (uniform: before any barrier)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec = (ld % 4 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)Xq % 16 == 0);
-    double acc[TB][SB][4];
+    const bool norms = (blockIdx.y == gridDim.y - 1) && wave == 0;
+    double acc[TB][SB][2], accn[SB];
 #pragma unroll
     for (int a = 0; a < TB; ++a)
 #pragma unroll
-        for (int s = 0; s < SB; ++s)
+        for (int s = 0; s < SB; ++s) { acc[a][s][0] = 0.0; acc[a][s][1] = 0.0; }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[a][s][k] = 0.0;
+    for (int s = 0; s < SB; ++s) accn[s] = 0.0;
+
+    // wavefront w stages rows w, w + 4, ...: source row pointers once, outside the chunk loop
+    const float *src[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int r = wave + 4 * j;
+        int row = -1;
+        const float *base = Xq;
+        if (r < 4 * TB) row = t0 + r;
+        else if (r < 4 * TB + SB) { row = s0 + r - 4 * TB; base = X; }
+        else if (r < R) row = s0 + r - 4 * TB - SB;
+        src[j] = (row >= 0 && row < N) ? base + (int64_t)row * ld : nullptr;
+    }
 
     for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-        const int64_t c0 = ch * kGramCH;
+        const int64_t col = ch * kGramCH + 4 * lane;
         __syncthreads();
-        // stage the 4*TB + 2*SB row segments as 16-byte pieces (zero beyond N / m)
-        for (int idx = threadIdx.x; idx < (4 * TB + 2 * SB) * (kGramCH / 4); idx += kGramThreads) {
-            const int r = idx / (kGramCH / 4), c = (idx - r * (kGramCH / 4)) * 4;
-            const int64_t col = c0 + c;
-            const float *src;
-            float *dst;
-            int row;
-            if (r < 4 * TB)           { row = t0 + r;               src = Xq; dst = &lqt[r][c]; }
-            else if (r < 4 * TB + SB) { row = s0 + r - 4 * TB;      src = X;  dst = &lxs[r - 4 * TB][c]; }
-            else                      { row = s0 + r - 4 * TB - SB; src = Xq; dst = &lqs[r - 4 * TB - SB][c]; }
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < N && col < m) {
-                const float *g = src + (int64_t)row * ld + col;
-                if (vec && col + 4 <= m) v = *reinterpret_cast<const float4 *>(g);
-                else {
-                    v.x = g[0];
-                    if (col + 1 < m) v.y = g[1];
-                    if (col + 2 < m) v.z = g[2];
-                    if (col + 3 < m) v.w = g[3];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int r = wave + 4 * j;
+            if (r < R) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (src[j] && col < m) {
+                    const float *g = src[j] + col;
+                    if (vec && col + 4 <= m) v = *reinterpret_cast<const float4 *>(g);
+                    else {
+                        v.x = g[0];
+                        if (col + 1 < m) v.y = g[1];
+                        if (col + 2 < m) v.z = g[2];
+                        if (col + 3 < m) v.w = g[3];
+                    }
                 }
+                *reinterpret_cast<float4 *>(&lrow[r][4 * lane]) = v;
             }
-            *reinterpret_cast<float4 *>(dst) = v;
         }
         __syncthreads();
         // lane l feeds columns 4l..4l+3 of the chunk: one 16-byte LDS read per row
         float4 qt4[TB];
 #pragma unroll
-        for (int a = 0; a < TB; ++a) qt4[a] = *reinterpret_cast<const float4 *>(&lqt[wave * TB + a][4 * lane]);
+        for (int a = 0; a < TB; ++a) qt4[a] = *reinterpret_cast<const float4 *>(&lrow[wave * TB + a][4 * lane]);
 #pragma unroll
         for (int s = 0; s < SB; ++s) {
-            const float4 xs4 = *reinterpret_cast<const float4 *>(&lxs[s][4 * lane]);
-            const float4 qs4 = *reinterpret_cast<const float4 *>(&lqs[s][4 * lane]);
+            const float4 xs4 = *reinterpret_cast<const float4 *>(&lrow[4 * TB + s][4 * lane]);
+            const float4 qs4 = *reinterpret_cast<const float4 *>(&lrow[4 * TB + SB + s][4 * lane]);
             const float xsv[4] = {xs4.x, xs4.y, xs4.z, xs4.w}, qsv[4] = {qs4.x, qs4.y, qs4.z, qs4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const double xs = (double)xsv[e], qs = (double)qsv[e];
-                const double xsa = fabs(xs), qsa = fabs(qs);
 #pragma unroll
                 for (int a = 0; a < TB; ++a) {
                     const float qtf = e == 0 ? qt4[a].x : e == 1 ? qt4[a].y : e == 2 ? qt4[a].z : qt4[a].w;
-                    const double qt = (double)qtf, qta = fabs(qt);
+                    const double qt = (double)qtf;
                     acc[a][s][0] = fma(qt, xs, acc[a][s][0]);
                     acc[a][s][1] = fma(qt, qs, acc[a][s][1]);
-                    acc[a][s][2] = fma(qta, xsa, acc[a][s][2]);
-                    acc[a][s][3] = fma(qta, qsa, acc[a][s][3]);
                 }
             }
         }
+        if (norms) {                                   // one wavefront of the last tile row: <X_s, X_s>
+#pragma unroll
+            for (int s = 0; s < SB; ++s) {
+                const float4 xs4 = *reinterpret_cast<const float4 *>(&lrow[4 * TB + s][4 * lane]);
+                accn[s] = fma((double)xs4.x, (double)xs4.x, accn[s]);
+                accn[s] = fma((double)xs4.y, (double)xs4.y, accn[s]);
+                accn[s] = fma((double)xs4.z, (double)xs4.z, accn[s]);
+                accn[s] = fma((double)xs4.w, (double)xs4.w, accn[s]);
+            }
+        }
     }
+    double *out = part + (int64_t)blockIdx.x * gram_record(N);
 #pragma unroll
     for (int a = 0; a < TB; ++a) {
         const int t = t0 + wave * TB + a;
 #pragma unroll
         for (int s = 0; s < SB; ++s)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 2; ++k) {
                 const double v = wave_sum(acc[a][s][k]);
-                if (lane == 0 && t < N && s0 + s < N)
-                    part[(((int64_t)blockIdx.x * N + t) * N + (s0 + s)) * 4 + k] = v;
+                if (lane == 0 && t < N && s0 + s < N) out[((int64_t)t * N + (s0 + s)) * 2 + k] = v;
             }
+    }
+    if (norms) {
+#pragma unroll
+        for (int s = 0; s < SB; ++s) {
+            const double v = wave_sum(accn[s]);
+            if (lane == 0 && s0 + s < N) out[(int64_t)N * N * 2 + s0 + s] = v;
+        }
     }
 }
 
-// gram[t][s][k] = sum over the partial blocks in block order (deterministic); one wavefront per entry.
+// ---- N <= 9 (3x3 kernels on patch matrices): every wavefront keeps the whole record ----------------
+// No LDS, no barriers: lane l of wavefront (block x, wave w) feeds columns 64(4x + w) + l + k*256*gridDim.x, the
+// 18 row values of the next column are in flight while the 99 sums of the current one are updated.  One
+// partial record per wavefront.  Rows >= N read as zeros.
+__global__ void __launch_bounds__(kGramThreads, 2)
+gpfq_gram_rows9_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int N, int64_t m,
+                       double *__restrict__ part)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Gram9 acc;
+    gram9_zero(acc);
+    const int64_t stride = (int64_t)gridDim.x * kGramThreads;
+    int64_t i = (int64_t)blockIdx.x * kGramThreads + threadIdx.x;
+    float xf[9], qf[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        xf[s] = (s < N && i < m) ? X[(int64_t)s * ld + i] : 0.f;
+        qf[s] = (s < N && i < m) ? Xq[(int64_t)s * ld + i] : 0.f;
+    }
+    while (i < m) {
+        double x[9], q[9];
+#pragma unroll
+        for (int s = 0; s < 9; ++s) { x[s] = (double)xf[s]; q[s] = (double)qf[s]; }
+        i += stride;
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            xf[s] = (s < N && i < m) ? X[(int64_t)s * ld + i] : 0.f;
+            qf[s] = (s < N && i < m) ? Xq[(int64_t)s * ld + i] : 0.f;
+        }
+        gram9_add(acc, q, x);
+    }
+    double *out = part + ((int64_t)blockIdx.x * 4 + wave) * gram_record(N);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int s = 0; s <= t; ++s)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double v = wave_sum(acc.g[t * (t + 1) / 2 + s][k]);
+                if (lane == 0 && t < N) out[(t * N + s) * 2 + k] = v;
+            }
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        const double v = wave_sum(acc.nx[s]);
+        if (lane == 0 && s < N) out[N * N * 2 + s] = v;
+    }
+}
+
+// total[e] = sum over the partial records in record order (deterministic); one wavefront per entry, zeros
+// above the diagonal.  blockIdx.y = channel of a batched launch.  Also the float32-rounded row norms
+// nrm32[t] = (float)sqrt(<Xq_t, Xq_t>) (:83, :89) from the diagonal of G2 (when nrm32 != NULL).
 __global__ void __launch_bounds__(256)
-gpfq_gram_reduce_kernel(const double *__restrict__ part, int64_t nparts, int N, double *__restrict__ gram)
+gpfq_gram_reduce_kernel(const double *__restrict__ part, int64_t nparts, int N, double *__restrict__ gram,
+                        float *__restrict__ nrm32)
 {
-    const int64_t total = (int64_t)N * N * 4;
+    const int64_t rec = gram_record(N);
     const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (e >= total) return;
+    if (e >= rec) return;
+    part += (int64_t)blockIdx.y * nparts * rec;
+    gram += (int64_t)blockIdx.y * rec;
+    int t = -1, s = -1, k = -1;
+    if (e < (int64_t)N * N * 2) { k = (int)(e & 1); t = (int)((e >> 1) / N); s = (int)((e >> 1) - (int64_t)t * N); }
     double v = 0.0;
-    for (int64_t c = threadIdx.x & 63; c < nparts; c += 64) v += part[c * total + e];
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) gram[e] = v;
+    if (s <= t) {
+        for (int64_t c = threadIdx.x & 63; c < nparts; c += 64) v += part[c * rec + e];
+        v = wave_sum(v);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        gram[e] = v;
+        if (nrm32 && t >= 0 && s == t && k == 1) nrm32[(int64_t)blockIdx.y * N + t] = (float)sqrt(v);
+    }
 }
 
-// nrm32[t] = (float)sqrt(<Xq_t, Xq_t>): the float32-rounded row norm (:83, :89) from the Gram diagonal.
-__global__ void gpfq_gram_norms_kernel(const double *__restrict__ gram, int N, float *__restrict__ nrm32)
+// The N-step recurrence of one neuron on a Gram record with certified decisions.  Returns 0 when every
+// decision was certified, else 1 + the step that could not be.  t0 >= 0 resumes a chain that stopped at step
+// t0: steps before it take the recorded decisions (qh), step t0 takes the EXACT decision from the two
+// element-wise dot products dot_u = <Xq_t0, u>, dot_uw = <Xq_t0, u + w X_t0> (:86-89), later steps are
+// certified as usual.
+__device__ __forceinline__ int decide_chain(const double *__restrict__ gram, const float *__restrict__ nrm32,
+                                            const float *__restrict__ w, float *__restrict__ qh, const AlphabetArg &A, int N,
+                                            double slack, int8_t *__restrict__ qidx, float *__restrict__ Qt,
+                                            int t0, double dot_u, double dot_uw)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < N) nrm32[t] = (float)sqrt(gram[((int64_t)t * N + t) * 4 + 1]);
-}
-
-// One thread per neuron: the N-step recurrence on the Gram matrices with certified decisions.
-__global__ void __launch_bounds__(64)
-gpfq_gram_decide_kernel(const double *__restrict__ gram, const float *__restrict__ nrm32,
-                        const float *__restrict__ Wt, int64_t ldw, AlphabetArg A, int N, int64_t C,
-                        double slack, int8_t *__restrict__ qidx, float *__restrict__ Qt,
-                        int32_t *__restrict__ uncertified, float *__restrict__ q32_hist)
-{
-    const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (j >= C) return;
-    const float *w = Wt + j * ldw;
-    float *qh = q32_hist + j * N;                       // this neuron's chosen values (f32), for s < t
-    const double c = 0x1p-21 * slack;                   // slack = 1 in production; tests shrink margins with it
-    bool ok = true;
+    const double *nx2 = gram + (int64_t)N * N * 2;
+    const double c = 0x1p-22 * slack;                   // slack = 1 in production; tests shrink margins with it
+    // Cauchy-Schwarz needs upper bounds of the norms: one ulp-scale inflation covers sqrt and product roundings
+    const double up = 1.0 + 0x1p-48;
+    double R = 0.0;                                     // sum_{s<t} |w_s| ||X_s|| + |q_s| ||Xq_s||
     for (int t = 0; t < N; ++t) {
         int idx = A.zero_idx;
         float q32 = 0.f;
         const float nrm = nrm32[t];
-        if (!((double)nrm < 1e-16)) {                                                  // not rule (i)
-            double acc = 0.0, B = 0.0;
-            for (int s = 0; s < t; ++s) {
-                const double *g = gram + ((int64_t)t * N + s) * 4;
-                const double ws = (double)w[s], qs = (double)qh[s];
-                acc += ws * g[0] - qs * g[1];
-                B += fabs(ws) * g[2] + fabs(qs) * g[3];
+        const double nq = sqrt(gram[((int64_t)t * N + t) * 2 + 1]) * up;
+        const double nx = sqrt(nx2[t]) * up;
+        if (t < t0) {                                                                  // decided in an earlier pass
+            R += fabs((double)w[t]) * nx + fabs((double)qh[t]) * nq;
+            continue;
+        }
+        if (t == t0) {                                                                 // exact flow (:83-89)
+            if (!((double)nrm < 1e-16)) {
+                const double tq = fabs(dot_u) < 1e-10 ? (double)w[t] : dot_uw / ((double)nrm * (double)nrm);
+                double d1 = fabs(A.a[0] - tq);
+                int best = 0;
+                for (int k = 1; k < A.M; ++k) {
+                    const double d = fabs(A.a[k] - tq);
+                    if (d < d1) { d1 = d; best = k; }
+                }
+                idx = best;
+                q32 = (float)A.a[best];
             }
-            const double err0 = c * B;
+        } else if (!((double)nrm < 1e-16)) {                                           // not rule (i)
+            double acc = 0.0;
+            for (int s = 0; s < t; ++s) {
+                const double *g = gram + ((int64_t)t * N + s) * 2;
+                acc += (double)w[s] * g[0] - (double)qh[s] * g[1];
+            }
+            const double err0 = c * nq * R + 0x1p-128 * nq;     // second term: products rounded in the subnormal range
             double tq;
             double delta;
             if (fabs(acc) + err0 < 1e-10) {                                            // certainly rule (ii)
                 tq = (double)w[t];
                 delta = 0.0;
             } else if (fabs(acc) - err0 >= 1e-10) {                                    // certainly rule (iii)
-                const double *g = gram + ((int64_t)t * N + t) * 4;
                 const double wt = (double)w[t];
                 const double denom = (double)nrm * (double)nrm;
-                tq = (acc + wt * g[0]) / denom;
-                delta = (err0 + 0x1p-23 * fabs(wt) * g[2] * slack) / denom + 0x1p-44 * fabs(tq);
+                tq = (acc + wt * gram[((int64_t)t * N + t) * 2]) / denom;
+                delta = (err0 + 0x1p-23 * fabs(wt) * nq * nx * slack) / denom + 0x1p-44 * fabs(tq);
             } else {
-                ok = false;                                                            // cannot tell (ii) from (iii)
-                break;
+                return t + 1;                                                          // cannot tell (ii) from (iii)
             }
             // first minimum of |a_k - tq| and the runner-up distance
             double d1 = fabs(A.a[0] - tq), d2 = __longlong_as_double(0x7ff0000000000000LL);
@@ -185,15 +286,140 @@ gpfq_gram_decide_kernel(const double *__restrict__ gram, const float *__restrict
                 if (d < d1) { d2 = d1; d1 = d; best = k; }
                 else if (d < d2) d2 = d;
             }
-            if (!(0.5 * (d2 - d1) > delta)) { ok = false; break; }                      // too close to a boundary (or NaN)
+            if (!(0.5 * (d2 - d1) > delta)) return t + 1;                               // too close to a boundary (or NaN)
             idx = best;
             q32 = (float)A.a[best];
         }
+        R += fabs((double)w[t]) * nx + fabs((double)q32) * nq;
         qh[t] = q32;
-        if (qidx) qidx[j * N + t] = (int8_t)idx;
-        if (Qt) Qt[j * N + t] = q32;
+        if (qidx) qidx[t] = (int8_t)idx;
+        if (Qt) Qt[t] = q32;
     }
-    uncertified[j] = ok ? 0 : 1;
+    return 0;
+}
+
+// Device-side repair of the rare uncertified chains (no host round trip): the decide pass lists them, one
+// pass over the data forms the exact dot products of the step that stopped each chain, the chain resumes.
+constexpr int kFixMax = 16;        // chains repaired per round (more stay flagged for the caller)
+constexpr int kFixBlocks = 256;    // column walkers per listed chain
+constexpr int kFixRounds = 2;
+struct FixState {
+    int32_t count[kFixRounds + 1];
+    int32_t list[kFixRounds + 1][kFixMax];               // channel * C + neuron
+    double part[kFixMax][kFixBlocks][2];
+};
+
+// One thread per neuron (blockIdx.y = channel of a batched conv launch; all strides 0 for a single problem).
+__global__ void __launch_bounds__(64)
+gpfq_gram_decide_kernel(const double *__restrict__ gram, const float *__restrict__ nrm32,
+                        const float *__restrict__ Wt, int64_t ldw, AlphabetArg A, int N, int64_t C,
+                        double slack, int8_t *__restrict__ qidx, float *__restrict__ Qt,
+                        int32_t *__restrict__ uncertified, float *__restrict__ q32_hist, DecideBatch bs,
+                        FixState *__restrict__ fix)
+{
+    const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (j >= C) return;
+    const int64_t ch = blockIdx.y;
+    const int r = decide_chain(gram + ch * bs.gram_cs, nrm32 + ch * bs.nrm_cs, Wt + ch * bs.w_cs + j * ldw,
+                               q32_hist + ch * bs.hist_cs + j * N, A, N, slack,
+                               qidx ? qidx + ch * bs.out_cs + j * N : nullptr, Qt ? Qt + ch * bs.out_cs + j * N : nullptr,
+                               -1, 0.0, 0.0);
+    uncertified[ch * bs.unc_cs + j] = r;
+    if (r && fix) {
+        const int k = atomicAdd(&fix->count[0], 1);
+        if (k < kFixMax) fix->list[0][k] = (int32_t)(ch * C + j);
+    }
+}
+
+__device__ __forceinline__ void fix_fetch(const FixSrc &src, int64_t ch, int s, int64_t i, int64_t b, int oy, int ox,
+                                          float &x, float &xq)
+{
+    if (!src.planes) {
+        x = src.X[(int64_t)s * src.ld + i];
+        xq = src.Xq[(int64_t)s * src.ld + i];
+        return;
+    }
+    const int iy = oy + s / 3 - src.pad, ix = ox + s % 3 - src.pad;
+    x = 0.f; xq = 0.f;
+    if (iy >= 0 && iy < src.H && ix >= 0 && ix < src.W) {
+        const int64_t o = ch * src.plane + (b * src.H + iy) * src.W + ix;
+        x = src.X[o];
+        xq = src.Xq[o];
+    }
+}
+
+// Exact dot products of the stopped step of every listed chain: per column the residual is rebuilt with
+// the reference's element-wise flow (:228) from the recorded decisions, never stored.
+__global__ void __launch_bounds__(256)
+gpfq_gram_fix_kernel(FixSrc src, const float *__restrict__ Wt, int64_t ldw, int N, int64_t C,
+                     const int32_t *__restrict__ uncertified, const float *__restrict__ q32_hist, DecideBatch bs,
+                     FixState *__restrict__ fix, int round)
+{
+    __shared__ double sm[4][2];
+    const int k = blockIdx.y;
+    const int cnt = fix->count[round];
+    if (k >= (cnt < kFixMax ? cnt : kFixMax)) return;
+    const int64_t gid = fix->list[round][k];
+    const int64_t ch = gid / C, j = gid - ch * C;
+    const int t0 = uncertified[ch * bs.unc_cs + j] - 1;
+    const float *w = Wt + ch * bs.w_cs + j * ldw;
+    const float *qh = q32_hist + ch * bs.hist_cs + j * N;
+    double a0 = 0.0, a1 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < src.m; i += (int64_t)kFixBlocks * 256) {
+        int64_t b = 0;
+        int oy = 0, ox = 0;
+        if (src.planes) {
+            b = i / ((int64_t)src.oh * src.ow);
+            const int rem = (int)(i - b * src.oh * src.ow);
+            oy = rem / src.ow;
+            ox = rem - oy * src.ow;
+        }
+        double u = 0.0;
+        float x, xq;
+        for (int s = 0; s < t0; ++s) {
+            fix_fetch(src, ch, s, i, b, oy, ox, x, xq);
+            u += (double)__fsub_rn(__fmul_rn(w[s], x), __fmul_rn(qh[s], xq));
+        }
+        fix_fetch(src, ch, t0, i, b, oy, ox, x, xq);
+        const double v = u + (double)__fmul_rn(w[t0], x);
+        a0 = fma((double)xq, u, a0);                                   // <Xq_t, u>          (:86)
+        a1 = fma((double)xq, v, a1);                                   // <Xq_t, u + w*X_t>  (:89)
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = a0; sm[threadIdx.x >> 6][1] = a1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        fix->part[k][blockIdx.x][0] = sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0];
+        fix->part[k][blockIdx.x][1] = sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1];
+    }
+}
+
+// Resume the listed chains from their exact step; chains that stop again are listed for the next round.
+__global__ void __launch_bounds__(64)
+gpfq_gram_resume_kernel(const double *__restrict__ gram, const float *__restrict__ nrm32,
+                        const float *__restrict__ Wt, int64_t ldw, AlphabetArg A, int N, int64_t C,
+                        double slack, int8_t *__restrict__ qidx, float *__restrict__ Qt,
+                        int32_t *__restrict__ uncertified, float *__restrict__ q32_hist, DecideBatch bs,
+                        FixState *__restrict__ fix, int round)
+{
+    const int k = threadIdx.x;
+    const int cnt = fix->count[round];
+    if (k >= (cnt < kFixMax ? cnt : kFixMax)) return;
+    const int64_t gid = fix->list[round][k];
+    const int64_t ch = gid / C, j = gid - ch * C;
+    const int t0 = uncertified[ch * bs.unc_cs + j] - 1;
+    double dot_u = 0.0, dot_uw = 0.0;
+    for (int b = 0; b < kFixBlocks; ++b) { dot_u += fix->part[k][b][0]; dot_uw += fix->part[k][b][1]; }
+    const int r = decide_chain(gram + ch * bs.gram_cs, nrm32 + ch * bs.nrm_cs, Wt + ch * bs.w_cs + j * ldw,
+                               q32_hist + ch * bs.hist_cs + j * N, A, N, slack,
+                               qidx ? qidx + ch * bs.out_cs + j * N : nullptr, Qt ? Qt + ch * bs.out_cs + j * N : nullptr,
+                               t0, dot_u, dot_uw);
+    uncertified[ch * bs.unc_cs + j] = r;
+    if (r) {
+        const int kk = atomicAdd(&fix->count[round + 1], 1);
+        if (kk < kFixMax) fix->list[round + 1][kk] = (int32_t)gid;
+    }
 }
 
 // Exact replay of the residual for known decisions: u = sum_t f32(f32(w_t X_t) - f32(q_t Xq_t)) with the
@@ -262,69 +488,107 @@ gpfq_replay_finish_kernel(const double *__restrict__ part, int64_t nchunks, int6
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-constexpr int kGramBlocksX = 512;          // column-chunk walkers per (t-set, s-set)
+constexpr int kGramBlocksX = 512;          // column walkers (per tile for N > 9)
 
-static int64_t gram_parts(int64_t m)
+static int64_t gram_blocks(int64_t m)
 {
     const int64_t nchunks = (m + kGramCH - 1) / kGramCH;
     return nchunks < kGramBlocksX ? (nchunks > 0 ? nchunks : 1) : kGramBlocksX;
 }
 
+// partial records: one per workgroup (tile kernel) or per wavefront (rows9 kernel)
+static int64_t gram_parts(int64_t N, int64_t m) { return N <= 9 ? gram_blocks(m) * 4 : gram_blocks(m); }
+
 size_t gram_workspace_bytes(int64_t N, int64_t m, int64_t C)
 {
     const int64_t rchunks = (m + 1023) / 1024;
     size_t b = 0;
-    b += al256((size_t)gram_parts(m) * N * N * 4 * sizeof(double));   // Gram partials
-    b += al256((size_t)N * N * 4 * sizeof(double) + 8);               // Gram matrices
-    b += al256((size_t)C * N * sizeof(float));                        // chosen values (f32) per neuron and step
-    b += al256((size_t)C * rchunks * sizeof(double));                 // replay partials
+    b += al256((size_t)gram_parts(N, m) * gram_record(N) * sizeof(double));   // Gram partials
+    b += al256((size_t)gram_record(N) * sizeof(double) + 8);                  // Gram record
+    b += al256((size_t)C * N * sizeof(float));                                // chosen values (f32) per neuron and step
+    b += al256(sizeof(FixState));                                             // device-side repair of uncertified chains
+    b += al256((size_t)C * rchunks * sizeof(double));                         // replay partials
     return b;
+}
+
+hipError_t launch_gram_reduce(const double *part, int64_t nparts, int N, double *gram, float *nrm32, int64_t nch,
+                              hipStream_t stream)
+{
+    if (nch == 0 || N == 0) return hipSuccess;
+    hipLaunchKernelGGL(gpfq_gram_reduce_kernel, dim3((unsigned)((gram_record(N) + 3) / 4), (unsigned)nch), dim3(256), 0, stream,
+                       part, nparts, N, gram, nrm32);
+    return hipGetLastError();
+}
+
+size_t gram_fix_bytes() { return al256(sizeof(FixState)); }
+
+hipError_t launch_gram_decide(const double *gram, const float *nrm32, const float *Wt, int64_t ldw, const AlphabetArg &A,
+                              int N, int64_t C, double slack, int8_t *qidx, float *Qt, int32_t *uncertified,
+                              float *q32_hist, const DecideBatch &bs, const FixSrc *src, void *fix_ws, hipStream_t stream)
+{
+    if (C == 0 || bs.nch == 0) return hipSuccess;
+    FixState *fix = (src && fix_ws && src->m > 0 && bs.nch * C < (1LL << 31)) ? static_cast<FixState *>(fix_ws) : nullptr;
+    if (fix) {
+        hipError_t e = hipMemsetAsync(fix, 0, sizeof(int32_t) * (kFixRounds + 1), stream);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(gpfq_gram_decide_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)bs.nch), dim3(64), 0, stream,
+                       gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, bs, fix);
+    for (int round = 0; fix && round < kFixRounds; ++round) {
+        hipLaunchKernelGGL(gpfq_gram_fix_kernel, dim3(kFixBlocks, kFixMax), dim3(256), 0, stream,
+                           *src, Wt, ldw, N, C, uncertified, q32_hist, bs, fix, round);
+        hipLaunchKernelGGL(gpfq_gram_resume_kernel, dim3(1), dim3(64), 0, stream,
+                           gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, bs, fix, round);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_gram(const GramArgs &a, hipStream_t stream)
 {
     const int64_t nchunks = (a.m + kGramCH - 1) / kGramCH;
-    const int64_t nparts = gram_parts(a.m);
+    const int64_t nblocks = gram_blocks(a.m), nparts = gram_parts(a.N, a.m);
     const int64_t rchunks = (a.m + 1023) / 1024;
+    const int64_t rec = gram_record(a.N);
     char *ws = static_cast<char *>(a.workspace);
-    double *part = reinterpret_cast<double *>(ws);  ws += al256((size_t)nparts * a.N * a.N * 4 * sizeof(double));
-    double *gram = reinterpret_cast<double *>(ws);  ws += al256((size_t)a.N * a.N * 4 * sizeof(double) + 8);
+    double *part = reinterpret_cast<double *>(ws);  ws += al256((size_t)nparts * rec * sizeof(double));
+    double *gram = reinterpret_cast<double *>(ws);  ws += al256((size_t)rec * sizeof(double) + 8);
     float *q32h  = reinterpret_cast<float *>(ws);   ws += al256((size_t)a.C * a.N * sizeof(float));
+    void *fixws = ws;                               ws += gram_fix_bytes();
     double *rpart = reinterpret_cast<double *>(ws);
 
     const int N = (int)a.N;
     if (a.m > 0 && N > 0) {
-        if (N <= 9 && a.variant == 1) {
-            hipLaunchKernelGGL((gpfq_gram_tile_kernel<1, 9>), dim3((unsigned)nparts, (unsigned)((N + 3) / 4), 1), dim3(kGramThreads), 0, stream,
-                               a.X, a.Xq, a.ld, N, a.m, nchunks, part);
-        } else if (N <= 9 && a.variant == 2) {
-            hipLaunchKernelGGL((gpfq_gram_tile_kernel<2, 9>), dim3((unsigned)nparts, (unsigned)((N + 7) / 8), 1), dim3(kGramThreads), 0, stream,
-                               a.X, a.Xq, a.ld, N, a.m, nchunks, part);
-        } else if (N <= 9) {
-            hipLaunchKernelGGL((gpfq_gram_tile_kernel<3, 9>), dim3((unsigned)nparts, 1, 1), dim3(kGramThreads), 0, stream,
-                               a.X, a.Xq, a.ld, N, a.m, nchunks, part);
+        if (N <= 9) {
+            hipLaunchKernelGGL(gpfq_gram_rows9_kernel, dim3((unsigned)nblocks), dim3(kGramThreads), 0, stream,
+                               a.X, a.Xq, a.ld, N, a.m, part);
         } else {
-            hipLaunchKernelGGL((gpfq_gram_tile_kernel<2, 12>), dim3((unsigned)nparts, (unsigned)((N + 7) / 8), (unsigned)((N + 11) / 12)),
+            // all tiles of the last tile row are launched (they carry nx2); tiles above the diagonal exit at once
+            hipLaunchKernelGGL((gpfq_gram_tile_kernel<2, 12>), dim3((unsigned)nblocks, (unsigned)((N + 7) / 8), (unsigned)((N + 11) / 12)),
                                dim3(kGramThreads), 0, stream, a.X, a.Xq, a.ld, N, a.m, nchunks, part);
         }
-        hipLaunchKernelGGL(gpfq_gram_reduce_kernel, dim3((unsigned)((a.N * a.N * 4 + 3) / 4)), dim3(256), 0, stream,
-                           part, nparts, N, gram);
-    } else {
-        hipError_t e = hipMemsetAsync(gram, 0, (size_t)a.N * a.N * 4 * sizeof(double) + 8, stream);
+        hipError_t e = launch_gram_reduce(part, nparts, N, gram, a.nrm32_out, 1, stream);
         if (e != hipSuccess) return e;
+    } else {
+        hipError_t e = hipMemsetAsync(gram, 0, (size_t)rec * sizeof(double) + 8, stream);
+        if (e != hipSuccess) return e;
+        if (a.nrm32_out && N > 0) {
+            e = hipMemsetAsync(a.nrm32_out, 0, (size_t)N * sizeof(float), stream);
+            if (e != hipSuccess) return e;
+        }
     }
-    if (a.nrm32_out && N > 0)
-        hipLaunchKernelGGL(gpfq_gram_norms_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, stream, gram, N, a.nrm32_out);
-    hipLaunchKernelGGL(gpfq_gram_decide_kernel, dim3((unsigned)((a.C + 63) / 64)), dim3(64), 0, stream,
-                       gram, a.nrm32, a.Wt, a.ldw, a.A, N, a.C, a.slack, a.qidx, a.Qt, a.uncertified, q32h);
+    FixSrc src{};
+    src.X = a.X; src.Xq = a.Xq; src.ld = a.ld; src.m = a.m; src.planes = 0;
+    hipError_t e = launch_gram_decide(gram, a.nrm32, a.Wt, a.ldw, a.A, N, a.C, a.slack, a.qidx, a.Qt, a.uncertified, q32h,
+                                      DecideBatch(), &src, fixws, stream);
+    if (e != hipSuccess) return e;
     if (a.resid) {
         if (a.m > 0 && N > 0) {
             hipLaunchKernelGGL(gpfq_replay_norm_kernel, dim3((unsigned)rchunks, (unsigned)((a.C + kReplayNG - 1) / kReplayNG)),
                                dim3(256), 0, stream, a.X, a.Xq, a.ld, N, a.m, a.C, a.Wt, a.ldw, q32h, rchunks, rpart);
             hipLaunchKernelGGL(gpfq_replay_finish_kernel, dim3((unsigned)a.C), dim3(64), 0, stream, rpart, rchunks, a.C, a.resid);
         } else {
-            hipError_t e = hipMemsetAsync(a.resid, 0, (size_t)a.C * sizeof(double), stream);
-            if (e != hipSuccess) return e;
+            hipError_t e2 = hipMemsetAsync(a.resid, 0, (size_t)a.C * sizeof(double), stream);
+            if (e2 != hipSuccess) return e2;
         }
     }
     return hipGetLastError();

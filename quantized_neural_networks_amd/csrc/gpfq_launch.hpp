@@ -85,6 +85,50 @@ struct GramArgs {
 size_t gram_workspace_bytes(int64_t N, int64_t m, int64_t C);
 hipError_t launch_gram(const GramArgs &a, hipStream_t stream);
 
+// Batched decide step (one launch for all channels of a conv shard): element strides per channel.
+struct DecideBatch {
+    int64_t nch = 1, gram_cs = 0, nrm_cs = 0, w_cs = 0, out_cs = 0, unc_cs = 0, hist_cs = 0;
+};
+// Gram records (gpfq_gram.hip): [N][N][2] (G1, G2; lower triangle) + [N] (squared norms of the X rows).
+// part: [nch][nparts] records -> gram: [nch] records, nrm32 (may be NULL): [nch][N].
+hipError_t launch_gram_reduce(const double *part, int64_t nparts, int N, double *gram, float *nrm32, int64_t nch,
+                              hipStream_t stream);
+// Where the patch rows of the exact repair pass come from: a patch matrix in memory, or the channel planes
+// (3x3 / stride 1: row (ky, kx) is the plane shifted by (ky - pad, kx - pad), zero outside the image).
+struct FixSrc {
+    const float *X, *Xq;
+    int64_t ld, m;               // m = columns (n*oh*ow for planes)
+    int planes;                  // 0: X/Xq are [N][ld] patch rows; 1: [nch][n][H][W] channel planes
+    int64_t plane;               // floats per channel plane
+    int n, H, W, pad, oh, ow;
+};
+size_t gram_fix_bytes();
+// decide pass + (src != NULL) two rounds of device-side repair of the chains it could not certify;
+// fix_ws: gram_fix_bytes() of scratch.  Chains still flagged afterwards are the caller's to rerun.
+hipError_t launch_gram_decide(const double *gram, const float *nrm32, const float *Wt, int64_t ldw, const AlphabetArg &A,
+                              int N, int64_t C, double slack, int8_t *qidx, float *Qt, int32_t *uncertified,
+                              float *q32_hist, const DecideBatch &bs, const FixSrc *src, void *fix_ws, hipStream_t stream);
+
+// Fused conv path for 3x3 / stride 1 / rate 1 kernels (gpfq_gram_image.hip): the Gram matrices of all
+// channels straight from the channel planes, then one batched decide launch -- no patch matrices.
+struct ImageGramArgs {
+    const float *act_w, *act_q;   // channel-major planes [nch][n][H][W]
+    int64_t n, H, W, nch;
+    int pad;                      // 1 = SAME (one ring of zeros), 0 = VALID
+    const float *Wt;              // [nch][F][9]
+    AlphabetArg A;
+    int64_t F;
+    int8_t *qidx;                 // [nch][F][9]
+    float *Qt;                    // [nch][F][9]
+    int32_t *uncertified;         // [nch][F]
+    void *workspace;
+    double slack = 1.0;
+    int variant = 0;              // tuning hook: forces the strip length (1, 2, 4, 7)
+};
+bool gram_image_supported(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw, int rh, int rw, int same_padding);
+size_t gram_image_workspace_bytes(int64_t nch, int64_t F);
+hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream);
+
 hipError_t launch_row_stats(const float *X, const float *Xq, int64_t N, int64_t m, int64_t ld, const float *nrm32,
                             RowStats *stats, hipStream_t stream);
 hipError_t launch_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, float *nrm32, hipStream_t stream);
@@ -94,6 +138,8 @@ hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, 
 hipError_t launch_pack(const int8_t *qidx, int64_t N, int64_t C, int bits, uint8_t *packed, hipStream_t stream);
 size_t median_workspace_bytes();
 hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream);
+hipError_t launch_channel_planes(const float *act, int64_t npos, int64_t Cin, int64_t c_lo, int64_t nch, float *planes,
+                                 hipStream_t stream);
 hipError_t launch_extract_patches(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t c,
                                   int kh, int kw, int sh, int sw, int rh, int rw, int pad_top, int pad_left,
                                   int64_t oh, int64_t ow, float *P, int64_t ldp, hipStream_t stream);

@@ -149,6 +149,49 @@ hipError_t launch_extract_patches(const float *act, int64_t n, int64_t H, int64_
     return hipGetLastError();
 }
 
+// ---- channel planes: NHWC activations -> channel-major [nch][n*H*W] ------------------------------
+// planes[c][p] = act[p][c_lo + c]: the `[..., channel_idx]` slices of scripts/quantized_network.py:769-770
+// for a whole shard of channels in one pass.  256 positions x 32 channels per workgroup through LDS:
+// reads run along the channels of a position, writes along the positions of a channel.
+__global__ void __launch_bounds__(256)
+gpfq_planes_kernel(const float *__restrict__ act, int64_t npos, int64_t Cin, int64_t c_lo, int64_t nch,
+                   float *__restrict__ planes)
+{
+    __shared__ float tile[256][33];
+    const int64_t p0 = (int64_t)blockIdx.x * 256;
+    const int cb = blockIdx.y * 32;
+    const int tc = (int)(nch - cb < 32 ? nch - cb : 32);
+    const int np = (int)(npos - p0 < 256 ? npos - p0 : 256);
+    const float *src = act + p0 * Cin + c_lo + cb;
+    if (tc == 32) {
+        for (int i = threadIdx.x; i < np * 32; i += 256) tile[i >> 5][i & 31] = src[(int64_t)(i >> 5) * Cin + (i & 31)];
+    } else {
+        for (int i = threadIdx.x; i < np * tc; i += 256) {
+            const int p = i / tc, c = i - p * tc;
+            tile[p][c] = src[(int64_t)p * Cin + c];
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < tc; c += 4) {
+        float *dst = planes + (int64_t)(cb + c) * npos + p0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = lane + 64 * k;
+            if (p < np) dst[p] = tile[p][c];
+        }
+    }
+}
+
+hipError_t launch_channel_planes(const float *act, int64_t npos, int64_t Cin, int64_t c_lo, int64_t nch, float *planes,
+                                 hipStream_t stream)
+{
+    if (npos == 0 || nch == 0) return hipSuccess;
+    hipLaunchKernelGGL(gpfq_planes_kernel, dim3((unsigned)((npos + 255) / 256), (unsigned)((nch + 31) / 32)), dim3(256), 0, stream,
+                       act, npos, Cin, c_lo, nch, planes);
+    return hipGetLastError();
+}
+
 // ---- kernel assembly: [C][N] indices -> Keras-layout [N][C] values (+ indices) ------------------
 // Q[t][j] = (float)alphabet[qidx[j][t]] (0 for the literal-zero index -1), i.e. `Q[:, neuron_idx] =
 // future.result()` for every neuron (scripts/quantized_network.py:562) fused with the transpose from

@@ -32,7 +32,8 @@ SYMBOLS = {
     "gpfq_gram_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "gpfq_quantize_neurons_gram": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _i64, _dp, _int, _int, _i64, _i64, _i64,
                                           _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "gpfq_conv_channels_workspace_bytes": (_sz, [_i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _i64]),
+    "gpfq_channel_planes": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "gpfq_conv_channels_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _i64, _int]),
     "gpfq_quantize_conv_channels": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int,
                                            _vp, _dp, _int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpfq_msq_round": (_int, [_vp, _i64, _dp, _int, _vp, _vp, _vp]),
@@ -221,6 +222,19 @@ class GramPlan:
         _check(rc, "gpfq_quantize_neurons_gram")
 
 
+def channel_planes(act, c_lo, c_hi):
+    """NHWC f32 [n][H][W][Cin] -> channel-major f32 [c_hi - c_lo][n][H][W] (gpfq_channel_planes)."""
+    _dev(act, torch.float32, "act")
+    if act.dim() != 4 or not act.is_contiguous():
+        raise GpfqError("channel_planes needs a contiguous NHWC tensor")
+    n, H, W, Cin = act.shape
+    out = torch.empty((c_hi - c_lo, n, H, W), dtype=torch.float32, device=act.device)
+    with torch.cuda.device(act.device):
+        rc = load().gpfq_channel_planes(act.data_ptr(), n * H * W, Cin, c_lo, c_hi - c_lo, out.data_ptr(), _stream())
+    _check(rc, "gpfq_channel_planes")
+    return out
+
+
 def quantize_conv_channels(act_w_cm, act_q_cm, Wt_all, alphabet, kernel_size, strides, rate, padding,
                            idx, Q, resid, unc):
     """All channels of a conv layer shard in one library call (gpfq_quantize_conv_channels).
@@ -245,7 +259,7 @@ def quantize_conv_channels(act_w_cm, act_q_cm, Wt_all, alphabet, kernel_size, st
         raise GpfqError("quantize_conv_channels: shape mismatch")
     arr, M, zero_idx = _alphabet(alphabet)
     lib = load()
-    nbytes = lib.gpfq_conv_channels_workspace_bytes(n, H, W, kh, kw, sh, sw, rh, rw, same, F)
+    nbytes = lib.gpfq_conv_channels_workspace_bytes(n, H, W, nch, kh, kw, sh, sw, rh, rw, same, F, 0 if resid is None else 1)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=act_w_cm.device)
     with torch.cuda.device(act_w_cm.device):
         rc = lib.gpfq_quantize_conv_channels(act_w_cm.data_ptr(), act_q_cm.data_ptr(), n, H, W, nch, kh, kw, sh, sw, rh, rw,

@@ -159,11 +159,16 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
     c_lo, c_hi = shard_bounds(Cin, world, rank) if by_channel else (0, Cin)
     f_lo, f_hi = (0, F) if by_channel else shard_bounds(F, world, rank)
     Pw = Pq = None
+    reruns = 0                                 # filters of this rank rerun through the exact path (diagnostics)
     # channel-major copies [Cin][n][H][W] of this rank's channels: the per-channel gather then reads
     # contiguous planes instead of one float out of every Cin (one transposing pass per layer)
     same = act_q is act_w
-    cm_w = act_w[..., c_lo:c_hi].permute(3, 0, 1, 2).contiguous()
-    cm_q = cm_w if same else act_q[..., c_lo:c_hi].permute(3, 0, 1, 2).contiguous()
+    if _extract_patches is hip.extract_patches:
+        planes = lambda a: hip.channel_planes(a.contiguous(), c_lo, c_hi)
+    else:                                      # stand-ins of the collective-plumbing tests (CPU tensors)
+        planes = lambda a: a[..., c_lo:c_hi].permute(3, 0, 1, 2).contiguous()
+    cm_w = planes(act_w)
+    cm_q = cm_w if same else planes(act_q)
     def patches(c):
         nonlocal Pw, Pq
         Pw = _extract_patches(cm_w[c - c_lo].unsqueeze(-1), 0, (kh, kw), strides, rate, padding, out=Pw)
@@ -195,7 +200,9 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
             hip.quantize_conv_channels(cm_w, cm_q, Wt_f, alphabet, (kh, kw), strides, rate, padding, i_f, q_f,
                                        r_f if want_resid else None, u_f)
             Ic[:, f_lo:f_hi], Qc[:, f_lo:f_hi], Rc[:, f_lo:f_hi], Unc[:, f_lo:f_hi] = i_f, q_f, r_f, u_f
-        for c, f in torch.nonzero(Unc).tolist():                      # one sync per layer; ~1 filter in 10^5
+        flagged = torch.nonzero(Unc).tolist()                         # one sync per layer; ~1 filter in 10^4
+        reruns = len(flagged)
+        for c, f in flagged:
             patches(c)
             r = hip.quantize_neurons(Pw, Pq, Wt_all[c, f:f + 1], alphabet, path=hip.GPFQ_PATH_STREAM)
             Qc[c, f], Ic[c, f], Rc[c, f] = r["Q"][0], r["idx"][0], r["resid"][0]
@@ -219,4 +226,4 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
             Rc = all_gather_units(Rc[:, f_lo:f_hi].transpose(0, 1).contiguous(), F, group).transpose(0, 1)
     Q = Qc.reshape(Cin, F, kh, kw).permute(2, 3, 0, 1).contiguous()
     idx = Ic.reshape(Cin, F, kh, kw).permute(2, 3, 0, 1).contiguous()
-    return dict(Q=Q, idx=idx, resid=Rc.contiguous())
+    return dict(Q=Q, idx=idx, resid=Rc.contiguous(), reruns=torch.tensor(reruns))

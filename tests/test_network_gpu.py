@@ -302,10 +302,11 @@ def test_single_rank_nccl_group(qn, ks):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("slack", [0, 60])
+@pytest.mark.parametrize("slack", [0, 14, 60])
 def test_conv_layer_gram_fast_path(oracle_mod, slack):
     """layer.quantize_conv2d on patch matrices long enough for the Gram plan (no per-channel sync);
-    slack=60 makes every filter uncertified, exercising the once-per-layer exact rerun."""
+    slack=14 leaves a few chains uncertified (repaired on the device from the exact dot products),
+    slack=60 every step of every filter, exercising the once-per-layer exact rerun too."""
     from quantized_neural_networks_amd import hip, layer
     r = np.random.default_rng(21)
     act_w = r.random((36, 24, 24, 2)).astype(np.float32)
@@ -328,6 +329,64 @@ def test_conv_layer_gram_fast_path(oracle_mod, slack):
             qo, _, uo = oracle_mod.neuron(W[:, :, c, f].reshape(-1), Pw, Pq, alphabet)
             assert np.array_equal(Q[:, :, c, f].reshape(-1), qo.astype(np.float32)), (c, f)
             np.testing.assert_allclose(out["resid"][c, f].item(), np.linalg.norm(uo), rtol=1e-5)
+
+
+@pytest.mark.parametrize("n,H,W,Cin,F,padding,strip,first", [
+    (36, 24, 24, 2, 3, "SAME", 0, False),      # strips of 4, one image per band
+    (100, 14, 14, 3, 4, "SAME", 0, False),     # strips of 2, bands straddle images
+    (400, 7, 7, 2, 3, "SAME", 0, False),       # one strip per row, ~36 images per band
+    (300, 9, 11, 2, 3, "VALID", 0, False),     # 7 x 9 outputs: single-position strips
+    (220, 12, 10, 2, 3, "VALID", 0, False),    # VALID with strips of 4
+    (170, 13, 8, 1, 2, "SAME", 2, False),      # forced strips of 2
+    (170, 13, 8, 2, 2, "SAME", 1, True),       # first layer (both networks see the same data), strips of 1
+    (60, 28, 28, 1, 3, "SAME", 2, False),      # 28 = 4*7: forced strips of 2
+])
+def test_conv_fused_3x3(oracle_mod, n, H, W, Cin, F, padding, strip, first):
+    """3x3 / stride-1 layers never build patch matrices (gpfq_gram_image.hip): the result must equal the
+    oracle on the reference's patch matrices, and the per-channel patch path (conv_fused = 0)."""
+    from quantized_neural_networks_amd import hip, layer
+    r = np.random.default_rng(n + W)
+    act_w = (r.random((n, H, W, Cin)) - (0.3 if first else 0.0)).astype(np.float32)
+    act_q = act_w if first else np.maximum(act_w + 0.05 * r.standard_normal(act_w.shape), 0).astype(np.float32)
+    if Cin > 2:
+        act_q[..., 2] = 0.0                                              # dead channel: rule (i) everywhere
+    Wk = (r.standard_normal((3, 3, Cin, F)) / 3).astype(np.float32)
+    Wd = torch.from_numpy(Wk).cuda()
+    alphabet, _ = layer.layer_alphabet(Wd, np.linspace(-1, 1, 8), 4)
+    aw = torch.from_numpy(act_w).cuda()
+    aq = aw if first else torch.from_numpy(act_q).cuda()
+    try:
+        hip.set_option("conv_strip", strip)
+        out = layer.quantize_conv2d(Wd, aw, aq, alphabet, strides=(1, 1), padding=padding, rate=(1, 1), want_resid=False)
+        hip.set_option("conv_fused", 0)
+        old = layer.quantize_conv2d(Wd, aw, aq, alphabet, strides=(1, 1), padding=padding, rate=(1, 1), want_resid=False)
+    finally:
+        hip.set_option("conv_fused", 1)
+        hip.set_option("conv_strip", 0)
+    assert torch.equal(out["Q"], old["Q"]) and torch.equal(out["idx"], old["idx"])
+    Q = out["Q"].cpu().numpy()
+    for c in range(Cin):
+        Pw = ref_patches(act_w, c, 3, 3, 1, 1, 1, 1, padding)
+        Pq = ref_patches(act_q, c, 3, 3, 1, 1, 1, 1, padding)
+        assert Pw.shape[1] > hip.GPFQ_ONCHIP_MAX_M
+        for f in range(F):
+            qo, _, _ = oracle_mod.neuron(Wk[:, :, c, f].reshape(-1), Pw, Pq, alphabet)
+            assert np.array_equal(Q[:, :, c, f].reshape(-1), qo.astype(np.float32)), (c, f)
+    if Cin > 2:
+        assert (Q[:, :, 2] == 0).all()
+    if n in (36, 400):
+        # inflated error bounds: some (2^14) or all (2^60) chains stop and are repaired on the device from the
+        # exact dot products (two rounds), the rest by the caller's exact rerun -- results never change
+        counts = []
+        try:
+            for slack in (14, 60):
+                hip.set_option("gram_slack_log2", slack)
+                rep = layer.quantize_conv2d(Wd, aw, aq, alphabet, strides=(1, 1), padding=padding, rate=(1, 1), want_resid=False)
+                assert torch.equal(rep["Q"], out["Q"]) and torch.equal(rep["idx"], out["idx"]), slack
+                counts.append(int(rep["reruns"]))
+        finally:
+            hip.set_option("gram_slack_log2", 0)
+        assert counts[0] <= counts[1] == Cin * F, counts
 
 
 @pytest.mark.parametrize("stride,bits", [(1, 2), (2, np.log2(3)), (1, 4)])

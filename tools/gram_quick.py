@@ -13,7 +13,7 @@ plan = hip.GramPlan(N, m, C, alphabet, X.device)
 idx = torch.empty((C, N), dtype=torch.int8, device="cuda"); Q = torch.empty((C, N), device="cuda")
 res = torch.empty(C, dtype=torch.float64, device="cuda"); unc = torch.empty(C, dtype=torch.int32, device="cuda")
 ref = None
-for var in (0, 1, 2):
+for var in (0, 1, 3):
     hip.set_option("variant", var)
     for it in range(3):
         torch.cuda.synchronize(); t0 = time.time()
