@@ -73,30 +73,6 @@ __device__ __forceinline__ void load_window_row(const float *p, float (&v)[S + 2
     }
 }
 
-// One band row into LDS: virtual row v of the stack of zero-padded planes -> floats [4*c4, 4*c4 + 4).
-__device__ __forceinline__ float4 stage_piece(const float *plane, const ImgParams &p, int v, int c4)
-{
-    int r;
-    const int b = div_small(v, p.PH, p.inv_PH, r);
-    const int iy = r - p.pad;
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (b < p.n && iy >= 0 && iy < p.H) {
-        const float *src = plane + ((int64_t)b * p.H + iy) * p.W;
-        const int ix = 4 * c4 - p.pad;
-        if (ix >= 0 && ix + 3 < p.W) {
-            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-            const f4u t = *reinterpret_cast<const f4u *>(src + ix);
-            o = make_float4(t.x, t.y, t.z, t.w);
-        } else {
-            if (ix >= 0 && ix < p.W) o.x = src[ix];
-            if (ix + 1 >= 0 && ix + 1 < p.W) o.y = src[ix + 1];
-            if (ix + 2 >= 0 && ix + 2 < p.W) o.z = src[ix + 2];
-            if (ix + 3 >= 0 && ix + 3 < p.W) o.w = src[ix + 3];
-        }
-    }
-    return o;
-}
-
 template <int S, int G>
 __device__ __forceinline__ void image_gram_body(const ImgParams &p, float *lds)
 {
@@ -108,6 +84,11 @@ __device__ __forceinline__ void image_gram_body(const ImgParams &p, float *lds)
     float *lw = lds;
     float *lq = p.same_act ? lds : lds + (size_t)p.lrows * p.LP;
     const int L4 = p.LP >> 2;
+    // staging role of this thread: column piece st_c4 of rows st_row0 + k*st_step
+    const int st_c4 = threadIdx.x & ((1 << p.lpr_log2) - 1), st_row0 = threadIdx.x >> p.lpr_log2;
+    const int st_step = kImgThreads >> p.lpr_log2;
+    const int st_ix = 4 * st_c4 - p.pad;
+    const bool st_inside = st_ix >= 0 && st_ix + 3 < p.W;
 
     for (int band = blockIdx.x; band < p.nbands; band += gridDim.x) {
         const int g0 = band * p.RB;
@@ -118,12 +99,34 @@ __device__ __forceinline__ void image_gram_body(const ImgParams &p, float *lds)
         const int v0 = b0 * p.PH + oy0;
         const int nv = b1 * p.PH + oy1 + 2 - v0 + 1;
         __syncthreads();                                   // the previous band has been consumed
-        for (int idx = threadIdx.x; idx < (nv << p.lpr_log2); idx += kImgThreads) {
-            const int row = idx >> p.lpr_log2, c4 = idx & ((1 << p.lpr_log2) - 1);
-            if (c4 < L4) {
-                *reinterpret_cast<float4 *>(lw + (size_t)row * p.LP + 4 * c4) = stage_piece(pw, p, v0 + row, c4);
-                if (!p.same_act)
-                    *reinterpret_cast<float4 *>(lq + (size_t)row * p.LP + 4 * c4) = stage_piece(pq, p, v0 + row, c4);
+        if (st_c4 < L4) {
+            // this thread's column piece is fixed; walk its rows st_row0, st_row0 + st_step, ... of the band
+            int r;
+            int b = div_small(v0 + st_row0, p.PH, p.inv_PH, r);
+            for (int row = st_row0; row < nv; row += st_step) {
+                const int iy = r - p.pad;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+                if (b < p.n && iy >= 0 && iy < p.H) {
+                    const unsigned o = ((unsigned)b * p.H + iy) * p.W + st_ix;      // plane < 2^30 floats
+                    if (st_inside) {
+                        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                        const f4u t = *reinterpret_cast<const f4u *>(pw + o);
+                        a = make_float4(t.x, t.y, t.z, t.w);
+                        if (!p.same_act) {
+                            const f4u u = *reinterpret_cast<const f4u *>(pq + o);
+                            c = make_float4(u.x, u.y, u.z, u.w);
+                        }
+                    } else {
+                        if (st_ix >= 0 && st_ix < p.W) { a.x = pw[o]; c.x = pq[o]; }
+                        if (st_ix + 1 >= 0 && st_ix + 1 < p.W) { a.y = pw[o + 1]; c.y = pq[o + 1]; }
+                        if (st_ix + 2 >= 0 && st_ix + 2 < p.W) { a.z = pw[o + 2]; c.z = pq[o + 2]; }
+                        if (st_ix + 3 >= 0 && st_ix + 3 < p.W) { a.w = pw[o + 3]; c.w = pq[o + 3]; }
+                    }
+                }
+                *reinterpret_cast<float4 *>(lw + row * p.LP + 4 * st_c4) = a;
+                if (!p.same_act) *reinterpret_cast<float4 *>(lq + row * p.LP + 4 * st_c4) = c;
+                r += st_step;
+                while (r >= p.PH) { r -= p.PH; ++b; }
             }
         }
         __syncthreads();
@@ -204,7 +207,8 @@ static bool image_plan(int64_t n, int64_t H, int64_t W, int pad, int variant, Im
     const int64_t oh = H + 2 * pad - 2, ow = W + 2 * pad - 2;
     if (oh <= 0 || ow <= 0 || n <= 0) return false;
     // div_small() is exact for dividends below 2^24 (float holds them exactly)
-    if (n * (H + 2 * pad) >= (1LL << 24) || n * oh * ow >= (1LL << 30)) return false;
+    if (n * (H + 2 * pad) >= (1LL << 24) || n * oh * ow >= (1LL << 30) || n * H * W >= (1LL << 30)) return false;
+    if (W + 2 * pad > 1020) return false;                  // a staged row is at most one piece per thread
     const int S = image_strip(ow, variant);
     ImgParams p{};
     p.n = (int)n; p.H = (int)H; p.W = (int)W; p.pad = pad;

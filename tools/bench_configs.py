@@ -99,10 +99,10 @@ def main():
         # one layer of each spatial size (the net has 3/4/6/3 of the 3x3 ones) + conv1 (7x7/2 on the padded 230x230 input)
         n = 4096
         recs.append(time_conv("cfg5 ResNet50 conv1 7x7/2 VALID (3->64 @230x230 padded input), 4096 images, ternary, scalar 3",
-                              3, 64, 230, n, np.log2(3), 3, dev, k=7, stride=2, padding="VALID", reps=1))
+                              3, 64, 230, n, np.log2(3), 3, dev, k=7, stride=2, padding="VALID", reps=2))
         for cin, hw in [(64, 56), (128, 28), (256, 14), (512, 7)]:
             recs.append(time_conv(f"cfg5 ResNet50 3x3 conv ({cin}->{cin} @{hw}x{hw}), 4096 images, ternary, scalar 3",
-                                  cin, cin, hw, n, np.log2(3), 3, dev, reps=1))
+                                  cin, cin, hw, n, np.log2(3), 3, dev, reps=3))
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(dict(note="tools/bench_configs.py on one MI355X; best of 2-3 runs per layer; whole layer driver "
                         "(median, norms, kernel, assemble) with inputs resident in HBM", records=recs),

@@ -1,0 +1,17 @@
+"""ResNet50 conv1 (7x7 / stride 2, VALID on the padded 230x230 input, 3 -> 64) through the layer driver.
+usage: conv1_probe.py [n_images]"""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from quantized_neural_networks_amd import hip, layer
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+g = torch.Generator(device="cuda").manual_seed(2)
+act_w = torch.rand((n, 230, 230, 3), device="cuda", generator=g)
+act_q = torch.relu(act_w + 0.05 * torch.randn((n, 230, 230, 3), device="cuda", generator=g))
+W = torch.randn((7, 7, 3, 64), device="cuda", generator=g) / 7
+alphabet, rad = layer.layer_alphabet(W, np.linspace(-1, 1, 3), 3)
+for it in range(2):
+    torch.cuda.synchronize(); t0 = time.time()
+    out = layer.quantize_conv2d(W, act_w, act_q, alphabet, strides=(2, 2), padding="VALID", rate=(1, 1), want_resid=False)
+    torch.cuda.synchronize(); dt = time.time() - t0
+    print(f"conv1 n={n}: {dt*1e3:.1f} ms, host reruns {int(out['reruns'])}")

@@ -7,11 +7,15 @@ sys.path.insert(0, ".")
 from quantized_neural_networks_amd import hip, layer
 
 SHAPES = {0: (3, 32, 32), 2: (32, 32, 32), 6: (32, 64, 16), 8: (64, 64, 16), 12: (64, 128, 8), 14: (128, 128, 8)}
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+args = [a for i, a in enumerate(sys.argv[1:], 1) if a.isdigit() and sys.argv[i - 1] not in ("--strip", "--shape")]
 layers = [int(a) for a in args] or [2]
 if "--strip" in sys.argv:
     hip.set_option("conv_strip", int(sys.argv[sys.argv.index("--strip") + 1]))
 n = 5008
+if "--shape" in sys.argv:                                   # --shape cin,cout,hw,n  (e.g. 512,512,7,4096)
+    cin, cout, hw, n = (int(v) for v in sys.argv[sys.argv.index("--shape") + 1].split(","))
+    SHAPES[99] = (cin, cout, hw)
+    layers = [99]
 for L in layers:
     cin, cout, hw = SHAPES[L]
     g = torch.Generator(device="cuda").manual_seed(0)
