@@ -179,6 +179,132 @@ gpfq_wide_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int6
     }
 }
 
+// One neuron per workgroup (narrow layers: nothing to share through LDS): every wavefront reads its slice of
+// the rows X_t, Xq_t straight into registers, one step ahead of their use, so no staging sits on the
+// step-to-step critical path; the only LDS traffic is the W pairs of partial dot products per step.
+template <int EPL>
+__device__ __forceinline__ void wide_fetch(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t t,
+                                           int base, int lane, int m, float (&x)[EPL], float (&xq)[EPL])
+{
+    static_assert(EPL % 4 == 0, "direct mode reads 16-byte pieces");
+#pragma unroll
+    for (int c = 0; c < EPL / 4; ++c) {
+        const int i = base + 256 * c + 4 * lane;                   // m % 4 == 0: a piece is inside or outside
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (i < m) {
+            a = *reinterpret_cast<const float4 *>(X + t * ld + i);
+            b = *reinterpret_cast<const float4 *>(Xq + t * ld + i);
+        }
+        x[4 * c] = a.x; x[4 * c + 1] = a.y; x[4 * c + 2] = a.z; x[4 * c + 3] = a.w;
+        xq[4 * c] = b.x; xq[4 * c + 1] = b.y; xq[4 * c + 2] = b.z; xq[4 * c + 3] = b.w;
+    }
+}
+
+template <int EPL>
+__global__ void __launch_bounds__(EPL >= 16 ? 512 : 1024)   // 16 elements per lane + their prefetch need > 128 VGPRs
+gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld,
+                        const float *__restrict__ nrm32, const float *__restrict__ Wt, int64_t ldw,
+                        AlphabetArg A, int64_t N, int m, int64_t C, int W,
+                        int8_t *__restrict__ qidx, float *__restrict__ Qt,
+                        double *__restrict__ resid, double *__restrict__ u_out)
+{
+    __shared__ double red[2][16][2];                      // [step parity][wave][dot_u, dot_uw]
+    const int lane = threadIdx.x & 63;
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t j = blockIdx.x;
+    const float *__restrict__ wrow = Wt + j * ldw;
+    const int base = part * 64 * EPL;
+
+    const double a_lane = alphabet_lane(A, lane);
+    const bool ascending = A.ascending != 0;
+
+    double u[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) u[e] = 0.0;            // zeros(m), :115
+    int   my_idx = 0;
+    float my_q   = 0.f;
+
+    float w_next = 0.f, nrm_next = 0.f;
+    float xn[EPL], xqn[EPL];
+    if (N > 0) {
+        w_next = wrow[0]; nrm_next = nrm32[0];
+        wide_fetch<EPL>(X, Xq, ld, 0, base, lane, m, xn, xqn);
+    }
+    for (int64_t t = 0; t < N; ++t) {
+        const float w = w_next, nrm = nrm_next;
+        float x[EPL], xq[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { x[e] = xn[e]; xq[e] = xqn[e]; }
+        if (t + 1 < N) {
+            w_next = wrow[t + 1]; nrm_next = nrm32[t + 1];
+            wide_fetch<EPL>(X, Xq, ld, t + 1, base, lane, m, xn, xqn);
+        }
+        // this wave's share of <Xq_t, u> (:86) and <Xq_t, u + f32(w*X_t)> (:89)
+        double d0a = 0.0, d0b = 0.0, d1a = 0.0, d1b = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const float p = __fmul_rn(w, x[e]);
+            const double xd = (double)xq[e];
+            const double v  = u[e] + (double)p;
+            if (e & 1) { d0b = fma(xd, u[e], d0b); d1b = fma(xd, v, d1b); }
+            else       { d0a = fma(xd, u[e], d0a); d1a = fma(xd, v, d1a); }
+        }
+        double dot_u, dot_uw;
+        wave_sum2(d0a + d0b, d1a + d1b, dot_u, dot_uw);
+        double (*slot)[2] = red[t & 1];                   // slots alternate with the step parity: one barrier per step
+        if (lane == 0) { slot[part][0] = dot_u; slot[part][1] = dot_uw; }
+        __syncthreads();
+        dot_u = 0.0; dot_uw = 0.0;
+        for (int p2 = 0; p2 < W; ++p2) { dot_u += slot[p2][0]; dot_uw += slot[p2][1]; }   // fixed order
+
+        const Decision dec = decide(w, nrm, dot_u, dot_uw, a_lane, A.M, A.zero_idx, ascending);
+
+        // u += w*X_t - q*Xq_t  (:119)
+        const float q32 = (float)dec.q;
+        if (q32 == 0.0f) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) u[e] += (double)__fmul_rn(w, x[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+                u[e] += (double)__fsub_rn(__fmul_rn(w, x[e]), __fmul_rn(q32, xq[e]));
+        }
+
+        if (lane == (int)(t & 63)) { my_idx = dec.idx; my_q = q32; }
+        if (((t + 1) & 63) == 0 || t + 1 == N) {
+            const int64_t b0 = t & ~(int64_t)63;
+            if (part == 0 && lane <= (int)(t & 63)) {
+                if (qidx) qidx[j * N + b0 + lane] = (int8_t)my_idx;
+                if (Qt)   Qt[j * N + b0 + lane]   = my_q;
+            }
+        }
+    }
+
+    if (resid) {
+        double ss = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) ss = fma(u[e], u[e], ss);
+        ss = wave_sum(ss);
+        __syncthreads();                                  // all step slots consumed
+        if (lane == 0) red[0][part][0] = ss;
+        __syncthreads();
+        if (part == 0 && lane == 0) {
+            double s2 = 0.0;
+            for (int p2 = 0; p2 < W; ++p2) s2 += red[0][p2][0];
+            resid[j] = sqrt(s2);
+        }
+    }
+    if (u_out) {
+#pragma unroll
+        for (int c = 0; c < EPL / 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = base + 256 * c + 4 * lane + e;
+                if (i < m) u_out[j * (int64_t)m + i] = u[c * 4 + e];
+            }
+    }
+}
+
 template <int EPL>
 static hipError_t launch_wide_epl(const OnchipArgs &a, int W, hipStream_t stream)
 {
@@ -186,6 +312,17 @@ static hipError_t launch_wide_epl(const OnchipArgs &a, int W, hipStream_t stream
     int G = 16 / W;                                       // neurons per workgroup (<= 16 wavefronts)
     if (G < 1) G = 1;
     while (G > 1 && (a.C + G - 1) / G < 256) G >>= 1;     // narrow layers: spread the neurons over the CUs
+    if constexpr (EPL % 4 == 0) {
+        // register-prefetch mode, one neuron per workgroup: faster than sharing LDS-staged rows between the
+        // neurons of a workgroup at every shape measured (tools/narrow_quick.py), the rows come from L2 anyway
+        const bool aligned = (a.ld % 4 == 0) && (a.m % 4 == 0) && ((uintptr_t)a.X % 16 == 0) && ((uintptr_t)a.Xq % 16 == 0);
+        if (aligned && !(a.variant & 2) && (EPL < 16 || W <= 8)) {
+            hipLaunchKernelGGL((gpfq_wide_direct_kernel<EPL>), dim3((unsigned)a.C), dim3(64 * W), 0, stream,
+                               a.X, a.Xq, a.ld, a.nrm32, a.Wt, a.ldw, a.A, a.N, (int)a.m, a.C, W,
+                               a.qidx, a.Qt, a.resid, a.u_out);
+            return hipGetLastError();
+        }
+    }
     int ts = 16;
     while (ts > 1 && (size_t)2 * ts * MP * sizeof(float) > 96 * 1024) ts >>= 1;
     if (a.ts_override > 0 && (size_t)2 * a.ts_override * MP * sizeof(float) <= 150 * 1024) ts = a.ts_override;
