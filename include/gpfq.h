@@ -216,10 +216,12 @@ int gpfq_channel_planes(const float *act, int64_t npos, int64_t Cin, int64_t c_l
  *                row-major (:215);  outputs qidx/Qt [nch][F][kh*kw], resid [nch][F] (may be NULL),
  *                uncertified i32 [nch][F] (see gpfq_quantize_neurons_gram: flagged pairs must be rerun).
  *   Needs kh*kw <= GPFQ_GRAM_MAX_N and n*oh*ow < 2^30.
- * 3x3 kernels with stride 1 and rate 1 (when resid == NULL) never materialise the patch matrices: row
- * t = (ky, kx) of a patch matrix is the channel plane shifted by (ky, kx), so the Gram matrices of all
- * channels are accumulated straight from the planes in one launch, followed by one batched decide launch
- * (option "conv_fused" = 0 switches back to the per-channel patch matrices; results are identical).
+ * When resid == NULL no patch matrix is materialised: row t = (ky, kx) of a patch matrix is the channel
+ * plane sampled at (oy*sh + ky*rh - pad_top, ox*sw + kx*rw - pad_left), so the Gram records of all channels
+ * are accumulated straight from the planes in one launch (a plane-correlation kernel for 3x3 / stride 1,
+ * the register-tile kernel with implicit im2col for every other shape), followed by one batched decide
+ * launch and the device-side repair of uncertified chains (option "conv_fused" = 0 switches back to the
+ * per-channel patch matrices; results are identical).
  * The workspace size depends on whether resid is requested (want_resid = resid != NULL).
  */
 size_t gpfq_conv_channels_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t nch, int kh, int kw, int sh, int sw,

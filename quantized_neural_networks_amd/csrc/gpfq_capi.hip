@@ -350,11 +350,14 @@ static size_t al256c(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t gpfq_conv_channels_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t nch, int kh, int kw, int sh, int sw,
                                           int rh, int rw, int same_padding, int64_t F, int want_resid)
 {
-    const int64_t cols = n * gpfq_patch_out_dim(H, kh, sh, rh, same_padding) * gpfq_patch_out_dim(W, kw, sw, rw, same_padding);
+    const int64_t oh = gpfq_patch_out_dim(H, kh, sh, rh, same_padding), ow = gpfq_patch_out_dim(W, kw, sw, rw, same_padding);
+    const int64_t cols = n * oh * ow;
     const int64_t K = (int64_t)kh * kw;
     if (cols <= 0 || K <= 0 || F < 0 || nch < 0) return 0;
     if (!want_resid && g_conv_fused && gpfq::gram_image_supported(n, H, W, kh, kw, sh, sw, rh, rw, same_padding))
         return gpfq::gram_image_workspace_bytes(nch, F);
+    if (!want_resid && g_conv_fused && gpfq::gram_conv_supported(n, H, W, nch, kh, kw, oh, ow))
+        return gpfq::gram_conv_workspace_bytes(K, nch, F, cols);
     const int64_t ldp = (cols + 3) & ~(int64_t)3;
     return 2 * al256c((size_t)K * ldp * sizeof(float)) + al256c((size_t)K * sizeof(float)) + gpfq::gram_workspace_bytes(K, cols, F);
 }
@@ -396,6 +399,17 @@ int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t 
         int64_t tw = (ow - 1) * sw + kew - W; if (tw < 0) tw = 0;
         pad_top = (int)(th / 2);
         pad_left = (int)(tw / 2);
+    }
+    if (!resid && g_conv_fused && gpfq::gram_conv_supported(n, H, W, nch, kh, kw, oh, ow)) {
+        // any other shape: the tile kernel gathers its patch rows from the planes (implicit im2col)
+        gpfq::ConvGramArgs g;
+        g.act_w = act_w; g.act_q = act_q; g.n = n; g.H = H; g.W = W; g.nch = nch;
+        g.kh = kh; g.kw = kw; g.sh = sh; g.sw = sw; g.rh = rh; g.rw = rw; g.pt = pad_top; g.pl = pad_left; g.oh = oh; g.ow = ow;
+        g.Wt = Wt; g.A = A; g.F = F; g.qidx = qidx; g.Qt = Qt; g.uncertified = uncertified;
+        g.workspace = workspace;
+        g.slack = std::ldexp(1.0, g_gram_slack_log2);
+        hipError_t e = gpfq::launch_gram_conv(g, static_cast<hipStream_t>(stream));
+        return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_conv_channels(implicit)");
     }
     const int64_t ldp = (cols + 3) & ~(int64_t)3;
     char *ws = static_cast<char *>(workspace);

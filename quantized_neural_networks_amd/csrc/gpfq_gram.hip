@@ -24,41 +24,32 @@
 // Layout of one Gram record (partials and totals): G[t][s][k] at (t*N + s)*2 + k, k = 0: G1, 1: G2,
 // then nx2[s] at N*N*2 + s.  Entries above the diagonal are never read (totals hold 0 there).
 #include "gpfq_device.hpp"
+#include "gpfq_gram_tile.hpp"
 #include "gpfq_launch.hpp"
 
 namespace gpfq {
 
-constexpr int kGramThreads = 256;
-constexpr int kGramCH = 256;               // columns staged per chunk (tile kernel)
-
-__host__ __device__ inline int64_t gram_record(int64_t N) { return N * N * 2 + N; }
-
-// ---- N > 9: register tiles over LDS-staged column chunks --------------------------------------------
-// Block (x, ty, sz) owns rows t in [t0, t0 + 4*TB), t0 = 4*TB*ty (wave w: TB of them) against rows s in
-// [s0, s0 + SB), s0 = SB*sz, and walks the column chunks x, x + gridDim.x, ...: each chunk of 256 columns of the
-// 4*TB + 2*SB rows it needs is staged in LDS once, every lane then feeds 4 columns into its TB*SB*2 float64
-// accumulators.  Tiles entirely above the diagonal exit at once.  The blocks of the last tile row (which
-// meets every column tile) also accumulate nx2 for their SB columns.
+// ---- N > 9: register tiles over LDS-staged column chunks (gpfq_gram_tile.hpp) -------------------------
+// Block (x, e) owns tile e of the lower triangle (rows t0.. against rows s0..) and walks the column chunks
+// x, x + gridDim.x, ...: each chunk of 256 columns of the 4*TB + 2*SB rows it needs is staged in LDS once.
+// The tiles of the last tile row (which meets every column tile) also accumulate nx2 for their SB columns.
 template <int TB, int SB>
 __global__ void __launch_bounds__(kGramThreads, 2)
 gpfq_gram_tile_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int N, int64_t m,
                       int64_t nchunks, double *__restrict__ part)
 {
-    constexpr int R = 4 * TB + 2 * SB;                 // staged rows: Xq_t | X_s | Xq_s
-    constexpr int J = (R + 3) / 4;                     // rows per wavefront
+    using Tile = GramTile<TB, SB>;
+    constexpr int R = Tile::R, J = Tile::J;
     __shared__ __attribute__((aligned(16))) float lrow[R][kGramCH];
-    const int t0 = blockIdx.y * 4 * TB, s0 = blockIdx.z * SB;
-    if (s0 > t0 + 4 * TB - 1) return;                  // tile above the diagonal (uniform: before any barrier)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int ty, sz;
+    tile_decode<TB, SB>(blockIdx.y, N, ty, sz);
+    const int t0 = ty * 4 * TB, s0 = sz * SB;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // uniform: row pointers live in SGPRs
     const bool vec = (ld % 4 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)Xq % 16 == 0);
-    const bool norms = (blockIdx.y == gridDim.y - 1) && wave == 0;
-    double acc[TB][SB][2], accn[SB];
-#pragma unroll
-    for (int a = 0; a < TB; ++a)
-#pragma unroll
-        for (int s = 0; s < SB; ++s) { acc[a][s][0] = 0.0; acc[a][s][1] = 0.0; }
-#pragma unroll
-    for (int s = 0; s < SB; ++s) accn[s] = 0.0;
+    const bool norms = (t0 + 4 * TB >= N) && wave == 0;
+    Tile tile;
+    tile.zero();
 
     // wavefront w stages rows w, w + 4, ...: source row pointers once, outside the chunk loop
     const float *src[J];
@@ -95,57 +86,9 @@ gpfq_gram_tile_kernel(const float *__restrict__ X, const float *__restrict__ Xq,
             }
         }
         __syncthreads();
-        // lane l feeds columns 4l..4l+3 of the chunk: one 16-byte LDS read per row
-        float4 qt4[TB];
-#pragma unroll
-        for (int a = 0; a < TB; ++a) qt4[a] = *reinterpret_cast<const float4 *>(&lrow[wave * TB + a][4 * lane]);
-#pragma unroll
-        for (int s = 0; s < SB; ++s) {
-            const float4 xs4 = *reinterpret_cast<const float4 *>(&lrow[4 * TB + s][4 * lane]);
-            const float4 qs4 = *reinterpret_cast<const float4 *>(&lrow[4 * TB + SB + s][4 * lane]);
-            const float xsv[4] = {xs4.x, xs4.y, xs4.z, xs4.w}, qsv[4] = {qs4.x, qs4.y, qs4.z, qs4.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const double xs = (double)xsv[e], qs = (double)qsv[e];
-#pragma unroll
-                for (int a = 0; a < TB; ++a) {
-                    const float qtf = e == 0 ? qt4[a].x : e == 1 ? qt4[a].y : e == 2 ? qt4[a].z : qt4[a].w;
-                    const double qt = (double)qtf;
-                    acc[a][s][0] = fma(qt, xs, acc[a][s][0]);
-                    acc[a][s][1] = fma(qt, qs, acc[a][s][1]);
-                }
-            }
-        }
-        if (norms) {                                   // one wavefront of the last tile row: <X_s, X_s>
-#pragma unroll
-            for (int s = 0; s < SB; ++s) {
-                const float4 xs4 = *reinterpret_cast<const float4 *>(&lrow[4 * TB + s][4 * lane]);
-                accn[s] = fma((double)xs4.x, (double)xs4.x, accn[s]);
-                accn[s] = fma((double)xs4.y, (double)xs4.y, accn[s]);
-                accn[s] = fma((double)xs4.z, (double)xs4.z, accn[s]);
-                accn[s] = fma((double)xs4.w, (double)xs4.w, accn[s]);
-            }
-        }
+        tile.accumulate(lrow, wave, lane, norms);
     }
-    double *out = part + (int64_t)blockIdx.x * gram_record(N);
-#pragma unroll
-    for (int a = 0; a < TB; ++a) {
-        const int t = t0 + wave * TB + a;
-#pragma unroll
-        for (int s = 0; s < SB; ++s)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const double v = wave_sum(acc[a][s][k]);
-                if (lane == 0 && t < N && s0 + s < N) out[((int64_t)t * N + (s0 + s)) * 2 + k] = v;
-            }
-    }
-    if (norms) {
-#pragma unroll
-        for (int s = 0; s < SB; ++s) {
-            const double v = wave_sum(accn[s]);
-            if (lane == 0 && s0 + s < N) out[(int64_t)N * N * 2 + s0 + s] = v;
-        }
-    }
+    tile.store(part + (int64_t)blockIdx.x * gram_record(N), N, t0, s0, wave, lane, norms);
 }
 
 // ---- N <= 9 (3x3 kernels on patch matrices): every wavefront keeps the whole record ----------------
@@ -339,7 +282,8 @@ __device__ __forceinline__ void fix_fetch(const FixSrc &src, int64_t ch, int s, 
         xq = src.Xq[(int64_t)s * src.ld + i];
         return;
     }
-    const int iy = oy + s / 3 - src.pad, ix = ox + s % 3 - src.pad;
+    const int ky = s / src.kw, kx = s - ky * src.kw;
+    const int iy = oy * src.sh + ky * src.rh - src.pt, ix = ox * src.sw + kx * src.rw - src.pl;
     x = 0.f; xq = 0.f;
     if (iy >= 0 && iy < src.H && ix >= 0 && ix < src.W) {
         const int64_t o = ch * src.plane + (b * src.H + iy) * src.W + ix;
@@ -562,8 +506,8 @@ hipError_t launch_gram(const GramArgs &a, hipStream_t stream)
             hipLaunchKernelGGL(gpfq_gram_rows9_kernel, dim3((unsigned)nblocks), dim3(kGramThreads), 0, stream,
                                a.X, a.Xq, a.ld, N, a.m, part);
         } else {
-            // all tiles of the last tile row are launched (they carry nx2); tiles above the diagonal exit at once
-            hipLaunchKernelGGL((gpfq_gram_tile_kernel<2, 12>), dim3((unsigned)nblocks, (unsigned)((N + 7) / 8), (unsigned)((N + 11) / 12)),
+            // only the tiles that meet the lower triangle are launched
+            hipLaunchKernelGGL((gpfq_gram_tile_kernel<2, 12>), dim3((unsigned)nblocks, (unsigned)tile_count<2, 12>(N)),
                                dim3(kGramThreads), 0, stream, a.X, a.Xq, a.ld, N, a.m, nchunks, part);
         }
         hipError_t e = launch_gram_reduce(part, nparts, N, gram, a.nrm32_out, 1, stream);

@@ -289,7 +289,8 @@ hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream)
     bs.nch = a.nch; bs.gram_cs = kRec9; bs.nrm_cs = 9; bs.w_cs = a.F * 9; bs.out_cs = a.F * 9; bs.unc_cs = a.F; bs.hist_cs = a.F * 9;
     FixSrc src{};
     src.X = a.act_w; src.Xq = a.act_q; src.ld = 0; src.planes = 1; src.plane = p.plane;
-    src.n = p.n; src.H = p.H; src.W = p.W; src.pad = p.pad; src.oh = p.oh; src.ow = p.SPR * S;
+    src.n = p.n; src.H = p.H; src.W = p.W; src.oh = p.oh; src.ow = p.SPR * S;
+    src.kw = 3; src.sh = src.sw = src.rh = src.rw = 1; src.pt = src.pl = p.pad;
     src.m = (int64_t)p.grows * src.ow;
     return launch_gram_decide(gram, nrm, a.Wt, 9, a.A, 9, a.F, a.slack, a.qidx, a.Qt, a.uncertified, q32h, bs, &src, fixws, stream);
 }

@@ -94,13 +94,14 @@ struct DecideBatch {
 hipError_t launch_gram_reduce(const double *part, int64_t nparts, int N, double *gram, float *nrm32, int64_t nch,
                               hipStream_t stream);
 // Where the patch rows of the exact repair pass come from: a patch matrix in memory, or the channel planes
-// (3x3 / stride 1: row (ky, kx) is the plane shifted by (ky - pad, kx - pad), zero outside the image).
+// (row (ky, kx), column (b, oy, ox) is plane[b][oy*sh + ky*rh - pt][ox*sw + kx*rw - pl], zero outside the image).
 struct FixSrc {
     const float *X, *Xq;
     int64_t ld, m;               // m = columns (n*oh*ow for planes)
     int planes;                  // 0: X/Xq are [N][ld] patch rows; 1: [nch][n][H][W] channel planes
     int64_t plane;               // floats per channel plane
-    int n, H, W, pad, oh, ow;
+    int n, H, W, oh, ow;
+    int kw, sh, sw, rh, rw, pt, pl;
 };
 size_t gram_fix_bytes();
 // decide pass + (src != NULL) two rounds of device-side repair of the chains it could not certify;
@@ -125,6 +126,26 @@ struct ImageGramArgs {
     double slack = 1.0;
     int variant = 0;              // tuning hook: forces the strip length (1, 2, 4, 7)
 };
+// Any other kernel shape / stride / rate (gpfq_gram_conv.hip): the register-tile Gram kernel with implicit
+// im2col staging from the channel planes, all channels of the shard in one launch, then the batched decide.
+struct ConvGramArgs {
+    const float *act_w, *act_q;   // channel-major planes [nch][n][H][W]
+    int64_t n, H, W, nch;
+    int kh, kw, sh, sw, rh, rw, pt, pl;
+    int64_t oh, ow;
+    const float *Wt;              // [nch][F][kh*kw]
+    AlphabetArg A;
+    int64_t F;
+    int8_t *qidx;                 // [nch][F][kh*kw]
+    float *Qt;
+    int32_t *uncertified;         // [nch][F]
+    void *workspace;
+    double slack = 1.0;
+};
+bool gram_conv_supported(int64_t n, int64_t H, int64_t W, int64_t nch, int kh, int kw, int64_t oh, int64_t ow);
+size_t gram_conv_workspace_bytes(int64_t K, int64_t nch, int64_t F, int64_t m);
+hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream);
+
 bool gram_image_supported(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw, int rh, int rw, int same_padding);
 size_t gram_image_workspace_bytes(int64_t nch, int64_t F);
 hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream);

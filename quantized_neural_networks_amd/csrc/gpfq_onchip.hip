@@ -300,7 +300,12 @@ hipError_t launch_onchip(const OnchipArgs &a, hipStream_t stream)
     const bool narrow = a.wpn == 0 && a.lpn == 0 && a.m >= 512 && a.C <= 1024;
     if (a.wpn > 1 || a.m > 2048 || narrow) {
         int W = a.wpn > 1 ? a.wpn : (int)((a.m + 1023) / 1024);
-        if (narrow && a.m <= 2048) W = a.C > 512 ? 2 : 4;
+        if (narrow && a.m <= 2048) {
+            // 4 (8 above 512 neurons) elements per lane, 2..4 wavefronts: multiples of 4 elements per lane keep the
+            // register-prefetch mode of the wide kernel (tools/narrow_quick.py: m = 512, C = 128: 0.92 -> 0.77 us/step)
+            W = (int)(a.m / (64 * (a.C > 512 ? 8 : 4)));
+            W = W < 2 ? 2 : W > 4 ? 4 : W;
+        }
         while ((a.m + 64 * (int64_t)W - 1) / (64 * (int64_t)W) > 16) ++W;
         return launch_wide(a, W, stream);
     }

@@ -389,6 +389,51 @@ def test_conv_fused_3x3(oracle_mod, n, H, W, Cin, F, padding, strip, first):
         assert counts[0] <= counts[1] == Cin * F, counts
 
 
+@pytest.mark.parametrize("n,H,W,Cin,F,kh,kw,stride,rate,padding,first", [
+    (40, 23, 23, 2, 3, 5, 5, 1, 1, "SAME", False),       # 25 patch rows: 4 x 3 tiles of the lower triangle
+    (70, 38, 38, 2, 2, 7, 7, 2, 1, "VALID", False),      # ResNet conv1 in small: 49 rows, stride 2, no padding
+    (45, 37, 41, 1, 2, 7, 7, 2, 1, "SAME", True),        # the same with SAME padding on a first layer
+    (90, 28, 28, 3, 4, 3, 3, 2, 1, "SAME", False),       # strided 3x3 (not the plane-correlation kernel's case)
+    (25, 30, 30, 2, 3, 3, 3, 1, 2, "SAME", False),       # dilated 3x3
+    (150, 24, 20, 2, 3, 2, 2, 2, 1, "VALID", False),     # 2x2 / 2
+    (60, 20, 31, 2, 2, 1, 5, 1, 1, "SAME", False),       # 1x5 row kernel
+])
+def test_conv_implicit_im2col(oracle_mod, n, H, W, Cin, F, kh, kw, stride, rate, padding, first):
+    """Kernel shapes other than 3x3/stride-1 gather their patch rows from the channel planes inside the Gram
+    tile kernel (gpfq_gram_conv.hip): equal to the oracle on the reference's patch matrices and to the
+    per-channel patch-matrix path (conv_fused = 0)."""
+    from quantized_neural_networks_amd import hip, layer
+    r = np.random.default_rng(n + W + kh)
+    act_w = (r.random((n, H, W, Cin)) - (0.3 if first else 0.0)).astype(np.float32)
+    act_q = act_w if first else np.maximum(act_w + 0.05 * r.standard_normal(act_w.shape), 0).astype(np.float32)
+    Wk = (r.standard_normal((kh, kw, Cin, F)) / np.sqrt(kh * kw)).astype(np.float32)
+    Wd = torch.from_numpy(Wk).cuda()
+    alphabet, _ = layer.layer_alphabet(Wd, np.linspace(-1, 1, 8), 4)
+    aw = torch.from_numpy(act_w).cuda()
+    aq = aw if first else torch.from_numpy(act_q).cuda()
+    kwargs = dict(strides=(stride, stride), padding=padding, rate=(rate, rate), want_resid=False)
+    try:
+        out = layer.quantize_conv2d(Wd, aw, aq, alphabet, **kwargs)
+        hip.set_option("conv_fused", 0)
+        old = layer.quantize_conv2d(Wd, aw, aq, alphabet, **kwargs)
+        hip.set_option("conv_fused", 1)
+        hip.set_option("gram_slack_log2", 14)               # some chains repaired on the device, from the planes
+        rep = layer.quantize_conv2d(Wd, aw, aq, alphabet, **kwargs)
+    finally:
+        hip.set_option("conv_fused", 1)
+        hip.set_option("gram_slack_log2", 0)
+    assert torch.equal(out["Q"], old["Q"]) and torch.equal(out["idx"], old["idx"])
+    assert torch.equal(out["Q"], rep["Q"]) and torch.equal(out["idx"], rep["idx"])
+    Q = out["Q"].cpu().numpy()
+    for c in range(Cin):
+        Pw = ref_patches(act_w, c, kh, kw, stride, stride, rate, rate, padding)
+        Pq = ref_patches(act_q, c, kh, kw, stride, stride, rate, rate, padding)
+        assert Pw.shape[1] > hip.GPFQ_ONCHIP_MAX_M
+        for f in range(F):
+            qo, _, _ = oracle_mod.neuron(Wk[:, :, c, f].reshape(-1), Pw, Pq, alphabet)
+            assert np.array_equal(Q[:, :, c, f].reshape(-1), qo.astype(np.float32)), (c, f)
+
+
 @pytest.mark.parametrize("stride,bits", [(1, 2), (2, np.log2(3)), (1, 4)])
 def test_conv1x1_shortcut_equals_general_path(oracle_mod, stride, bits):
     """1x1 kernels take the MSQ shortcut; it must give what the general per-channel path gives,
