@@ -36,9 +36,10 @@ namespace gpfq {
 template <int TB, int SB>
 __global__ void __launch_bounds__(kGramThreads, 2)
 gpfq_gram_tile_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int N, int64_t m,
-                      int64_t nchunks, double *__restrict__ part)
+                      int64_t nchunks, double *__restrict__ part, int *__restrict__ negflag)
 {
     using Tile = GramTile<TB, SB>;
+    unsigned signs = 0;                                  // OR of the sign bits of everything this thread staged
     constexpr int R = Tile::R, J = Tile::J;
     __shared__ __attribute__((aligned(16))) float lrow[R][kGramCH];
     int ty, sz;
@@ -83,11 +84,13 @@ gpfq_gram_tile_kernel(const float *__restrict__ X, const float *__restrict__ Xq,
                     }
                 }
                 *reinterpret_cast<float4 *>(&lrow[r][4 * lane]) = v;
+                signs |= __float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z) | __float_as_uint(v.w);
             }
         }
         __syncthreads();
         tile.accumulate(lrow, wave, lane, norms);
     }
+    if (__ballot(signs >> 31) && lane == 0) atomicOr(negflag, 1);          // a negative element was seen
     tile.store(part + (int64_t)blockIdx.x * gram_record(N), N, t0, s0, wave, lane, norms);
 }
 
@@ -97,11 +100,12 @@ gpfq_gram_tile_kernel(const float *__restrict__ X, const float *__restrict__ Xq,
 // partial record per wavefront.  Rows >= N read as zeros.
 __global__ void __launch_bounds__(kGramThreads, 2)
 gpfq_gram_rows9_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int N, int64_t m,
-                       double *__restrict__ part)
+                       double *__restrict__ part, int *__restrict__ negflag)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     Gram9 acc;
     gram9_zero(acc);
+    unsigned signs = 0;
     const int64_t stride = (int64_t)gridDim.x * kGramThreads;
     int64_t i = (int64_t)blockIdx.x * kGramThreads + threadIdx.x;
     float xf[9], qf[9];
@@ -113,7 +117,10 @@ gpfq_gram_rows9_kernel(const float *__restrict__ X, const float *__restrict__ Xq
     while (i < m) {
         double x[9], q[9];
 #pragma unroll
-        for (int s = 0; s < 9; ++s) { x[s] = (double)xf[s]; q[s] = (double)qf[s]; }
+        for (int s = 0; s < 9; ++s) {
+            x[s] = (double)xf[s]; q[s] = (double)qf[s];
+            signs |= __float_as_uint(xf[s]) | __float_as_uint(qf[s]);
+        }
         i += stride;
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
@@ -122,6 +129,7 @@ gpfq_gram_rows9_kernel(const float *__restrict__ X, const float *__restrict__ Xq
         }
         gram9_add(acc, q, x);
     }
+    if (__ballot(signs >> 31) && lane == 0) atomicOr(negflag, 1);          // a negative element was seen
     double *out = part + ((int64_t)blockIdx.x * 4 + wave) * gram_record(N);
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -172,12 +180,16 @@ gpfq_gram_reduce_kernel(const double *__restrict__ part, int64_t nparts, int N, 
 __device__ __forceinline__ int decide_chain(const double *__restrict__ gram, const float *__restrict__ nrm32,
                                             const float *__restrict__ w, float *__restrict__ qh, const AlphabetArg &A, int N,
                                             double slack, int8_t *__restrict__ qidx, float *__restrict__ Qt,
-                                            int t0, double dot_u, double dot_uw)
+                                            int t0, double dot_u, double dot_uw, bool nonneg)
 {
     const double *nx2 = gram + (int64_t)N * N * 2;
     const double c = 0x1p-22 * slack;                   // slack = 1 in production; tests shrink margins with it
     // Cauchy-Schwarz needs upper bounds of the norms: one ulp-scale inflation covers sqrt and product roundings
     const double up = 1.0 + 0x1p-48;
+    // nonneg: no element of X, Xq is negative (inputs that come out of a ReLU), so the absolute inner products
+    // ARE the Gram entries (inflated for their own accumulation error) -- much tighter than Cauchy-Schwarz when
+    // the activations are sparse
+    const double upg = 1.0 + 0x1p-30;
     double R = 0.0;                                     // sum_{s<t} |w_s| ||X_s|| + |q_s| ||Xq_s||
     for (int t = 0; t < N; ++t) {
         int idx = A.zero_idx;
@@ -202,12 +214,15 @@ __device__ __forceinline__ int decide_chain(const double *__restrict__ gram, con
                 q32 = (float)A.a[best];
             }
         } else if (!((double)nrm < 1e-16)) {                                           // not rule (i)
-            double acc = 0.0;
+            double acc = 0.0, B = 0.0;
             for (int s = 0; s < t; ++s) {
                 const double *g = gram + ((int64_t)t * N + s) * 2;
                 acc += (double)w[s] * g[0] - (double)qh[s] * g[1];
+                B += fabs((double)w[s]) * g[0] + fabs((double)qh[s]) * g[1];
             }
-            const double err0 = c * nq * R + 0x1p-128 * nq;     // second term: products rounded in the subnormal range
+            B = nonneg ? B * upg : nq * R;
+            const double a_tt = nonneg ? gram[((int64_t)t * N + t) * 2] * upg : nq * nx;     // <|Xq_t|, |X_t|>
+            const double err0 = c * B + 0x1p-128 * nq;          // second term: products rounded in the subnormal range
             double tq;
             double delta;
             if (fabs(acc) + err0 < 1e-10) {                                            // certainly rule (ii)
@@ -217,7 +232,7 @@ __device__ __forceinline__ int decide_chain(const double *__restrict__ gram, con
                 const double wt = (double)w[t];
                 const double denom = (double)nrm * (double)nrm;
                 tq = (acc + wt * gram[((int64_t)t * N + t) * 2]) / denom;
-                delta = (err0 + 0x1p-23 * fabs(wt) * nq * nx * slack) / denom + 0x1p-44 * fabs(tq);
+                delta = (err0 + 0x1p-23 * fabs(wt) * a_tt * slack) / denom + 0x1p-44 * fabs(tq);
             } else {
                 return t + 1;                                                          // cannot tell (ii) from (iii)
             }
@@ -258,7 +273,7 @@ gpfq_gram_decide_kernel(const double *__restrict__ gram, const float *__restrict
                         const float *__restrict__ Wt, int64_t ldw, AlphabetArg A, int N, int64_t C,
                         double slack, int8_t *__restrict__ qidx, float *__restrict__ Qt,
                         int32_t *__restrict__ uncertified, float *__restrict__ q32_hist, DecideBatch bs,
-                        FixState *__restrict__ fix)
+                        FixState *__restrict__ fix, const int *__restrict__ negflag)
 {
     const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (j >= C) return;
@@ -266,7 +281,7 @@ gpfq_gram_decide_kernel(const double *__restrict__ gram, const float *__restrict
     const int r = decide_chain(gram + ch * bs.gram_cs, nrm32 + ch * bs.nrm_cs, Wt + ch * bs.w_cs + j * ldw,
                                q32_hist + ch * bs.hist_cs + j * N, A, N, slack,
                                qidx ? qidx + ch * bs.out_cs + j * N : nullptr, Qt ? Qt + ch * bs.out_cs + j * N : nullptr,
-                               -1, 0.0, 0.0);
+                               -1, 0.0, 0.0, negflag && negflag[ch] == 0);
     uncertified[ch * bs.unc_cs + j] = r;
     if (r && fix) {
         const int k = atomicAdd(&fix->count[0], 1);
@@ -345,7 +360,7 @@ gpfq_gram_resume_kernel(const double *__restrict__ gram, const float *__restrict
                         const float *__restrict__ Wt, int64_t ldw, AlphabetArg A, int N, int64_t C,
                         double slack, int8_t *__restrict__ qidx, float *__restrict__ Qt,
                         int32_t *__restrict__ uncertified, float *__restrict__ q32_hist, DecideBatch bs,
-                        FixState *__restrict__ fix, int round)
+                        FixState *__restrict__ fix, int round, const int *__restrict__ negflag)
 {
     const int k = threadIdx.x;
     const int cnt = fix->count[round];
@@ -358,7 +373,7 @@ gpfq_gram_resume_kernel(const double *__restrict__ gram, const float *__restrict
     const int r = decide_chain(gram + ch * bs.gram_cs, nrm32 + ch * bs.nrm_cs, Wt + ch * bs.w_cs + j * ldw,
                                q32_hist + ch * bs.hist_cs + j * N, A, N, slack,
                                qidx ? qidx + ch * bs.out_cs + j * N : nullptr, Qt ? Qt + ch * bs.out_cs + j * N : nullptr,
-                               t0, dot_u, dot_uw);
+                               t0, dot_u, dot_uw, negflag && negflag[ch] == 0);
     uncertified[ch * bs.unc_cs + j] = r;
     if (r) {
         const int kk = atomicAdd(&fix->count[round + 1], 1);
@@ -468,7 +483,8 @@ size_t gram_fix_bytes() { return al256(sizeof(FixState)); }
 
 hipError_t launch_gram_decide(const double *gram, const float *nrm32, const float *Wt, int64_t ldw, const AlphabetArg &A,
                               int N, int64_t C, double slack, int8_t *qidx, float *Qt, int32_t *uncertified,
-                              float *q32_hist, const DecideBatch &bs, const FixSrc *src, void *fix_ws, hipStream_t stream)
+                              float *q32_hist, const DecideBatch &bs, const FixSrc *src, void *fix_ws, const int *negflag,
+                              hipStream_t stream)
 {
     if (C == 0 || bs.nch == 0) return hipSuccess;
     FixState *fix = (src && fix_ws && src->m > 0 && bs.nch * C < (1LL << 31)) ? static_cast<FixState *>(fix_ws) : nullptr;
@@ -477,12 +493,12 @@ hipError_t launch_gram_decide(const double *gram, const float *nrm32, const floa
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(gpfq_gram_decide_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)bs.nch), dim3(64), 0, stream,
-                       gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, bs, fix);
+                       gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, bs, fix, negflag);
     for (int round = 0; fix && round < kFixRounds; ++round) {
         hipLaunchKernelGGL(gpfq_gram_fix_kernel, dim3(kFixBlocks, kFixMax), dim3(256), 0, stream,
                            *src, Wt, ldw, N, C, uncertified, q32_hist, bs, fix, round);
         hipLaunchKernelGGL(gpfq_gram_resume_kernel, dim3(1), dim3(64), 0, stream,
-                           gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, bs, fix, round);
+                           gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, bs, fix, round, negflag);
     }
     return hipGetLastError();
 }
@@ -501,14 +517,17 @@ hipError_t launch_gram(const GramArgs &a, hipStream_t stream)
     double *rpart = reinterpret_cast<double *>(ws);
 
     const int N = (int)a.N;
+    int *negflag = reinterpret_cast<int *>(gram + rec);          // the 8 spare bytes behind the record
     if (a.m > 0 && N > 0) {
+        hipError_t e0 = hipMemsetAsync(negflag, 0, sizeof(int), stream);
+        if (e0 != hipSuccess) return e0;
         if (N <= 9) {
             hipLaunchKernelGGL(gpfq_gram_rows9_kernel, dim3((unsigned)nblocks), dim3(kGramThreads), 0, stream,
-                               a.X, a.Xq, a.ld, N, a.m, part);
+                               a.X, a.Xq, a.ld, N, a.m, part, negflag);
         } else {
             // only the tiles that meet the lower triangle are launched
             hipLaunchKernelGGL((gpfq_gram_tile_kernel<2, 12>), dim3((unsigned)nblocks, (unsigned)tile_count<2, 12>(N)),
-                               dim3(kGramThreads), 0, stream, a.X, a.Xq, a.ld, N, a.m, nchunks, part);
+                               dim3(kGramThreads), 0, stream, a.X, a.Xq, a.ld, N, a.m, nchunks, part, negflag);
         }
         hipError_t e = launch_gram_reduce(part, nparts, N, gram, a.nrm32_out, 1, stream);
         if (e != hipSuccess) return e;
@@ -523,7 +542,7 @@ hipError_t launch_gram(const GramArgs &a, hipStream_t stream)
     FixSrc src{};
     src.X = a.X; src.Xq = a.Xq; src.ld = a.ld; src.m = a.m; src.planes = 0;
     hipError_t e = launch_gram_decide(gram, a.nrm32, a.Wt, a.ldw, a.A, N, a.C, a.slack, a.qidx, a.Qt, a.uncertified, q32h,
-                                      DecideBatch(), &src, fixws, stream);
+                                      DecideBatch(), &src, fixws, negflag, stream);
     if (e != hipSuccess) return e;
     if (a.resid) {
         if (a.m > 0 && N > 0) {

@@ -23,6 +23,7 @@ struct ConvParams {
     int d64[3], dch[3];          // (images, rows, columns) decomposition of 64 columns / of the chunk stride
     int nparts;
     double *part;                // [nch][nparts] Gram records
+    int *negflag;                // [nch], set when a channel has a negative activation
 };
 
 // (b, oy, ox) += d with carries; every component of d is below its modulus.
@@ -87,7 +88,7 @@ gpfq_gram_conv_kernel(ConvParams p)
     // masked afterwards, one chunk ahead of its use: their latencies overlap each other and the FMAs.
     static_assert(J <= 8, "one mask bit per gathered value");
     float v[J][4];
-    unsigned vmask = 0;
+    unsigned vmask = 0, signs = 0;
     auto gather = [&]() {
         int base[4], iy0[4], ix0[4];
         bool cok[4];
@@ -122,7 +123,11 @@ gpfq_gram_conv_kernel(ConvParams p)
             const int r = wave + 4 * j;
             if (r < R) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) lrow[r][lane + 64 * e] = (vmask >> (4 * j + e)) & 1u ? v[j][e] : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    const float val = (vmask >> (4 * j + e)) & 1u ? v[j][e] : 0.f;
+                    lrow[r][lane + 64 * e] = val;
+                    signs |= __float_as_uint(val);
+                }
             }
         }
         __syncthreads();
@@ -131,6 +136,7 @@ gpfq_gram_conv_kernel(ConvParams p)
         if (ch + nwalk < p.nchunks) gather();              // in flight during the FMAs below
         tile.accumulate(lrow, wave, lane, norms);
     }
+    if (__ballot(signs >> 31) && lane == 0) atomicOr(p.negflag + blockIdx.z, 1);   // a negative activation was seen
     tile.store(p.part + ((int64_t)blockIdx.z * p.nparts + walker) * gram_record(p.K), p.K, t0, s0, wave, lane, norms);
 }
 
@@ -165,6 +171,7 @@ size_t gram_conv_workspace_bytes(int64_t K, int64_t nch, int64_t F, int64_t m)
     b += al256v((size_t)nch * K * sizeof(float));                                           // row norms
     b += al256v((size_t)nch * F * K * sizeof(float));                                       // chosen values per filter and step
     b += gram_fix_bytes();
+    b += al256v((size_t)nch * sizeof(int));                                                 // negative-activation flags
     return b;
 }
 
@@ -200,8 +207,12 @@ hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream)
     double *gram = reinterpret_cast<double *>(ws);  ws += al256v((size_t)a.nch * gram_record(K) * sizeof(double));
     float *nrm = reinterpret_cast<float *>(ws);     ws += al256v((size_t)a.nch * K * sizeof(float));
     float *q32h = reinterpret_cast<float *>(ws);    ws += al256v((size_t)a.nch * a.F * K * sizeof(float));
-    void *fixws = ws;
+    void *fixws = ws;                               ws += gram_fix_bytes();
+    int *negflag = reinterpret_cast<int *>(ws);
+    hipError_t e0 = hipMemsetAsync(negflag, 0, (size_t)a.nch * sizeof(int), stream);
+    if (e0 != hipSuccess) return e0;
     p.part = part;
+    p.negflag = negflag;
     hipLaunchKernelGGL((gpfq_gram_conv_kernel<kConvTB, kConvSB>),
                        dim3((unsigned)tile_count<kConvTB, kConvSB>((int)K), (unsigned)nparts, (unsigned)a.nch), dim3(kGramThreads), 0, stream, p);
     hipError_t e = hipGetLastError();
@@ -215,7 +226,8 @@ hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream)
     src.X = a.act_w; src.Xq = a.act_q; src.ld = 0; src.m = m; src.planes = 1; src.plane = p.plane;
     src.n = (int)a.n; src.H = p.H; src.W = p.W; src.oh = p.oh; src.ow = p.ow;
     src.kw = a.kw; src.sh = a.sh; src.sw = a.sw; src.rh = a.rh; src.rw = a.rw; src.pt = a.pt; src.pl = a.pl;
-    return launch_gram_decide(gram, nrm, a.Wt, K, a.A, (int)K, a.F, a.slack, a.qidx, a.Qt, a.uncertified, q32h, bs, &src, fixws, stream);
+    return launch_gram_decide(gram, nrm, a.Wt, K, a.A, (int)K, a.F, a.slack, a.qidx, a.Qt, a.uncertified, q32h, bs, &src, fixws, negflag,
+                              stream);
 }
 
 }  // namespace gpfq

@@ -40,6 +40,7 @@ struct ImgParams {
     int same_act;
     int nbx;
     double *part;         // [nch][nbx*2] Gram records (N = 9)
+    int *negflag;         // [nch], set when a channel has a negative activation
 };
 
 // floor(v / d) for 0 <= v < 2^24 (exact in float): float estimate, one correction step.
@@ -89,6 +90,7 @@ __device__ __forceinline__ void image_gram_body(const ImgParams &p, float *lds)
     const int st_step = kImgThreads >> p.lpr_log2;
     const int st_ix = 4 * st_c4 - p.pad;
     const bool st_inside = st_ix >= 0 && st_ix + 3 < p.W;
+    unsigned signs = 0;                                  // OR of the sign bits of everything this thread staged
 
     for (int band = blockIdx.x; band < p.nbands; band += gridDim.x) {
         const int g0 = band * p.RB;
@@ -125,6 +127,8 @@ __device__ __forceinline__ void image_gram_body(const ImgParams &p, float *lds)
                 }
                 *reinterpret_cast<float4 *>(lw + row * p.LP + 4 * st_c4) = a;
                 if (!p.same_act) *reinterpret_cast<float4 *>(lq + row * p.LP + 4 * st_c4) = c;
+                signs |= __float_as_uint(a.x) | __float_as_uint(a.y) | __float_as_uint(a.z) | __float_as_uint(a.w)
+                       | __float_as_uint(c.x) | __float_as_uint(c.y) | __float_as_uint(c.z) | __float_as_uint(c.w);
                 r += st_step;
                 while (r >= p.PH) { r -= p.PH; ++b; }
             }
@@ -165,6 +169,7 @@ __device__ __forceinline__ void image_gram_body(const ImgParams &p, float *lds)
             }
         }
     }
+    if (__ballot(signs >> 31) && lane == 0) atomicOr(p.negflag + blockIdx.y, 1);   // a negative activation was seen
     // the two wavefronts of a pair fill disjoint columns of one record
     double *out = p.part + (((int64_t)blockIdx.y * p.nbx + blockIdx.x) * 2 + pair) * kRec9;
 #pragma unroll
@@ -245,6 +250,7 @@ size_t gram_image_workspace_bytes(int64_t nch, int64_t F)
     b += al256i((size_t)nch * 9 * sizeof(float));                           // row norms
     b += al256i((size_t)nch * F * 9 * sizeof(float));                       // chosen values per filter and step
     b += gram_fix_bytes();                                                  // device-side repair of uncertified chains
+    b += al256i((size_t)nch * sizeof(int));                                 // "channel has negative activations" flags
     return b;
 }
 
@@ -273,8 +279,12 @@ hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream)
     double *gram = reinterpret_cast<double *>(ws);  ws += al256i((size_t)a.nch * kRec9 * sizeof(double));
     float *nrm = reinterpret_cast<float *>(ws);     ws += al256i((size_t)a.nch * 9 * sizeof(float));
     float *q32h = reinterpret_cast<float *>(ws);    ws += al256i((size_t)a.nch * a.F * 9 * sizeof(float));
-    void *fixws = ws;
+    void *fixws = ws;                               ws += gram_fix_bytes();
+    int *negflag = reinterpret_cast<int *>(ws);
+    hipError_t e0 = hipMemsetAsync(negflag, 0, (size_t)a.nch * sizeof(int), stream);
+    if (e0 != hipSuccess) return e0;
     p.part = part;
+    p.negflag = negflag;
     const dim3 grid((unsigned)nbx, (unsigned)a.nch), block(kImgThreads);
     switch (S) {
     case 4:  hipLaunchKernelGGL(gpfq_gram_image_kernel<4>, grid, block, lds, stream, p); break;
@@ -292,7 +302,8 @@ hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream)
     src.n = p.n; src.H = p.H; src.W = p.W; src.oh = p.oh; src.ow = p.SPR * S;
     src.kw = 3; src.sh = src.sw = src.rh = src.rw = 1; src.pt = src.pl = p.pad;
     src.m = (int64_t)p.grows * src.ow;
-    return launch_gram_decide(gram, nrm, a.Wt, 9, a.A, 9, a.F, a.slack, a.qidx, a.Qt, a.uncertified, q32h, bs, &src, fixws, stream);
+    return launch_gram_decide(gram, nrm, a.Wt, 9, a.A, 9, a.F, a.slack, a.qidx, a.Qt, a.uncertified, q32h, bs, &src, fixws, negflag,
+                              stream);
 }
 
 }  // namespace gpfq

@@ -108,7 +108,11 @@ size_t gram_fix_bytes();
 // fix_ws: gram_fix_bytes() of scratch.  Chains still flagged afterwards are the caller's to rerun.
 hipError_t launch_gram_decide(const double *gram, const float *nrm32, const float *Wt, int64_t ldw, const AlphabetArg &A,
                               int N, int64_t C, double slack, int8_t *qidx, float *Qt, int32_t *uncertified,
-                              float *q32_hist, const DecideBatch &bs, const FixSrc *src, void *fix_ws, hipStream_t stream);
+                              float *q32_hist, const DecideBatch &bs, const FixSrc *src, void *fix_ws, const int *negflag,
+                              hipStream_t stream);
+// negflag (may be NULL): one int per channel, zeroed by the caller before its Gram kernel runs and set by
+// that kernel when it meets a negative element of X or Xq; 0 lets the decide step use the Gram entries
+// themselves as the absolute inner products of its error bound (post-ReLU inputs) instead of Cauchy-Schwarz.
 
 // Fused conv path for 3x3 / stride 1 / rate 1 kernels (gpfq_gram_image.hip): the Gram matrices of all
 // channels straight from the channel planes, then one batched decide launch -- no patch matrices.

@@ -149,6 +149,8 @@ class QuantizedNeuralNetwork:
         ``transpose`` (feature-major for Dense).  Batch b is written at offset b*(its own size), as
         in the reference (:491-495): with a partial last batch that overwrites earlier columns and
         leaves a zero tail.  ``fix_partial_batch=True`` writes batches back to back instead."""
+        if self._incremental_capture_possible():
+            return self._capture_incremental(layer_idx, transpose)
         if layer_idx == 0:
             inbound_analog = inbound_quant = None
         else:
@@ -200,8 +202,81 @@ class QuantizedNeuralNetwork:
             written += k
         return wX_all, qX_all
 
+    # -- activation capture without recomputation (torch-backed Sequential networks) -------------------
+    # The reference re-runs both truncated networks from the input for every layer and every batch
+    # (:483-484): O(L^2) layer evaluations in 16-sample batches.  Layers are quantized front to back, so
+    # the activations at the input of layer l follow from those at the input of the previously captured
+    # layer by running only the layers in between -- with the weights layer l' has NOW (it was quantized
+    # after its inputs were captured).  Samples are pushed through in large chunks; the reference's
+    # batch structure only decides where columns land (including the partial-last-batch quirk).
+    _capture_chunk = 2048
+
+    def _incremental_capture_possible(self):
+        return (getattr(self, "incremental_capture", True) and hasattr(self.trained_net, "forward_upto")
+                and hasattr(self.quantized_net, "forward_upto") and len(self.trained_net.layers) == len(self.quantized_net.layers))
+
+    def _raw_inputs(self):
+        if getattr(self, "_raw", None) is None:
+            batches = [np.asarray(self.get_data.__getitem__(b)[0]) for b in range(self.get_data.__len__())]
+            sizes = [int(a.shape[0]) for a in batches]
+            self._raw = (self._to_device(np.concatenate(batches, axis=0)), sizes)
+        return self._raw
+
+    @torch.no_grad()
+    def _advance(self, layer, x):
+        step = self._capture_chunk
+        if x.shape[0] <= step:
+            return layer.call(x)
+        return torch.cat([layer.call(x[i:i + step]) for i in range(0, x.shape[0], step)])
+
+    def _capture_incremental(self, layer_idx, transpose):
+        raw, sizes = self._raw_inputs()
+        fr = getattr(self, "_frontier", None)
+        if fr is None or fr["k"] > layer_idx - 1:
+            fr = dict(k=-1, w=raw, q=raw)                       # outputs of "layer -1" = the data itself
+        tl, ql = self.trained_net.layers, self.quantized_net.layers
+        for k in range(fr["k"] + 1, layer_idx):
+            same = fr["q"] is fr["w"] and all(torch.equal(a, b) for a, b in zip(tl[k]._weights, ql[k]._weights))
+            w = self._advance(tl[k], fr["w"])
+            q = w if same else self._advance(ql[k], fr["q"])
+            fr = dict(k=k, w=w, q=q)
+        self._frontier = fr
+        wX = self._assemble_capture(fr["w"], sizes, transpose)
+        # both networks still agree up to here (first quantized layer): one tensor, as for layer 0 (:478-481)
+        return wX, (wX if fr["q"] is fr["w"] else self._assemble_capture(fr["q"], sizes, transpose))
+
+    def _assemble_capture(self, act, sizes, transpose):
+        """Columns in the reference's layout (:491-495): batch b lands at offset b*(its own size)."""
+        bs = self.get_data.batch_size
+        n_batches = len(sizes)
+        shape = (n_batches * bs,) + tuple(act.shape[1:])
+        out = torch.zeros(shape[::-1] if transpose else shape, dtype=torch.float32, device=self.device)
+        perm = tuple(range(act.dim() - 1, -1, -1))
+
+        def put(lo, src):
+            if transpose:
+                out[..., lo:lo + src.shape[0]] = src.permute(perm)
+            else:
+                out[lo:lo + src.shape[0]] = src
+        nfull = 0
+        while nfull < n_batches and sizes[nfull] == bs:
+            nfull += 1
+        if nfull:
+            put(0, act[:nfull * bs])                             # full batches: offset = running count
+        start = nfull * bs
+        written = start
+        for b in range(nfull, n_batches):                        # partial batches (normally just the last)
+            k = sizes[b]
+            put(written if self.fix_partial_batch else b * k, act[start:start + k])
+            start += k
+            written += k
+        return out
+
     def _update_weights(self, layer_idx, Q):
         """Install Q in the quantized network; the bias is carried over from the analog one (:504-521)."""
+        fr = getattr(self, "_frontier", None)
+        if fr is not None and fr["k"] >= layer_idx:
+            self._frontier = None                                 # captured activations downstream of this layer are stale
         if self.trained_net.layers[layer_idx].use_bias:
             bias = self.trained_net.layers[layer_idx].get_weights()[1]
             self.quantized_net.layers[layer_idx].set_weights([Q, bias])
@@ -303,7 +378,7 @@ class QuantizedCNN(QuantizedNeuralNetwork):
         self._log(f"\t\tdone. {time()-tic:.2f} seconds.")
         self._update_weights(layer_idx, Q)
         self.last_layer_stats[layer_idx] = dict(rad=rad, alphabet=alphabet, resid=out["resid"].cpu().numpy(),
-                                                idx=out["idx"].cpu().numpy())
+                                                idx=out["idx"].cpu().numpy(), reruns=int(out.get("reruns", 0)))
 
     def quantize_network(self):
         num_layers = len(self.trained_net.layers)

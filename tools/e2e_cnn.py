@@ -1,0 +1,60 @@
+"""End-to-end QuantizedCNN.quantize_network() on BASELINE cfg4: the CIFAR10 CNN of train_cifar10_cnn.py:63-86
+(random weights), 5000 synthetic calibration images in batches of 16 (=> 5008 columns with the partial-batch
+quirk), 3 bits, alphabet_scalar 4.  Prints where the wall time goes: activation capture vs quantization.
+usage: e2e_cnn.py [n_images] [batch]"""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from quantized_neural_networks_amd import keras_shim as ks, quantized_network as qn
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+
+
+class TimingLogger:
+    def __init__(self):
+        self.t0 = time.time()
+        self.lines = []
+
+    def info(self, msg):
+        self.lines.append((time.time() - self.t0, msg))
+
+
+def build():
+    L = [ks.Conv2D(32, (3, 3), activation="relu", padding="same", input_shape=(32, 32, 3)), ks.BatchNormalization(),
+         ks.Conv2D(32, (3, 3), activation="relu", padding="same"), ks.BatchNormalization(), ks.MaxPooling2D((2, 2)), ks.Dropout(0.2),
+         ks.Conv2D(64, (3, 3), activation="relu", padding="same"), ks.BatchNormalization(),
+         ks.Conv2D(64, (3, 3), activation="relu", padding="same"), ks.BatchNormalization(), ks.MaxPooling2D((2, 2)), ks.Dropout(0.3),
+         ks.Conv2D(128, (3, 3), activation="relu", padding="same"), ks.BatchNormalization(),
+         ks.Conv2D(128, (3, 3), activation="relu", padding="same"), ks.BatchNormalization(), ks.MaxPooling2D((2, 2)), ks.Dropout(0.4),
+         ks.Flatten(), ks.Dense(128, activation="relu"), ks.BatchNormalization(), ks.Dropout(0.5), ks.Dense(10, activation="softmax")]
+    return ks.Sequential(L)
+
+
+r = np.random.default_rng(0)
+x = r.random((n, 32, 32, 3)).astype(np.float32)
+y = np.zeros((n, 10), dtype=np.float32)
+for it in range(2):
+    net = build()
+    log = TimingLogger()
+    q = qn.QuantizedCNN(network=net, batch_size=batch, get_data=qn.CIFAR10Sequence(x, y, batch), logger=log, bits=3, alphabet_scalar=4)
+    torch.cuda.synchronize(); t0 = time.time()
+    if it == 1 and "--profile" in sys.argv:
+        import cProfile, pstats
+        pr = cProfile.Profile(); pr.enable()
+        q.quantize_network()
+        torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+    else:
+        q.quantize_network()
+    torch.cuda.synchronize(); total = time.time() - t0
+    print(f"run {it}: quantize_network() {total*1e3:.1f} ms for {n} images, batch {batch}")
+# phase split of the last run from the log: "Feeding input data ... done. X seconds."
+feed = 0.0
+lines = [m for _, m in log.lines]
+for i, m in enumerate(lines):
+    if "Feeding input data" in m and i + 1 < len(lines) and "done." in lines[i + 1]:
+        feed += float(lines[i + 1].split("done.")[1].split("seconds")[0])
+print("host reruns per conv layer:", {k: v.get("reruns") for k, v in q.last_layer_stats.items() if "reruns" in v})
+print(f"activation capture (a8): {feed*1e3:.1f} ms; everything else (quantization, host copies, logging): {(total-feed)*1e3:.1f} ms")
