@@ -226,6 +226,35 @@ def test_cnn_against_oracle(qn, ks, oracle_mod):
     assert any("(Conv2D)" in l for l in logger.lines) and any("(DepthwiseConv2D)" in l for l in logger.lines)
 
 
+def test_incremental_capture_equals_recomputation(qn, ks):
+    """The cached-frontier capture (only the layers since the previous capture are run, in large chunks) gives
+    the reference's per-batch recomputation from the input: same layout including the partial-batch quirk,
+    values equal up to the batch-size dependence of the GPU conv/GEMM kernels; both networks share one tensor
+    until the first quantized layer."""
+    r = np.random.default_rng(3)
+    x = r.random((20, 16, 16, 3)).astype(np.float32)
+    y = np.zeros((20, 6), dtype=np.float32)
+    nets = [_cnn(ks), _cnn(ks)]
+    nets[1].set_weights(nets[0].get_weights())
+    qs = [qn.QuantizedCNN(network=n, batch_size=8, get_data=qn.CIFAR10Sequence(x, y, 8), logger=ListLogger(), bits=3,
+                          alphabet_scalar=4) for n in nets]
+    qs[1].incremental_capture = False
+    recs = [_record_captures(q) for q in qs]
+    for q in qs:
+        q.quantize_network()
+    assert recs[0].keys() == recs[1].keys() and len(recs[0]) >= 3
+    for k in recs[0]:
+        for a, b in zip(recs[0][k], recs[1][k]):
+            assert a.shape == b.shape and np.array_equal(a == 0, b == 0)
+            np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-5)
+    k0 = min(recs[0])
+    wX, qX = qs[0]._get_layer_data_generator(k0)
+    assert wX is qX                                                  # layer 0: the data itself for both networks
+    for la, lb in zip(qs[0].quantized_net.layers, qs[1].quantized_net.layers):
+        for wa, wb in zip(la.get_weights(), lb.get_weights()):
+            assert np.mean(wa == wb) > 0.97                          # a few decisions may move with the last bits
+
+
 def test_cnn_dense_only(qn, ks):
     net = _cnn(ks)
     x = np.random.default_rng(1).random((8, 16, 16, 3)).astype(np.float32)

@@ -28,7 +28,14 @@ def build():
          ks.Conv2D(128, (3, 3), activation="relu", padding="same"), ks.BatchNormalization(),
          ks.Conv2D(128, (3, 3), activation="relu", padding="same"), ks.BatchNormalization(), ks.MaxPooling2D((2, 2)), ks.Dropout(0.4),
          ks.Flatten(), ks.Dense(128, activation="relu"), ks.BatchNormalization(), ks.Dropout(0.5), ks.Dense(10, activation="softmax")]
-    return ks.Sequential(L)
+    net = ks.Sequential(L)
+    if "--bn" in sys.argv:          # trained-looking BatchNorm statistics: the conv inputs become signed
+        g = np.random.default_rng(5)
+        for layer in net.layers:
+            if layer.__class__.__name__ == "BatchNormalization":
+                c = layer.get_weights()[0].shape[0]
+                layer.set_weights([g.uniform(0.5, 1.5, c), g.normal(0, 0.3, c), g.normal(0.3, 0.3, c), g.uniform(0.5, 1.5, c)])
+    return net
 
 
 r = np.random.default_rng(0)
