@@ -61,7 +61,8 @@ extern "C" {
 #define GPFQ_PATH_ONCHIP    1   /* residual u lives in VGPRs (of up to 16 wavefronts per neuron), rows staged through LDS (m <= GPFQ_ONCHIP_MAX_M) */
 #define GPFQ_PATH_STREAM    2   /* residual u lives in HBM (any m; conv patch matrices)          */
 
-#define GPFQ_ONCHIP_MAX_M 16384
+#define GPFQ_ONCHIP_MAX_M 28672   /* 16 wavefronts x 64 lanes x 28 residual elements (float64) per lane */
+#define GPFQ_GRAM_MIN_M   16384   /* conv layers / short walks take the Gram path above this many columns */
 
 int         gpfq_version(void);
 const char *gpfq_last_error(void);

@@ -306,7 +306,8 @@ hipError_t launch_onchip(const OnchipArgs &a, hipStream_t stream)
             W = (int)(a.m / (64 * (a.C > 512 ? 8 : 4)));
             W = W < 2 ? 2 : W > 4 ? 4 : W;
         }
-        while ((a.m + 64 * (int64_t)W - 1) / (64 * (int64_t)W) > 16) ++W;
+        while (W < 16 && (a.m + 64 * (int64_t)W - 1) / (64 * (int64_t)W) > 16) ++W;
+        if (W > 16) W = 16;                          // rows beyond 16384: the long-row form, up to 28 elements per lane
         return launch_wide(a, W, stream);
     }
     if (a.mode == MODE_CERTIFIED && a.stats) {

@@ -182,29 +182,42 @@ gpfq_wide_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int6
 // One neuron per workgroup (narrow layers: nothing to share through LDS): every wavefront reads its slice of
 // the rows X_t, Xq_t straight into registers, one step ahead of their use, so no staging sits on the
 // step-to-step critical path; the only LDS traffic is the W pairs of partial dot products per step.
+//
+// PREFETCH = false is the long-row form (16384 < m <= 28672: 20..28 elements per lane of 16 wavefronts, the
+// most a 1024-thread workgroup's 128 VGPRs per lane hold): the rows are read at the top of their own step --
+// their latency is exposed, but u still never leaves the chip (the alternative streams it through HBM with
+// two launches per step); `aligned` = 0 reads element-wise (any pitch, any m).
 template <int EPL>
 __device__ __forceinline__ void wide_fetch(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t t,
-                                           int base, int lane, int m, float (&x)[EPL], float (&xq)[EPL])
+                                           int base, int lane, int m, bool aligned, float (&x)[EPL], float (&xq)[EPL])
 {
     static_assert(EPL % 4 == 0, "direct mode reads 16-byte pieces");
 #pragma unroll
     for (int c = 0; c < EPL / 4; ++c) {
-        const int i = base + 256 * c + 4 * lane;                   // m % 4 == 0: a piece is inside or outside
+        const int i = base + 256 * c + 4 * lane;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        if (i < m) {
-            a = *reinterpret_cast<const float4 *>(X + t * ld + i);
-            b = *reinterpret_cast<const float4 *>(Xq + t * ld + i);
+        if (aligned) {                                             // m % 4 == 0: a piece is inside or outside
+            if (i < m) {
+                a = *reinterpret_cast<const float4 *>(X + t * ld + i);
+                b = *reinterpret_cast<const float4 *>(Xq + t * ld + i);
+            }
+        } else {
+            const float *px = X + t * ld + i, *pq = Xq + t * ld + i;
+            if (i < m)     { a.x = px[0]; b.x = pq[0]; }
+            if (i + 1 < m) { a.y = px[1]; b.y = pq[1]; }
+            if (i + 2 < m) { a.z = px[2]; b.z = pq[2]; }
+            if (i + 3 < m) { a.w = px[3]; b.w = pq[3]; }
         }
         x[4 * c] = a.x; x[4 * c + 1] = a.y; x[4 * c + 2] = a.z; x[4 * c + 3] = a.w;
         xq[4 * c] = b.x; xq[4 * c + 1] = b.y; xq[4 * c + 2] = b.z; xq[4 * c + 3] = b.w;
     }
 }
 
-template <int EPL>
-__global__ void __launch_bounds__(EPL >= 16 ? 512 : 1024)   // 16 elements per lane + their prefetch need > 128 VGPRs
+template <int EPL, bool PREFETCH>
+__global__ void __launch_bounds__((PREFETCH && EPL >= 16) ? 512 : 1024)   // 16 elements per lane + their prefetch need > 128 VGPRs
 gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld,
                         const float *__restrict__ nrm32, const float *__restrict__ Wt, int64_t ldw,
-                        AlphabetArg A, int64_t N, int m, int64_t C, int W,
+                        AlphabetArg A, int64_t N, int m, int64_t C, int W, int aligned,
                         int8_t *__restrict__ qidx, float *__restrict__ Qt,
                         double *__restrict__ resid, double *__restrict__ u_out)
 {
@@ -225,29 +238,38 @@ gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ X
     float my_q   = 0.f;
 
     float w_next = 0.f, nrm_next = 0.f;
-    float xn[EPL], xqn[EPL];
+    float xn[PREFETCH ? EPL : 1], xqn[PREFETCH ? EPL : 1];
     if (N > 0) {
         w_next = wrow[0]; nrm_next = nrm32[0];
-        wide_fetch<EPL>(X, Xq, ld, 0, base, lane, m, xn, xqn);
+        if constexpr (PREFETCH) wide_fetch<EPL>(X, Xq, ld, 0, base, lane, m, aligned != 0, xn, xqn);
     }
     for (int64_t t = 0; t < N; ++t) {
         const float w = w_next, nrm = nrm_next;
-        float x[EPL], xq[EPL];
+        // PREFETCH: the step's row slices are already in registers.  Long-row form: they are read 4 elements at a
+        // time where they are used, here and again (from L2) in the update -- no register holds them in between.
+        float x[PREFETCH ? EPL : 4], xq[PREFETCH ? EPL : 4];
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) { x[e] = xn[e]; xq[e] = xqn[e]; }
+            for (int e = 0; e < EPL; ++e) { x[e] = xn[e]; xq[e] = xqn[e]; }
+        }
         if (t + 1 < N) {
             w_next = wrow[t + 1]; nrm_next = nrm32[t + 1];
-            wide_fetch<EPL>(X, Xq, ld, t + 1, base, lane, m, xn, xqn);
+            if constexpr (PREFETCH) wide_fetch<EPL>(X, Xq, ld, t + 1, base, lane, m, aligned != 0, xn, xqn);
         }
         // this wave's share of <Xq_t, u> (:86) and <Xq_t, u + f32(w*X_t)> (:89)
         double d0a = 0.0, d0b = 0.0, d1a = 0.0, d1b = 0.0;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const float p = __fmul_rn(w, x[e]);
-            const double xd = (double)xq[e];
-            const double v  = u[e] + (double)p;
-            if (e & 1) { d0b = fma(xd, u[e], d0b); d1b = fma(xd, v, d1b); }
-            else       { d0a = fma(xd, u[e], d0a); d1a = fma(xd, v, d1a); }
+        for (int c = 0; c < EPL / 4; ++c) {
+            if constexpr (!PREFETCH) wide_fetch<4>(X, Xq, ld, t, base + 256 * c, lane, m, aligned != 0, x, xq);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = 4 * c + k, r = PREFETCH ? e : k;
+                const float p = __fmul_rn(w, x[r]);
+                const double xd = (double)xq[r];
+                const double v  = u[e] + (double)p;
+                if (e & 1) { d0b = fma(xd, u[e], d0b); d1b = fma(xd, v, d1b); }
+                else       { d0a = fma(xd, u[e], d0a); d1a = fma(xd, v, d1a); }
+            }
         }
         double dot_u, dot_uw;
         wave_sum2(d0a + d0b, d1a + d1b, dot_u, dot_uw);
@@ -261,13 +283,23 @@ gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ X
 
         // u += w*X_t - q*Xq_t  (:119)
         const float q32 = (float)dec.q;
-        if (q32 == 0.0f) {
+        if constexpr (PREFETCH) {
+            if (q32 == 0.0f) {
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) u[e] += (double)__fmul_rn(w, x[e]);
+                for (int e = 0; e < EPL; ++e) u[e] += (double)__fmul_rn(w, x[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e)
+                    u[e] += (double)__fsub_rn(__fmul_rn(w, x[e]), __fmul_rn(q32, xq[e]));
+            }
         } else {
 #pragma unroll
-            for (int e = 0; e < EPL; ++e)
-                u[e] += (double)__fsub_rn(__fmul_rn(w, x[e]), __fmul_rn(q32, xq[e]));
+            for (int c = 0; c < EPL / 4; ++c) {
+                wide_fetch<4>(X, Xq, ld, t, base + 256 * c, lane, m, aligned != 0, x, xq);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)        // q = 0: f32(q*xq) = +-0 and p - (+-0) = p, the same sum
+                    u[4 * c + k] += (double)__fsub_rn(__fmul_rn(w, x[k]), __fmul_rn(q32, xq[k]));
+            }
         }
 
         if (lane == (int)(t & 63)) { my_idx = dec.idx; my_q = q32; }
@@ -317,8 +349,8 @@ static hipError_t launch_wide_epl(const OnchipArgs &a, int W, hipStream_t stream
         // neurons of a workgroup at every shape measured (tools/narrow_quick.py), the rows come from L2 anyway
         const bool aligned = (a.ld % 4 == 0) && (a.m % 4 == 0) && ((uintptr_t)a.X % 16 == 0) && ((uintptr_t)a.Xq % 16 == 0);
         if (aligned && !(a.variant & 2) && (EPL < 16 || W <= 8)) {
-            hipLaunchKernelGGL((gpfq_wide_direct_kernel<EPL>), dim3((unsigned)a.C), dim3(64 * W), 0, stream,
-                               a.X, a.Xq, a.ld, a.nrm32, a.Wt, a.ldw, a.A, a.N, (int)a.m, a.C, W,
+            hipLaunchKernelGGL((gpfq_wide_direct_kernel<EPL, true>), dim3((unsigned)a.C), dim3(64 * W), 0, stream,
+                               a.X, a.Xq, a.ld, a.nrm32, a.Wt, a.ldw, a.A, a.N, (int)a.m, a.C, W, 1,
                                a.qidx, a.Qt, a.resid, a.u_out);
             return hipGetLastError();
         }
@@ -348,6 +380,18 @@ hipError_t launch_wide(const OnchipArgs &a, int W, hipStream_t stream)
     if (per_lane <= 4)  return launch_wide_epl<4>(a, W, stream);
     if (per_lane <= 8)  return launch_wide_epl<8>(a, W, stream);
     if (per_lane <= 16) return launch_wide_epl<16>(a, W, stream);
+    if (W == 16 && per_lane <= 28) {                      // long rows: 16 wavefronts, rows read at the top of each step
+        const int aligned = (a.ld % 4 == 0) && (a.m % 4 == 0) && ((uintptr_t)a.X % 16 == 0) && ((uintptr_t)a.Xq % 16 == 0);
+#define GPFQ_LONG(EPL_)                                                                                                   \
+        hipLaunchKernelGGL((gpfq_wide_direct_kernel<EPL_, false>), dim3((unsigned)a.C), dim3(1024), 0, stream,            \
+                           a.X, a.Xq, a.ld, a.nrm32, a.Wt, a.ldw, a.A, a.N, (int)a.m, a.C, 16, aligned,                   \
+                           a.qidx, a.Qt, a.resid, a.u_out)
+        if (per_lane <= 20) GPFQ_LONG(20);
+        else if (per_lane <= 24) GPFQ_LONG(24);
+        else GPFQ_LONG(28);
+#undef GPFQ_LONG
+        return hipGetLastError();
+    }
     return hipErrorInvalidValue;
 }
 

@@ -13,9 +13,10 @@ from . import build as _build
 
 GPFQ_PATH_AUTO, GPFQ_PATH_ONCHIP, GPFQ_PATH_STREAM = 0, 1, 2
 GPFQ_PATH_GRAM = 3                 # binding-level selector: gpfq_quantize_neurons_gram + exact rerun of flagged neurons
-GPFQ_GRAM_AUTO_MAX_N = 64          # AUTO takes the Gram path for walks this short over rows longer than GPFQ_ONCHIP_MAX_M
+GPFQ_GRAM_AUTO_MAX_N = 64          # AUTO takes the Gram path for walks this short over rows longer than GPFQ_GRAM_MIN_M
 GPFQ_MAX_ALPHABET = 64
-GPFQ_ONCHIP_MAX_M = 16384
+GPFQ_ONCHIP_MAX_M = 28672          # longest row whose residual stays in registers (include/gpfq.h)
+GPFQ_GRAM_MIN_M = 16384
 
 # every symbol include/gpfq.h declares: (restype, argtypes)
 _i64, _int, _vp, _sz = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
@@ -136,7 +137,7 @@ def quantize_neurons(X, Xq, Wt, alphabet, nrm32=None, want_u=False, path=GPFQ_PA
         raise GpfqError("X and Xq must share one row pitch")
     arr, M, zero_idx = _alphabet(alphabet)
     dev = X.device
-    if path == GPFQ_PATH_GRAM or (path == GPFQ_PATH_AUTO and not want_u and m > GPFQ_ONCHIP_MAX_M
+    if path == GPFQ_PATH_GRAM or (path == GPFQ_PATH_AUTO and not want_u and m > GPFQ_GRAM_MIN_M
                                   and N <= GPFQ_GRAM_AUTO_MAX_N):
         return _quantize_neurons_gram(X, Xq, Wt, alphabet, nrm32, want_values)
     if nrm32 is None:

@@ -343,7 +343,7 @@ def test_conv_layer_gram_fast_path(oracle_mod, slack):
     W = (r.standard_normal((3, 3, 2, 3)) / 3).astype(np.float32)
     Wd = torch.from_numpy(W).cuda()
     alphabet, _ = layer.layer_alphabet(Wd, np.linspace(-1, 1, 8), 4)
-    assert 36 * 24 * 24 > hip.GPFQ_ONCHIP_MAX_M
+    assert 36 * 24 * 24 > hip.GPFQ_GRAM_MIN_M
     try:
         hip.set_option("gram_slack_log2", slack)
         out = layer.quantize_conv2d(Wd, torch.from_numpy(act_w).cuda(), torch.from_numpy(act_q).cuda(), alphabet,
@@ -397,7 +397,7 @@ def test_conv_fused_3x3(oracle_mod, n, H, W, Cin, F, padding, strip, first):
     for c in range(Cin):
         Pw = ref_patches(act_w, c, 3, 3, 1, 1, 1, 1, padding)
         Pq = ref_patches(act_q, c, 3, 3, 1, 1, 1, 1, padding)
-        assert Pw.shape[1] > hip.GPFQ_ONCHIP_MAX_M
+        assert Pw.shape[1] > hip.GPFQ_GRAM_MIN_M
         for f in range(F):
             qo, _, _ = oracle_mod.neuron(Wk[:, :, c, f].reshape(-1), Pw, Pq, alphabet)
             assert np.array_equal(Q[:, :, c, f].reshape(-1), qo.astype(np.float32)), (c, f)
@@ -457,7 +457,7 @@ def test_conv_implicit_im2col(oracle_mod, n, H, W, Cin, F, kh, kw, stride, rate,
     for c in range(Cin):
         Pw = ref_patches(act_w, c, kh, kw, stride, stride, rate, rate, padding)
         Pq = ref_patches(act_q, c, kh, kw, stride, stride, rate, rate, padding)
-        assert Pw.shape[1] > hip.GPFQ_ONCHIP_MAX_M
+        assert Pw.shape[1] > hip.GPFQ_GRAM_MIN_M
         for f in range(F):
             qo, _, _ = oracle_mod.neuron(Wk[:, :, c, f].reshape(-1), Pw, Pq, alphabet)
             assert np.array_equal(Q[:, :, c, f].reshape(-1), qo.astype(np.float32)), (c, f)
