@@ -112,7 +112,8 @@ __device__ __forceinline__ void update_residual(double (&u)[EPL], float w, float
 // XQD: additionally stage Xq converted to float64 (conversion done once per workgroup instead of
 // once per neuron) for the dot product; the f32 copy stays for the update of non-zero decisions.
 template <int LPN, int EPL, bool XQD>
-__global__ void __launch_bounds__(LPN * 16)     // (4 waves per SIMD at <= 128 VGPRs measured slower: 6.1 vs 5.4 ms)
+__global__ void __launch_bounds__(LPN * 16)     // (4 waves per SIMD at <= 128 VGPRs measured slower: 6.1 vs 5.4 ms;
+                                                // 16 lanes per neuron with 32 neurons per workgroup, 2 waves per SIMD: 8.9 ms)
 gpfq_rows_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld,
                  const float *__restrict__ nrm32, const RowStats *__restrict__ stats,
                  const float *__restrict__ Wt, int64_t ldw,
