@@ -99,7 +99,7 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i_timed=None):
-        alphabet, _ = layer.layer_alphabet(Wd, unit_alphabet, args.alphabet_scalar)
+        alphabet, _ = layer.layer_alphabet(Wd, unit_alphabet, args.alphabet_scalar, group)   # N > 1: counting sharded over ranks
         lo, hi = layer.shard_bounds(C_total, world, rank)
         Wt = Wd[:, lo:hi].t().contiguous()
         nrm = hip.row_norms(Xqd)

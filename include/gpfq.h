@@ -184,6 +184,20 @@ int gpfq_median_abs(const float *W, int64_t n, float *median_out, void *workspac
                     void *stream);
 
 /*
+ * The same median with the counting sharded over ranks (every rank holds the layer's n_total weights and counts
+ * its own slice; multi-GPU runs would otherwise repeat the whole select on every GPU).  Protocol, identical on
+ * all ranks:  begin;  for pass = 0, 1, 2: { count(slice, pass);  sum the GPFQ_MEDIAN_HIST_WORDS 32-bit counters
+ * at workspace + GPFQ_MEDIAN_HIST_OFFSET over the ranks (one all-reduce);  pick(pass) };  end -> median_out.
+ * Slices must partition the n_total elements (start them on multiples of 4 elements for the 16-byte loads).
+ */
+#define GPFQ_MEDIAN_HIST_OFFSET 64
+#define GPFQ_MEDIAN_HIST_WORDS  4096
+int gpfq_median_abs_begin(int64_t n_total, void *workspace, size_t workspace_bytes, void *stream);
+int gpfq_median_abs_count(const float *W_local, int64_t n_local, int64_t n_total, int pass, void *workspace, void *stream);
+int gpfq_median_abs_pick(int64_t n_total, int pass, void *workspace, void *stream);
+int gpfq_median_abs_end(int64_t n_total, void *workspace, float *median_out, void *stream);
+
+/*
  * Per-channel im2col: the patch matrices of ONE input channel for the analog and quantized
  * activations, transposed to feature-major [kh*kw][n*oh*ow].  Replaces _build_patch_array
  * (scripts/quantized_network.py:729-809) + _segment_data2D (:123-183), i.e.

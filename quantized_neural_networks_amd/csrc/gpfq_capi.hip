@@ -298,6 +298,44 @@ int gpfq_median_abs(const float *W, int64_t n, float *median_out, void *workspac
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_median_abs");
 }
 
+static int median_ws_ok(void *workspace, size_t workspace_bytes)
+{
+    if (!workspace || workspace_bytes < gpfq::median_workspace_bytes() || (uintptr_t)workspace % 16 != 0)
+        return fail(GPFQ_ERR_WORKSPACE, "median needs %zu aligned workspace bytes", gpfq::median_workspace_bytes());
+    return GPFQ_OK;
+}
+
+int gpfq_median_abs_begin(int64_t n_total, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (n_total <= 0) return fail(GPFQ_ERR_INVALID_ARG, "median of %lld elements", (long long)n_total);
+    int rc = median_ws_ok(workspace, workspace_bytes);
+    if (rc != GPFQ_OK) return rc;
+    hipError_t e = gpfq::launch_median_begin(n_total, workspace, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_median_abs_begin");
+}
+
+int gpfq_median_abs_count(const float *W_local, int64_t n_local, int64_t n_total, int pass, void *workspace, void *stream)
+{
+    if (n_local < 0 || n_total <= 0 || n_local > n_total || pass < 0 || pass > 2) return fail(GPFQ_ERR_INVALID_ARG, "bad slice/pass");
+    if ((n_local > 0 && !W_local) || !workspace) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    hipError_t e = gpfq::launch_median_count(W_local, n_local, n_total, pass, workspace, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_median_abs_count");
+}
+
+int gpfq_median_abs_pick(int64_t n_total, int pass, void *workspace, void *stream)
+{
+    if (n_total <= 0 || pass < 0 || pass > 2 || !workspace) return fail(GPFQ_ERR_INVALID_ARG, "bad pass / NULL workspace");
+    hipError_t e = gpfq::launch_median_pick(n_total, pass, workspace, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_median_abs_pick");
+}
+
+int gpfq_median_abs_end(int64_t n_total, void *workspace, float *median_out, void *stream)
+{
+    if (n_total <= 0 || !workspace || !median_out) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    hipError_t e = gpfq::launch_median_end(n_total, workspace, median_out, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_median_abs_end");
+}
+
 int64_t gpfq_patch_out_dim(int64_t in, int64_t k, int64_t stride, int64_t rate, int same_padding)
 {
     if (in <= 0 || k <= 0 || stride <= 0 || rate <= 0) return 0;

@@ -162,6 +162,16 @@ __device__ __forceinline__ Decision decide(float w, float nrm, double dot_u, dou
     return r;
 }
 
+// ---- "has this channel a negative activation?" ----------------------------------------------------
+// Running maximum of the raw bit patterns: every negative non-zero float is above 0x80000000 (= -0.0,
+// which counts as non-negative here), every non-negative one below.
+__device__ __forceinline__ void neg_track(unsigned &acc, float v) { acc = max(acc, __float_as_uint(v)); }
+__device__ __forceinline__ void neg_track(unsigned &acc, const float4 &v)
+{
+    acc = max(max(acc, max(__float_as_uint(v.x), __float_as_uint(v.y))), max(__float_as_uint(v.z), __float_as_uint(v.w)));
+}
+__device__ __forceinline__ bool neg_seen(unsigned acc) { return acc > 0x80000000u; }
+
 // ---- Gram accumulators of the 3x3 conv case (gpfq_gram.hip, gpfq_gram_image.hip) -----------------
 // One column (sample) of the 9 patch rows: q[t] = Xq_t, x[s] = X_s in float64 (products of two float32
 // values are exact in float64).  Only what the decide step reads: the lower triangle s <= t of

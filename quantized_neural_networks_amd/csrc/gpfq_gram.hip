@@ -39,7 +39,7 @@ gpfq_gram_tile_kernel(const float *__restrict__ X, const float *__restrict__ Xq,
                       int64_t nchunks, double *__restrict__ part, int *__restrict__ negflag)
 {
     using Tile = GramTile<TB, SB>;
-    unsigned signs = 0;                                  // OR of the sign bits of everything this thread staged
+    unsigned signs = 0;                                  // neg_track() of everything this thread staged
     constexpr int R = Tile::R, J = Tile::J;
     __shared__ __attribute__((aligned(16))) float lrow[R][kGramCH];
     int ty, sz;
@@ -84,13 +84,13 @@ gpfq_gram_tile_kernel(const float *__restrict__ X, const float *__restrict__ Xq,
                     }
                 }
                 *reinterpret_cast<float4 *>(&lrow[r][4 * lane]) = v;
-                signs |= __float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z) | __float_as_uint(v.w);
+                neg_track(signs, v);
             }
         }
         __syncthreads();
         tile.accumulate(lrow, wave, lane, norms);
     }
-    if (__ballot(signs >> 31) && lane == 0) atomicOr(negflag, 1);          // a negative element was seen
+    if (__ballot(neg_seen(signs)) && lane == 0) atomicOr(negflag, 1);      // a negative element was seen
     tile.store(part + (int64_t)blockIdx.x * gram_record(N), N, t0, s0, wave, lane, norms);
 }
 
@@ -119,7 +119,8 @@ gpfq_gram_rows9_kernel(const float *__restrict__ X, const float *__restrict__ Xq
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             x[s] = (double)xf[s]; q[s] = (double)qf[s];
-            signs |= __float_as_uint(xf[s]) | __float_as_uint(qf[s]);
+            neg_track(signs, xf[s]);
+            neg_track(signs, qf[s]);
         }
         i += stride;
 #pragma unroll
@@ -129,7 +130,7 @@ gpfq_gram_rows9_kernel(const float *__restrict__ X, const float *__restrict__ Xq
         }
         gram9_add(acc, q, x);
     }
-    if (__ballot(signs >> 31) && lane == 0) atomicOr(negflag, 1);          // a negative element was seen
+    if (__ballot(neg_seen(signs)) && lane == 0) atomicOr(negflag, 1);      // a negative element was seen
     double *out = part + ((int64_t)blockIdx.x * 4 + wave) * gram_record(N);
 #pragma unroll
     for (int t = 0; t < 9; ++t)

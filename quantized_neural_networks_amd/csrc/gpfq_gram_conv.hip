@@ -126,7 +126,7 @@ gpfq_gram_conv_kernel(ConvParams p)
                 for (int e = 0; e < 4; ++e) {
                     const float val = (vmask >> (4 * j + e)) & 1u ? v[j][e] : 0.f;
                     lrow[r][lane + 64 * e] = val;
-                    signs |= __float_as_uint(val);
+                    neg_track(signs, val);
                 }
             }
         }
@@ -136,7 +136,7 @@ gpfq_gram_conv_kernel(ConvParams p)
         if (ch + nwalk < p.nchunks) gather();              // in flight during the FMAs below
         tile.accumulate(lrow, wave, lane, norms);
     }
-    if (__ballot(signs >> 31) && lane == 0) atomicOr(p.negflag + blockIdx.z, 1);   // a negative activation was seen
+    if (__ballot(neg_seen(signs)) && lane == 0) atomicOr(p.negflag + blockIdx.z, 1);   // a negative activation was seen
     tile.store(p.part + ((int64_t)blockIdx.z * p.nparts + walker) * gram_record(p.K), p.K, t0, s0, wave, lane, norms);
 }
 

@@ -90,7 +90,7 @@ __device__ __forceinline__ void image_gram_body(const ImgParams &p, float *lds)
     const int st_step = kImgThreads >> p.lpr_log2;
     const int st_ix = 4 * st_c4 - p.pad;
     const bool st_inside = st_ix >= 0 && st_ix + 3 < p.W;
-    unsigned signs = 0;                                  // OR of the sign bits of everything this thread staged
+    unsigned signs = 0;                                  // neg_track() of everything this thread staged
 
     for (int band = blockIdx.x; band < p.nbands; band += gridDim.x) {
         const int g0 = band * p.RB;
@@ -127,8 +127,8 @@ __device__ __forceinline__ void image_gram_body(const ImgParams &p, float *lds)
                 }
                 *reinterpret_cast<float4 *>(lw + row * p.LP + 4 * st_c4) = a;
                 if (!p.same_act) *reinterpret_cast<float4 *>(lq + row * p.LP + 4 * st_c4) = c;
-                signs |= __float_as_uint(a.x) | __float_as_uint(a.y) | __float_as_uint(a.z) | __float_as_uint(a.w)
-                       | __float_as_uint(c.x) | __float_as_uint(c.y) | __float_as_uint(c.z) | __float_as_uint(c.w);
+                neg_track(signs, a);
+                neg_track(signs, c);
                 r += st_step;
                 while (r >= p.PH) { r -= p.PH; ++b; }
             }
@@ -169,7 +169,7 @@ __device__ __forceinline__ void image_gram_body(const ImgParams &p, float *lds)
             }
         }
     }
-    if (__ballot(signs >> 31) && lane == 0) atomicOr(p.negflag + blockIdx.y, 1);   // a negative activation was seen
+    if (__ballot(neg_seen(signs)) && lane == 0) atomicOr(p.negflag + blockIdx.y, 1);   // a negative activation was seen
     // the two wavefronts of a pair fill disjoint columns of one record
     double *out = p.part + (((int64_t)blockIdx.y * p.nbx + blockIdx.x) * 2 + pair) * kRec9;
 #pragma unroll

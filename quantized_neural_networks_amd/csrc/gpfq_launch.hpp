@@ -163,6 +163,10 @@ hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, 
 hipError_t launch_pack(const int8_t *qidx, int64_t N, int64_t C, int bits, uint8_t *packed, hipStream_t stream);
 size_t median_workspace_bytes();
 hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream);
+hipError_t launch_median_begin(int64_t n_total, void *workspace, hipStream_t stream);
+hipError_t launch_median_count(const float *W_local, int64_t n_local, int64_t n_total, int pass, void *workspace, hipStream_t stream);
+hipError_t launch_median_pick(int64_t n_total, int pass, void *workspace, hipStream_t stream);
+hipError_t launch_median_end(int64_t n_total, void *workspace, float *out, hipStream_t stream);
 hipError_t launch_channel_planes(const float *act, int64_t npos, int64_t Cin, int64_t c_lo, int64_t nch, float *planes,
                                  hipStream_t stream);
 hipError_t launch_extract_patches(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t c,

@@ -407,4 +407,51 @@ hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *worksp
     return hipGetLastError();
 }
 
+// The same select with the elements partitioned over ranks (every rank holds the whole layer, each counts
+// one slice): per pass the ranks histogram their slices for both order statistics, the caller sums the two
+// histograms over the ranks (8 KiB each, one all-reduce), and every rank picks the same bins.
+hipError_t launch_median_begin(int64_t n_total, void *workspace, hipStream_t stream)
+{
+    SelState *st = static_cast<SelState *>(workspace);
+    unsigned *hist = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + 64);
+    hipError_t e = hipMemsetAsync(hist, 0, 2 * kSelBins * sizeof(unsigned), stream);
+    if (e != hipSuccess) return e;
+    const bool even = (n_total % 2) == 0;
+    const unsigned long long k0 = even ? (unsigned long long)(n_total / 2 - 1) : (unsigned long long)(n_total / 2);
+    hipLaunchKernelGGL(gpfq_select_init_kernel, dim3(1), dim3(1), 0, stream, st, k0, (unsigned long long)(n_total / 2));
+    return hipGetLastError();
+}
+
+static const int kSelShifts[3] = {21, 10, 0}, kSelWidths[3] = {11, 11, 10};
+
+hipError_t launch_median_count(const float *W_local, int64_t n_local, int64_t n_total, int pass, void *workspace, hipStream_t stream)
+{
+    SelState *st = static_cast<SelState *>(workspace);
+    unsigned *hist = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + 64);
+    if (n_local <= 0) return hipSuccess;
+    int64_t blocks = (n_local + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 1024) blocks = 1024;
+    for (int sel = 0; sel < ((n_total % 2) == 0 ? 2 : 1); ++sel)
+        hipLaunchKernelGGL(gpfq_select_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                           W_local, n_local, st + sel, kSelShifts[pass], kSelWidths[pass], hist + sel * kSelBins);
+    return hipGetLastError();
+}
+
+hipError_t launch_median_pick(int64_t n_total, int pass, void *workspace, hipStream_t stream)
+{
+    SelState *st = static_cast<SelState *>(workspace);
+    unsigned *hist = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + 64);
+    for (int sel = 0; sel < ((n_total % 2) == 0 ? 2 : 1); ++sel)
+        hipLaunchKernelGGL(gpfq_select_pick_kernel, dim3(1), dim3(256), 0, stream,
+                           hist + sel * kSelBins, st + sel, kSelShifts[pass], kSelWidths[pass], static_cast<SelState *>(nullptr));
+    return hipGetLastError();
+}
+
+hipError_t launch_median_end(int64_t n_total, void *workspace, float *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(gpfq_select_finish_kernel, dim3(1), dim3(1), 0, stream, static_cast<SelState *>(workspace),
+                       (n_total % 2) == 0 ? 1 : 0, out);
+    return hipGetLastError();
+}
+
 }  // namespace gpfq

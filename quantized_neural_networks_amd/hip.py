@@ -43,6 +43,10 @@ SYMBOLS = {
     "gpfq_assemble_kernel": (_int, [_vp, _int, _dp, _int, _i64, _i64, _vp, _vp, _vp]),
     "gpfq_median_abs_workspace_bytes": (_sz, []),
     "gpfq_median_abs": (_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    "gpfq_median_abs_begin": (_int, [_i64, _vp, _sz, _vp]),
+    "gpfq_median_abs_count": (_int, [_vp, _i64, _i64, _int, _vp, _vp]),
+    "gpfq_median_abs_pick": (_int, [_i64, _int, _vp, _vp]),
+    "gpfq_median_abs_end": (_int, [_i64, _vp, _vp, _vp]),
     "gpfq_patch_out_dim": (_i64, [_i64, _i64, _i64, _i64, _int]),
     "gpfq_extract_patches": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int,
                                     _vp, _i64, _vp]),
@@ -347,6 +351,31 @@ def median_abs(W):
     with torch.cuda.device(W.device):
         _check(lib.gpfq_median_abs(Wc.data_ptr(), Wc.numel(), out.data_ptr(), ws.data_ptr(), nbytes, _stream()),
                "gpfq_median_abs")
+    return np.float32(out.item())
+
+
+GPFQ_MEDIAN_HIST_OFFSET, GPFQ_MEDIAN_HIST_WORDS = 64, 4096
+
+
+def median_abs_sharded(W_local, n_total, all_reduce_sum):
+    """The same median when every rank counts one slice of the layer's n_total weights (W_local: this rank's
+    contiguous float32 slice; slices partition the flattened kernel).  `all_reduce_sum(t)` must sum the int32
+    tensor t in place over the ranks (dist.all_reduce): three 16 KiB all-reduces per median."""
+    import numpy as np
+    _dev(W_local, torch.float32, "W_local")
+    Wc = W_local.contiguous()
+    lib = load()
+    nbytes = lib.gpfq_median_abs_workspace_bytes()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=W_local.device)
+    hist = ws[GPFQ_MEDIAN_HIST_OFFSET:GPFQ_MEDIAN_HIST_OFFSET + 4 * GPFQ_MEDIAN_HIST_WORDS].view(torch.int32)
+    out = torch.empty(1, dtype=torch.float32, device=W_local.device)
+    with torch.cuda.device(W_local.device):
+        _check(lib.gpfq_median_abs_begin(n_total, ws.data_ptr(), nbytes, _stream()), "gpfq_median_abs_begin")
+        for p in range(3):
+            _check(lib.gpfq_median_abs_count(Wc.data_ptr(), Wc.numel(), n_total, p, ws.data_ptr(), _stream()), "gpfq_median_abs_count")
+            all_reduce_sum(hist)
+            _check(lib.gpfq_median_abs_pick(n_total, p, ws.data_ptr(), _stream()), "gpfq_median_abs_pick")
+        _check(lib.gpfq_median_abs_end(n_total, ws.data_ptr(), out.data_ptr(), _stream()), "gpfq_median_abs_end")
     return np.float32(out.item())
 
 

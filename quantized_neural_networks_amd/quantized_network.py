@@ -284,7 +284,7 @@ class QuantizedNeuralNetwork:
             self.quantized_net.layers[layer_idx].set_weights([Q])
 
     def _layer_alphabet(self, Wd):
-        return _layer.layer_alphabet(Wd, self.alphabet, self.alphabet_scalar)      # (:544-545)
+        return _layer.layer_alphabet(Wd, self.alphabet, self.alphabet_scalar, self.process_group)   # (:544-545)
 
     # -- Dense layer (reference :523-574) ---------------------------------------------------
     def _quantize_layer_parallel(self, layer_idx):
