@@ -130,9 +130,11 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
  * m = n_img*oh*ow columns, _quantize_filter2D_parallel_jit, scripts/quantized_network.py:185-233), done on
  * N x N Gram matrices of the rows instead of on the rows: the patch data are read once per call instead of
  * once per neuron and step.  Every decision is certified against a rigorous bound on the float32 roundings
- * the Gram formulation skips; neurons whose chain cannot be certified (about 1 in 10^5) are flagged in
- * `uncertified` and MUST be rerun by the caller through gpfq_quantize_neurons -- the outputs of flagged
- * neurons are undefined, those of unflagged neurons equal the exact flow's.
+ * the Gram formulation skips; chains that stop at an uncertifiable step (about 1 in 10^4) are repaired on the
+ * device from the exact element-wise dot products of that step (two rounds, up to 16 chains each); whatever is
+ * still open afterwards (practically nothing) is flagged non-zero in `uncertified` and MUST be rerun by the
+ * caller through gpfq_quantize_neurons -- the outputs of flagged neurons are undefined, those of unflagged
+ * neurons equal the exact flow's.
  *   N <= GPFQ_GRAM_MAX_N, m < 2^30.  Arguments as gpfq_quantize_neurons; uncertified [device] i32 [C].
  *   resid (optional) is produced by an exact element-wise replay of the residual with the chosen q.
  *   compute_norms != 0: nrm32 is an OUTPUT, filled with (float)sqrt(<Xq_t,Xq_t>) from the Gram diagonal (the
