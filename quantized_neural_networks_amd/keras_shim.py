@@ -192,14 +192,18 @@ class Conv2D(Layer):
         return self._weights[0].permute(3, 2, 0, 1), 1                      # OIHW, groups
 
     def call(self, x):
-        x = x.permute(0, 3, 1, 2)                                           # NHWC -> NCHW
+        x = x.permute(0, 3, 1, 2)                                           # NHWC -> NCHW (a channels-last view)
+        pad = (0, 0)
         if self.padding.lower() == "same":
             pt, pb = _same_pads(x.shape[2], self.kernel_size[0], self.strides[0], self.dilation_rate[0])
             pl, pr = _same_pads(x.shape[3], self.kernel_size[1], self.strides[1], self.dilation_rate[1])
-            x = F.pad(x, (pl, pr, pt, pb))
+            if pt == pb and pl == pr:
+                pad = (pt, pl)                                              # symmetric: the conv pads, no padded copy
+            else:
+                x = F.pad(x, (pl, pr, pt, pb))
         w, groups = self._torch_weight()
         y = F.conv2d(x, w.contiguous(), self._weights[1] if self.use_bias else None, stride=self.strides,
-                     dilation=self.dilation_rate, groups=groups)
+                     padding=pad, dilation=self.dilation_rate, groups=groups)
         return _activation(self.activation)(y.permute(0, 2, 3, 1).contiguous())
 
 
