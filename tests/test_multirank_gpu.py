@@ -1,0 +1,84 @@
+"""GPU, several ranks on ONE device (gloo carries the collectives through host memory): the real HIP path
+under sharding -- neurons of a Dense layer, input channels of a conv layer (3x3 from planes, 5x5 implicit
+im2col), filters when there are fewer channels than ranks, index packing for the all-gather, the median of the
+alphabet radius with its counting sharded over the ranks -- reassembles the single-process result bit for bit.
+(The multi-GPU runs use the same code with backend nccl = RCCL; only the transport differs.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _inputs(case, dev):
+    g = torch.Generator(device=dev).manual_seed(11)
+    if case == "dense":
+        N, m, C = 300, 1024, 70                                  # 70 neurons: uneven shards
+        W = torch.randn((N, C), device=dev, generator=g) / np.sqrt(N)
+        G = torch.randn((N, m), device=dev, generator=g)
+        return dict(W=W, X=torch.relu(G), Xq=torch.relu(G + 0.1 * torch.randn((N, m), device=dev, generator=g)), bits=2)
+    if case == "dense_big_median":
+        N, m, C = 2100, 256, 2048                                # 4.3 M weights: the sharded median path
+        W = torch.randn((N, C), device=dev, generator=g) / np.sqrt(N)
+        G = torch.randn((N, m), device=dev, generator=g)
+        return dict(W=W[:, :], X=torch.relu(G), Xq=torch.relu(G + 0.1 * torch.randn((N, m), device=dev, generator=g)), bits=np.log2(3),
+                    neurons=64)
+    cin, k = {"conv3x3": (5, 3), "conv5x5": (4, 5), "conv_filters": (1, 3)}[case]
+    act_w = torch.rand((40, 24, 24, cin), device=dev, generator=g)
+    act_q = torch.relu(act_w + 0.05 * torch.randn(act_w.shape, device=dev, generator=g))
+    W = torch.randn((k, k, cin, 6), device=dev, generator=g) / k
+    return dict(W=W, act_w=act_w, act_q=act_q, bits=3)
+
+
+def _run(case, dev, group):
+    from quantized_neural_networks_amd import layer
+    d = _inputs(case, dev)
+    unit = np.linspace(-1, 1, int(round(2 ** d["bits"])))
+    alphabet, rad = layer.layer_alphabet(d["W"], unit, 3, group)
+    if case.startswith("dense"):
+        W = d["W"][:, :d["neurons"]].contiguous() if "neurons" in d else d["W"]
+        out = layer.quantize_dense(W, d["X"], d["Xq"], alphabet, group=group)
+    else:
+        out = layer.quantize_conv2d(d["W"], d["act_w"], d["act_q"], alphabet, strides=(1, 1), padding="SAME", rate=(1, 1),
+                                    group=group, want_resid=False)
+    res = {k: v.cpu().numpy() for k, v in out.items() if isinstance(v, torch.Tensor) and k != "reruns"}
+    res["rad"] = np.float64(rad)
+    return res
+
+
+def _worker(rank, world, port, case, result_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = _run(case, torch.device("cuda", 0), dist.group.WORLD)
+    np.savez(os.path.join(result_dir, f"{case}_{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,world", [("dense", 2), ("dense", 3), ("dense_big_median", 2), ("conv3x3", 2), ("conv5x5", 3),
+                                        ("conv_filters", 2)])
+def test_ranks_sharing_one_gpu(case, world, tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(tmp_path / f"{case}_{r}.npz") for r in range(world)]
+    single = _run(case, torch.device("cuda", 0), None)
+    for k, v in single.items():
+        if k == "resid" and not case.startswith("dense"):
+            continue                                             # NaN placeholders when residual norms are not requested
+        for r in range(world):
+            assert np.array_equal(res[r][k], v), (k, r)
