@@ -183,10 +183,12 @@ gpfq_wide_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int6
 // the rows X_t, Xq_t straight into registers, one step ahead of their use, so no staging sits on the
 // step-to-step critical path; the only LDS traffic is the W pairs of partial dot products per step.
 //
-// PREFETCH = false is the long-row form (16384 < m <= 28672: 20..28 elements per lane of 16 wavefronts, the
-// most a 1024-thread workgroup's 128 VGPRs per lane hold): the rows are read at the top of their own step --
-// their latency is exposed, but u still never leaves the chip (the alternative streams it through HBM with
-// two launches per step); `aligned` = 0 reads element-wise (any pitch, any m).
+// PREFETCH = false is the long-row form (16384 < m <= 28672: 36..56 elements per lane of 8 wavefronts, 256 VGPRs
+// each): the Xq slice is requested whole at the top of its step and kept; the X slice streams through a ring of
+// four 4-element pieces, requested four pieces ahead of their use, once for the dot products and once more (from
+// L2) for the update; u never leaves the chip (the alternative streams it through HBM with two launches per
+// step).  `aligned` = 0 reads element-wise (any pitch, any m).  (Holding both slices, or 4 wavefronts of 512
+// registers, spills: only 256 registers are directly addressable.)
 template <int EPL>
 __device__ __forceinline__ void wide_fetch(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t t,
                                            int base, int lane, int m, bool aligned, float (&x)[EPL], float (&xq)[EPL])
@@ -213,8 +215,29 @@ __device__ __forceinline__ void wide_fetch(const float *__restrict__ X, const fl
     }
 }
 
+template <int EPL>
+__device__ __forceinline__ void wide_fetch1(const float *__restrict__ P, int64_t ld, int64_t t, int base, int lane, int m,
+                                            bool aligned, float (&v)[EPL])
+{
+#pragma unroll
+    for (int c = 0; c < EPL / 4; ++c) {
+        const int i = base + 256 * c + 4 * lane;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (aligned) {
+            if (i < m) a = *reinterpret_cast<const float4 *>(P + t * ld + i);
+        } else {
+            const float *p = P + t * ld + i;
+            if (i < m)     a.x = p[0];
+            if (i + 1 < m) a.y = p[1];
+            if (i + 2 < m) a.z = p[2];
+            if (i + 3 < m) a.w = p[3];
+        }
+        v[4 * c] = a.x; v[4 * c + 1] = a.y; v[4 * c + 2] = a.z; v[4 * c + 3] = a.w;
+    }
+}
+
 template <int EPL, bool PREFETCH>
-__global__ void __launch_bounds__((PREFETCH && EPL >= 16) ? 512 : 1024)   // 16 elements per lane + their prefetch need > 128 VGPRs
+__global__ void __launch_bounds__((!PREFETCH || EPL >= 16) ? 512 : 1024)  // 16+ elements per lane need > 128 VGPRs
 gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld,
                         const float *__restrict__ nrm32, const float *__restrict__ Wt, int64_t ldw,
                         AlphabetArg A, int64_t N, int m, int64_t C, int W, int aligned,
@@ -245,12 +268,19 @@ gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ X
     }
     for (int64_t t = 0; t < N; ++t) {
         const float w = w_next, nrm = nrm_next;
-        // PREFETCH: the step's row slices are already in registers.  Long-row form: they are read 4 elements at a
-        // time where they are used, here and again (from L2) in the update -- no register holds them in between.
-        float x[PREFETCH ? EPL : 4], xq[PREFETCH ? EPL : 4];
+        // PREFETCH: the step's row slices are already in registers.  Long-row form: the Xq slice is requested whole
+        // at the top of the step and kept for both sweeps; the X slice streams through a ring of kRing 4-element
+        // pieces, requested kRing pieces ahead of their use, once per sweep (the second time from L2).
+        constexpr int NCH = EPL / 4, kRing = NCH < 4 ? NCH : 4;
+        float x[PREFETCH ? EPL : 4 * kRing], xq[EPL];
         if constexpr (PREFETCH) {
 #pragma unroll
             for (int e = 0; e < EPL; ++e) { x[e] = xn[e]; xq[e] = xqn[e]; }
+        } else {
+            wide_fetch1<EPL>(Xq, ld, t, base, lane, m, aligned != 0, xq);
+#pragma unroll
+            for (int c = 0; c < kRing; ++c)
+                wide_fetch1<4>(X, ld, t, base + 256 * c, lane, m, aligned != 0, *reinterpret_cast<float (*)[4]>(&x[4 * c]));
         }
         if (t + 1 < N) {
             w_next = wrow[t + 1]; nrm_next = nrm32[t + 1];
@@ -259,17 +289,32 @@ gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ X
         // this wave's share of <Xq_t, u> (:86) and <Xq_t, u + f32(w*X_t)> (:89)
         double d0a = 0.0, d0b = 0.0, d1a = 0.0, d1b = 0.0;
 #pragma unroll
-        for (int c = 0; c < EPL / 4; ++c) {
-            if constexpr (!PREFETCH) wide_fetch<4>(X, Xq, ld, t, base + 256 * c, lane, m, aligned != 0, x, xq);
+        for (int c = 0; c < NCH; ++c) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int e = 4 * c + k, r = PREFETCH ? e : k;
+                const int e = 4 * c + k, r = PREFETCH ? e : 4 * (c % kRing) + k;
                 const float p = __fmul_rn(w, x[r]);
-                const double xd = (double)xq[r];
+                const double xd = (double)xq[e];
                 const double v  = u[e] + (double)p;
                 if (e & 1) { d0b = fma(xd, u[e], d0b); d1b = fma(xd, v, d1b); }
                 else       { d0a = fma(xd, u[e], d0a); d1a = fma(xd, v, d1a); }
             }
+            if constexpr (!PREFETCH) {
+                __builtin_amdgcn_sched_barrier(0);                 // the piece is consumed: its slot can be refilled
+                if (c + kRing < NCH)
+                    wide_fetch1<4>(X, ld, t, base + 256 * (c + kRing), lane, m, aligned != 0,
+                                   *reinterpret_cast<float (*)[4]>(&x[4 * (c % kRing)]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // The update sweep re-reads X (from L2) through a pointer the compiler cannot match with the first sweep's:
+        // otherwise it merges the two reads and keeps the whole slice in registers across the decision.
+        const float *X2 = X;
+        if constexpr (!PREFETCH) {
+            asm volatile("" : "+s"(X2));
+#pragma unroll
+            for (int c = 0; c < kRing; ++c)                        // its first pieces are in flight during the decision
+                wide_fetch1<4>(X2, ld, t, base + 256 * c, lane, m, aligned != 0, *reinterpret_cast<float (*)[4]>(&x[4 * c]));
         }
         double dot_u, dot_uw;
         wave_sum2(d0a + d0b, d1a + d1b, dot_u, dot_uw);
@@ -294,11 +339,17 @@ gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ X
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < EPL / 4; ++c) {
-                wide_fetch<4>(X, Xq, ld, t, base + 256 * c, lane, m, aligned != 0, x, xq);
+            for (int c = 0; c < NCH; ++c) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k)        // q = 0: f32(q*xq) = +-0 and p - (+-0) = p, the same sum
-                    u[4 * c + k] += (double)__fsub_rn(__fmul_rn(w, x[k]), __fmul_rn(q32, xq[k]));
+                for (int k = 0; k < 4; ++k) {      // q = 0: f32(q*xq) = +-0 and p - (+-0) = p, the same sum
+                    const int r = 4 * (c % kRing) + k;
+                    u[4 * c + k] += (double)__fsub_rn(__fmul_rn(w, x[r]), __fmul_rn(q32, xq[4 * c + k]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + kRing < NCH)
+                    wide_fetch1<4>(X2, ld, t, base + 256 * (c + kRing), lane, m, aligned != 0,
+                                   *reinterpret_cast<float (*)[4]>(&x[4 * (c % kRing)]));
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 
@@ -380,15 +431,19 @@ hipError_t launch_wide(const OnchipArgs &a, int W, hipStream_t stream)
     if (per_lane <= 4)  return launch_wide_epl<4>(a, W, stream);
     if (per_lane <= 8)  return launch_wide_epl<8>(a, W, stream);
     if (per_lane <= 16) return launch_wide_epl<16>(a, W, stream);
-    if (W == 16 && per_lane <= 28) {                      // long rows: 16 wavefronts, rows read at the top of each step
+    const int64_t per_lane8 = (a.m + 511) / 512;
+    if (W == 16 && per_lane8 <= 56) {                     // long rows: 8 wavefronts, rows streamed through a register ring
         const int aligned = (a.ld % 4 == 0) && (a.m % 4 == 0) && ((uintptr_t)a.X % 16 == 0) && ((uintptr_t)a.Xq % 16 == 0);
 #define GPFQ_LONG(EPL_)                                                                                                   \
-        hipLaunchKernelGGL((gpfq_wide_direct_kernel<EPL_, false>), dim3((unsigned)a.C), dim3(1024), 0, stream,            \
-                           a.X, a.Xq, a.ld, a.nrm32, a.Wt, a.ldw, a.A, a.N, (int)a.m, a.C, 16, aligned,                   \
+        hipLaunchKernelGGL((gpfq_wide_direct_kernel<EPL_, false>), dim3((unsigned)a.C), dim3(512), 0, stream,             \
+                           a.X, a.Xq, a.ld, a.nrm32, a.Wt, a.ldw, a.A, a.N, (int)a.m, a.C, 8, aligned,                    \
                            a.qidx, a.Qt, a.resid, a.u_out)
-        if (per_lane <= 20) GPFQ_LONG(20);
-        else if (per_lane <= 24) GPFQ_LONG(24);
-        else GPFQ_LONG(28);
+        if (per_lane8 <= 36) GPFQ_LONG(36);
+        else if (per_lane8 <= 40) GPFQ_LONG(40);
+        else if (per_lane8 <= 44) GPFQ_LONG(44);
+        else if (per_lane8 <= 48) GPFQ_LONG(48);
+        else if (per_lane8 <= 52) GPFQ_LONG(52);
+        else GPFQ_LONG(56);
 #undef GPFQ_LONG
         return hipGetLastError();
     }
