@@ -45,7 +45,7 @@ def agreement(net, ref_out, x):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--samples", type=int, default=5000, help="calibration samples (reference: 25000)")
+    ap.add_argument("--samples", type=int, default=25000, help="calibration samples (the reference's quant_train_size)")
     ap.add_argument("--scalars", type=float, nargs="+", default=[2, 3, 4])
     args = ap.parse_args()
 

@@ -21,14 +21,19 @@ __global__ void __launch_bounds__(256) k_mfma(double *out, int iters, double see
     if (s == 123.456) out[0] = s;
 }
 
+// MODE 0: both multiplicands are the same registers in every instruction; 1: one of them changes from one
+// instruction to the next (8 different registers); 2: both change.
+template <int MODE>
 __global__ void __launch_bounds__(256) k_fma(double *out, int iters, double seed)
 {
     double acc[4 * U];
     for (int i = 0; i < 4 * U; ++i) acc[i] = i;
-    const double a = seed + threadIdx.x, b = seed * 0.5 + threadIdx.x;
+    double av[8], bv[8];
+    for (int i = 0; i < 8; ++i) { av[i] = seed + threadIdx.x + i; bv[i] = seed * 0.5 + threadIdx.x - i; }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 4 * U; ++i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+        for (int i = 0; i < 4 * U; ++i)
+            asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(av[MODE == 2 ? i % 8 : 0]), "v"(bv[MODE >= 1 ? (i + 3) % 8 : 0]));
     }
     double s = 0;
     for (int i = 0; i < 4 * U; ++i) s += acc[i];
@@ -61,22 +66,27 @@ int main()
     int hb = -1; hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost);
     printf("layout check: %d wrong results (0 = maps are as documented)\n", hb);
     const int iters = 20000;
+    const char *names[4] = {"v_mfma_f64_16x16x4            ", "v_fma_f64, same multiplicands ", "v_fma_f64, one changing       ",
+                            "v_fma_f64, both changing      "};
     for (int waves = 1; waves <= 2; ++waves) {
-        for (int which = 0; which < 2; ++which) {
+        for (int which = 0; which < 4; ++which) {
             hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
             dim3 grid(256 * waves), block(256);
-            if (which == 0) hipLaunchKernelGGL(k_mfma, grid, block, 0, 0, out, 10, 1.0);
-            else hipLaunchKernelGGL(k_fma, grid, block, 0, 0, out, 10, 1.0);
+            auto launch = [&](int n) {
+                if (which == 0) hipLaunchKernelGGL(k_mfma, grid, block, 0, 0, out, n, 1.0);
+                else if (which == 1) hipLaunchKernelGGL(k_fma<0>, grid, block, 0, 0, out, n, 1.0);
+                else if (which == 2) hipLaunchKernelGGL(k_fma<1>, grid, block, 0, 0, out, n, 1.0);
+                else hipLaunchKernelGGL(k_fma<2>, grid, block, 0, 0, out, n, 1.0);
+            };
+            launch(10);
             hipEventRecord(a);
-            if (which == 0) hipLaunchKernelGGL(k_mfma, grid, block, 0, 0, out, iters, 1.0);
-            else hipLaunchKernelGGL(k_fma, grid, block, 0, 0, out, iters, 1.0);
+            launch(iters);
             hipEventRecord(b); hipEventSynchronize(b);
             float ms; hipEventElapsedTime(&ms, a, b);
             const double fma_per_wave = which == 0 ? (double)iters * U * 1024 : (double)iters * 4 * U * 64;
             const double total = fma_per_wave * 256 * waves * 4;      // waves in flight: grid * 4 per block
-            printf("%s, %d wave(s) per SIMD: %.3f ms, %.1f TFLOP/s (%.1f FMA/clk/SIMD at 2.4 GHz)\n",
-                   which == 0 ? "v_mfma_f64_16x16x4" : "v_fma_f64        ", waves, ms, 2 * total / ms / 1e9,
-                   total / (ms * 1e-3) / 2.4e9 / 1024);
+            printf("%s %d wave(s) per SIMD: %.3f ms, %.1f TFLOP/s (%.1f FMA/clk/SIMD at 2.4 GHz)\n",
+                   names[which], waves, ms, 2 * total / ms / 1e9, total / (ms * 1e-3) / 2.4e9 / 1024);
         }
     }
     return 0;
