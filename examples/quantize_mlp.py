@@ -8,7 +8,7 @@ what this image has: no TensorFlow and no MNIST files, so the network (the refer
 with BatchNormalization, train_mnist_mlp.py:60-73) is built with the torch-backed Keras shim, weights are
 random, data are synthetic, and "accuracy" is agreement with the analog network's own predictions.
 
-    python examples/quantize_mlp.py [--samples 5000] [--scalars 2 3 4]
+    python examples/quantize_mlp.py [--samples 25000] [--scalars 2 3 4]
 """
 import argparse
 import os
