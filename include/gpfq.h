@@ -91,8 +91,13 @@ size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path);
  *   "group_waves"  neurons (wavefronts) per workgroup 1..16 of the wave-per-neuron kernel, 0 = heuristic
  *   "lanes_per_neuron"  0 = heuristic, 16/32/64 = row-group kernel with that many lanes per neuron,
  *                  1 = wave-per-neuron kernel
- *   "variant"      bit 0: row-group kernel without the float64 copy of Xq in LDS
- *   "waves_per_neuron"  2..16: force the wide kernel (one neuron over that many wavefronts), 0 = only for m > 2048
+ *   "variant"      bit 0: row-group kernel without the float64 copy of Xq in LDS; bit 1: wide kernel with
+ *                  LDS-staged rows instead of register prefetch
+ *   "waves_per_neuron"  2..16: force the wide kernel (one neuron over that many wavefronts), 0 = heuristic
+ *                  (rows longer than 2048 samples, and layers too narrow to fill the chip)
+ *   "gram_slack_log2"   Gram paths: error bounds multiplied by 2^value (tests force the repair/rerun branches)
+ *   "conv_fused"   1 (default): conv layers read their patch rows from the channel planes; 0: per-channel patch matrices
+ *   "conv_strip"   plane-correlation kernel: output positions per lane (0 = heuristic, 1, 2 or 4)
  */
 int gpfq_set_option(const char *key, int value);
 

@@ -102,7 +102,7 @@ static int g_group_waves = 0;      // 0 = heuristic
 static int g_lpn = 0;              // 0 = heuristic, 1 = wave-per-neuron kernel, 16/32/64 = row-group kernel
 static int g_gram_slack_log2 = 0;  // Gram path: error bounds multiplied by 2^this (tests force the uncertified branch)
 static int g_wpn = 0;              // wide kernel: wavefronts per neuron (0 = heuristic: only for rows > 2048)
-static int g_variant = 0;          // bit 0: row-group kernel without the float64 copy of Xq in LDS
+static int g_variant = 0;          // bit 0: row-group kernel without the float64 copy of Xq in LDS; bit 1: wide kernel with LDS-staged rows
 static int g_conv_fused = 1;       // conv channel loop: 3x3/stride-1 Gram matrices straight from the planes
 static int g_conv_strip = 0;       // fused conv kernel: forced strip length (0 = heuristic)
 

@@ -79,7 +79,7 @@ struct GramArgs {
     int32_t *uncertified;   // [C]: 1 = decision chain not certified, rerun through the exact path
     void *workspace;
     double slack = 1.0;     // multiplies the error bounds (tests)
-    int variant = 0;        // tuning hook: Gram tile shape
+    int variant = 0;        // tuning hook (unused by the Gram kernels at present)
 };
 
 size_t gram_workspace_bytes(int64_t N, int64_t m, int64_t C);
@@ -128,7 +128,7 @@ struct ImageGramArgs {
     int32_t *uncertified;         // [nch][F]
     void *workspace;
     double slack = 1.0;
-    int variant = 0;              // tuning hook: forces the strip length (1, 2, 4, 7)
+    int variant = 0;              // tuning hook: forces the strip length (1, 2, 4)
 };
 // Any other kernel shape / stride / rate (gpfq_gram_conv.hip): the register-tile Gram kernel with implicit
 // im2col staging from the channel planes, all channels of the shard in one launch, then the batched decide.
