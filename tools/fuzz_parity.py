@@ -1,0 +1,110 @@
+"""Randomised parity sweep on the GPU: random dense layers (all on-chip kernels + streaming) and random conv
+layers (kernel size, stride, rate, padding, image size, channel / filter counts, alphabets, sparse or signed
+activations) against the CPU oracle, bit for bit.  Not part of the test suite (minutes of GPU time).
+usage: fuzz_parity.py [seconds] [seed]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+from quantized_neural_networks_amd import hip, layer
+from _im2col_ref import patches as ref_patches
+import oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = torch.device("cuda")
+t_end = time.time() + budget
+n_dense = n_conv = 0
+bad = []
+
+
+def activations(shape, kind):
+    g = rng.standard_normal(shape)
+    if kind == "relu":
+        a = np.maximum(g, 0)
+    elif kind == "sparse":
+        a = np.maximum(g - 1.5, 0)                  # ~7 % non-zero
+    elif kind == "signed":
+        a = g
+    else:
+        a = rng.random(shape)
+    return a.astype(np.float32)
+
+
+while time.time() < t_end:
+    bits = rng.choice([np.log2(3), 2, 3, 4, 5])
+    M = int(round(2 ** bits))
+    scalar = float(rng.choice([1, 2, 3, 5]))
+    if rng.random() < 0.5:
+        # ---- dense ------------------------------------------------------------------------
+        N = int(rng.integers(1, 200)); C = int(rng.integers(1, 60))
+        m = int(rng.choice([rng.integers(1, 300), rng.integers(300, 3000), rng.integers(3000, 30000)]))
+        kind = rng.choice(["relu", "sparse", "signed", "uniform"])
+        X = activations((N, m), kind)
+        Xq = X if rng.random() < 0.2 else (X + 0.1 * rng.standard_normal((N, m)).astype(np.float32) * (X != 0 if kind == "sparse" else 1)).astype(np.float32)
+        if kind in ("relu", "sparse", "uniform"):
+            Xq = np.maximum(Xq, 0).astype(np.float32)
+        if rng.random() < 0.3:
+            Xq[int(rng.integers(0, N))] = 0.0       # a dead row: rule (i)
+        W = (rng.standard_normal((N, C)) / np.sqrt(N)).astype(np.float32)
+        alphabet, _ = oracle.layer_alphabet(W, np.linspace(-1, 1, M), scalar)
+        Qo, io, ro = oracle.layer(W, X, Xq, alphabet)
+        path = int(rng.choice([0, 1, 2])) if m <= hip.GPFQ_ONCHIP_MAX_M else int(rng.choice([0, 2]))
+        opts = {}
+        if path == 1:
+            opts = dict(lanes_per_neuron=int(rng.choice([0, 1, 16, 32, 64])), waves_per_neuron=int(rng.choice([0, 0, 2, 4, 8, 16])),
+                        onchip_mode=int(rng.integers(0, 2)))
+        try:
+            for k, v in opts.items():
+                hip.set_option(k, v)
+            r = hip.quantize_neurons(torch.from_numpy(X).to(dev), torch.from_numpy(Xq).to(dev), torch.from_numpy(W.T.copy()).to(dev),
+                                     alphabet, path=path)
+        finally:
+            for k in opts:
+                hip.set_option(k, 1 if k == "onchip_mode" else 0)
+        ok = np.array_equal(r["idx"].cpu().numpy(), io) and np.allclose(r["resid"].cpu().numpy(), ro, rtol=1e-5, atol=0)
+        n_dense += 1
+        if not ok:
+            bad.append(("dense", N, m, C, M, scalar, kind, path, opts))
+    else:
+        # ---- conv ---------------------------------------------------------------------------
+        kh = int(rng.choice([1, 2, 3, 3, 3, 5, 7])); kw = kh if rng.random() < 0.8 else int(rng.choice([1, 2, 3, 5]))
+        stride = int(rng.choice([1, 1, 1, 2])); rate = int(rng.choice([1, 1, 1, 2])) if stride == 1 else 1
+        padding = str(rng.choice(["SAME", "VALID"]))
+        H = int(rng.integers(max(kh + (kh - 1) * (rate - 1), 4), 30)); Wd = int(rng.integers(max(kw + (kw - 1) * (rate - 1), 4), 30))
+        cin = int(rng.integers(1, 6)); F = int(rng.integers(1, 7))
+        oh, ow = hip.patch_out_dim(H, kh, stride, rate, padding == "SAME"), hip.patch_out_dim(Wd, kw, stride, rate, padding == "SAME")
+        if oh * ow == 0:
+            continue
+        n = int(rng.choice([rng.integers(1, 20), -(-hip.GPFQ_GRAM_MIN_M // (oh * ow)) + int(rng.integers(1, 40))]))
+        kind = rng.choice(["relu", "sparse", "signed", "uniform"])
+        act_w = activations((n, H, Wd, cin), kind)
+        first = rng.random() < 0.15
+        act_q = act_w if first else (act_w + 0.05 * rng.standard_normal(act_w.shape).astype(np.float32) * (act_w != 0 if kind == "sparse" else 1)).astype(np.float32)
+        if not first and kind != "signed":
+            act_q = np.maximum(act_q, 0).astype(np.float32)
+        Wk = (rng.standard_normal((kh, kw, cin, F)) / np.sqrt(kh * kw)).astype(np.float32)
+        Wt = torch.from_numpy(Wk).to(dev)
+        alphabet, _ = layer.layer_alphabet(Wt, np.linspace(-1, 1, M), scalar)
+        aw = torch.from_numpy(act_w).to(dev); aq = aw if first else torch.from_numpy(act_q).to(dev)
+        want_resid = bool(rng.random() < 0.3)
+        out = layer.quantize_conv2d(Wt, aw, aq, alphabet, strides=(stride, stride), padding=padding, rate=(rate, rate), want_resid=want_resid)
+        Q = out["Q"].cpu().numpy()
+        ok = True
+        for c in range(cin):
+            Pw = ref_patches(act_w, c, kh, kw, stride, stride, rate, rate, padding)
+            Pq = ref_patches(act_q, c, kh, kw, stride, stride, rate, rate, padding)
+            for f in range(F):
+                qo, _, uo = oracle.neuron(Wk[:, :, c, f].reshape(-1), Pw, Pq, alphabet)
+                ok &= np.array_equal(Q[:, :, c, f].reshape(-1), qo.astype(np.float32))
+                if want_resid:
+                    ok &= bool(np.isclose(out["resid"][c, f].item(), np.linalg.norm(uo), rtol=1e-5, atol=0))
+        n_conv += 1
+        if not ok:
+            bad.append(("conv", n, H, Wd, cin, F, kh, kw, stride, rate, padding, kind, first, M, scalar, want_resid))
+    if bad:
+        break
+print(f"dense cases {n_dense}, conv cases {n_conv}, mismatches {len(bad)}")
+for b in bad:
+    print("MISMATCH", b)
+sys.exit(1 if bad else 0)
