@@ -142,6 +142,48 @@ def test_keras_shim_cpu():
                           np.array([[1, 1, 1], [2, 2, 2]], dtype=np.float32))
 
 
+def test_activation_capture_host_logic():
+    """The cached-frontier capture equals the reference's per-batch recomputation from the input (CPU tensors):
+    same column layout including the partial-last-batch quirk, with and without fix_partial_batch, transposed
+    (Dense) and not (conv), and the two networks share one tensor until their weights differ."""
+    import torch
+    from quantized_neural_networks_amd import keras_shim as ks
+    from quantized_neural_networks_amd.quantized_network import CIFAR10Sequence, QuantizedCNN
+
+    def build():
+        return ks.Sequential([ks.Conv2D(3, 3, padding="same", activation="relu", input_shape=(6, 6, 2)), ks.BatchNormalization(),
+                              ks.MaxPooling2D(), ks.Conv2D(4, 3, padding="valid"), ks.Flatten(), ks.Dense(5, activation="relu"),
+                              ks.Dense(2)], device="cpu", seed=4)
+
+    x = np.random.default_rng(0).random((10, 6, 6, 2)).astype(np.float32)        # 10 samples, batches of 4: 4 + 4 + 2
+    y = np.zeros((10, 1), dtype=np.float32)
+    for fix in (False, True):
+        qs = []
+        for incremental in (True, False):
+            q = QuantizedCNN(network=build(), batch_size=4, get_data=CIFAR10Sequence(x, y, 4), logger=None, device="cpu",
+                             fix_partial_batch=fix)
+            q.incremental_capture = incremental
+            # make the quantized network differ from layer 3 on, as it would after quantizing that layer
+            w = q.quantized_net.layers[3].get_weights()
+            q.quantized_net.layers[3].set_weights([w[0] * 0.5] + w[1:])
+            qs.append(q)
+        for k, transpose in [(0, False), (1, False), (3, False), (5, True), (6, True)]:
+            got = qs[0]._get_layer_data_generator(k, transpose)
+            want = qs[1]._get_layer_data_generator(k, transpose)
+            for a, b in zip(got, want):
+                assert a.shape == b.shape and torch.equal(a == 0, b == 0)
+                assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+            assert (got[0] is got[1]) == (k <= 3)                                 # shared until the weights differ
+            n_cols = got[0].shape[-1] if transpose else got[0].shape[0]
+            assert n_cols == 12                                                   # 3 batches x batch_size columns
+            tail = got[0][..., 10:] if transpose else got[0][10:]
+            head = got[0][..., 4:6] if transpose else got[0][4:6]
+            if fix:
+                assert (tail == 0).all()
+            elif k > 0:
+                assert (tail == 0).all() and not (head == 0).all()                # batch 2 landed at offset 2*2 = 4
+
+
 def test_header_is_plain_c(tmp_path):
     """include/gpfq.h is a C header: it must compile as C99 without any HIP/C++ context."""
     import subprocess
