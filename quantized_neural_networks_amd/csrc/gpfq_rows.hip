@@ -243,6 +243,8 @@ gpfq_rows_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int6
                 const double tt = msq ? wd : tq;
                 // twice the modelling error of the prediction (quotient units) + float64 slack
                 const double delta2 = 2.0 * (fabs(wd) * st.cbound + st.cabs) + 0x1p-43 * (fabs(dot_u) + fabs(wg)) * st.rden;
+                // (a per-lane scan of the members for alphabets of <= 4 instead of the 16-lane search + broadcast
+                //  measured slower: 5.7 vs 5.5 ms ternary -- f64 compares and 64-bit selects cost more than the DPP ops)
                 const double d  = fabs(a - tt), dn = fabs(a_next - tt), dp = fabs(a_prev - tt);
                 const bool c_lt = a < tt, n_lt = a_next < tt;
                 const bool is_lo = c_lt && !n_lt;                                // k = p-1: last member below t
