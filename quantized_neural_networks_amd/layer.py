@@ -194,7 +194,9 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
         same_pad = str(padding).upper() == "SAME"
         cols = (act_w.shape[0] * hip.patch_out_dim(act_w.shape[1], kh, strides[0], rh, same_pad)
                 * hip.patch_out_dim(act_w.shape[2], kw, strides[1], rw, same_pad))
-        if K <= hip.GPFQ_GRAM_AUTO_MAX_N and cols > hip.GPFQ_GRAM_MIN_M:
+        # the whole-shard Gram call for every conv layer (one launch chain instead of a Python loop over the
+        # channels); with residual norms requested it builds patch matrices, which only pays for long ones
+        if K <= hip.GPFQ_GRAM_AUTO_MAX_N and cols > (hip.GPFQ_GRAM_MIN_M if want_resid else 0):
             plan = True
     if plan is not None:
         # Gram path, the whole channel loop (:844-860) in one library call: no per-channel allocation,
