@@ -277,32 +277,42 @@ class QuantizedNeuralNetwork:
         fr = getattr(self, "_frontier", None)
         if fr is not None and fr["k"] >= layer_idx:
             self._frontier = None                                 # captured activations downstream of this layer are stale
-        if self.trained_net.layers[layer_idx].use_bias:
-            bias = self.trained_net.layers[layer_idx].get_weights()[1]
-            self.quantized_net.layers[layer_idx].set_weights([Q, bias])
+        src, dst = self.trained_net.layers[layer_idx], self.quantized_net.layers[layer_idx]
+        on_device = isinstance(getattr(dst, "_weights", None), list)      # torch-backed layer: weights never leave HBM
+        if isinstance(Q, torch.Tensor) and not on_device:
+            Q = Q.cpu().numpy()                                           # a real Keras layer wants arrays
+        if src.use_bias:
+            bias = src._weights[1] if on_device and isinstance(getattr(src, "_weights", None), list) else src.get_weights()[1]
+            dst.set_weights([Q, bias])
         else:
-            self.quantized_net.layers[layer_idx].set_weights([Q])
+            dst.set_weights([Q])
+
+    def _kernel_on_device(self, layer):
+        """The layer's kernel as a float32 tensor on the quantizer's device (no host round trip for torch-backed layers)."""
+        ws = getattr(layer, "_weights", None)
+        if isinstance(ws, list) and ws and isinstance(ws[0], torch.Tensor) and ws[0].device == self.device:
+            return ws[0]
+        return self._to_device(layer.get_weights()[0])
 
     def _layer_alphabet(self, Wd):
         return _layer.layer_alphabet(Wd, self.alphabet, self.alphabet_scalar, self.process_group)   # (:544-545)
 
     # -- Dense layer (reference :523-574) ---------------------------------------------------
     def _quantize_layer_parallel(self, layer_idx):
-        W = self.trained_net.layers[layer_idx].get_weights()[0]
-        N_ell, N_ell_plus_1 = W.shape
+        Wd = self._kernel_on_device(self.trained_net.layers[layer_idx])
+        N_ell, N_ell_plus_1 = Wd.shape
         self._log("\tFeeding input data through hidden layers...")
         tic = time()
         wX, qX = self._get_layer_data_generator(layer_idx, transpose=True)
         self._log(f"\tdone. {time()-tic:2f} seconds.")
 
-        Wd = self._to_device(W)
         layer_alphabet, rad = self._layer_alphabet(Wd)
 
         self._log("\tQuantizing neurons (in parallel)...")
         tic = time()
         try:
             out = _layer.quantize_dense(Wd, wX, qX, layer_alphabet, group=self.process_group)
-            Q = out["Q"].cpu().numpy()
+            Q = out["Q"]
         except Exception as exc:
             self._log(f"\t\tLayer {layer_idx} generated an exception: {exc}")
             raise exc
@@ -360,10 +370,9 @@ class QuantizedCNN(QuantizedNeuralNetwork):
             rate = layer.dilation_rate
         except Exception:
             rate = None
-        W = layer.get_weights()[0]
-        Wd = self._to_device(W)
+        Wd = self._kernel_on_device(layer)
         alphabet, rad = self._layer_alphabet(Wd)                                   # (:831-832)
-        num_channels = W.shape[-2]
+        num_channels = Wd.shape[-2]
         tic = time()
         self._log(f"\t\tBuilding patch arrays and quantizing channel filters for {num_channels} channels...")
         try:
@@ -371,7 +380,7 @@ class QuantizedCNN(QuantizedNeuralNetwork):
                                          padding=layer.padding.upper(), rate=tuple(rate) if rate else None,
                                          group=self.process_group,
                                          want_resid=False)      # residual norms are diagnostics: skip their replay
-            Q = out["Q"].cpu().numpy()
+            Q = out["Q"]
         except Exception as exc:
             self._log(f"\t\t\tLayer {layer_idx} generated an exception: {exc}")
             raise Exception
