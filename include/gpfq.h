@@ -136,7 +136,8 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
  * N x N Gram matrices of the rows instead of on the rows: the patch data are read once per call instead of
  * once per neuron and step.  Every decision is certified against a rigorous bound on the float32 roundings
  * the Gram formulation skips; chains that stop at an uncertifiable step (about 1 in 10^4) are repaired on the
- * device from the exact element-wise dot products of that step (two rounds, up to 16 chains each); whatever is
+ * device from the exact element-wise dot products of that step (lists of up to 1024 chains; two rounds,
+ * twelve for walks longer than 64 steps -- dense layers whose rows are too long to stay on chip); whatever is
  * still open afterwards (practically nothing) is flagged non-zero in `uncertified` and MUST be rerun by the
  * caller through gpfq_quantize_neurons -- the outputs of flagged neurons are undefined, those of unflagged
  * neurons equal the exact flow's.
@@ -146,7 +147,7 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
  *   row norms come for free here; pass the same array on to the rerun of flagged neurons); else an input.
  *   Option "gram_slack_log2" (gpfq_set_option) multiplies the error bounds by 2^value (tests).
  */
-#define GPFQ_GRAM_MAX_N 256
+#define GPFQ_GRAM_MAX_N 1024
 size_t gpfq_gram_workspace_bytes(int64_t N, int64_t m, int64_t C);
 int gpfq_quantize_neurons_gram(const float *X, const float *Xq, int64_t ld, float *nrm32, int compute_norms,
                                const float *Wt, int64_t ldw,

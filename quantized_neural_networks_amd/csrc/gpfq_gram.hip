@@ -259,12 +259,14 @@ __device__ __forceinline__ int decide_chain(const double *__restrict__ gram, con
 
 // Device-side repair of the rare uncertified chains (no host round trip): the decide pass lists them, one
 // pass over the data forms the exact dot products of the step that stopped each chain, the chain resumes.
-constexpr int kFixMax = 16;        // chains repaired per round (more stay flagged for the caller)
+constexpr int kFixMax = 1024;      // chains repaired per round (more stay flagged for the caller)
 constexpr int kFixBlocks = 256;    // column walkers per listed chain
-constexpr int kFixRounds = 2;
+constexpr int kFixSlots = 64;      // listed chains in flight per launch (the kernels loop over the list)
+constexpr int kFixRounds = 2;      // short walks (conv channels): flags are rare
+constexpr int kFixRoundsLong = 12; // long walks: the bound grows with t, a chain may stop several times
 struct FixState {
-    int32_t count[kFixRounds + 1];
-    int32_t list[kFixRounds + 1][kFixMax];               // channel * C + neuron
+    int32_t count[kFixRoundsLong + 1];
+    int32_t list[kFixRoundsLong + 1][kFixMax];           // channel * C + neuron
     double part[kFixMax][kFixBlocks][2];
 };
 
@@ -287,6 +289,115 @@ gpfq_gram_decide_kernel(const double *__restrict__ gram, const float *__restrict
     if (r && fix) {
         const int k = atomicAdd(&fix->count[0], 1);
         if (k < kFixMax) fix->list[0][k] = (int32_t)(ch * C + j);
+    }
+}
+
+// Long walks (64 < N <= kWaveChainMaxN: dense layers whose rows are too long for the on-chip residual): the same
+// chain with one WAVEFRONT per neuron -- the O(t) sums of step t are split over the lanes (lane l takes
+// s = l, l + 64, ...), everything else is computed redundantly by all lanes.  w and the decisions so far live in
+// LDS (wl, ql: this wavefront's kWaveChainMaxN floats each).
+constexpr int kWaveChainMaxN = 1024;
+__device__ __forceinline__ int decide_chain_wave(const double *__restrict__ gram, const float *__restrict__ nrm32,
+                                                 const float *__restrict__ w, float *__restrict__ qh, const AlphabetArg &A, int N,
+                                                 double slack, int8_t *__restrict__ qidx, float *__restrict__ Qt,
+                                                 int t0, double dot_u, double dot_uw, bool nonneg, float *wl, float *ql)
+{
+    const int lane = threadIdx.x & 63;
+    const double *nx2 = gram + (int64_t)N * N * 2;
+    const double c = 0x1p-22 * slack;
+    const double up = 1.0 + 0x1p-48, upg = 1.0 + 0x1p-30;
+    for (int s = lane; s < N; s += 64) { wl[s] = w[s]; ql[s] = (s < t0) ? qh[s] : 0.f; }
+    double R = 0.0;
+    for (int t = 0; t < N; ++t) {
+        int idx = A.zero_idx;
+        float q32 = 0.f;
+        const float nrm = nrm32[t];
+        const float wt32 = wl[t];
+        const double nq = sqrt(gram[((int64_t)t * N + t) * 2 + 1]) * up;
+        const double nx = sqrt(nx2[t]) * up;
+        if (t < t0) {                                                                  // decided in an earlier pass
+            R += fabs((double)wt32) * nx + fabs((double)ql[t]) * nq;
+            continue;
+        }
+        if (t == t0) {                                                                 // exact flow (:83-89)
+            if (!((double)nrm < 1e-16)) {
+                const double tq = fabs(dot_u) < 1e-10 ? (double)wt32 : dot_uw / ((double)nrm * (double)nrm);
+                double d1 = fabs(A.a[0] - tq);
+                int best = 0;
+                for (int k = 1; k < A.M; ++k) {
+                    const double d = fabs(A.a[k] - tq);
+                    if (d < d1) { d1 = d; best = k; }
+                }
+                idx = best;
+                q32 = (float)A.a[best];
+            }
+        } else if (!((double)nrm < 1e-16)) {                                           // not rule (i)
+            double acc = 0.0, B = 0.0;
+            const double *row = gram + (int64_t)t * N * 2;
+            for (int s = lane; s < t; s += 64) {
+                const double g0 = row[2 * s], g1 = row[2 * s + 1];
+                const double ws = (double)wl[s], qs = (double)ql[s];
+                acc += ws * g0 - qs * g1;
+                B += fabs(ws) * g0 + fabs(qs) * g1;
+            }
+            wave_sum2(acc, B, acc, B);
+            B = nonneg ? B * upg : nq * R;
+            const double a_tt = nonneg ? row[2 * t] * upg : nq * nx;
+            const double err0 = c * B + 0x1p-128 * nq;
+            double tq, delta;
+            if (fabs(acc) + err0 < 1e-10) {                                            // certainly rule (ii)
+                tq = (double)wt32;
+                delta = 0.0;
+            } else if (fabs(acc) - err0 >= 1e-10) {                                    // certainly rule (iii)
+                const double wt = (double)wt32;
+                const double denom = (double)nrm * (double)nrm;
+                tq = (acc + wt * row[2 * t]) / denom;
+                delta = (err0 + 0x1p-23 * fabs(wt) * a_tt * slack) / denom + 0x1p-44 * fabs(tq);
+            } else {
+                return t + 1;                                                          // cannot tell (ii) from (iii)
+            }
+            double d1 = fabs(A.a[0] - tq), d2 = __longlong_as_double(0x7ff0000000000000LL);
+            int best = 0;
+            for (int k = 1; k < A.M; ++k) {
+                const double d = fabs(A.a[k] - tq);
+                if (d < d1) { d2 = d1; d1 = d; best = k; }
+                else if (d < d2) d2 = d;
+            }
+            if (!(0.5 * (d2 - d1) > delta)) return t + 1;                               // too close to a boundary (or NaN)
+            idx = best;
+            q32 = (float)A.a[best];
+        }
+        R += fabs((double)wt32) * nx + fabs((double)q32) * nq;
+        if (lane == 0) {
+            ql[t] = q32;
+            qh[t] = q32;
+            if (qidx) qidx[t] = (int8_t)idx;
+            if (Qt) Qt[t] = q32;
+        }
+    }
+    return 0;
+}
+
+__global__ void __launch_bounds__(256)
+gpfq_gram_decide_wave_kernel(const double *__restrict__ gram, const float *__restrict__ nrm32,
+                             const float *__restrict__ Wt, int64_t ldw, AlphabetArg A, int N, int64_t C,
+                             double slack, int8_t *__restrict__ qidx, float *__restrict__ Qt,
+                             int32_t *__restrict__ uncertified, float *__restrict__ q32_hist,
+                             FixState *__restrict__ fix, const int *__restrict__ negflag)
+{
+    __shared__ float wl[4][kWaveChainMaxN], ql[4][kWaveChainMaxN];
+    const int wave = threadIdx.x >> 6;
+    const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+    if (j >= C) return;                                                                // no block-wide barriers below
+    const int r = decide_chain_wave(gram, nrm32, Wt + j * ldw, q32_hist + j * N, A, N, slack,
+                                    qidx ? qidx + j * N : nullptr, Qt ? Qt + j * N : nullptr, -1, 0.0, 0.0,
+                                    negflag && negflag[0] == 0, wl[wave], ql[wave]);
+    if ((threadIdx.x & 63) == 0) {
+        uncertified[j] = r;
+        if (r && fix) {
+            const int k = atomicAdd(&fix->count[0], 1);
+            if (k < kFixMax) fix->list[0][k] = (int32_t)j;
+        }
     }
 }
 
@@ -316,9 +427,8 @@ gpfq_gram_fix_kernel(FixSrc src, const float *__restrict__ Wt, int64_t ldw, int 
                      FixState *__restrict__ fix, int round)
 {
     __shared__ double sm[4][2];
-    const int k = blockIdx.y;
-    const int cnt = fix->count[round];
-    if (k >= (cnt < kFixMax ? cnt : kFixMax)) return;
+    const int cnt = fix->count[round] < kFixMax ? fix->count[round] : kFixMax;
+    for (int k = blockIdx.y; k < cnt; k += kFixSlots) {
     const int64_t gid = fix->list[round][k];
     const int64_t ch = gid / C, j = gid - ch * C;
     const int t0 = uncertified[ch * bs.unc_cs + j] - 1;
@@ -353,6 +463,8 @@ gpfq_gram_fix_kernel(FixSrc src, const float *__restrict__ Wt, int64_t ldw, int 
         fix->part[k][blockIdx.x][0] = sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0];
         fix->part[k][blockIdx.x][1] = sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1];
     }
+    __syncthreads();
+    }
 }
 
 // Resume the listed chains from their exact step; chains that stop again are listed for the next round.
@@ -363,9 +475,8 @@ gpfq_gram_resume_kernel(const double *__restrict__ gram, const float *__restrict
                         int32_t *__restrict__ uncertified, float *__restrict__ q32_hist, DecideBatch bs,
                         FixState *__restrict__ fix, int round, const int *__restrict__ negflag)
 {
-    const int k = threadIdx.x;
-    const int cnt = fix->count[round];
-    if (k >= (cnt < kFixMax ? cnt : kFixMax)) return;
+    const int cnt = fix->count[round] < kFixMax ? fix->count[round] : kFixMax;
+    for (int k = blockIdx.x * 64 + threadIdx.x; k < cnt; k += gridDim.x * 64) {
     const int64_t gid = fix->list[round][k];
     const int64_t ch = gid / C, j = gid - ch * C;
     const int t0 = uncertified[ch * bs.unc_cs + j] - 1;
@@ -379,6 +490,35 @@ gpfq_gram_resume_kernel(const double *__restrict__ gram, const float *__restrict
     if (r) {
         const int kk = atomicAdd(&fix->count[round + 1], 1);
         if (kk < kFixMax) fix->list[round + 1][kk] = (int32_t)gid;
+    }
+    }
+}
+
+// The same for long walks: one wavefront per listed chain (grid = kFixMax workgroups of one wavefront).
+__global__ void __launch_bounds__(64)
+gpfq_gram_resume_wave_kernel(const double *__restrict__ gram, const float *__restrict__ nrm32,
+                             const float *__restrict__ Wt, int64_t ldw, AlphabetArg A, int N, int64_t C,
+                             double slack, int8_t *__restrict__ qidx, float *__restrict__ Qt,
+                             int32_t *__restrict__ uncertified, float *__restrict__ q32_hist,
+                             FixState *__restrict__ fix, int round, const int *__restrict__ negflag)
+{
+    __shared__ float wl[kWaveChainMaxN], ql[kWaveChainMaxN];
+    const int cnt = fix->count[round] < kFixMax ? fix->count[round] : kFixMax;
+    for (int k = blockIdx.x; k < cnt; k += gridDim.x) {
+    const int64_t j = fix->list[round][k];
+    const int t0 = uncertified[j] - 1;
+    double dot_u = 0.0, dot_uw = 0.0;
+    for (int b = 0; b < kFixBlocks; ++b) { dot_u += fix->part[k][b][0]; dot_uw += fix->part[k][b][1]; }
+    const int r = decide_chain_wave(gram, nrm32, Wt + j * ldw, q32_hist + j * N, A, N, slack,
+                                    qidx ? qidx + j * N : nullptr, Qt ? Qt + j * N : nullptr, t0, dot_u, dot_uw,
+                                    negflag && negflag[0] == 0, wl, ql);
+    if (threadIdx.x == 0) {
+        uncertified[j] = r;
+        if (r) {
+            const int kk = atomicAdd(&fix->count[round + 1], 1);
+            if (kk < kFixMax) fix->list[round + 1][kk] = (int32_t)j;
+        }
+    }
     }
 }
 
@@ -450,14 +590,21 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 constexpr int kGramBlocksX = 512;          // column walkers (per tile for N > 9)
 
-static int64_t gram_blocks(int64_t m)
+static int64_t gram_blocks(int64_t N, int64_t m)
 {
     const int64_t nchunks = (m + kGramCH - 1) / kGramCH;
-    return nchunks < kGramBlocksX ? (nchunks > 0 ? nchunks : 1) : kGramBlocksX;
+    int64_t cap = kGramBlocksX;
+    if (N > 9) {                              // many tiles already fill the chip: fewer walkers (and partial records) each
+        const int64_t tiles = tile_count<2, 12>((int)N);
+        cap = (8192 + tiles - 1) / tiles;
+        if (cap > kGramBlocksX) cap = kGramBlocksX;
+        if (cap < 1) cap = 1;
+    }
+    return nchunks < cap ? (nchunks > 0 ? nchunks : 1) : cap;
 }
 
 // partial records: one per workgroup (tile kernel) or per wavefront (rows9 kernel)
-static int64_t gram_parts(int64_t N, int64_t m) { return N <= 9 ? gram_blocks(m) * 4 : gram_blocks(m); }
+static int64_t gram_parts(int64_t N, int64_t m) { return N <= 9 ? gram_blocks(N, m) * 4 : gram_blocks(N, m); }
 
 size_t gram_workspace_bytes(int64_t N, int64_t m, int64_t C)
 {
@@ -490,16 +637,27 @@ hipError_t launch_gram_decide(const double *gram, const float *nrm32, const floa
     if (C == 0 || bs.nch == 0) return hipSuccess;
     FixState *fix = (src && fix_ws && src->m > 0 && bs.nch * C < (1LL << 31)) ? static_cast<FixState *>(fix_ws) : nullptr;
     if (fix) {
-        hipError_t e = hipMemsetAsync(fix, 0, sizeof(int32_t) * (kFixRounds + 1), stream);
+        hipError_t e = hipMemsetAsync(fix, 0, sizeof(int32_t) * (kFixRoundsLong + 1), stream);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(gpfq_gram_decide_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)bs.nch), dim3(64), 0, stream,
-                       gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, bs, fix, negflag);
-    for (int round = 0; fix && round < kFixRounds; ++round) {
-        hipLaunchKernelGGL(gpfq_gram_fix_kernel, dim3(kFixBlocks, kFixMax), dim3(256), 0, stream,
+    // long walks of a single problem (dense layers with very long rows): one wavefront per neuron
+    const bool wave_chain = N > 64 && N <= kWaveChainMaxN && bs.nch == 1;
+    if (wave_chain)
+        hipLaunchKernelGGL(gpfq_gram_decide_wave_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, stream,
+                           gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, fix, negflag);
+    else
+        hipLaunchKernelGGL(gpfq_gram_decide_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)bs.nch), dim3(64), 0, stream,
+                           gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, bs, fix, negflag);
+    const int rounds = wave_chain ? kFixRoundsLong : kFixRounds;
+    for (int round = 0; fix && round < rounds; ++round) {
+        hipLaunchKernelGGL(gpfq_gram_fix_kernel, dim3(kFixBlocks, kFixSlots), dim3(256), 0, stream,
                            *src, Wt, ldw, N, C, uncertified, q32_hist, bs, fix, round);
-        hipLaunchKernelGGL(gpfq_gram_resume_kernel, dim3(1), dim3(64), 0, stream,
-                           gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, bs, fix, round, negflag);
+        if (wave_chain)
+            hipLaunchKernelGGL(gpfq_gram_resume_wave_kernel, dim3(kFixSlots * 4), dim3(64), 0, stream,
+                               gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, fix, round, negflag);
+        else
+            hipLaunchKernelGGL(gpfq_gram_resume_kernel, dim3(kFixMax / 64), dim3(64), 0, stream,
+                               gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, bs, fix, round, negflag);
     }
     return hipGetLastError();
 }
@@ -507,7 +665,7 @@ hipError_t launch_gram_decide(const double *gram, const float *nrm32, const floa
 hipError_t launch_gram(const GramArgs &a, hipStream_t stream)
 {
     const int64_t nchunks = (a.m + kGramCH - 1) / kGramCH;
-    const int64_t nblocks = gram_blocks(a.m), nparts = gram_parts(a.N, a.m);
+    const int64_t nblocks = gram_blocks(a.N, a.m), nparts = gram_parts(a.N, a.m);
     const int64_t rchunks = (a.m + 1023) / 1024;
     const int64_t rec = gram_record(a.N);
     char *ws = static_cast<char *>(a.workspace);

@@ -13,7 +13,8 @@ from . import build as _build
 
 GPFQ_PATH_AUTO, GPFQ_PATH_ONCHIP, GPFQ_PATH_STREAM = 0, 1, 2
 GPFQ_PATH_GRAM = 3                 # binding-level selector: gpfq_quantize_neurons_gram + exact rerun of flagged neurons
-GPFQ_GRAM_AUTO_MAX_N = 64          # AUTO takes the Gram path for walks this short over rows longer than GPFQ_GRAM_MIN_M
+GPFQ_GRAM_AUTO_MAX_N = 64          # conv layers with kh*kw up to this take the whole-shard Gram call
+GPFQ_GRAM_MAX_N = 1024             # longest walk the Gram path takes (include/gpfq.h)
 GPFQ_MAX_ALPHABET = 64
 GPFQ_ONCHIP_MAX_M = 28672          # longest row whose residual stays in registers (include/gpfq.h)
 GPFQ_GRAM_MIN_M = 16384
@@ -141,8 +142,10 @@ def quantize_neurons(X, Xq, Wt, alphabet, nrm32=None, want_u=False, path=GPFQ_PA
         raise GpfqError("X and Xq must share one row pitch")
     arr, M, zero_idx = _alphabet(alphabet)
     dev = X.device
+    # rows beyond GPFQ_GRAM_MIN_M samples: the Gram path (N x N records + scalar recurrences) beats walking such rows
+    # step by step whenever the records are affordable (N <= GPFQ_GRAM_MAX_N); the reference's MNIST run is this case
     if path == GPFQ_PATH_GRAM or (path == GPFQ_PATH_AUTO and not want_u and m > GPFQ_GRAM_MIN_M
-                                  and N <= GPFQ_GRAM_AUTO_MAX_N):
+                                  and N <= GPFQ_GRAM_MAX_N):
         return _quantize_neurons_gram(X, Xq, Wt, alphabet, nrm32, want_values)
     if nrm32 is None:
         nrm32 = row_norms(Xq)
