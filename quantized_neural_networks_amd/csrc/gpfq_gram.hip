@@ -294,55 +294,98 @@ gpfq_gram_decide_kernel(const double *__restrict__ gram, const float *__restrict
 
 // Long walks (64 < N <= kWaveChainMaxN: dense layers whose rows are too long for the on-chip residual): the same
 // chain with one WAVEFRONT per neuron -- the O(t) sums of step t are split over the lanes (lane l takes
-// s = l, l + 64, ...), everything else is computed redundantly by all lanes.  w and the decisions so far live in
-// LDS (wl, ql: this wavefront's kWaveChainMaxN floats each).
+// s = l, l + 64, ...; PER = ceil(N / 64) entries of a Gram row per lane), everything else is computed redundantly
+// by all lanes.  w and the decisions so far live in LDS (wl, ql: this wavefront's 64 * PER floats each).  The
+// per-step scalars that do not depend on the chain (norm bounds, diagonal, 1 / nrm^2) are formed once per
+// workgroup (wave_chain_aux) and the Gram rows are requested three steps ahead into three register sets, so a
+// step waits on neither a square root nor memory.
 constexpr int kWaveChainMaxN = 1024;
-__device__ __forceinline__ int decide_chain_wave(const double *__restrict__ gram, const float *__restrict__ nrm32,
-                                                 const float *__restrict__ w, float *__restrict__ qh, const AlphabetArg &A, int N,
+constexpr int kAuxW = 5;               // per step: nq, nx (inflated norms), <Xq_t, X_t>, nrm^2 (or -1: rule (i)), 1 / nrm^2
+
+__device__ __forceinline__ void wave_chain_aux(const double *__restrict__ gram, const float *__restrict__ nrm32, int N,
+                                               double *__restrict__ aux, int tid, int nthreads)
+{
+    const double *nx2 = gram + (int64_t)N * N * 2;
+    const double up = 1.0 + 0x1p-48;       // Cauchy-Schwarz needs upper bounds: covers the sqrt and product roundings
+    for (int t = tid; t < N; t += nthreads) {
+        const double nrm = (double)nrm32[t];
+        const double den = nrm * nrm;
+        aux[t * kAuxW + 0] = sqrt(gram[((int64_t)t * N + t) * 2 + 1]) * up;
+        aux[t * kAuxW + 1] = sqrt(nx2[t]) * up;
+        aux[t * kAuxW + 2] = gram[((int64_t)t * N + t) * 2];
+        aux[t * kAuxW + 3] = nrm < 1e-16 ? -1.0 : den;
+        aux[t * kAuxW + 4] = 1.0 / den;
+    }
+}
+
+template <int PER>
+__device__ __forceinline__ int decide_chain_wave(const double *__restrict__ gram, const float *__restrict__ w,
+                                                 float *__restrict__ qh, const AlphabetArg &A, int N,
                                                  double slack, int8_t *__restrict__ qidx, float *__restrict__ Qt,
-                                                 int t0, double dot_u, double dot_uw, bool nonneg, float *wl, float *ql)
+                                                 int t0, double dot_u, double dot_uw, bool nonneg, float *wl, float *ql,
+                                                 const double *aux)
 {
     const int lane = threadIdx.x & 63;
-    const double *nx2 = gram + (int64_t)N * N * 2;
     const double c = 0x1p-22 * slack;
-    const double up = 1.0 + 0x1p-48, upg = 1.0 + 0x1p-30;
-    for (int s = lane; s < N; s += 64) { wl[s] = w[s]; ql[s] = (s < t0) ? qh[s] : 0.f; }
-    double R = 0.0;
-    for (int t = 0; t < N; ++t) {
+    const double upg = 1.0 + 0x1p-30;
+    const int ts = t0 > 0 ? t0 : 0;
+    const double a_lane = alphabet_lane(A, lane);       // ascending alphabets only (the launcher checks)
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int s = lane + 64 * i;
+        wl[s] = s < N ? w[s] : 0.f;
+        ql[s] = s < ts ? qh[s] : 0.f;
+    }
+    double R = 0.0;                                      // sum_{s<t} |w_s| ||X_s|| + |q_s| ||Xq_s||
+    if (!nonneg) {
+        for (int s = lane; s < ts; s += 64)
+            R += fabs((double)wl[s]) * aux[s * kAuxW + 1] + fabs((double)ql[s]) * aux[s * kAuxW + 0];
+        R = wave_sum(R);
+    }
+
+    // row r of the record, entries s = lane + 64 i (raw: the consumer masks s >= r through w and q)
+    auto fill = [&](int r, double (&g0)[PER], double (&g1)[PER]) __attribute__((always_inline)) {
+        // always the same number of requests (clamped addresses): the compiler can then count the outstanding
+        // loads exactly and a step waits only for its own row, not for the rows requested after it
+        const double2 *row = reinterpret_cast<const double2 *>(gram + (int64_t)(r < N ? r : N - 1) * N * 2);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int s = lane + 64 * i;
+            const double2 v = row[s < N ? s : N - 1];
+            g0[i] = v.x;
+            g1[i] = v.y;
+        }
+    };
+    // step t on the register set that holds row t; the set is refilled with row t + 3 as soon as it is consumed
+    auto step = [&](int t, double (&g0)[PER], double (&g1)[PER]) __attribute__((always_inline)) -> int {
         int idx = A.zero_idx;
         float q32 = 0.f;
-        const float nrm = nrm32[t];
+        const double nq = aux[t * kAuxW + 0], nx = aux[t * kAuxW + 1], g_tt = aux[t * kAuxW + 2];
+        const double den = aux[t * kAuxW + 3], rden = aux[t * kAuxW + 4];
         const float wt32 = wl[t];
-        const double nq = sqrt(gram[((int64_t)t * N + t) * 2 + 1]) * up;
-        const double nx = sqrt(nx2[t]) * up;
-        if (t < t0) {                                                                  // decided in an earlier pass
-            R += fabs((double)wt32) * nx + fabs((double)ql[t]) * nq;
-            continue;
-        }
-        if (t == t0) {                                                                 // exact flow (:83-89)
-            if (!((double)nrm < 1e-16)) {
-                const double tq = fabs(dot_u) < 1e-10 ? (double)wt32 : dot_uw / ((double)nrm * (double)nrm);
-                double d1 = fabs(A.a[0] - tq);
-                int best = 0;
-                for (int k = 1; k < A.M; ++k) {
-                    const double d = fabs(A.a[k] - tq);
-                    if (d < d1) { d1 = d; best = k; }
+        double acc = 0.0, B = 0.0;
+        if (t != t0 && den >= 0.0) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i)
+                if (64 * i < t) {                                                     // wave-uniform
+                    const int s = lane + 64 * i;
+                    const float wv = wl[s], qv = ql[s];                               // unconditional reads: no branch
+                    const double ws = s < t ? (double)wv : 0.0, qs = s < t ? (double)qv : 0.0;
+                    acc += ws * g0[i] - qs * g1[i];
+                    B += fabs(ws) * g0[i] + fabs(qs) * g1[i];
                 }
-                idx = best;
-                q32 = (float)A.a[best];
-            }
-        } else if (!((double)nrm < 1e-16)) {                                           // not rule (i)
-            double acc = 0.0, B = 0.0;
-            const double *row = gram + (int64_t)t * N * 2;
-            for (int s = lane; s < t; s += 64) {
-                const double g0 = row[2 * s], g1 = row[2 * s + 1];
-                const double ws = (double)wl[s], qs = (double)ql[s];
-                acc += ws * g0 - qs * g1;
-                B += fabs(ws) * g0 + fabs(qs) * g1;
-            }
             wave_sum2(acc, B, acc, B);
+        }
+        fill(t + 3, g0, g1);
+        if (t == t0) {                                                                 // exact flow (:83-89)
+            if (den >= 0.0) {
+                const double tq = fabs(dot_u) < 1e-10 ? (double)wt32 : dot_uw / den;
+                idx = nearest(tq, a_lane, A.M, true);
+                q32 = (float)readlane_f64(a_lane, idx);
+            }
+        } else if (den >= 0.0) {                                                       // not rule (i)
             B = nonneg ? B * upg : nq * R;
-            const double a_tt = nonneg ? row[2 * t] * upg : nq * nx;
+            const double a_tt = nonneg ? g_tt * upg : nq * nx;                         // <|Xq_t|, |X_t|>
             const double err0 = c * B + 0x1p-128 * nq;
             double tq, delta;
             if (fabs(acc) + err0 < 1e-10) {                                            // certainly rule (ii)
@@ -350,22 +393,15 @@ __device__ __forceinline__ int decide_chain_wave(const double *__restrict__ gram
                 delta = 0.0;
             } else if (fabs(acc) - err0 >= 1e-10) {                                    // certainly rule (iii)
                 const double wt = (double)wt32;
-                const double denom = (double)nrm * (double)nrm;
-                tq = (acc + wt * row[2 * t]) / denom;
-                delta = (err0 + 0x1p-23 * fabs(wt) * a_tt * slack) / denom + 0x1p-44 * fabs(tq);
+                tq = (acc + wt * g_tt) * rden;          // the reciprocal's rounding sits inside the 2^-44 |tq| margin
+                delta = (err0 + 0x1p-23 * fabs(wt) * a_tt * slack) * rden * upg + 0x1p-44 * fabs(tq);
             } else {
                 return t + 1;                                                          // cannot tell (ii) from (iii)
             }
-            double d1 = fabs(A.a[0] - tq), d2 = __longlong_as_double(0x7ff0000000000000LL);
-            int best = 0;
-            for (int k = 1; k < A.M; ++k) {
-                const double d = fabs(A.a[k] - tq);
-                if (d < d1) { d2 = d1; d1 = d; best = k; }
-                else if (d < d2) d2 = d;
-            }
-            if (!(0.5 * (d2 - d1) > delta)) return t + 1;                               // too close to a boundary (or NaN)
-            idx = best;
-            q32 = (float)A.a[best];
+            double margin;                              // half the gap between the runner-up and the chosen member
+            idx = nearest_margin(tq, a_lane, A.M, true, margin);
+            if (!(margin > delta)) return t + 1;                                       // too close to a boundary (or NaN)
+            q32 = (float)readlane_f64(a_lane, idx);
         }
         R += fabs((double)wt32) * nx + fabs((double)q32) * nq;
         if (lane == 0) {
@@ -374,10 +410,27 @@ __device__ __forceinline__ int decide_chain_wave(const double *__restrict__ gram
             if (qidx) qidx[t] = (int8_t)idx;
             if (Qt) Qt[t] = q32;
         }
+        return 0;
+    };
+
+    double g0[3][PER], g1[3][PER];
+    fill(ts, g0[0], g1[0]);
+    fill(ts + 1, g0[1], g1[1]);
+    fill(ts + 2, g0[2], g1[2]);
+    for (int t = ts; t < N; t += 3) {
+        int r = step(t, g0[0], g1[0]);
+        if (r) return r;
+        if (t + 1 >= N) break;
+        r = step(t + 1, g0[1], g1[1]);
+        if (r) return r;
+        if (t + 2 >= N) break;
+        r = step(t + 2, g0[2], g1[2]);
+        if (r) return r;
     }
     return 0;
 }
 
+template <int PER>
 __global__ void __launch_bounds__(256)
 gpfq_gram_decide_wave_kernel(const double *__restrict__ gram, const float *__restrict__ nrm32,
                              const float *__restrict__ Wt, int64_t ldw, AlphabetArg A, int N, int64_t C,
@@ -385,13 +438,16 @@ gpfq_gram_decide_wave_kernel(const double *__restrict__ gram, const float *__res
                              int32_t *__restrict__ uncertified, float *__restrict__ q32_hist,
                              FixState *__restrict__ fix, const int *__restrict__ negflag)
 {
-    __shared__ float wl[4][kWaveChainMaxN], ql[4][kWaveChainMaxN];
+    __shared__ float wl[4][64 * PER], ql[4][64 * PER];
+    __shared__ double aux[64 * PER * kAuxW];
+    wave_chain_aux(gram, nrm32, N, aux, threadIdx.x, 256);
+    __syncthreads();
     const int wave = threadIdx.x >> 6;
     const int64_t j = (int64_t)blockIdx.x * 4 + wave;
     if (j >= C) return;                                                                // no block-wide barriers below
-    const int r = decide_chain_wave(gram, nrm32, Wt + j * ldw, q32_hist + j * N, A, N, slack,
-                                    qidx ? qidx + j * N : nullptr, Qt ? Qt + j * N : nullptr, -1, 0.0, 0.0,
-                                    negflag && negflag[0] == 0, wl[wave], ql[wave]);
+    const int r = decide_chain_wave<PER>(gram, Wt + j * ldw, q32_hist + j * N, A, N, slack,
+                                         qidx ? qidx + j * N : nullptr, Qt ? Qt + j * N : nullptr, -1, 0.0, 0.0,
+                                         negflag && negflag[0] == 0, wl[wave], ql[wave], aux);
     if ((threadIdx.x & 63) == 0) {
         uncertified[j] = r;
         if (r && fix) {
@@ -494,7 +550,8 @@ gpfq_gram_resume_kernel(const double *__restrict__ gram, const float *__restrict
     }
 }
 
-// The same for long walks: one wavefront per listed chain (grid = kFixMax workgroups of one wavefront).
+// The same for long walks: one wavefront per listed chain (the workgroups loop over the list).
+template <int PER>
 __global__ void __launch_bounds__(64)
 gpfq_gram_resume_wave_kernel(const double *__restrict__ gram, const float *__restrict__ nrm32,
                              const float *__restrict__ Wt, int64_t ldw, AlphabetArg A, int N, int64_t C,
@@ -502,23 +559,26 @@ gpfq_gram_resume_wave_kernel(const double *__restrict__ gram, const float *__res
                              int32_t *__restrict__ uncertified, float *__restrict__ q32_hist,
                              FixState *__restrict__ fix, int round, const int *__restrict__ negflag)
 {
-    __shared__ float wl[kWaveChainMaxN], ql[kWaveChainMaxN];
+    __shared__ float wl[64 * PER], ql[64 * PER];
+    __shared__ double aux[64 * PER * kAuxW];
     const int cnt = fix->count[round] < kFixMax ? fix->count[round] : kFixMax;
+    if ((int)blockIdx.x >= cnt) return;
+    wave_chain_aux(gram, nrm32, N, aux, threadIdx.x, 64);
     for (int k = blockIdx.x; k < cnt; k += gridDim.x) {
-    const int64_t j = fix->list[round][k];
-    const int t0 = uncertified[j] - 1;
-    double dot_u = 0.0, dot_uw = 0.0;
-    for (int b = 0; b < kFixBlocks; ++b) { dot_u += fix->part[k][b][0]; dot_uw += fix->part[k][b][1]; }
-    const int r = decide_chain_wave(gram, nrm32, Wt + j * ldw, q32_hist + j * N, A, N, slack,
-                                    qidx ? qidx + j * N : nullptr, Qt ? Qt + j * N : nullptr, t0, dot_u, dot_uw,
-                                    negflag && negflag[0] == 0, wl, ql);
-    if (threadIdx.x == 0) {
-        uncertified[j] = r;
-        if (r) {
-            const int kk = atomicAdd(&fix->count[round + 1], 1);
-            if (kk < kFixMax) fix->list[round + 1][kk] = (int32_t)j;
+        const int64_t j = fix->list[round][k];
+        const int t0 = uncertified[j] - 1;
+        double dot_u = 0.0, dot_uw = 0.0;
+        for (int b = 0; b < kFixBlocks; ++b) { dot_u += fix->part[k][b][0]; dot_uw += fix->part[k][b][1]; }
+        const int r = decide_chain_wave<PER>(gram, Wt + j * ldw, q32_hist + j * N, A, N, slack,
+                                             qidx ? qidx + j * N : nullptr, Qt ? Qt + j * N : nullptr, t0, dot_u, dot_uw,
+                                             negflag && negflag[0] == 0, wl, ql, aux);
+        if (threadIdx.x == 0) {
+            uncertified[j] = r;
+            if (r) {
+                const int kk = atomicAdd(&fix->count[round + 1], 1);
+                if (kk < kFixMax) fix->list[round + 1][kk] = (int32_t)j;
+            }
         }
-    }
     }
 }
 
@@ -641,10 +701,18 @@ hipError_t launch_gram_decide(const double *gram, const float *nrm32, const floa
         if (e != hipSuccess) return e;
     }
     // long walks of a single problem (dense layers with very long rows): one wavefront per neuron
-    const bool wave_chain = N > 64 && N <= kWaveChainMaxN && bs.nch == 1;
+    const bool wave_chain = N > 64 && N <= kWaveChainMaxN && bs.nch == 1 && A.ascending;
+    const int per = (N + 63) / 64;
+#define GPFQ_WAVE_CHAIN(KERNEL, GRID, BLOCK, ...)                                                                  \
+    do {                                                                                                             \
+        if (per <= 4) hipLaunchKernelGGL(KERNEL<4>, GRID, BLOCK, 0, stream, __VA_ARGS__);                            \
+        else if (per <= 8) hipLaunchKernelGGL(KERNEL<8>, GRID, BLOCK, 0, stream, __VA_ARGS__);                       \
+        else if (per <= 12) hipLaunchKernelGGL(KERNEL<12>, GRID, BLOCK, 0, stream, __VA_ARGS__);                     \
+        else hipLaunchKernelGGL(KERNEL<16>, GRID, BLOCK, 0, stream, __VA_ARGS__);                                    \
+    } while (0)
     if (wave_chain)
-        hipLaunchKernelGGL(gpfq_gram_decide_wave_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, stream,
-                           gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, fix, negflag);
+        GPFQ_WAVE_CHAIN(gpfq_gram_decide_wave_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256),
+                        gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, fix, negflag);
     else
         hipLaunchKernelGGL(gpfq_gram_decide_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)bs.nch), dim3(64), 0, stream,
                            gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, bs, fix, negflag);
@@ -653,12 +721,13 @@ hipError_t launch_gram_decide(const double *gram, const float *nrm32, const floa
         hipLaunchKernelGGL(gpfq_gram_fix_kernel, dim3(kFixBlocks, kFixSlots), dim3(256), 0, stream,
                            *src, Wt, ldw, N, C, uncertified, q32_hist, bs, fix, round);
         if (wave_chain)
-            hipLaunchKernelGGL(gpfq_gram_resume_wave_kernel, dim3(kFixSlots * 4), dim3(64), 0, stream,
-                               gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, fix, round, negflag);
+            GPFQ_WAVE_CHAIN(gpfq_gram_resume_wave_kernel, dim3(kFixSlots * 4), dim3(64),
+                            gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, fix, round, negflag);
         else
             hipLaunchKernelGGL(gpfq_gram_resume_kernel, dim3(kFixMax / 64), dim3(64), 0, stream,
                                gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, bs, fix, round, negflag);
     }
+#undef GPFQ_WAVE_CHAIN
     return hipGetLastError();
 }
 
