@@ -92,7 +92,8 @@ size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path);
  *   "lanes_per_neuron"  0 = heuristic, 16/32/64 = row-group kernel with that many lanes per neuron,
  *                  1 = wave-per-neuron kernel
  *   "variant"      bit 0: row-group kernel without the float64 copy of Xq in LDS; bit 1: wide kernel with
- *                  LDS-staged rows instead of register prefetch
+ *                  LDS-staged rows instead of register prefetch; bit 2: Gram records of walks longer than 64
+ *                  steps on the vector units instead of the matrix cores (v_mfma_f64_16x16x4_f64)
  *   "waves_per_neuron"  2..16: force the wide kernel (one neuron over that many wavefronts), 0 = heuristic
  *                  (rows longer than 2048 samples, and layers too narrow to fill the chip)
  *   "gram_slack_log2"   Gram paths: error bounds multiplied by 2^value (tests force the repair/rerun branches)

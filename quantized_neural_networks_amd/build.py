@@ -9,7 +9,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libgpfq_hip.so")
-SOURCES = ["gpfq_capi.hip", "gpfq_onchip.hip", "gpfq_rows.hip", "gpfq_wide.hip", "gpfq_stream.hip", "gpfq_gram.hip", "gpfq_gram_image.hip", "gpfq_gram_conv.hip",
+SOURCES = ["gpfq_capi.hip", "gpfq_onchip.hip", "gpfq_rows.hip", "gpfq_wide.hip", "gpfq_stream.hip", "gpfq_gram.hip", "gpfq_gram_image.hip", "gpfq_gram_conv.hip", "gpfq_gram_mfma.hip",
            "gpfq_misc.hip"]
 HEADERS = ["gpfq_device.hpp", "gpfq_launch.hpp", "gpfq_gram_tile.hpp", os.path.join("..", "..", "include", "gpfq.h")]
 

@@ -670,7 +670,9 @@ size_t gram_workspace_bytes(int64_t N, int64_t m, int64_t C)
 {
     const int64_t rchunks = (m + 1023) / 1024;
     size_t b = 0;
-    b += al256((size_t)gram_parts(N, m) * gram_record(N) * sizeof(double));   // Gram partials
+    int64_t parts = gram_parts(N, m);                                         // either record kernel may be chosen at launch
+    if (N > 64 && gram_mfma_walkers(N, m) > parts) parts = gram_mfma_walkers(N, m);
+    b += al256((size_t)parts * gram_record(N) * sizeof(double));              // Gram partials
     b += al256((size_t)gram_record(N) * sizeof(double) + 8);                  // Gram record
     b += al256((size_t)C * N * sizeof(float));                                // chosen values (f32) per neuron and step
     b += al256(sizeof(FixState));                                             // device-side repair of uncertified chains
@@ -734,11 +736,14 @@ hipError_t launch_gram_decide(const double *gram, const float *nrm32, const floa
 hipError_t launch_gram(const GramArgs &a, hipStream_t stream)
 {
     const int64_t nchunks = (a.m + kGramCH - 1) / kGramCH;
-    const int64_t nblocks = gram_blocks(a.N, a.m), nparts = gram_parts(a.N, a.m);
+    const bool mfma = gram_mfma_supported(a.X, a.Xq, a.ld, a.N) && !(a.variant & 4);     // long walks: matrix cores
+    const int64_t nblocks = gram_blocks(a.N, a.m), nparts = mfma ? gram_mfma_walkers(a.N, a.m) : gram_parts(a.N, a.m);
     const int64_t rchunks = (a.m + 1023) / 1024;
     const int64_t rec = gram_record(a.N);
+    int64_t maxparts = gram_parts(a.N, a.m);
+    if (a.N > 64 && gram_mfma_walkers(a.N, a.m) > maxparts) maxparts = gram_mfma_walkers(a.N, a.m);
     char *ws = static_cast<char *>(a.workspace);
-    double *part = reinterpret_cast<double *>(ws);  ws += al256((size_t)nparts * rec * sizeof(double));
+    double *part = reinterpret_cast<double *>(ws);  ws += al256((size_t)maxparts * rec * sizeof(double));
     double *gram = reinterpret_cast<double *>(ws);  ws += al256((size_t)rec * sizeof(double) + 8);
     float *q32h  = reinterpret_cast<float *>(ws);   ws += al256((size_t)a.C * a.N * sizeof(float));
     void *fixws = ws;                               ws += gram_fix_bytes();
@@ -749,7 +754,10 @@ hipError_t launch_gram(const GramArgs &a, hipStream_t stream)
     if (a.m > 0 && N > 0) {
         hipError_t e0 = hipMemsetAsync(negflag, 0, sizeof(int), stream);
         if (e0 != hipSuccess) return e0;
-        if (N <= 9) {
+        if (mfma) {
+            hipError_t em = launch_gram_mfma(a.X, a.Xq, a.ld, a.N, a.m, part, negflag, stream);
+            if (em != hipSuccess) return em;
+        } else if (N <= 9) {
             hipLaunchKernelGGL(gpfq_gram_rows9_kernel, dim3((unsigned)nblocks), dim3(kGramThreads), 0, stream,
                                a.X, a.Xq, a.ld, N, a.m, part, negflag);
         } else {

@@ -79,11 +79,17 @@ struct GramArgs {
     int32_t *uncertified;   // [C]: 1 = decision chain not certified, rerun through the exact path
     void *workspace;
     double slack = 1.0;     // multiplies the error bounds (tests)
-    int variant = 0;        // tuning hook (unused by the Gram kernels at present)
+    int variant = 0;        // bit 2: records of long walks on the vector units instead of the matrix cores
 };
 
 size_t gram_workspace_bytes(int64_t N, int64_t m, int64_t C);
 hipError_t launch_gram(const GramArgs &a, hipStream_t stream);
+
+// Gram records of long walks (N > 64) on the matrix cores (gpfq_gram_mfma.hip); partial records as gpfq_gram.hip's.
+bool gram_mfma_supported(const float *X, const float *Xq, int64_t ld, int64_t N);
+int64_t gram_mfma_walkers(int64_t N, int64_t m);
+hipError_t launch_gram_mfma(const float *X, const float *Xq, int64_t ld, int64_t N, int64_t m, double *part, int *negflag,
+                            hipStream_t stream);
 
 // Batched decide step (one launch for all channels of a conv shard): element strides per channel.
 struct DecideBatch {

@@ -1,4 +1,4 @@
-"""Randomised parity sweep on the GPU: random dense layers (all on-chip kernels + streaming) and random conv
+"""Randomised parity sweep on the GPU: random dense layers (all on-chip kernels, streaming, Gram path) and random conv
 layers (kernel size, stride, rate, padding, image size, channel / filter counts, alphabets, sparse or signed
 activations) against the CPU oracle, bit for bit.  Not part of the test suite (minutes of GPU time).
 usage: fuzz_parity.py [seconds] [seed]"""
@@ -39,6 +39,8 @@ while time.time() < t_end:
         # ---- dense ------------------------------------------------------------------------
         N = int(rng.integers(1, 200)); C = int(rng.integers(1, 60))
         m = int(rng.choice([rng.integers(1, 300), rng.integers(300, 3000), rng.integers(3000, 30000)]))
+        if rng.random() < 0.15:                     # long walks (Gram path: one wavefront per neuron)
+            N = int(rng.integers(200, 1025)); m = int(rng.integers(1, 2500))
         kind = rng.choice(["relu", "sparse", "signed", "uniform"])
         X = activations((N, m), kind)
         Xq = X if rng.random() < 0.2 else (X + 0.1 * rng.standard_normal((N, m)).astype(np.float32) * (X != 0 if kind == "sparse" else 1)).astype(np.float32)
@@ -49,7 +51,9 @@ while time.time() < t_end:
         W = (rng.standard_normal((N, C)) / np.sqrt(N)).astype(np.float32)
         alphabet, _ = oracle.layer_alphabet(W, np.linspace(-1, 1, M), scalar)
         Qo, io, ro = oracle.layer(W, X, Xq, alphabet)
-        path = int(rng.choice([0, 1, 2])) if m <= hip.GPFQ_ONCHIP_MAX_M else int(rng.choice([0, 2]))
+        path = int(rng.choice([0, 1, 2, 3])) if m <= hip.GPFQ_ONCHIP_MAX_M else int(rng.choice([0, 2, 3]))
+        if N > 200:
+            path = 3
         opts = {}
         if path == 1:
             opts = dict(lanes_per_neuron=int(rng.choice([0, 1, 16, 32, 64])), waves_per_neuron=int(rng.choice([0, 0, 2, 4, 8, 16])),
