@@ -127,10 +127,13 @@ def row_norms(Xq):
     return out
 
 
-def quantize_neurons(X, Xq, Wt, alphabet, nrm32=None, want_u=False, path=GPFQ_PATH_AUTO, want_values=True):
+def quantize_neurons(X, Xq, Wt, alphabet, nrm32=None, want_u=False, path=GPFQ_PATH_AUTO, want_values=True,
+                     want_resid=True):
     """Greedy recurrence for all C neurons (rows of Wt [C][N]) against X, Xq [N][m].
 
     Returns dict(idx=i8 [C][N], Q=f32 [C][N], resid=f64 [C], u=f64 [C][m] or None).
+    want_resid=None: residual norms only where they come for free (the kernels that hold u); the Gram path, which
+    would replay the residual in an extra pass, then returns NaN for them.
     """
     _dev(X, torch.float32, "X"); _dev(Xq, torch.float32, "Xq"); _dev(Wt, torch.float32, "Wt")
     xp, N, m, ld = _rows(X, "X")
@@ -146,7 +149,7 @@ def quantize_neurons(X, Xq, Wt, alphabet, nrm32=None, want_u=False, path=GPFQ_PA
     # step by step whenever the records are affordable (N <= GPFQ_GRAM_MAX_N); the reference's MNIST run is this case
     if path == GPFQ_PATH_GRAM or (path == GPFQ_PATH_AUTO and not want_u and m > GPFQ_GRAM_MIN_M
                                   and N <= GPFQ_GRAM_MAX_N):
-        return _quantize_neurons_gram(X, Xq, Wt, alphabet, nrm32, want_values)
+        return _quantize_neurons_gram(X, Xq, Wt, alphabet, nrm32, want_values, bool(want_resid))
     if nrm32 is None:
         nrm32 = row_norms(Xq)
     _dev(nrm32, torch.float32, "nrm32")
@@ -168,7 +171,7 @@ def quantize_neurons(X, Xq, Wt, alphabet, nrm32=None, want_u=False, path=GPFQ_PA
     return dict(idx=idx, Q=Q, resid=resid, u=u if want_u else None, workspace=None if streaming else ws)
 
 
-def _quantize_neurons_gram(X, Xq, Wt, alphabet, nrm32, want_values=True):
+def _quantize_neurons_gram(X, Xq, Wt, alphabet, nrm32, want_values=True, want_resid=True):
     """Gram-matrix path (short walks over long rows) + exact rerun of the uncertified neurons."""
     xp, N, m, ld = _rows(X, "X")
     xqp, _, _, _ = _rows(Xq, "Xq")
@@ -178,7 +181,8 @@ def _quantize_neurons_gram(X, Xq, Wt, alphabet, nrm32, want_values=True):
     lib = load()
     idx = torch.empty((C, N), dtype=torch.int8, device=dev)
     Q = torch.empty((C, N), dtype=torch.float32, device=dev)
-    resid = torch.empty(C, dtype=torch.float64, device=dev)
+    resid = torch.empty(C, dtype=torch.float64, device=dev) if want_resid else \
+        torch.full((C,), float("nan"), dtype=torch.float64, device=dev)
     unc = torch.empty(C, dtype=torch.int32, device=dev)
     compute_norms = nrm32 is None            # the row norms are the Gram diagonal: no separate pass
     if compute_norms:
@@ -188,8 +192,8 @@ def _quantize_neurons_gram(X, Xq, Wt, alphabet, nrm32, want_values=True):
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = lib.gpfq_quantize_neurons_gram(xp, xqp, ld, nrm32.data_ptr(), 1 if compute_norms else 0, wp, ldw, arr, M, zero_idx, N, m, C,
-                                            idx.data_ptr(), Q.data_ptr(), resid.data_ptr(), unc.data_ptr(),
-                                            ws.data_ptr(), nbytes, _stream())
+                                            idx.data_ptr(), Q.data_ptr(), resid.data_ptr() if want_resid else None,
+                                            unc.data_ptr(), ws.data_ptr(), nbytes, _stream())
     _check(rc, "gpfq_quantize_neurons_gram")
     bad = torch.nonzero(unc).flatten()                    # one sync per call
     if bad.numel():

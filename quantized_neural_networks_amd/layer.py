@@ -96,14 +96,15 @@ def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True):
     X, Xq    f32 [N][m]  feature-major analog / quantized activations (the transposed wX, qX)
     alphabet f64 [M]     the layer alphabet rad * linspace(-1, 1, M)
 
-    Returns dict(Q f32 [N][C], idx i8 [N][C], resid f64 [C]) on every rank.
+    Returns dict(Q f32 [N][C], idx i8 [N][C], resid f64 [C]) on every rank.  want_resid=None: residual norms only
+    where the kernel holds the residual anyway (NaN from the Gram path, which would replay it in an extra pass).
     """
     N, C = W.shape
     world, rank = _group_info(group)
     lo, hi = shard_bounds(C, world, rank)
     Wt = W[:, lo:hi].t().contiguous()                        # neuron-major shard [C_local][N]
     if hi > lo:
-        r = _local_quantize(X, Xq, Wt, alphabet, want_values=False)
+        r = _local_quantize(X, Xq, Wt, alphabet, want_values=False, want_resid=want_resid)
         i_loc, res_loc = r["idx"], r["resid"]
     else:
         i_loc = torch.empty((0, N), dtype=torch.int8, device=W.device)
@@ -116,7 +117,7 @@ def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True):
     else:
         Q, idx = _assemble(all_gather_units(i_loc, C, group).contiguous(), alphabet)
     out = dict(Q=Q, idx=idx)
-    if want_resid:
+    if want_resid is not False:
         out["resid"] = all_gather_units(res_loc, C, group)
     return out
 

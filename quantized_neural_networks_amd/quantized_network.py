@@ -311,7 +311,8 @@ class QuantizedNeuralNetwork:
         self._log("\tQuantizing neurons (in parallel)...")
         tic = time()
         try:
-            out = _layer.quantize_dense(Wd, wX, qX, layer_alphabet, group=self.process_group)
+            # residual norms are diagnostics (last_layer_stats): kept where the kernel holds the residual anyway
+            out = _layer.quantize_dense(Wd, wX, qX, layer_alphabet, group=self.process_group, want_resid=None)
             Q = out["Q"]
         except Exception as exc:
             self._log(f"\t\tLayer {layer_idx} generated an exception: {exc}")
