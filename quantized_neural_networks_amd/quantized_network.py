@@ -72,7 +72,7 @@ class _SliceSequence(_SequenceBase):
 
     def __getitem__(self, idx):
         bx, by = self._slice(idx)
-        return np.array(bx), np.array(by)
+        return np.asarray(bx), np.asarray(by)       # views: the reference copies here (np.array), nothing mutates them
 
 
 class MNISTSequence(_SliceSequence):
@@ -219,7 +219,7 @@ class QuantizedNeuralNetwork:
         if getattr(self, "_raw", None) is None:
             batches = [np.asarray(self.get_data.__getitem__(b)[0]) for b in range(self.get_data.__len__())]
             sizes = [int(a.shape[0]) for a in batches]
-            self._raw = (self._to_device(np.concatenate(batches, axis=0)), sizes)
+            self._raw = (self._to_device(batches[0] if len(batches) == 1 else np.concatenate(batches, axis=0)), sizes)
         return self._raw
 
     @torch.no_grad()

@@ -44,7 +44,7 @@ for it in range(3):
         q.quantize_network()
         torch.cuda.synchronize()
         pr.disable()
-        pstats.Stats(pr).sort_stats("cumulative").print_stats(30)
+        pstats.Stats(pr).sort_stats("tottime").print_stats(25)
     else:
         q.quantize_network()
     torch.cuda.synchronize(); total = time.time() - t0
