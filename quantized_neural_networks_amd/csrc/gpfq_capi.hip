@@ -446,6 +446,7 @@ int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t 
         g.Wt = Wt; g.A = A; g.F = F; g.qidx = qidx; g.Qt = Qt; g.uncertified = uncertified;
         g.workspace = workspace;
         g.slack = std::ldexp(1.0, g_gram_slack_log2);
+        g.variant = g_variant;
         hipError_t e = gpfq::launch_gram_conv(g, static_cast<hipStream_t>(stream));
         return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_conv_channels(implicit)");
     }

@@ -151,6 +151,7 @@ struct ConvGramArgs {
     int32_t *uncertified;         // [nch][F]
     void *workspace;
     double slack = 1.0;
+    int variant = 0;        // bit 2: vector-unit tiles instead of the matrix cores for 16 < kh*kw <= 64
 };
 bool gram_conv_supported(int64_t n, int64_t H, int64_t W, int64_t nch, int kh, int kw, int64_t oh, int64_t ow);
 size_t gram_conv_workspace_bytes(int64_t K, int64_t nch, int64_t F, int64_t m);

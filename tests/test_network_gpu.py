@@ -426,6 +426,10 @@ def test_conv_fused_3x3(oracle_mod, n, H, W, Cin, F, padding, strip, first):
     (25, 30, 30, 2, 3, 3, 3, 1, 2, "SAME", False),       # dilated 3x3
     (150, 24, 20, 2, 3, 2, 2, 2, 1, "VALID", False),     # 2x2 / 2
     (60, 20, 31, 2, 2, 1, 5, 1, 1, "SAME", False),       # 1x5 row kernel
+    (50, 26, 26, 1, 2, 8, 8, 1, 1, "VALID", False),      # 64 rows: four block rows on the matrix cores
+    (40, 24, 30, 1, 2, 3, 11, 1, 1, "SAME", False),      # 33 rows: two block rows + one row on the vector units
+    (40, 24, 30, 2, 2, 5, 7, 1, 1, "SAME", True),        # 35 rows, first layer (one input: G2 = G1)
+    (45, 22, 40, 1, 2, 1, 17, 1, 1, "VALID", False),     # 17 rows
 ])
 def test_conv_implicit_im2col(oracle_mod, n, H, W, Cin, F, kh, kw, stride, rate, padding, first):
     """Kernel shapes other than 3x3/stride-1 gather their patch rows from the channel planes inside the Gram
@@ -446,12 +450,17 @@ def test_conv_implicit_im2col(oracle_mod, n, H, W, Cin, F, kh, kw, stride, rate,
         hip.set_option("conv_fused", 0)
         old = layer.quantize_conv2d(Wd, aw, aq, alphabet, **kwargs)
         hip.set_option("conv_fused", 1)
+        hip.set_option("variant", 4)                        # 16 < kh*kw <= 64: vector-unit tiles instead of the matrix cores
+        vec = layer.quantize_conv2d(Wd, aw, aq, alphabet, **kwargs)
+        hip.set_option("variant", 0)
         hip.set_option("gram_slack_log2", 14)               # some chains repaired on the device, from the planes
         rep = layer.quantize_conv2d(Wd, aw, aq, alphabet, **kwargs)
     finally:
         hip.set_option("conv_fused", 1)
+        hip.set_option("variant", 0)
         hip.set_option("gram_slack_log2", 0)
     assert torch.equal(out["Q"], old["Q"]) and torch.equal(out["idx"], old["idx"])
+    assert torch.equal(out["Q"], vec["Q"]) and torch.equal(out["idx"], vec["idx"])
     assert torch.equal(out["Q"], rep["Q"]) and torch.equal(out["idx"], rep["idx"])
     Q = out["Q"].cpu().numpy()
     for c in range(Cin):
