@@ -141,7 +141,7 @@ gpfq_gram_conv_kernel(ConvParams p)
     tile.store(p.part + ((int64_t)blockIdx.z * p.nparts + walker) * gram_record(p.K), p.K, t0, s0, wave, lane, norms);
 }
 
-// ---- 16 < K <= 64 (5x5, 7x7 kernels): the same records on the matrix cores ------------------------------------
+// ---- 6 <= K <= 64 (strided 3x3, 5x5, 7x7 kernels): the same records on the matrix cores ------------------------
 // The register-tile kernel above gathers the rows of every 8 x 8 tile again (28 tiles x 24 rows for a 7x7 kernel:
 // the gathers, not the FMAs, set its pace).  Here one workgroup keeps ALL K rows of a 128-column chunk in LDS
 // (gathered once, one chunk ahead) and forms the 16 x 16 blocks of the lower triangle with
@@ -346,7 +346,8 @@ gpfq_gram_conv_mfma_kernel(ConvParams p)
     }
 }
 
-static bool conv_mfma_shape(int64_t K) { return K > 16 && K <= 64; }
+// measured against the register-tile kernel: 3x3/2 (K = 9) 37 -> 20 ms, 5x5 18 -> 6 ms, 7x7/2 100 -> 37 ms; 2x2/2 loses (1.7 vs 1.3 ms)
+static bool conv_mfma_shape(int64_t K) { return K >= 6 && K <= 64; }
 
 static int64_t conv_mfma_walkers(int64_t nch, int64_t m)
 {
@@ -441,7 +442,8 @@ hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream)
     p.negflag = negflag;
     if (mfma) {
         const dim3 grid((unsigned)walkers, 1, (unsigned)a.nch);
-        if (K == 17) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<1, true>), grid, dim3(kGramThreads), 0, stream, p);
+        if (K <= 16) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<1, false>), grid, dim3(kGramThreads), 0, stream, p);
+        else if (K == 17) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<1, true>), grid, dim3(kGramThreads), 0, stream, p);
         else if (K <= 32) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<2, false>), grid, dim3(kGramThreads), 0, stream, p);
         else if (K == 33) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<2, true>), grid, dim3(kGramThreads), 0, stream, p);
         else if (K <= 48) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<3, false>), grid, dim3(kGramThreads), 0, stream, p);
