@@ -52,7 +52,7 @@ for it in range(2):
         q.quantize_network()
         torch.cuda.synchronize()
         pr.disable()
-        pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+        pstats.Stats(pr).sort_stats("cumulative").print_stats("quantized_neural_networks_amd|method|built-in", 40)
     else:
         q.quantize_network()
     torch.cuda.synchronize(); total = time.time() - t0
