@@ -47,6 +47,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--samples", type=int, default=25000, help="calibration samples (the reference's quant_train_size)")
     ap.add_argument("--scalars", type=float, nargs="+", default=[2, 3, 4])
+    ap.add_argument("--save-dir", default=None, help="save every quantized model there (the reference's serialized_models/)")
     args = ap.parse_args()
 
     rng = np.random.default_rng(0)
@@ -66,6 +67,10 @@ def main():
         my_quant_net.quantize_network()
         quantization_time = time() - tic
         q_acc = agreement(my_quant_net.quantized_net, y_test, X_test)
+        if args.save_dir:                               # quantize_pretrained_mlp.py:87-95 (save_model of quantized_net)
+            os.makedirs(args.save_dir, exist_ok=True)
+            keras.save_model(my_quant_net.quantized_net,
+                             os.path.join(args.save_dir, f"Quantized_MLP_scaler{params.alphabet_scalar}_bits{params.bits:.3f}"))
 
         # MSQ baseline: same radius as the corresponding GPFQ layer (quantize_pretrained_mlp.py:97-112)
         MSQ_model = keras.clone_model(model)

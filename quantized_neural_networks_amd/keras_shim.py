@@ -456,3 +456,43 @@ def clone_model(net):
     for layer in net.layers:
         clone.add(layer.clone())
     return clone
+
+
+def save_model(model, filepath):
+    """Stand-in for ``tf.keras.models.save_model`` as the reference's drivers call it on ``quantized_net``
+    (quantize_pretrained_mlp.py:87-95, _imagenet.py:180-191): architecture (layer classes + configs) and weights
+    in ONE ``.npz`` file (no pickling; ``load_model`` rebuilds the network on the current device)."""
+    import json
+    arch = dict(input_shape=list(model._input_shape), layers=[dict(cls=l.__class__.__name__, name=l.name, config=l.config())
+                                                              for l in model.layers])
+    arrays = {"__arch__": np.frombuffer(json.dumps(arch).encode("utf-8"), dtype=np.uint8)}
+    for k, layer in enumerate(model.layers):
+        for j, w in enumerate(layer.get_weights()):
+            arrays[f"w{k}_{j}"] = w
+    path = str(filepath)
+    with open(path if path.endswith(".npz") else path + ".npz", "wb") as f:
+        np.savez(f, **arrays)
+
+
+def load_model(filepath, device=None):
+    """Inverse of ``save_model``."""
+    import json
+    path = str(filepath)
+    with np.load(path if path.endswith(".npz") else path + ".npz", allow_pickle=False) as z:
+        arch = json.loads(bytes(z["__arch__"]).decode("utf-8"))
+        known = {c.__name__: c for c in (Dense, Conv2D, DepthwiseConv2D, Flatten, MaxPooling2D, AveragePooling2D,
+                                         ZeroPadding2D, BatchNormalization, Activation, ReLU, Dropout)}
+        net = Sequential(input_shape=tuple(arch["input_shape"]), device=device)
+        for k, spec in enumerate(arch["layers"]):
+            if spec["cls"] not in known:
+                raise ValueError(f"load_model: unknown layer class {spec['cls']!r}")
+            def tup(v):
+                return tuple(tup(e) for e in v) if isinstance(v, list) else v
+            cfg = {key: tup(v) for key, v in spec["config"].items()}
+            layer = known[spec["cls"]](**cfg)
+            layer.name = spec["name"]
+            net.add(layer)
+            n = len(layer._weights)
+            if n:
+                layer.set_weights([z[f"w{k}_{j}"] for j in range(n)])
+    return net

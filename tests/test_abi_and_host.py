@@ -142,6 +142,23 @@ def test_keras_shim_cpu():
                           np.array([[1, 1, 1], [2, 2, 2]], dtype=np.float32))
 
 
+def test_keras_shim_save_and_load(tmp_path):
+    """save_model / load_model (what the drivers do with quantized_net, quantize_pretrained_mlp.py:87-95): one .npz with
+    architecture and weights; the reloaded network predicts the same bits."""
+    import torch
+    from quantized_neural_networks_amd import keras_shim as ks
+    net = ks.Sequential([ks.InputLayer(input_shape=(8, 8, 2)), ks.ZeroPadding2D(((1, 0), (0, 1))),
+                         ks.Conv2D(4, (3, 2), strides=(2, 1), padding="same", activation="relu", use_bias=False),
+                         ks.BatchNormalization(), ks.MaxPooling2D(), ks.Flatten(), ks.Dropout(0.3),
+                         ks.Dense(5, activation="softmax")], device="cpu")
+    x = np.random.default_rng(1).random((3, 8, 8, 2)).astype(np.float32)
+    ks.save_model(net, tmp_path / "quantized_model")
+    again = ks.load_model(tmp_path / "quantized_model", device="cpu")
+    assert [l.name for l in again.layers] == [l.name for l in net.layers]
+    assert all(np.array_equal(a, b) for a, b in zip(again.get_weights(), net.get_weights()))
+    assert torch.equal(again.predict_on_batch(x), net.predict_on_batch(x))
+
+
 def test_activation_capture_host_logic():
     """The cached-frontier capture equals the reference's per-batch recomputation from the input (CPU tensors):
     same column layout including the partial-last-batch quirk, with and without fix_partial_batch, transposed
