@@ -168,6 +168,7 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": _recorded_traffic(N, m, hi - lo),
                 "kernel_ms_avg": k_avg_s * 1e3, "kernel_ms_min": float(np.min(kernel_ms)),
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "valu_floor": _valu_floor(N, m, hi - lo, k_avg_s),
                 "note": "algorithmic bytes = (8m+8) per weight (SURVEY 8d); the 16 neurons of a workgroup share every "
                         "LDS-staged row and u stays in VGPRs, so achieved/peak exceeds 1 and the kernel is bound by "
                         "FP64-rate VALU issue, not HBM (DESIGN.md section 4); `traffic` is the PMC-measured HBM bytes",
@@ -178,6 +179,19 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _valu_floor(N, m, C_local, k_avg_s):
+    """The bound that actually holds: per (weight, sample) the reference's flow needs one f64 FMA
+    (<Xq_t, u>), one f32->f64 convert and one f64 add (u += d), and f32 mul, mul, sub for d.  A wavefront
+    instruction covers 64 elements; measured issue costs on gfx950 (tools/ubench): 5 cycles per f64-rate
+    instruction, 4 per f32 instruction; 1024 SIMDs at 2.4 GHz."""
+    wave_elems = N * C_local * m / 64.0
+    cycles = wave_elems * (3 * 5 + 3 * 4)
+    floor_s = cycles / (1024 * 2.4e9)
+    return {"bound": "valu_issue", "floor_ms": floor_s * 1e3, "frac": floor_s / k_avg_s,
+            "model": "3 f64-rate (5 cycles) + 3 f32 (4 cycles) wavefront instructions per 64 (weight, sample) elements; "
+                     "1024 SIMDs x 2.4 GHz"}
 
 
 def _recorded_traffic(N, m, C_local):
