@@ -72,10 +72,13 @@ while time.time() < t_end:
             bad.append(("dense", N, m, C, M, scalar, kind, path, opts))
     else:
         # ---- conv ---------------------------------------------------------------------------
-        kh = int(rng.choice([1, 2, 3, 3, 3, 5, 7])); kw = kh if rng.random() < 0.8 else int(rng.choice([1, 2, 3, 5]))
+        kh = int(rng.choice([1, 2, 3, 3, 3, 4, 5, 6, 7, 8])); kw = kh if rng.random() < 0.7 else int(rng.choice([1, 2, 3, 5, 7, 11, 17]))
+        if kh * kw > 64:
+            kw = 64 // kh
         stride = int(rng.choice([1, 1, 1, 2])); rate = int(rng.choice([1, 1, 1, 2])) if stride == 1 else 1
         padding = str(rng.choice(["SAME", "VALID"]))
-        H = int(rng.integers(max(kh + (kh - 1) * (rate - 1), 4), 30)); Wd = int(rng.integers(max(kw + (kw - 1) * (rate - 1), 4), 30))
+        lo_h, lo_w = max(kh + (kh - 1) * (rate - 1), 4), max(kw + (kw - 1) * (rate - 1), 4)
+        H = int(rng.integers(lo_h, max(30, lo_h + 4))); Wd = int(rng.integers(lo_w, max(30, lo_w + 4)))
         cin = int(rng.integers(1, 6)); F = int(rng.integers(1, 7))
         oh, ow = hip.patch_out_dim(H, kh, stride, rate, padding == "SAME"), hip.patch_out_dim(Wd, kw, stride, rate, padding == "SAME")
         if oh * ow == 0:
