@@ -147,6 +147,9 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
  *   compute_norms != 0: nrm32 is an OUTPUT, filled with (float)sqrt(<Xq_t,Xq_t>) from the Gram diagonal (the
  *   row norms come for free here; pass the same array on to the rerun of flagged neurons); else an input.
  *   Option "gram_slack_log2" (gpfq_set_option) multiplies the error bounds by 2^value (tests).
+ *   Walks longer than 64 steps (dense layers: the reference's MNIST run, 25000 samples per row) build their
+ *   records on the matrix cores (v_mfma_f64_16x16x4_f64; needs ld % 4 == 0 and 16-byte aligned X, Xq, otherwise
+ *   the vector-unit kernel runs) and walk them with one wavefront per neuron.
  */
 #define GPFQ_GRAM_MAX_N 1024
 size_t gpfq_gram_workspace_bytes(int64_t N, int64_t m, int64_t C);
@@ -242,8 +245,9 @@ int gpfq_channel_planes(const float *act, int64_t npos, int64_t Cin, int64_t c_l
  *   Needs kh*kw <= GPFQ_GRAM_MAX_N and n*oh*ow < 2^30.
  * When resid == NULL no patch matrix is materialised: row t = (ky, kx) of a patch matrix is the channel
  * plane sampled at (oy*sh + ky*rh - pad_top, ox*sw + kx*rw - pad_left), so the Gram records of all channels
- * are accumulated straight from the planes in one launch (a plane-correlation kernel for 3x3 / stride 1,
- * the register-tile kernel with implicit im2col for every other shape), followed by one batched decide
+ * are accumulated straight from the planes in one launch (a plane-correlation kernel for 3x3 / stride 1;
+ * implicit im2col for every other shape: 16x16 blocks on the matrix cores for 6 <= kh*kw <= 64 -- strided 3x3,
+ * 5x5, 7x7 --, register tiles on the vector units otherwise), followed by one batched decide
  * launch and the device-side repair of uncertified chains (option "conv_fused" = 0 switches back to the
  * per-channel patch matrices; results are identical).
  * The workspace size depends on whether resid is requested (want_resid = resid != NULL).
