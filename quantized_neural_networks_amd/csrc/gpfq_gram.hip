@@ -173,6 +173,26 @@ gpfq_gram_reduce_kernel(const double *__restrict__ part, int64_t nparts, int N, 
     }
 }
 
+// Few partial records (long walks: a dozen column walkers, records of 10^6 entries): one THREAD per entry, the
+// partials summed in record order; neighbouring threads read neighbouring entries.
+__global__ void __launch_bounds__(256)
+gpfq_gram_reduce_few_kernel(const double *__restrict__ part, int nparts, int N, double *__restrict__ gram,
+                            float *__restrict__ nrm32)
+{
+    const int64_t rec = gram_record(N);
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= rec) return;
+    part += (int64_t)blockIdx.y * nparts * rec;
+    gram += (int64_t)blockIdx.y * rec;
+    int t = -1, s = -1, k = -1;
+    if (e < (int64_t)N * N * 2) { k = (int)(e & 1); t = (int)((e >> 1) / N); s = (int)((e >> 1) - (int64_t)t * N); }
+    double v = 0.0;
+    if (s <= t)
+        for (int c = 0; c < nparts; ++c) v += part[c * rec + e];
+    gram[e] = v;
+    if (nrm32 && t >= 0 && s == t && k == 1) nrm32[(int64_t)blockIdx.y * N + t] = (float)sqrt(v);
+}
+
 // The N-step recurrence of one neuron on a Gram record with certified decisions.  Returns 0 when every
 // decision was certified, else 1 + the step that could not be.  t0 >= 0 resumes a chain that stopped at step
 // t0: steps before it take the recorded decisions (qh), step t0 takes the EXACT decision from the two
@@ -684,6 +704,11 @@ hipError_t launch_gram_reduce(const double *part, int64_t nparts, int N, double 
                               hipStream_t stream)
 {
     if (nch == 0 || N == 0) return hipSuccess;
+    if (nparts <= 32) {
+        hipLaunchKernelGGL(gpfq_gram_reduce_few_kernel, dim3((unsigned)((gram_record(N) + 255) / 256), (unsigned)nch), dim3(256), 0,
+                           stream, part, (int)nparts, N, gram, nrm32);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(gpfq_gram_reduce_kernel, dim3((unsigned)((gram_record(N) + 3) / 4), (unsigned)nch), dim3(256), 0, stream,
                        part, nparts, N, gram, nrm32);
     return hipGetLastError();

@@ -147,8 +147,10 @@ def quantize_neurons(X, Xq, Wt, alphabet, nrm32=None, want_u=False, path=GPFQ_PA
     dev = X.device
     # rows beyond GPFQ_GRAM_MIN_M samples: the Gram path (N x N records + scalar recurrences) beats walking such rows
     # step by step whenever the records are affordable (N <= GPFQ_GRAM_MAX_N); the reference's MNIST run is this case
-    if path == GPFQ_PATH_GRAM or (path == GPFQ_PATH_AUTO and not want_u and m > GPFQ_GRAM_MIN_M
-                                  and N <= GPFQ_GRAM_MAX_N):
+    # (measured, tools/dense_path_probe.py: with many neurons the crossover already comes at about 8192 samples --
+    # N = 128, C = 1000, m = 8192: 0.94 ms on chip, 0.41 ms here; N = 784, C = 500, m = 12288: 5.5 vs 4.0 ms)
+    long_rows = m > GPFQ_GRAM_MIN_M or (m > GPFQ_GRAM_MIN_M // 2 and C * m >= 5_000_000)
+    if path == GPFQ_PATH_GRAM or (path == GPFQ_PATH_AUTO and not want_u and long_rows and N <= GPFQ_GRAM_MAX_N):
         return _quantize_neurons_gram(X, Xq, Wt, alphabet, nrm32, want_values, bool(want_resid))
     if nrm32 is None:
         nrm32 = row_norms(Xq)
