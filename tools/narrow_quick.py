@@ -1,5 +1,5 @@
 """Narrow dense layers with long rows (cfg4's Dense(2048->128), m = 5008): wavefronts per neuron and the
-direct (register-prefetch) mode of the wide kernel against its LDS-staged mode (variant bit 2).
+direct (register-prefetch) mode of the wide kernel against its LDS-staged mode (option variant = 2, i.e. bit 1).
 usage: narrow_quick.py [N m C M]"""
 import sys, time
 import numpy as np, torch
