@@ -722,6 +722,13 @@ hipError_t launch_gram_decide(const double *gram, const float *nrm32, const floa
                               hipStream_t stream)
 {
     if (C == 0 || bs.nch == 0) return hipSuccess;
+    // The kernels' c = 2^-22 leaves a factor 2 for float64 accumulation chains of any length (m < 2^30).  Rows of up
+    // to 2^18 samples and walks of up to 1024 steps need far less: the float32 roundings of one step are bounded by
+    // (2^-23 + 2^-48)(|w x| + |q xq|) per element, and every float64 chain involved (residual: t terms; exact dot
+    // products: < 2^15; Gram entries and their reduction: <= m; the sums of the decide step: < 2^5) contributes at
+    // most 2^-53 of the same bound per term -- below 2^-34 in all, against the 2^-31 that c = 2^-23 (1 + 2^-8) keeps.
+    // Half as many uncertified steps: the repair rounds were 70 % of a 16-level 784-step layer.
+    if (src && src->m > 0 && src->m <= (1 << 18) && N <= 1024) slack *= 0.5 * (1.0 + 0x1p-8);
     FixState *fix = (src && fix_ws && src->m > 0 && bs.nch * C < (1LL << 31)) ? static_cast<FixState *>(fix_ws) : nullptr;
     if (fix) {
         hipError_t e = hipMemsetAsync(fix, 0, sizeof(int32_t) * (kFixRoundsLong + 1), stream);
