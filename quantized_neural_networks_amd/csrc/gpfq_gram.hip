@@ -13,7 +13,8 @@
 //     |error| <= c * B_t,   B_t = sum_{s<t} ( |w_s| <|Xq_t|,|X_s|> + |q_s| <|Xq_t|,|Xq_s|> ),   c = 2^-22
 // (2^-24 for each product and 2^-24 of their sum for the subtraction: 2^-23 B_t; the float64 accumulation
 // of u and of the dot products with m < 2^30 is orders below that; a factor 2 of slack; products that
-// round in the subnormal range add at most 2^-128 ||Xq_t||).  The absolute inner products are bounded by
+// round in the subnormal range add at most 2^-128 ||Xq_t||; launch_gram_decide spends the factor 2 only where
+// rows can be that long and uses c = 2^-23 (1 + 2^-8) for m <= 2^18).  The absolute inner products are bounded by
 // Cauchy-Schwarz, <|a|,|b|> <= ||a|| ||b||, so B_t <= ||Xq_t|| * sum_{s<t} ( |w_s| ||X_s|| + |q_s| ||Xq_s|| )
 // needs nothing beyond the diagonal of G2 and nx2.  A decision is accepted only if the predicted
 // quotient is farther from every decision boundary of the alphabet than that bound allows
