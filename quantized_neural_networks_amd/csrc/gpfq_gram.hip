@@ -390,8 +390,10 @@ __device__ __forceinline__ int decide_chain_wave(const double *__restrict__ gram
             for (int i = 0; i < PER; ++i)
                 if (64 * i < t) {                                                     // wave-uniform
                     const int s = lane + 64 * i;
-                    const float wv = wl[s], qv = ql[s];                               // unconditional reads: no branch
-                    const double ws = s < t ? (double)wv : 0.0, qs = s < t ? (double)qv : 0.0;
+                    // unconditional reads (no branch); q of the steps not taken yet is still 0 in LDS, only w needs the mask
+                    const float wraw = wl[s], qv = ql[s];
+                    const float wv = s < t ? wraw : 0.f;
+                    const double ws = (double)wv, qs = (double)qv;
                     acc += ws * g0[i] - qs * g1[i];
                     B += fabs(ws) * g0[i] + fabs(qs) * g1[i];
                 }
