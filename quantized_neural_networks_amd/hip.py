@@ -127,6 +127,21 @@ def row_norms(Xq):
     return out
 
 
+def auto_path(N, m, C, want_u=False):
+    """What GPFQ_PATH_AUTO resolves to for C neurons of N weights over rows of m samples.
+
+    Rows beyond GPFQ_GRAM_MIN_M samples: the Gram path (N x N records + scalar recurrences) beats walking such rows
+    step by step whenever the records are affordable (N <= GPFQ_GRAM_MAX_N); the reference's MNIST run is this case.
+    Measured (tools/dense_path_probe.py): with many neurons the crossover already comes at about 8192 samples --
+    N = 128, C = 1000, m = 8192: 0.94 ms on chip, 0.41 ms there; N = 784, C = 500, m = 12288: 5.5 vs 4.0 ms.
+    Otherwise the residual stays on chip up to GPFQ_ONCHIP_MAX_M samples and streams through HBM beyond
+    (the library chooses between those two itself)."""
+    long_rows = m > GPFQ_GRAM_MIN_M or (m > GPFQ_GRAM_MIN_M // 2 and C * m >= 5_000_000)
+    if not want_u and long_rows and N <= GPFQ_GRAM_MAX_N:
+        return GPFQ_PATH_GRAM
+    return GPFQ_PATH_ONCHIP if m <= GPFQ_ONCHIP_MAX_M else GPFQ_PATH_STREAM
+
+
 def quantize_neurons(X, Xq, Wt, alphabet, nrm32=None, want_u=False, path=GPFQ_PATH_AUTO, want_values=True,
                      want_resid=True):
     """Greedy recurrence for all C neurons (rows of Wt [C][N]) against X, Xq [N][m].
@@ -145,12 +160,7 @@ def quantize_neurons(X, Xq, Wt, alphabet, nrm32=None, want_u=False, path=GPFQ_PA
         raise GpfqError("X and Xq must share one row pitch")
     arr, M, zero_idx = _alphabet(alphabet)
     dev = X.device
-    # rows beyond GPFQ_GRAM_MIN_M samples: the Gram path (N x N records + scalar recurrences) beats walking such rows
-    # step by step whenever the records are affordable (N <= GPFQ_GRAM_MAX_N); the reference's MNIST run is this case
-    # (measured, tools/dense_path_probe.py: with many neurons the crossover already comes at about 8192 samples --
-    # N = 128, C = 1000, m = 8192: 0.94 ms on chip, 0.41 ms here; N = 784, C = 500, m = 12288: 5.5 vs 4.0 ms)
-    long_rows = m > GPFQ_GRAM_MIN_M or (m > GPFQ_GRAM_MIN_M // 2 and C * m >= 5_000_000)
-    if path == GPFQ_PATH_GRAM or (path == GPFQ_PATH_AUTO and not want_u and long_rows and N <= GPFQ_GRAM_MAX_N):
+    if path == GPFQ_PATH_GRAM or (path == GPFQ_PATH_AUTO and auto_path(N, m, C, want_u) == GPFQ_PATH_GRAM):
         return _quantize_neurons_gram(X, Xq, Wt, alphabet, nrm32, want_values, bool(want_resid))
     if nrm32 is None:
         nrm32 = row_norms(Xq)

@@ -71,6 +71,22 @@ def test_product_does_not_import_oracle():
                 assert "gpfq_oracle" not in src, f
 
 
+def test_auto_path_choice():
+    """What GPFQ_PATH_AUTO resolves to (host logic only): on chip for rows that fit, Gram records for long rows with
+    affordable walks (the reference's MNIST run), streaming for the rest."""
+    from quantized_neural_networks_amd import hip
+    ON, ST, GR = hip.GPFQ_PATH_ONCHIP, hip.GPFQ_PATH_STREAM, hip.GPFQ_PATH_GRAM
+    assert hip.auto_path(4096, 1024, 4096) == ON                  # cfg2
+    assert hip.auto_path(784, 512, 128) == ON                     # cfg1
+    assert hip.auto_path(2048, 5008, 128) == ON                   # cfg4's dense head: walk too long for records
+    assert hip.auto_path(784, 25000, 500) == GR                   # the MNIST MLP run: 25000 samples per row
+    assert hip.auto_path(9, 5128192, 32) == GR                    # a conv channel's patch matrix
+    assert hip.auto_path(128, 8193, 1000) == GR and hip.auto_path(128, 8193, 100) == ON     # wide layers cross over earlier
+    assert hip.auto_path(4096, 50000, 64) == ST                   # long rows AND long walks
+    assert hip.auto_path(784, 25000, 500, want_u=True) == ON      # residual vectors wanted: the kernels that hold u
+    assert hip.auto_path(784, 40000, 500, want_u=True) == ST
+
+
 def test_shard_bounds():
     from quantized_neural_networks_amd.layer import shard_bounds
     for n, w in [(4096, 8), (1000, 8), (3, 8), (10, 4), (0, 2)]:
