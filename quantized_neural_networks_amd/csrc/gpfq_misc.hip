@@ -183,10 +183,35 @@ gpfq_planes_kernel(const float *__restrict__ act, int64_t npos, int64_t Cin, int
     }
 }
 
+// Few channels in all (image inputs: 1..4): the LDS tile would be nearly empty -- one thread per position instead,
+// its CIN values read as one contiguous group, every plane written along the positions.
+template <int CIN>
+__global__ void __launch_bounds__(256)
+gpfq_planes_few_kernel(const float *__restrict__ act, int64_t npos, float *__restrict__ planes)
+{
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npos; p += (int64_t)gridDim.x * 256) {
+        float v[CIN];
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) v[c] = act[p * CIN + c];
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) planes[(int64_t)c * npos + p] = v[c];
+    }
+}
+
 hipError_t launch_channel_planes(const float *act, int64_t npos, int64_t Cin, int64_t c_lo, int64_t nch, float *planes,
                                  hipStream_t stream)
 {
     if (npos == 0 || nch == 0) return hipSuccess;
+    if (c_lo == 0 && nch == Cin && Cin <= 4) {
+        int64_t blocks = (npos + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        const dim3 grid((unsigned)blocks);
+        if (Cin == 1) hipLaunchKernelGGL(gpfq_planes_few_kernel<1>, grid, dim3(256), 0, stream, act, npos, planes);
+        else if (Cin == 2) hipLaunchKernelGGL(gpfq_planes_few_kernel<2>, grid, dim3(256), 0, stream, act, npos, planes);
+        else if (Cin == 3) hipLaunchKernelGGL(gpfq_planes_few_kernel<3>, grid, dim3(256), 0, stream, act, npos, planes);
+        else hipLaunchKernelGGL(gpfq_planes_few_kernel<4>, grid, dim3(256), 0, stream, act, npos, planes);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(gpfq_planes_kernel, dim3((unsigned)((npos + 255) / 256), (unsigned)((nch + 31) / 32)), dim3(256), 0, stream,
                        act, npos, Cin, c_lo, nch, planes);
     return hipGetLastError();
