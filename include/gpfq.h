@@ -260,6 +260,28 @@ int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t 
                                 int8_t *qidx, float *Qt, double *resid, int32_t *uncertified,
                                 void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * The same call in two halves, for layers with fewer input channels than GPUs (an image input has 3): the Gram
+ * records are SUMS over the patch columns, so every GPU forms them over its share of the images
+ * (gpfq_conv_channel_records on the planes of those images), the records are summed over the GPUs (an all-reduce of
+ * nch * (K*K*2 + K) doubles, K = kh*kw; the flags by maximum) and every GPU finishes from the summed records
+ * (gpfq_quantize_conv_channels_from_records on the planes of ALL images, which the repair of uncertified chains
+ * reads).  Certified decisions do not depend on the order in which the records were summed, so the results are
+ * those of the one-call form.
+ *   records [device] f64 [nch][K*K*2 + K], negflags [device] i32 [nch]; workspace as for
+ *   gpfq_quantize_conv_channels with want_resid = 0 (F = 0 for the records half).
+ *   GPFQ_ERR_UNSUPPORTED for kernel shapes that need patch matrices in memory (kh*kw > 256 ...): shard by channel.
+ */
+int gpfq_conv_channel_records(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,
+                              int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
+                              double *records, int32_t *negflags, void *workspace, size_t workspace_bytes, void *stream);
+int gpfq_quantize_conv_channels_from_records(const double *records, const int32_t *negflags,
+                                             const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,
+                                             int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
+                                             const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
+                                             int8_t *qidx, float *Qt, int32_t *uncertified,
+                                             void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -400,22 +400,29 @@ size_t gpfq_conv_channels_workspace_bytes(int64_t n, int64_t H, int64_t W, int64
     return 2 * al256c((size_t)K * ldp * sizeof(float)) + al256c((size_t)K * sizeof(float)) + gpfq::gram_workspace_bytes(K, cols, F);
 }
 
-int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,
-                                int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
-                                const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
-                                int8_t *qidx, float *Qt, double *resid, int32_t *uncertified,
-                                void *workspace, size_t workspace_bytes, void *stream)
+// phase 0: the whole channel loop; 1: Gram records only (-> records, negflags); 2: decide from given records
+static int conv_channels_impl(int phase, double *records, int32_t *negflags,
+                              const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,
+                              int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
+                              const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
+                              int8_t *qidx, float *Qt, double *resid, int32_t *uncertified,
+                              void *workspace, size_t workspace_bytes, void *stream)
 {
     if (n < 0 || H <= 0 || W <= 0 || nch < 0 || F < 0) return fail(GPFQ_ERR_INVALID_ARG, "bad shape");
     if (kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || rh <= 0 || rw <= 0) return fail(GPFQ_ERR_INVALID_ARG, "bad kernel/stride/rate");
-    gpfq::AlphabetArg A;
-    int rc = make_alphabet(alphabet, M, zero_idx, &A);
-    if (rc != GPFQ_OK) return rc;
+    gpfq::AlphabetArg A{};
+    if (phase != 1) {
+        int rc = make_alphabet(alphabet, M, zero_idx, &A);
+        if (rc != GPFQ_OK) return rc;
+    }
     const int64_t oh = gpfq_patch_out_dim(H, kh, sh, rh, same_padding), ow = gpfq_patch_out_dim(W, kw, sw, rw, same_padding);
     const int64_t cols = n * oh * ow, K = (int64_t)kh * kw;
-    if (nch == 0 || F == 0 || cols == 0) return GPFQ_OK;
+    if (phase && (!records || !negflags)) return fail(GPFQ_ERR_INVALID_ARG, "NULL records / negflags");
+    if (nch == 0 || (F == 0 && phase != 1) || cols == 0) return GPFQ_OK;
     if (K > GPFQ_GRAM_MAX_N || cols >= (1LL << 30)) return fail(GPFQ_ERR_UNSUPPORTED, "needs kh*kw <= %d and n*oh*ow < 2^30", GPFQ_GRAM_MAX_N);
-    if (!act_w || !act_q || !Wt || !qidx || !Qt || !uncertified) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    if (!act_w || !act_q) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    if (phase != 1 && (!Wt || !qidx || !Qt || !uncertified)) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    if (phase && resid) return fail(GPFQ_ERR_UNSUPPORTED, "residual norms need the whole call");
     const size_t need = gpfq_conv_channels_workspace_bytes(n, H, W, nch, kh, kw, sh, sw, rh, rw, same_padding, F, resid != nullptr);
     if (!workspace || workspace_bytes < need || (uintptr_t)workspace % 16 != 0)
         return fail(GPFQ_ERR_WORKSPACE, "conv channel loop needs %zu aligned workspace bytes", need);
@@ -427,6 +434,7 @@ int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t 
         g.workspace = workspace;
         g.slack = std::ldexp(1.0, g_gram_slack_log2);
         g.variant = g_conv_strip;
+        g.phase = phase; g.records = records; g.negflags = negflags;
         hipError_t e = gpfq::launch_gram_image(g, static_cast<hipStream_t>(stream));
         return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_conv_channels(fused)");
     }
@@ -447,9 +455,11 @@ int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t 
         g.workspace = workspace;
         g.slack = std::ldexp(1.0, g_gram_slack_log2);
         g.variant = g_variant;
+        g.phase = phase; g.records = records; g.negflags = negflags;
         hipError_t e = gpfq::launch_gram_conv(g, static_cast<hipStream_t>(stream));
         return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_conv_channels(implicit)");
     }
+    if (phase) return fail(GPFQ_ERR_UNSUPPORTED, "records in / out need a kernel shape the plane kernels take");
     const int64_t ldp = (cols + 3) & ~(int64_t)3;
     char *ws = static_cast<char *>(workspace);
     float *Pw = reinterpret_cast<float *>(ws);   ws += al256c((size_t)K * ldp * sizeof(float));
@@ -477,6 +487,36 @@ int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t 
         if (e != hipSuccess) return hip_fail(e, "gpfq_quantize_conv_channels(gram)");
     }
     return GPFQ_OK;
+}
+
+int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,
+                                int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
+                                const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
+                                int8_t *qidx, float *Qt, double *resid, int32_t *uncertified,
+                                void *workspace, size_t workspace_bytes, void *stream)
+{
+    return conv_channels_impl(0, nullptr, nullptr, act_w, act_q, n, H, W, nch, kh, kw, sh, sw, rh, rw, same_padding, Wt, alphabet, M,
+                              zero_idx, F, qidx, Qt, resid, uncertified, workspace, workspace_bytes, stream);
+}
+
+int gpfq_conv_channel_records(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,
+                              int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
+                              double *records, int32_t *negflags, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return conv_channels_impl(1, records, negflags, act_w, act_q, n, H, W, nch, kh, kw, sh, sw, rh, rw, same_padding, nullptr, nullptr, 0,
+                              -1, 0, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+int gpfq_quantize_conv_channels_from_records(const double *records, const int32_t *negflags,
+                                             const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,
+                                             int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
+                                             const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
+                                             int8_t *qidx, float *Qt, int32_t *uncertified,
+                                             void *workspace, size_t workspace_bytes, void *stream)
+{
+    return conv_channels_impl(2, const_cast<double *>(records), const_cast<int32_t *>(negflags), act_w, act_q, n, H, W, nch, kh, kw, sh, sw,
+                              rh, rw, same_padding, Wt, alphabet, M, zero_idx, F, qidx, Qt, nullptr, uncertified, workspace,
+                              workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -405,7 +405,7 @@ static void decompose(int64_t v, int64_t oh, int64_t ow, int (&d)[3])
 
 hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream)
 {
-    if (a.nch == 0 || a.F == 0) return hipSuccess;
+    if (a.nch == 0 || (a.F == 0 && a.phase != 1)) return hipSuccess;
     const int64_t K = (int64_t)a.kh * a.kw, m = a.n * a.oh * a.ow;
     if (!gram_conv_supported(a.n, a.H, a.W, a.nch, a.kh, a.kw, a.oh, a.ow)) return hipErrorInvalidValue;
     const bool mfma = conv_mfma_shape(K) && !(a.variant & 4);
@@ -440,23 +440,36 @@ hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream)
     if (e0 != hipSuccess) return e0;
     p.part = part;
     p.negflag = negflag;
-    if (mfma) {
-        const dim3 grid((unsigned)walkers, 1, (unsigned)a.nch);
-        if (K <= 16) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<1, false>), grid, dim3(kGramThreads), 0, stream, p);
-        else if (K == 17) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<1, true>), grid, dim3(kGramThreads), 0, stream, p);
-        else if (K <= 32) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<2, false>), grid, dim3(kGramThreads), 0, stream, p);
-        else if (K == 33) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<2, true>), grid, dim3(kGramThreads), 0, stream, p);
-        else if (K <= 48) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<3, false>), grid, dim3(kGramThreads), 0, stream, p);
-        else if (K == 49) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<3, true>), grid, dim3(kGramThreads), 0, stream, p);
-        else hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<4, false>), grid, dim3(kGramThreads), 0, stream, p);
+    hipError_t e;
+    if (a.phase == 2) {                                    // records formed elsewhere (and summed over the column shards)
+        e = hipMemcpyAsync(negflag, a.negflags, (size_t)a.nch * sizeof(int), hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return e;
+        e = launch_gram_reduce(a.records, 1, (int)K, gram, nrm, a.nch, stream);
+        if (e != hipSuccess) return e;
     } else {
-        hipLaunchKernelGGL((gpfq_gram_conv_kernel<kConvTB, kConvSB>),
-                           dim3((unsigned)tile_count<kConvTB, kConvSB>((int)K), (unsigned)nparts, (unsigned)a.nch), dim3(kGramThreads), 0, stream, p);
+        if (mfma) {
+            const dim3 grid((unsigned)walkers, 1, (unsigned)a.nch);
+            if (K <= 16) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<1, false>), grid, dim3(kGramThreads), 0, stream, p);
+            else if (K == 17) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<1, true>), grid, dim3(kGramThreads), 0, stream, p);
+            else if (K <= 32) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<2, false>), grid, dim3(kGramThreads), 0, stream, p);
+            else if (K == 33) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<2, true>), grid, dim3(kGramThreads), 0, stream, p);
+            else if (K <= 48) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<3, false>), grid, dim3(kGramThreads), 0, stream, p);
+            else if (K == 49) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<3, true>), grid, dim3(kGramThreads), 0, stream, p);
+            else hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<4, false>), grid, dim3(kGramThreads), 0, stream, p);
+        } else {
+            hipLaunchKernelGGL((gpfq_gram_conv_kernel<kConvTB, kConvSB>),
+                               dim3((unsigned)tile_count<kConvTB, kConvSB>((int)K), (unsigned)nparts, (unsigned)a.nch), dim3(kGramThreads), 0, stream, p);
+        }
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        e = launch_gram_reduce(part, nparts, (int)K, gram, nrm, a.nch, stream);
+        if (e != hipSuccess) return e;
+        if (a.phase == 1) {
+            e = hipMemcpyAsync(a.records, gram, (size_t)a.nch * gram_record(K) * sizeof(double), hipMemcpyDeviceToDevice, stream);
+            if (e != hipSuccess) return e;
+            return hipMemcpyAsync(a.negflags, negflag, (size_t)a.nch * sizeof(int), hipMemcpyDeviceToDevice, stream);
+        }
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    e = launch_gram_reduce(part, nparts, (int)K, gram, nrm, a.nch, stream);
-    if (e != hipSuccess) return e;
     DecideBatch bs;
     bs.nch = a.nch; bs.gram_cs = gram_record(K); bs.nrm_cs = K; bs.w_cs = a.F * K; bs.out_cs = a.F * K; bs.unc_cs = a.F;
     bs.hist_cs = a.F * K;

@@ -256,7 +256,7 @@ size_t gram_image_workspace_bytes(int64_t nch, int64_t F)
 
 hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream)
 {
-    if (a.nch == 0 || a.F == 0) return hipSuccess;
+    if (a.nch == 0 || (a.F == 0 && a.phase != 1)) return hipSuccess;
     ImgParams p;
     int S;
     size_t lds;
@@ -281,20 +281,33 @@ hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream)
     float *q32h = reinterpret_cast<float *>(ws);    ws += al256i((size_t)a.nch * a.F * 9 * sizeof(float));
     void *fixws = ws;                               ws += gram_fix_bytes();
     int *negflag = reinterpret_cast<int *>(ws);
-    hipError_t e0 = hipMemsetAsync(negflag, 0, (size_t)a.nch * sizeof(int), stream);
-    if (e0 != hipSuccess) return e0;
-    p.part = part;
-    p.negflag = negflag;
-    const dim3 grid((unsigned)nbx, (unsigned)a.nch), block(kImgThreads);
-    switch (S) {
-    case 4:  hipLaunchKernelGGL(gpfq_gram_image_kernel<4>, grid, block, lds, stream, p); break;
-    case 2:  hipLaunchKernelGGL(gpfq_gram_image_kernel<2>, grid, block, lds, stream, p); break;
-    default: hipLaunchKernelGGL(gpfq_gram_image_kernel<1>, grid, block, lds, stream, p); break;
+    hipError_t e;
+    if (a.phase == 2) {                                    // records formed elsewhere (and summed over the column shards)
+        e = hipMemcpyAsync(negflag, a.negflags, (size_t)a.nch * sizeof(int), hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return e;
+        e = launch_gram_reduce(a.records, 1, 9, gram, nrm, a.nch, stream);
+        if (e != hipSuccess) return e;
+    } else {
+        hipError_t e0 = hipMemsetAsync(negflag, 0, (size_t)a.nch * sizeof(int), stream);
+        if (e0 != hipSuccess) return e0;
+        p.part = part;
+        p.negflag = negflag;
+        const dim3 grid((unsigned)nbx, (unsigned)a.nch), block(kImgThreads);
+        switch (S) {
+        case 4:  hipLaunchKernelGGL(gpfq_gram_image_kernel<4>, grid, block, lds, stream, p); break;
+        case 2:  hipLaunchKernelGGL(gpfq_gram_image_kernel<2>, grid, block, lds, stream, p); break;
+        default: hipLaunchKernelGGL(gpfq_gram_image_kernel<1>, grid, block, lds, stream, p); break;
+        }
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        e = launch_gram_reduce(part, nbx * 2, 9, gram, nrm, a.nch, stream);
+        if (e != hipSuccess) return e;
+        if (a.phase == 1) {
+            e = hipMemcpyAsync(a.records, gram, (size_t)a.nch * kRec9 * sizeof(double), hipMemcpyDeviceToDevice, stream);
+            if (e != hipSuccess) return e;
+            return hipMemcpyAsync(a.negflags, negflag, (size_t)a.nch * sizeof(int), hipMemcpyDeviceToDevice, stream);
+        }
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    e = launch_gram_reduce(part, nbx * 2, 9, gram, nrm, a.nch, stream);
-    if (e != hipSuccess) return e;
     DecideBatch bs;
     bs.nch = a.nch; bs.gram_cs = kRec9; bs.nrm_cs = 9; bs.w_cs = a.F * 9; bs.out_cs = a.F * 9; bs.unc_cs = a.F; bs.hist_cs = a.F * 9;
     FixSrc src{};

@@ -135,6 +135,11 @@ struct ImageGramArgs {
     void *workspace;
     double slack = 1.0;
     int variant = 0;              // tuning hook: forces the strip length (1, 2, 4)
+    // phase 1: stop after the Gram records (written to `records` [nch][171] f64 and `negflags` [nch] i32);
+    // phase 2: take the records from there instead of forming them (column-sharded multi-GPU runs sum them in between)
+    int phase = 0;
+    double *records = nullptr;
+    int32_t *negflags = nullptr;
 };
 // Any other kernel shape / stride / rate (gpfq_gram_conv.hip): the register-tile Gram kernel with implicit
 // im2col staging from the channel planes, all channels of the shard in one launch, then the batched decide.
@@ -152,6 +157,9 @@ struct ConvGramArgs {
     void *workspace;
     double slack = 1.0;
     int variant = 0;        // bit 2: vector-unit tiles instead of the matrix cores for 16 < kh*kw <= 64
+    int phase = 0;          // as ImageGramArgs: 1 = records only, 2 = from records ([nch][K*K*2 + K] f64, [nch] i32)
+    double *records = nullptr;
+    int32_t *negflags = nullptr;
 };
 bool gram_conv_supported(int64_t n, int64_t H, int64_t W, int64_t nch, int kh, int kw, int64_t oh, int64_t ow);
 size_t gram_conv_workspace_bytes(int64_t K, int64_t nch, int64_t F, int64_t m);

@@ -38,6 +38,10 @@ SYMBOLS = {
     "gpfq_conv_channels_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _i64, _int]),
     "gpfq_quantize_conv_channels": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int,
                                            _vp, _dp, _int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gpfq_conv_channel_records": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int,
+                                         _vp, _vp, _vp, _sz, _vp]),
+    "gpfq_quantize_conv_channels_from_records": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int,
+                                                        _int, _int, _vp, _dp, _int, _int, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpfq_msq_round": (_int, [_vp, _i64, _dp, _int, _vp, _vp, _vp]),
     "gpfq_index_bits": (_int, [_int]),
     "gpfq_pack_indices": (_int, [_vp, _i64, _i64, _int, _vp, _vp]),
@@ -291,6 +295,64 @@ def quantize_conv_channels(act_w_cm, act_q_cm, Wt_all, alphabet, kernel_size, st
                                              resid.data_ptr() if resid is not None else None, unc.data_ptr(),
                                              ws.data_ptr(), nbytes, _stream())
     _check(rc, "gpfq_quantize_conv_channels")
+
+
+def conv_channel_records(act_w_cm, act_q_cm, kernel_size, strides, rate, padding):
+    """First half of quantize_conv_channels for column-sharded multi-GPU runs: the Gram records of all channels over
+    THESE images (planes f32 [nch][n][H][W]).  Returns (records f64 [nch][K*K*2 + K], negflags i32 [nch]); both are
+    summed / maximised over the ranks before conv_channels_from_records.  No sync."""
+    for t in (act_w_cm, act_q_cm):
+        _dev(t, torch.float32, "planes")
+        if not t.is_contiguous():
+            raise GpfqError("conv_channel_records needs contiguous planes")
+    nch, n, H, W = act_w_cm.shape
+    kh, kw = kernel_size
+    sh, sw = strides
+    rh, rw = rate if rate else (1, 1)
+    same = 1 if str(padding).upper() == "SAME" else 0
+    K = kh * kw
+    dev = act_w_cm.device
+    records = torch.zeros((nch, K * K * 2 + K), dtype=torch.float64, device=dev)
+    negflags = torch.zeros((nch,), dtype=torch.int32, device=dev)
+    if n == 0:
+        return records, negflags
+    lib = load()
+    nbytes = lib.gpfq_conv_channels_workspace_bytes(n, H, W, nch, kh, kw, sh, sw, rh, rw, same, 0, 0)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gpfq_conv_channel_records(act_w_cm.data_ptr(), act_q_cm.data_ptr(), n, H, W, nch, kh, kw, sh, sw, rh, rw, same,
+                                           records.data_ptr(), negflags.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    _check(rc, "gpfq_conv_channel_records")
+    return records, negflags
+
+
+def conv_channels_from_records(records, negflags, act_w_cm, act_q_cm, Wt_all, alphabet, kernel_size, strides, rate, padding,
+                               idx, Q, unc):
+    """Second half: decide (and repair) all channels from summed records; planes of ALL images.  No sync."""
+    nch, n, H, W = act_w_cm.shape
+    kh, kw = kernel_size
+    sh, sw = strides
+    rh, rw = rate if rate else (1, 1)
+    same = 1 if str(padding).upper() == "SAME" else 0
+    F, K = Wt_all.shape[1], Wt_all.shape[2]
+    if (tuple(records.shape) != (nch, K * K * 2 + K) or tuple(negflags.shape) != (nch,) or K != kh * kw
+            or tuple(idx.shape) != (nch, F, K) or tuple(Q.shape) != (nch, F, K) or tuple(unc.shape) != (nch, F)):
+        raise GpfqError("conv_channels_from_records: shape mismatch")
+    for t, dt in ((records, torch.float64), (negflags, torch.int32), (act_w_cm, torch.float32), (act_q_cm, torch.float32),
+                  (Wt_all, torch.float32), (idx, torch.int8), (Q, torch.float32), (unc, torch.int32)):
+        _dev(t, dt, "tensor")
+        if not t.is_contiguous():
+            raise GpfqError("conv_channels_from_records needs contiguous tensors")
+    arr, M, zero_idx = _alphabet(alphabet)
+    lib = load()
+    nbytes = lib.gpfq_conv_channels_workspace_bytes(n, H, W, nch, kh, kw, sh, sw, rh, rw, same, F, 0)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=act_w_cm.device)
+    with torch.cuda.device(act_w_cm.device):
+        rc = lib.gpfq_quantize_conv_channels_from_records(records.data_ptr(), negflags.data_ptr(), act_w_cm.data_ptr(),
+                                                          act_q_cm.data_ptr(), n, H, W, nch, kh, kw, sh, sw, rh, rw, same,
+                                                          Wt_all.data_ptr(), arr, M, zero_idx, F, idx.data_ptr(), Q.data_ptr(),
+                                                          unc.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    _check(rc, "gpfq_quantize_conv_channels_from_records")
 
 
 def exact_fallbacks(result):

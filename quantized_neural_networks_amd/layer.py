@@ -154,8 +154,9 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
     W          f32 [kh][kw][Cin][F]   Keras kernel layout
     act_w/q    f32 NHWC [n][H][W][Cin] analog / quantized layer inputs
     Each (input channel c, filter f) pair is an independent neuron of kh*kw weights whose data are
-    the rows of channel c's patch matrix (:652-727); channels are partitioned over the ranks
-    (when Cin < world, the filters of each channel are partitioned instead).
+    the rows of channel c's patch matrix (:652-727); channels are partitioned over the ranks.  When Cin < world the
+    Gram records are formed over image shards and all-reduced (or, where that does not apply, the filters of each
+    channel are partitioned instead).
 
     Returns dict(Q f32 [kh][kw][Cin][F], idx i8 same shape, resid f64 [Cin][F]).
     """
@@ -190,7 +191,40 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
     # neuron-major filters [Cin][F][K]: row-major flattening of each kh x kw filter (:215), t = ky*kw + kx
     Wt_all = W.permute(2, 3, 0, 1).reshape(Cin, F, K).contiguous()
     plan = None
-    if _local_quantize is hip.quantize_neurons and _extract_patches is hip.extract_patches and f_hi > f_lo:
+    replicated = False                         # every rank already holds the whole result (column-sharded records)
+    if (not by_channel and _local_quantize is hip.quantize_neurons and _extract_patches is hip.extract_patches
+            and not want_resid and K <= hip.GPFQ_GRAM_AUTO_MAX_N and act_w.shape[0] >= world):
+        # Fewer input channels than ranks (an image input has 3): the Gram records are sums over the patch columns, so
+        # every rank forms them over its share of the IMAGES, one all-reduce of Cin * (2 K^2 + K) doubles sums them,
+        # and every rank finishes (decide + repair, milliseconds) from the same records -- no gather afterwards.
+        # Certified decisions do not depend on the summation order of the records: same bits as on one GPU.
+        import torch.distributed as dist
+        n_lo, n_hi = shard_bounds(act_w.shape[0], world, rank)
+        try:
+            pw = hip.channel_planes(act_w[n_lo:n_hi].contiguous(), 0, Cin)
+            pq = pw if same else hip.channel_planes(act_q[n_lo:n_hi].contiguous(), 0, Cin)
+            rec, neg = hip.conv_channel_records(pw, pq, (kh, kw), strides, rate, padding)
+            supported = 1
+        except hip.GpfqError:
+            rec = torch.zeros((Cin, K * K * 2 + K), dtype=torch.float64, device=dev)
+            neg = torch.zeros((Cin,), dtype=torch.int32, device=dev)
+            supported = 0
+        ok = torch.tensor([supported], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)          # all ranks take the same branch
+        if int(ok.item()):
+            dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(neg, op=dist.ReduceOp.MAX, group=group)
+            Unc = torch.zeros((Cin, F), dtype=torch.int32, device=dev)
+            hip.conv_channels_from_records(rec, neg, cm_w, cm_q, Wt_all, alphabet, (kh, kw), strides, rate, padding, Ic, Qc, Unc)
+            for c, f in torch.nonzero(Unc).tolist():                       # the same (rare) pairs on every rank
+                patches(c)
+                r = hip.quantize_neurons(Pw, Pq, Wt_all[c, f:f + 1], alphabet, path=hip.GPFQ_PATH_STREAM)
+                Qc[c, f], Ic[c, f] = r["Q"][0], r["idx"][0]
+                reruns += 1
+            replicated = True
+    if replicated:
+        pass
+    elif _local_quantize is hip.quantize_neurons and _extract_patches is hip.extract_patches and f_hi > f_lo:
         rh, rw = rate if rate else (1, 1)
         same_pad = str(padding).upper() == "SAME"
         cols = (act_w.shape[0] * hip.patch_out_dim(act_w.shape[1], kh, strides[0], rh, same_pad)
@@ -199,7 +233,9 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
         # channels); with residual norms requested it builds patch matrices, which only pays for long ones
         if K <= hip.GPFQ_GRAM_AUTO_MAX_N and cols > (hip.GPFQ_GRAM_MIN_M if want_resid else 0):
             plan = True
-    if plan is not None:
+    if replicated:
+        pass
+    elif plan is not None:
         # Gram path, the whole channel loop (:844-860) in one library call: no per-channel allocation,
         # Python or sync; the filters whose decision chain could not be certified are collected once
         Unc = torch.zeros((Cin, F), dtype=torch.int32, device=dev)
@@ -230,7 +266,7 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
             Qc[c, f_lo:f_hi] = r["Q"]
             Ic[c, f_lo:f_hi] = r["idx"]
             Rc[c, f_lo:f_hi] = r["resid"]
-    if world > 1:
+    if world > 1 and not replicated:
         if by_channel:
             Qc = all_gather_units(Qc[c_lo:c_hi], Cin, group)
             Ic = all_gather_units(Ic[c_lo:c_hi], Cin, group)

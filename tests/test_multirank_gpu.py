@@ -1,6 +1,7 @@
 """GPU, several ranks on ONE device (gloo carries the collectives through host memory): the real HIP path
 under sharding -- neurons of a Dense layer, input channels of a conv layer (3x3 from planes, 5x5 implicit
-im2col), filters when there are fewer channels than ranks, index packing for the all-gather, the median of the
+im2col), image shards with all-reduced Gram records when there are fewer channels than ranks, index packing for
+the all-gather, the median of the
 alphabet radius with its counting sharded over the ranks -- reassembles the single-process result bit for bit.
 (The multi-GPU runs use the same code with backend nccl = RCCL; only the transport differs.)"""
 import os
@@ -34,7 +35,7 @@ def _inputs(case, dev):
         G = torch.randn((N, m), device=dev, generator=g)
         return dict(W=W[:, :], X=torch.relu(G), Xq=torch.relu(G + 0.1 * torch.randn((N, m), device=dev, generator=g)), bits=np.log2(3),
                     neurons=64)
-    cin, k = {"conv3x3": (5, 3), "conv5x5": (4, 5), "conv_filters": (1, 3)}[case]
+    cin, k = {"conv3x3": (5, 3), "conv5x5": (4, 5), "conv_filters": (1, 3), "conv_columns7": (2, 7)}[case]
     act_w = torch.rand((40, 24, 24, cin), device=dev, generator=g)
     act_q = torch.relu(act_w + 0.05 * torch.randn(act_w.shape, device=dev, generator=g))
     W = torch.randn((k, k, cin, 6), device=dev, generator=g) / k
@@ -71,7 +72,7 @@ def _worker(rank, world, port, case, result_dir):
 
 
 @pytest.mark.parametrize("case,world", [("dense", 2), ("dense", 3), ("dense_big_median", 2), ("conv3x3", 2), ("conv5x5", 3),
-                                        ("conv_filters", 2)])
+                                        ("conv_filters", 2), ("conv_columns7", 3)])   # fewer channels than ranks: image shards
 def test_ranks_sharing_one_gpu(case, world, tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
