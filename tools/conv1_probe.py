@@ -1,13 +1,14 @@
 """ResNet50 conv1 (7x7 / stride 2, VALID on the padded 230x230 input, 3 -> 64) through the layer driver.
-usage: conv1_probe.py [n_images]"""
+usage: conv1_probe.py [n_images] [--first]"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 from quantized_neural_networks_amd import hip, layer
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 4096
 g = torch.Generator(device="cuda").manual_seed(2)
 act_w = torch.rand((n, 230, 230, 3), device="cuda", generator=g)
-act_q = torch.relu(act_w + 0.05 * torch.randn((n, 230, 230, 3), device="cuda", generator=g))
+# --first: both networks see the same input, as for the first layer of a network (G2 = G1: half the MFMA work)
+act_q = act_w if "--first" in sys.argv else torch.relu(act_w + 0.05 * torch.randn((n, 230, 230, 3), device="cuda", generator=g))
 W = torch.randn((7, 7, 3, 64), device="cuda", generator=g) / 7
 alphabet, rad = layer.layer_alphabet(W, np.linspace(-1, 1, 3), 3)
 for it in range(2):
