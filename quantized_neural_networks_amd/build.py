@@ -2,38 +2,97 @@
 
 hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container; the
 resulting .so travels to the GPU box with the source tree (it is git-ignored, not gpurun-ignored).
+
+Every translation unit is compiled to its own object (in parallel) and the objects are linked into the
+library.  Staleness is decided by CONTENT, not by time stamps (a snapshot of the tree does not keep them):
+`libgpfq_hip.so.sha` holds the hash of all sources, headers and flags the library was built from, and
+hip.load() refuses a library whose hash does not match the tree.
 """
+import hashlib
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libgpfq_hip.so")
-SOURCES = ["gpfq_capi.hip", "gpfq_onchip.hip", "gpfq_rows.hip", "gpfq_wide.hip", "gpfq_stream.hip", "gpfq_gram.hip", "gpfq_gram_image.hip", "gpfq_gram_conv.hip", "gpfq_gram_mfma.hip",
-           "gpfq_misc.hip"]
+STAMP = LIB + ".sha"
+OBJDIR = os.path.join(CSRC, "build")
+SOURCES = ["gpfq_capi.hip", "gpfq_onchip.hip", "gpfq_rows.hip", "gpfq_pipe.hip", "gpfq_wide.hip", "gpfq_stream.hip",
+           "gpfq_gram.hip", "gpfq_gram_image.hip", "gpfq_gram_conv.hip", "gpfq_gram_mfma.hip", "gpfq_misc.hip"]
 HEADERS = ["gpfq_device.hpp", "gpfq_launch.hpp", "gpfq_gram_tile.hpp", os.path.join("..", "..", "include", "gpfq.h")]
 
 # -ffp-contract=off: the float32 products/subtraction of the residual update must round
 # separately (reference numerics, DESIGN.md); float64 accumulations use explicit fma().
-FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall"]
+# gpfq_pipe.hip writes its packed float32 operations itself; the SLP vectoriser pairs unrelated products
+# through extra register moves there.
+EXTRA_FLAGS = {"gpfq_pipe.hip": ["-fno-slp-vectorize"]}
+
+
+def _sha(paths, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def tree_hash():
+    """Hash of everything the library is built from (sources, headers, flags)."""
+    files = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return _sha(files, repr((FLAGS, sorted(EXTRA_FLAGS.items()))))
+
+
+def built_hash():
+    try:
+        with open(STAMP) as f:
+            return f.read().strip()
+    except OSError:
+        return None
 
 
 def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return not os.path.exists(LIB) or built_hash() != tree_hash()
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP library if missing or older than its sources; returns its path."""
-    if not force and not _stale():
-        return LIB
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + SOURCES
+def _compile(hipcc, src, verbose):
+    obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+    stamp = obj + ".sha"
+    flags = FLAGS + EXTRA_FLAGS.get(src, [])
+    want = _sha([os.path.join(CSRC, f) for f in [src] + HEADERS], repr(flags))
+    try:
+        with open(stamp) as f:
+            if f.read().strip() == want and os.path.exists(obj):
+                return obj
+    except OSError:
+        pass
+    cmd = [hipcc] + flags + ["-c", "-o", obj, src]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    with open(stamp, "w") as f:
+        f.write(want)
+    return obj
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library if missing or built from other sources/flags; returns its path."""
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(OBJDIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJDIR):
+            os.remove(os.path.join(OBJDIR, f))
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(lambda s: _compile(hipcc, s, verbose), SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    with open(STAMP, "w") as f:
+        f.write(tree_hash())
     return LIB
 
 

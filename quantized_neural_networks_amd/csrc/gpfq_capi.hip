@@ -53,7 +53,7 @@ int make_alphabet(const double *alphabet, int M, int zero_idx, gpfq::AlphabetArg
 
 extern "C" {
 
-int gpfq_version(void) { return 100; }
+int gpfq_version(void) { return 200; }
 
 const char *gpfq_last_error(void) { return g_err; }
 
@@ -85,13 +85,15 @@ static int resolve_path(int64_t m, int path)
     return path;
 }
 
-// on-chip workspace: [fallback counter, 64 B][RowStats x N]
-static size_t onchip_workspace_bytes(int64_t N) { return 64 + (size_t)N * sizeof(gpfq::RowStats); }
+// on-chip workspace: [fallback counter, 64 B][RowStats x N][iteration records of the pipelined kernel]
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+static size_t onchip_stats_bytes(int64_t N) { return al256(64 + (size_t)N * sizeof(gpfq::RowStats)); }
+static size_t onchip_workspace_bytes(int64_t N, int64_t m) { return onchip_stats_bytes(N) + gpfq::pipe_workspace_bytes(N, m); }
 
 size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path)
 {
     if (N < 0 || m < 0 || C < 0) return 0;
-    if (resolve_path(m, path) == GPFQ_PATH_ONCHIP) return onchip_workspace_bytes(N);
+    if (resolve_path(m, path) == GPFQ_PATH_ONCHIP) return onchip_workspace_bytes(N, m);
     return gpfq::stream_workspace_bytes(N, m, C, /*need_u=*/true);
 }
 
@@ -103,6 +105,7 @@ static int g_lpn = 0;              // 0 = heuristic, 1 = wave-per-neuron kernel,
 static int g_gram_slack_log2 = 0;  // Gram path: error bounds multiplied by 2^this (tests force the uncertified branch)
 static int g_wpn = 0;              // wide kernel: wavefronts per neuron (0 = heuristic: only for rows > 2048)
 static int g_variant = 0;          // bit 0: row-group kernel without the float64 copy of Xq in LDS; bit 1: wide kernel with LDS-staged rows
+static int g_pipe = -1;            // pipelined dense kernel: -1 = heuristic, 0 = never, 1/2/4 = forced neurons per wavefront
 static int g_conv_fused = 1;       // conv channel loop: 3x3/stride-1 Gram matrices straight from the planes
 static int g_conv_strip = 0;       // fused conv kernel: forced strip length (0 = heuristic)
 
@@ -119,6 +122,11 @@ int gpfq_set_option(const char *key, int value)
         g_group_waves = value; return GPFQ_OK;
     }
     if (!std::strcmp(key, "variant")) { g_variant = value; return GPFQ_OK; }
+    if (!std::strcmp(key, "pipe")) {
+        if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4)
+            return fail(GPFQ_ERR_INVALID_ARG, "pipe must be -1, 0, 1, 2 or 4");
+        g_pipe = value; return GPFQ_OK;
+    }
     if (!std::strcmp(key, "waves_per_neuron")) {
         if (value < 0 || value > 16) return fail(GPFQ_ERR_INVALID_ARG, "waves_per_neuron must be in [0, 16]");
         g_wpn = value; return GPFQ_OK;
@@ -172,10 +180,29 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
         a.wpn = g_wpn;
         a.variant = g_variant;
         // certified mode needs the per-row statistics in the workspace; without one, run the exact flow
-        const bool have_ws = workspace && workspace_bytes >= onchip_workspace_bytes(N) && (uintptr_t)workspace % 16 == 0;
+        const bool have_ws = workspace && workspace_bytes >= onchip_stats_bytes(N) && (uintptr_t)workspace % 16 == 0;
         if (have_ws) {
             hipError_t e0 = hipMemsetAsync(workspace, 0, 64, s);       // exact-fallback counter
             if (e0 != hipSuccess) return hip_fail(e0, "gpfq_quantize_neurons(workspace)");
+        }
+        // the pipelined kernel (gpfq_pipe.hip): rows of up to 2048 samples in layers wide enough to fill the chip
+        // with 16 neurons per workgroup; narrow layers keep the latency-oriented kernels below
+        {
+            gpfq::PipeArgs pa;
+            pa.X = X; pa.Xq = Xq; pa.ld = ld; pa.nrm32 = nrm32; pa.Wt = Wt; pa.ldw = ldw; pa.A = A;
+            pa.N = N; pa.m = m; pa.C = C; pa.qidx = qidx; pa.Qt = Qt; pa.resid = resid; pa.u_out = u_out;
+            pa.npl = g_pipe > 0 ? g_pipe : 0;
+            pa.ts_override = g_tile_steps; pa.variant = g_variant >> 4;
+            const bool forced_old = g_lpn != 0 || g_wpn != 0 || g_onchip_mode != 1 || g_pipe == 0;
+            const bool narrow = m >= 512 && C <= 1024;
+            const bool want = g_pipe > 0 || (g_pipe < 0 && !forced_old && !narrow && false);   // (experimental: opt-in)
+            if (want && N > 0 && m > 0 && gpfq::pipe_supported(pa) && workspace && (uintptr_t)workspace % 16 == 0 &&
+                workspace_bytes >= onchip_workspace_bytes(N, m)) {
+                pa.workspace = static_cast<char *>(workspace) + onchip_stats_bytes(N);
+                pa.fallback_count = static_cast<unsigned long long *>(workspace);
+                hipError_t e = gpfq::launch_pipe(pa, s);
+                return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_neurons(pipelined)");
+            }
         }
         if (a.mode == 1 && N > 0 && have_ws) {
             auto *stats = reinterpret_cast<gpfq::RowStats *>(static_cast<char *>(workspace) + 64);

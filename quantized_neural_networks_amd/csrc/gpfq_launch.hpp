@@ -56,6 +56,29 @@ struct StreamArgs {
     size_t workspace_bytes;
 };
 
+// Pipelined dense kernel (gpfq_pipe.hip): rows of up to 2048 samples, alphabets of up to 64 members.
+struct PipeArgs {
+    const float *X, *Xq;
+    int64_t ld;
+    const float *nrm32;
+    const float *Wt;
+    int64_t ldw;
+    AlphabetArg A;
+    int64_t N, m, C;
+    int8_t *qidx;
+    float *Qt;
+    double *resid;
+    double *u_out;
+    void *workspace;                       // pipe_workspace_bytes(N, m), 16-byte aligned
+    unsigned long long *fallback_count = nullptr;
+    int npl = 0;                           // neurons per wavefront: 1/2/4, 0 = heuristic
+    int ts_override = 0;                   // tuning hooks (bench/tests); 0 = heuristic
+    int variant = 0;                       // bit 0: no per-neuron zero-decision branch in the sweep
+};
+bool pipe_supported(const PipeArgs &a);
+size_t pipe_workspace_bytes(int64_t N, int64_t m);
+hipError_t launch_pipe(const PipeArgs &a, hipStream_t stream);
+
 hipError_t launch_onchip(const OnchipArgs &a, hipStream_t stream);
 bool rows_supported(const OnchipArgs &a, int lpn);
 hipError_t launch_rows(const OnchipArgs &a, int lpn, hipStream_t stream);

@@ -68,11 +68,22 @@ def lib_path():
     return _build.LIB
 
 
+ABI_VERSION = 200                  # gpfq_version() of the library this binding was written against
+
+
 def load():
-    """Load libgpfq_hip.so (must already be built in-tree: __graft_entry__.build() / build.py)."""
+    """Load libgpfq_hip.so (must already be built in-tree: __graft_entry__.build() / build.py).
+
+    A library built from other sources or flags than the tree holds (content hash, build.tree_hash) is rebuilt when
+    hipcc is at hand and refused otherwise; so is one whose gpfq_version() differs from ABI_VERSION."""
     global _lib
     if _lib is None:
         path = lib_path()
+        if os.path.exists(path) and _build.built_hash() != _build.tree_hash():
+            try:
+                _build.build()
+            except Exception as e:       # no hipcc here: do not run a stale binary silently
+                raise GpfqError(f"{path} was built from other sources than this tree and cannot be rebuilt: {e}")
         if not os.path.exists(path):
             raise GpfqError(f"{path} is missing: run `python -m quantized_neural_networks_amd.build` "
                             "(hipcc --offload-arch=gfx950); there is no CPU fallback")
@@ -80,6 +91,8 @@ def load():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)      # AttributeError if the ABI and the header disagree
             fn.restype, fn.argtypes = res, args
+        if lib.gpfq_version() != ABI_VERSION:
+            raise GpfqError(f"{path} reports ABI version {lib.gpfq_version()}, this binding expects {ABI_VERSION}")
         _lib = lib
     return _lib
 

@@ -28,7 +28,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_errors_without_gpu(lib):
-    assert lib.gpfq_version() >= 100
+    assert lib.gpfq_version() == 200
     # argument validation happens before any launch: safe without a device
     a = (ctypes.c_double * 3)(-1.0, 0.0, 1.0)
     rc = lib.gpfq_quantize_neurons(None, None, 4, None, None, 4, a, 3, 1, 4, 8, 2, None, None, None, None, None, 0, 0, None)
@@ -39,7 +39,9 @@ def test_version_and_errors_without_gpu(lib):
     rc = lib.gpfq_quantize_neurons(None, None, 2, None, None, 4, a, 3, 1, 4, 8, 2, None, None, None, None, None, 0, 0, None)
     assert rc == -1
     assert lib.gpfq_quantize_neurons(None, None, 8, None, None, 4, a, 3, 1, 4, 8, 0, None, None, None, None, None, 0, 0, None) == 0
-    assert lib.gpfq_workspace_bytes(9, 1024, 8, 0) == 64 + 9 * 32
+    # on-chip workspace: counter + row statistics (256-aligned) + iteration records of the pipelined kernel:
+    # (N + 1 + 16) records of 128 + 16 * 1024 bytes
+    assert lib.gpfq_workspace_bytes(9, 1024, 8, 0) == 512 + (9 + 17) * (128 + 16 * 1024)
     assert lib.gpfq_workspace_bytes(9, 100000, 8, 0) >= 8 * 100000 * 8
     assert lib.gpfq_workspace_bytes(9, 1024, 8, 2) > 0
 

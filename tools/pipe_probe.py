@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Pipelined dense kernel (csrc/gpfq_pipe.hip) against the row-group kernel and the oracle: bit-equality of
+indices / residual norms / residual vectors, exact-fallback counts and kernel time per variant.
+
+    python tools/pipe_probe.py [N C m bits scalar]      (default: BASELINE cfg2 4096 4096 1024 log2(3) 3)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quantized_neural_networks_amd import hip, layer  # noqa: E402
+import oracle  # noqa: E402
+
+
+def synth(N, m, C):
+    W = (np.random.default_rng(0).standard_normal((N, C)) / np.sqrt(N)).astype(np.float32)
+    G = np.random.default_rng(1).standard_normal((N, m))
+    X = np.maximum(G, 0).astype(np.float32)
+    Xq = np.maximum(G + 0.1 * np.random.default_rng(2).standard_normal((N, m)), 0).astype(np.float32)
+    return W, X, Xq
+
+
+def timed(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    ts = [a.elapsed_time(b) for a, b in ev]
+    return min(ts), float(np.mean(ts))
+
+
+def main():
+    args = sys.argv[1:]
+    N, C, m = (int(args[0]), int(args[1]), int(args[2])) if len(args) >= 3 else (4096, 4096, 1024)
+    bits = float(args[3]) if len(args) > 3 else float(np.log2(3))
+    scalar = float(args[4]) if len(args) > 4 else 3.0
+    n_or = int(args[5]) if len(args) > 5 else 64
+    dev = torch.device("cuda:0")
+    W, X, Xq = synth(N, m, C)
+    Wd, Xd, Xqd = (torch.from_numpy(a).to(dev) for a in (W, X, Xq))
+    M = int(round(2 ** bits))
+    alphabet, rad = layer.layer_alphabet(Wd, np.linspace(-1, 1, M), scalar)
+    Wt = Wd.t().contiguous()
+    nrm = hip.row_norms(Xqd)
+    want_u = C * m * 8 <= (1 << 31)
+
+    def run(**opts):
+        for k, v in opts.items():
+            hip.set_option(k, v)
+        r = hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm, want_u=want_u, path=hip.GPFQ_PATH_ONCHIP)
+        torch.cuda.synchronize()
+        return r
+
+    base = run(pipe=0)
+    print(f"shape N={N} C={C} m={m} M={M}; row-group kernel fallbacks={hip.exact_fallbacks(base)}")
+    if n_or:
+        oracle.build()
+        t0 = time.perf_counter()
+        Qo, io, ro = oracle.layer(W, X, Xq, alphabet, 0, n_or, threads=oracle.num_threads())
+        print(f"oracle {n_or} neurons {time.perf_counter() - t0:.1f}s; row-group kernel idx mismatches:",
+              int((base["idx"][:n_or].cpu().numpy() != io).sum()))
+    tmin, tavg = timed(lambda: hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm, want_values=False, path=hip.GPFQ_PATH_ONCHIP))
+    print(f"  old kernel: min {tmin:.3f} ms avg {tavg:.3f} ms (incl. pre-pass launches)")
+    for npl in (4, 2, 1):
+        if npl == 4 and M > 16 or npl == 2 and M > 32:
+            continue
+        for variant in (0, 16):
+            for ts in (0, 2, 1):
+                try:
+                    r = run(pipe=npl, variant=variant, tile_steps=ts)
+                except hip.GpfqError as e:
+                    print(f"  pipe npl={npl} variant={variant} ts={ts}: {e}")
+                    continue
+                bad_i = int((r["idx"] != base["idx"]).sum())
+                bad_q = int((r["Q"] != base["Q"]).sum())
+                bad_r = int((r["resid"] != base["resid"]).sum())
+                bad_u = int((r["u"] != base["u"]).sum()) if want_u else -1
+                fb = hip.exact_fallbacks(r)
+                tmin, tavg = timed(lambda: hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm, want_values=False,
+                                                                path=hip.GPFQ_PATH_ONCHIP))
+                print(f"  pipe npl={npl} branchy={0 if variant else 1} ts={ts or 'auto'}: min {tmin:.3f} ms avg {tavg:.3f} ms  "
+                      f"mismatch idx={bad_i} Q={bad_q} resid={bad_r} u={bad_u}  exact fallbacks={fb}")
+    hip.set_option("pipe", -1); hip.set_option("variant", 0); hip.set_option("tile_steps", 0)
+
+
+if __name__ == "__main__":
+    main()
