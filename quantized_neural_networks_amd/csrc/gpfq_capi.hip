@@ -105,7 +105,7 @@ static int g_lpn = 0;              // 0 = heuristic, 1 = wave-per-neuron kernel,
 static int g_gram_slack_log2 = 0;  // Gram path: error bounds multiplied by 2^this (tests force the uncertified branch)
 static int g_wpn = 0;              // wide kernel: wavefronts per neuron (0 = heuristic: only for rows > 2048)
 static int g_variant = 0;          // bit 0: row-group kernel without the float64 copy of Xq in LDS; bit 1: wide kernel with LDS-staged rows
-static int g_pipe = -1;            // pipelined dense kernel: -1 = heuristic, 0 = never, 1/2/4 = forced neurons per wavefront
+static int g_pipe = -1;            // pipelined dense kernel: -1 = heuristic, 0 = never, 1 = whenever it applies
 static int g_conv_fused = 1;       // conv channel loop: 3x3/stride-1 Gram matrices straight from the planes
 static int g_conv_strip = 0;       // fused conv kernel: forced strip length (0 = heuristic)
 
@@ -123,8 +123,8 @@ int gpfq_set_option(const char *key, int value)
     }
     if (!std::strcmp(key, "variant")) { g_variant = value; return GPFQ_OK; }
     if (!std::strcmp(key, "pipe")) {
-        if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4)
-            return fail(GPFQ_ERR_INVALID_ARG, "pipe must be -1, 0, 1, 2 or 4");
+        if (value != -1 && value != 0 && value != 1)
+            return fail(GPFQ_ERR_INVALID_ARG, "pipe must be -1, 0 or 1");
         g_pipe = value; return GPFQ_OK;
     }
     if (!std::strcmp(key, "waves_per_neuron")) {
@@ -191,11 +191,13 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
             gpfq::PipeArgs pa;
             pa.X = X; pa.Xq = Xq; pa.ld = ld; pa.nrm32 = nrm32; pa.Wt = Wt; pa.ldw = ldw; pa.A = A;
             pa.N = N; pa.m = m; pa.C = C; pa.qidx = qidx; pa.Qt = Qt; pa.resid = resid; pa.u_out = u_out;
-            pa.npl = g_pipe > 0 ? g_pipe : 0;
             pa.ts_override = g_tile_steps; pa.variant = g_variant >> 4;
             const bool forced_old = g_lpn != 0 || g_wpn != 0 || g_onchip_mode != 1 || g_pipe == 0;
-            const bool narrow = m >= 512 && C <= 1024;
-            const bool want = g_pipe > 0 || (g_pipe < 0 && !forced_old && !narrow && false);   // (experimental: opt-in)
+            // measured (tools/pipe_probe.py): ahead of the row-group kernel on wide layers with rows of 513..1024 samples
+            // (16 neurons per workgroup, one round of workgroups: 4096 x 4096, m = 1024: 4.9 vs 5.4 ms); behind it where a
+            // workgroup holds 8 neurons (m > 1024: 11.4 vs 10.0 ms) or the layer is too narrow to fill the chip
+            const bool fits = m > 512 && m <= 1024 && C >= 2048 && M <= 16;
+            const bool want = g_pipe > 0 || (g_pipe < 0 && !forced_old && fits);
             if (want && N > 0 && m > 0 && gpfq::pipe_supported(pa) && workspace && (uintptr_t)workspace % 16 == 0 &&
                 workspace_bytes >= onchip_workspace_bytes(N, m)) {
                 pa.workspace = static_cast<char *>(workspace) + onchip_stats_bytes(N);

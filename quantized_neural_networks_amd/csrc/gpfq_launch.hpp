@@ -71,9 +71,8 @@ struct PipeArgs {
     double *u_out;
     void *workspace;                       // pipe_workspace_bytes(N, m), 16-byte aligned
     unsigned long long *fallback_count = nullptr;
-    int npl = 0;                           // neurons per wavefront: 1/2/4, 0 = heuristic
-    int ts_override = 0;                   // tuning hooks (bench/tests); 0 = heuristic
-    int variant = 0;                       // bit 0: no per-neuron zero-decision branch in the sweep
+    int ts_override = 0;                   // tuning hook (bench/tests); 0 = heuristic
+    int variant = 0;                       // tuning / timing experiments (PipeK::flags)
 };
 bool pipe_supported(const PipeArgs &a);
 size_t pipe_workspace_bytes(int64_t N, int64_t m);

@@ -4,37 +4,39 @@
 // (scripts/quantized_network.py:91-121, :185-233); same contract and the same bits as
 // gpfq_rows_kernel / gpfq_onchip_kernel, which it supersedes on the layers it takes.
 //
-// What bound the row-group kernel (profiles/r01/sq_counters_rows_kernel.txt): its step is one
-// serial chain  dot -> all-reduce -> decision -> update,  its LDS reads ran three deep behind
-// scalar-cache waits, every neuron re-read every staged row from LDS, and staging was a
-// synchronous copy between two barriers.  Here:
+// What bound the row-group kernel (profiles/r01/sq_counters_rows_kernel.txt, tools/ubench/issue_cycles.hip):
+// instruction issue.  On gfx950 a float64-rate instruction (v_add_f64, v_fma_f64, v_cvt_f64_f32, and the packed
+// float32 ones) costs 5.6 shader cycles of a SIMD and a wavefront issues at most one vector instruction per 7.5
+// cycles, so a step costs (instructions per step) x ~5 cycles -- and more than half of the row-group kernel's
+// instructions were not the element-wise floor (3 packed f32 + 2 cvt + 2 add + 2 fma per two samples of a neuron)
+// but the per-step reduction and decision, executed once per wavefront for its two neurons, eight times per CU.
+// Here that work is done ONCE per workgroup and step:
 //
-//  * One-step look-ahead breaks the chain.  Iteration t sweeps the residual ONCE: it applies the
-//    update of step t-1 (u += f32(w X_{t-1}) - f32(q Xq_{t-1}), the reference's element-wise flow,
-//    :119) and in the same pass accumulates D_{t+1} = <Xq_{t+1}, u_{t-1}>.  Decision t does not
-//    wait for that sweep: it uses D_t (accumulated one iteration earlier, = <Xq_t, u_{t-2}>) plus
-//    the contribution of step t-1's increment, which is known in closed form from two entries of
-//    the Gram band,  <Xq_t, u_{t-1}> = D_t + w_{t-1} <Xq_t, X_{t-1}> - q_{t-1} <Xq_t, Xq_{t-1}>,
-//    up to the float32 roundings of that increment.  Those are bounded rigorously
-//    (|d_i - (w x_i - q xq_i)| <= 2^-23 (1 + 2^-24) (|w x_i| + |q xq_i|), subnormal products
-//    2^-149), so the predicted quotient is either farther from every decision boundary than the
-//    bound -- the decision is then provably the reference's -- or the wave falls back to the exact
-//    dot products of :86/:89 on the completed u_{t-1} (about one decision in 10^6).  Rule (ii)'s
-//    |<Xq_t,u>| < 1e-10 test is certified the same way (exact when the increment is orthogonal to
-//    Xq_t element by element, e.g. at t = 0 or on disjoint supports).  The residual itself is
-//    always updated by the exact element-wise flow, so u is bit-identical.
-//  * Neuron blocking per lane.  A wavefront owns NPL neurons and every lane holds the same
-//    EPL = m/64 sample positions of all of them, so each LDS value (X, Xq, and Xq as float64) is
-//    read once for NPL neurons, and the per-step reduction and decision are shared: a packed
-//    butterfly (v_permlane32_swap / v_permlane16_swap) leaves neuron n's sum in "its" 64/NPL
-//    lanes, whose 16-lane DPP rows each hold a copy of the alphabet and take the decision
-//    lane-parallel as the row-group kernel did.
-//  * The pre-pass lays the operands out per ITERATION: record t = [row statistics of step t]
-//    [X_{t-1}] [Xq_{t-1}] [Xq_{t+1} as float64, plane-swizzled for conflict-free ds_read_b128],
-//    zero-padded to 64*EPL samples.  A tile of TS records is one contiguous block that the
-//    workgroup streams into the other LDS buffer with global_load_lds_dwordx4 (LDS-DMA: no VGPRs,
-//    no ds_write, no conversion in the hot loop) while it works on the current one; the only
-//    barrier is at the tile boundary.
+//  * Roles.  A workgroup owns NB = 4G neurons (16 at m <= 1024) and has eight SWEEP wavefronts and one DECISION
+//    wavefront.  The sweep wavefronts split the SAMPLE axis: wavefront w owns PW_w sample pairs per k-lane for
+//    all NB neurons (lane = (neuron group ng, k-lane kq), four neurons per lane, so every LDS value is read once for
+//    four neurons); PW_w is uneven so that the SIMD that also hosts the decision wavefront gets less sweep work.
+//    Per step a sweep wavefront applies the residual update of the previous step (the reference's element-wise
+//    f32/f64 flow, :119), accumulates its share of the next dot product in the same pass, folds the four sums over
+//    its k-lanes (packed v_permlane32/16_swap butterfly + two DPP rotations) and leaves NB partial sums in LDS.
+//    The decision wavefront (lane = (neuron, sub-lane)) adds the eight partials, takes the decision of all NB
+//    neurons in one instruction stream (alphabet search by counting, lane-local) and publishes (w_t, q_t).
+//    One s_barrier per step.
+//  * One-step look-ahead makes the two roles concurrent.  The sweep of slot t applies update t-1 and accumulates
+//    D_{t+1} = <Xq_{t+1}, u_{t-1}>.  Decision t (same slot) uses D_t = <Xq_t, u_{t-2}> from the slot before plus
+//    the contribution of step t-1's increment in closed form from two entries of the Gram band,
+//    <Xq_t, u_{t-1}> = D_t + w_{t-1} <Xq_t, X_{t-1}> - q_{t-1} <Xq_t, Xq_{t-1}>, up to the float32 roundings of
+//    that increment.  Those are bounded rigorously (|d_i - (w x_i - q xq_i)| <= 2^-23 (1 + 2^-24) (|w x_i| + |q xq_i|),
+//    subnormal products 2^-149), so the predicted quotient is either farther from every decision boundary than the
+//    bound -- the decision is then provably the reference's -- or the step is flagged and redone from the exact
+//    dot products of :86/:89 on the completed residual (slow path: two extra barriers, about one decision in 10^6).
+//    Rule (ii)'s |<Xq_t,u>| < 1e-10 test is certified the same way (exact when the increment is orthogonal to Xq_t
+//    element by element, e.g. at t = 0 or on disjoint supports).  The residual itself is always updated by the exact
+//    element-wise flow, so u is bit-identical.
+//  * The pre-pass lays the operands out per SLOT: record t = [row statistics of step t][X_{t-1}][Xq_{t-1}]
+//    [Xq_{t+1} as float64], zero-padded.  A tile of TS records is one contiguous block that the sweep wavefronts
+//    stream into the other LDS buffer with global_load_lds_dwordx4 (LDS-DMA: no VGPRs, no ds_write, no conversion
+//    in the hot loop) while the current one is worked on.
 #include "gpfq_device.hpp"
 #include "gpfq_launch.hpp"
 
@@ -43,8 +45,9 @@ namespace gpfq {
 namespace {
 
 constexpr int kRecBytes = 128;
+constexpr int kSweepWaves = 8;
 
-// Step record (first 128 bytes of an iteration record); all float64.
+// Step record (first 128 bytes of a slot record); all float64.
 struct PipeRec {
     double rden;   // 1 / (f32-rounded ||Xq_t||)^2, 0 for rows that take rule (i)
     double G;      // <Xq_t, X_t>
@@ -60,35 +63,32 @@ struct PipeRec {
 };
 static_assert(sizeof(PipeRec) == kRecBytes, "record header is 128 bytes");
 
-__host__ __device__ constexpr int64_t pipe_rec_bytes(int epl) { return kRecBytes + 16 * 64 * (int64_t)epl; }
+__host__ __device__ constexpr int64_t pipe_rec_bytes(int64_t mp) { return kRecBytes + 16 * mp; }
 
 // ---- pre-pass ---------------------------------------------------------------------------------
-// One workgroup per iteration record t in [0, nrec): rows t-1 (f32 copies), t (statistics) and t+1
-// (float64 copy of Xq) of the caller's matrices.
+// One workgroup per slot record t in [0, nrec): rows t-1 (f32 copies), t (statistics) and t+1 (float64 copy of Xq)
+// of the caller's matrices, zero-padded to mp samples.
 __global__ void __launch_bounds__(256)
-gpfq_pipe_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t N, int m, int epl,
+gpfq_pipe_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t N, int m, int mp,
                       const float *__restrict__ nrm32, char *__restrict__ recs)
 {
     __shared__ double sm[7][4];
     const int64_t t = blockIdx.x;
-    const int MP = 64 * epl;
-    char *rb = recs + t * pipe_rec_bytes(epl);
+    char *rb = recs + t * pipe_rec_bytes(mp);
     float  *ox  = reinterpret_cast<float *>(rb + kRecBytes);
-    float  *oq  = ox + MP;
-    double *od  = reinterpret_cast<double *>(rb + kRecBytes + 8 * (int64_t)MP);
+    float  *oq  = ox + mp;
+    double *od  = reinterpret_cast<double *>(rb + kRecBytes + 8 * (int64_t)mp);
     const bool has_prev = t >= 1 && t - 1 < N, has_cur = t < N, has_next = t + 1 < N;
     const float *px = X + (t - 1) * ld, *pq = Xq + (t - 1) * ld;
     const float *cx = X + t * ld, *cq = Xq + t * ld;
     const float *nq = Xq + (t + 1) * ld;
     double g = 0.0, a = 0.0, s1 = 0.0, h1 = 0.0, h2 = 0.0, e1 = 0.0, e2 = 0.0;
-    for (int i = threadIdx.x; i < MP; i += 256) {
+    for (int i = threadIdx.x; i < mp; i += 256) {
         const bool in = i < m;
         const float xp = (has_prev && in) ? px[i] : 0.f, qp = (has_prev && in) ? pq[i] : 0.f;
         ox[i] = xp;
         oq[i] = qp;
-        const float qn = (has_next && in) ? nq[i] : 0.f;
-        const int c = i >> 8, r = i & 255, l = r >> 2, e = r & 3;
-        od[(((c * 2 + (e >> 1)) * 64 + l) << 1) + (e & 1)] = (double)qn;
+        od[i] = (double)((has_next && in) ? nq[i] : 0.f);
         if (has_cur && in) {
             const double q = (double)cq[i], x = (double)cx[i];
             const double pr = q * x;                       // products of two f32 are exact in f64
@@ -152,62 +152,21 @@ __device__ __forceinline__ double fold16(double x, double y)
     return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
 }
 
-// Sums of NPL per-lane values over the 64 lanes; neuron n's total lands (bitwise identical) in every one of "its"
-// 64/NPL lanes: lanes [n*64/NPL, (n+1)*64/NPL).
-template <int NPL>
-__device__ __forceinline__ double packed_allreduce(const double (&a)[NPL])
-{
-    double x;
-    if constexpr (NPL == 4) {
-        const double s02 = fold32(a[0], a[2]);       // halves: a0 | a2
-        const double s13 = fold32(a[1], a[3]);       //         a1 | a3
-        x = fold16(s02, s13);                        // rows:   a0, a1, a2, a3
-    } else if constexpr (NPL == 2) {
-        const double s = fold32(a[0], a[1]);         // halves: a0 | a1
-        x = fold16(s, s);
-    } else {
-        const double s = fold32(a[0], a[0]);
-        x = fold16(s, s);
-    }
-    x = ror_add<8>(x);
-    x = ror_add<4>(x);
-    x = ror_add<2>(x);
-    x = ror_add<1>(x);
-    return x;
-}
-
-// OR over the lanes of each neuron's group (GL = 16, 32 or 64 lanes), delivered to all of them.
-template <int GL>
-__device__ __forceinline__ unsigned group_or(unsigned x)
-{
-    x |= (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xF, 0xF, true);
-    x |= (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x124, 0xF, 0xF, true);
-    x |= (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x122, 0xF, 0xF, true);
-    x |= (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x121, 0xF, 0xF, true);
-    if constexpr (GL >= 32) {
-        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-        x = r[0] | r[1];
-    }
-    if constexpr (GL >= 64) {
-        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-        x = r[0] | r[1];
-    }
-    return x;
-}
-
 // LDS-DMA (global_load_lds): lane l's 16 (4) bytes land at lds_dst + 16 l (4 l); lds_dst is a wave-uniform LDS byte
 // address.  Issued from inline asm so that hipcc does not count it: with the builtin form it puts s_waitcnt vmcnt(0)
 // in front of the next ds_read of ANY LDS address and the prefetch of the next tile would stop the current one
 // (cdna_hip_programming.md 5.7).  The tile loop waits for the DMA itself (dma_wait) before its barrier.  M0 is
 // saved and restored inside the statement.
-__device__ __forceinline__ void glds16(const void *g, unsigned lds_dst)
+__device__ __forceinline__ void glds16(const void *g, unsigned lds_dst_uniform)
 {
+    const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst_uniform);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
 }
-__device__ __forceinline__ void glds4(const void *g, unsigned lds_dst)
+__device__ __forceinline__ void glds4(const void *g, unsigned lds_dst_uniform)
 {
+    const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst_uniform);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
@@ -218,383 +177,575 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
 }
 
-// u += f32(w x) - f32(q xq) (:119) for four consecutive samples, then acc += xqd * u (float64).
-// The float32 products and the subtraction are written on two-element vectors, so they become v_pk_mul_f32 /
-// v_pk_add_f32 on adjacent registers: each half rounds exactly as the scalar instruction does (no contraction:
-// the translation unit is built with -ffp-contract=off), and a lone wavefront on a SIMD issues two float32
-// results per slot instead of one.
+// ---- more cross-lane plumbing -------------------------------------------------------------------
+// Four per-lane values summed over the k-lanes of a sweep wavefront (lane = ng + G * kq): packed butterfly over lane
+// bits 5 and 4 (rows), then rotations inside the rows for the k-lane bits below 4.  Afterwards row i of the wavefront
+// holds the sums of the lane's neuron i, lane-in-row ng + G * j (any j) the one of neuron group ng.
+template <int G>
+__device__ __forceinline__ double fold_klanes(const double (&a)[4])
+{
+    const double s02 = fold32(a[0], a[2]);           // halves: a0 | a2
+    const double s13 = fold32(a[1], a[3]);           //         a1 | a3
+    double x = fold16(s02, s13);                     // rows:   a0, a1, a2, a3
+    if constexpr (G <= 8) x = ror_add<8>(x);
+    if constexpr (G <= 4) x = ror_add<4>(x);
+    if constexpr (G <= 2) x = ror_add<2>(x);
+    return x;
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double x)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
+    return x + __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_addi(int x) { return x + __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, true); }
+
+// Sum over the R adjacent sub-lanes of a neuron in the decision wavefront (R = 1, 2, 4, 8), identical bits in all of
+// them: quad_perm [1,0,3,2] (0xB1), quad_perm [2,3,0,1] (0x4E), row_half_mirror (0x141).
+template <int R> __device__ __forceinline__ double sub_sum(double x)
+{
+    if constexpr (R >= 2) x = dpp_add<0xB1>(x);
+    if constexpr (R >= 4) x = dpp_add<0x4E>(x);
+    if constexpr (R >= 8) x = dpp_add<0x141>(x);
+    return x;
+}
+template <int R> __device__ __forceinline__ int sub_sumi(int x)
+{
+    if constexpr (R >= 2) x = dpp_addi<0xB1>(x);
+    if constexpr (R >= 4) x = dpp_addi<0x4E>(x);
+    if constexpr (R >= 8) x = dpp_addi<0x141>(x);
+    return x;
+}
+
+// One barrier per slot: LDS writes of this wavefront done (lgkmcnt), then s_barrier.  Raw instructions: __syncthreads()
+// would also wait for the output stores (vmcnt) every step.  The "memory" clobber keeps LDS accesses on their side.
+__device__ __forceinline__ void slot_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 typedef float pk2 __attribute__((ext_vector_type(2)));
 
-template <bool ZERO>
-__device__ __forceinline__ void sweep4(double *u, double *acc, float w, float q, const float4 &x4, const float4 &q4,
-                                       const double2 &da, const double2 &db)
+// Sample-pair split over the eight sweep wavefronts (pairs per k-lane).  Wavefronts 0 and 4 share their SIMD with the
+// decision wavefront (a workgroup's wavefronts go to the SIMDs in cyclic order: speed only), so they get fewer.
+template <int S> struct PairSplit;
+template <> struct PairSplit<32> { static constexpr int pw[8] = {2, 4, 4, 4, 3, 5, 5, 5}; };
+template <> struct PairSplit<24> { static constexpr int pw[8] = {1, 3, 3, 3, 2, 4, 4, 4}; };
+template <> struct PairSplit<16> { static constexpr int pw[8] = {1, 2, 2, 2, 1, 3, 3, 2}; };
+
+// LDS carve-up (byte offsets), shared by host and device.
+struct PipeLds {
+    int tile_bytes, tile_pitch, off_w, off_d, off_wq, off_x2, off_e, off_out, off_flag, total;
+};
+__host__ __device__ inline PipeLds pipe_lds(int mp, int nb, int ts)
 {
-    const pk2 w2 = {w, w}, q2 = {q, q};
-    pk2 d01 = w2 * pk2{x4.x, x4.y}, d23 = w2 * pk2{x4.z, x4.w};
-    if constexpr (!ZERO) {
-        const pk2 r01 = q2 * pk2{q4.x, q4.y}, r23 = q2 * pk2{q4.z, q4.w};
-        d01 = d01 - r01;
-        d23 = d23 - r23;
+    PipeLds L;
+    L.tile_bytes = ts * (int)pipe_rec_bytes(mp);
+    L.tile_pitch = (L.tile_bytes + 1023) & ~1023;               // the DMA moves whole 1 KiB pieces
+    int o = 2 * L.tile_pitch;
+    L.off_w = o;    o += 2 * nb * ts * 4;   o = (o + 15) & ~15;     // [2][NB][TS] f32   weights of the tile
+    L.off_d = o;    o += 2 * kSweepWaves * nb * 8;                  // [2][8][NB] f64    partial dot products
+    L.off_wq = o;   o += 2 * nb * 8;                                // [2][NB] (w, q) f32 of the step just decided
+    L.off_x2 = o;   o += kSweepWaves * nb * 16;                     // [8][NB] (f64, f64) exact partials (slow path)
+    L.off_e = o;    o += 68 * 8;                                    // [2 + 64 + 2] f64  -inf, -inf, alphabet, +inf, +inf
+    L.off_out = o;  o += 2 * nb * ts * 8;   o = (o + 15) & ~15;     // [2][NB][TS] (idx i32, q f32) until the tile's flush
+    L.off_flag = o; o += 16;                                        // [2] i32 flagged decisions of the slot
+    L.total = o;
+    return L;
+}
+
+struct PipeK {
+    const char *recs;
+    const float *X, *Xq;
+    int64_t ld;
+    const float *Wt;
+    int64_t ldw;
+    int64_t N, C;
+    int m, TS, M, zero_idx;
+    int flags;             // tuning / timing experiments: bit 0 = spread the DMA issue over the slots of a tile;
+                           // bits 1, 2 (WRONG RESULTS, timing only) = skip the decision math / the sweep arithmetic
+    int8_t *qidx;
+    float *Qt;
+    double *resid, *u_out;
+    unsigned long long *fallback_count;
+};
+
+// LDS through 32-bit address-space-3 pointers: offsets stay 32-bit integer arithmetic (generic pointers into the
+// dynamic LDS array cost 64-bit adds and multiplies per access in the hot loop).
+typedef __attribute__((address_space(3))) char lchar;
+typedef float  nf2 __attribute__((ext_vector_type(2)));
+typedef float  nf4 __attribute__((ext_vector_type(4)));
+typedef double nd2 __attribute__((ext_vector_type(2)));
+typedef int    ni2 __attribute__((ext_vector_type(2)));
+// (HIP's float2 / double2 ... are classes and cannot be read through an address-space pointer: native vectors underneath)
+template <typename T> struct LdsNative { using type = T; };
+template <> struct LdsNative<float2>  { using type = nf2; };
+template <> struct LdsNative<float4>  { using type = nf4; };
+template <> struct LdsNative<double2> { using type = nd2; };
+template <> struct LdsNative<int2>    { using type = ni2; };
+template <typename T> __device__ __forceinline__ T lds_ld(lchar *base, int off)
+{
+    using NT = typename LdsNative<T>::type;
+    const NT v = *reinterpret_cast<__attribute__((address_space(3))) const NT *>(base + off);
+    T out;
+    __builtin_memcpy(&out, &v, sizeof(T));
+    return out;
+}
+template <typename T> __device__ __forceinline__ void lds_st(lchar *base, int off, const T &v)
+{
+    using NT = typename LdsNative<T>::type;
+    NT nv;
+    __builtin_memcpy(&nv, &v, sizeof(T));
+    *reinterpret_cast<__attribute__((address_space(3))) NT *>(base + off) = nv;
+}
+
+// ---- sweep wavefront -------------------------------------------------------------------------------
+template <int G, int PW, int MP>
+__device__ __forceinline__ void sweep_role(const PipeK &K, char *lds_generic, const PipeLds &L, int wave, int lane, int pbase)
+{
+    constexpr int NB = 4 * G, KQ = 64 / G;
+    constexpr int RB = (int)pipe_rec_bytes(MP);
+    lchar *lds = (lchar *)lds_generic;
+    const int ng = lane & (G - 1), kq = lane / G, row = lane >> 4;
+    const bool writer = (lane & 15 & ~(G - 1)) == 0;             // one lane per (row, ng) publishes the folded sums
+    const int nloc = 4 * ng;                                      // first of this lane's four neurons
+    const int64_t jbase = (int64_t)blockIdx.x * NB;
+    const unsigned ldsT_addr = lds_addr(lds_generic), ldsW_addr = lds_addr(lds_generic + L.off_w);
+    const int64_t N = K.N;
+    const int TS = K.TS;
+    const int64_t nrec = N + 1;                                   // slots 0..N (slot N only applies update N-1)
+    const int ntiles = (int)((nrec + TS - 1) / TS);
+    // per-lane LDS byte offsets that do not change: operand slices inside a record, the (w, q) quadruple, partial sums
+    const int o_x  = kRecBytes + 8 * (pbase + kq);               // float2 x   [pair]
+    const int o_q  = o_x + 4 * MP;                                // float2 xq  [pair]
+    const int o_d  = kRecBytes + 8 * MP + 16 * (pbase + kq);     // double2 xqd[pair]
+    const int o_wq = L.off_wq + nloc * 8;
+    const int o_dw = L.off_d + (wave * NB + nloc + row) * 8;
+    const int o_x2 = L.off_x2 + (wave * NB + nloc + row) * 16;
+
+    double u[4][2 * PW];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 2 * PW; ++e) u[i][e] = 0.0;          // zeros(m), :115
+
+    // LDS-DMA of tile k, 1 KiB pieces: this wavefront's pieces are wave, wave + 8, ...; `part` of `parts` (the
+    // pieces are spread over the slots of the tile before so that no slot starts with a burst of issue work)
+    const int npieces = (L.tile_bytes + 1023) >> 10;              // the last piece may run into the next record: harmless
+    auto load_tile = [&](int k, int part, int parts) {
+        const char *src = K.recs + (int64_t)k * L.tile_bytes + lane * 16;
+        const unsigned dst = ldsT_addr + (unsigned)(k & 1) * (unsigned)L.tile_pitch;
+        int j = 0;
+        for (int pc = wave; pc < npieces; pc += kSweepWaves, ++j)
+            if (j % parts == part) glds16(src + ((size_t)pc << 10), dst + ((unsigned)pc << 10));
+        if (part == 0) {
+            const unsigned dw = ldsW_addr + (unsigned)((k & 1) * NB * TS * 4);
+            for (int i0 = wave * 64; i0 < NB * TS; i0 += kSweepWaves * 64) {
+                const int i = i0 + lane;
+                const int n = i / TS, s = i - n * TS;
+                const int64_t jn = jbase + n, t = (int64_t)k * TS + s;
+                if (i < NB * TS && jn < K.C && t < N) glds4(K.Wt + jn * K.ldw + t, dw + 4 * (unsigned)i0);
+            }
+        }
+    };
+
+    load_tile(0, 0, 1);
+    dma_wait();
+    slot_barrier();
+
+    for (int k = 0; k < ntiles; ++k) {
+        const int tbase = (k & 1) * L.tile_pitch;
+        const int ts = (int)((nrec - (int64_t)k * TS) < TS ? (nrec - (int64_t)k * TS) : TS);
+        const int parts = (ts > 1 && (K.flags & 1)) ? ts - 1 : 1; // next tile's DMA: in slot 0, or spread over slots 0 .. ts-2
+        for (int s = 0; s < ts; ++s) {
+            const int64_t t = (int64_t)k * TS + s;
+            const int pb = (int)((t - 1) & 1);                    // buffer of step t-1's (w, q) and flag
+            const int rb = tbase + s * RB;
+            const int flag = lds_ld<int>(lds, L.off_flag + 4 * pb);
+            float4 wq01 = lds_ld<float4>(lds, o_wq + pb * NB * 8), wq23 = lds_ld<float4>(lds, o_wq + pb * NB * 8 + 16);
+            if (k + 1 < ntiles && s < parts) load_tile(k + 1, s, parts);   // streams into the other buffer meanwhile
+            if (__builtin_amdgcn_readfirstlane(flag) != 0) {
+                // slow path: step t-1 has decisions the look-ahead could not certify.  u is u_{t-2} here, exactly
+                // what :86 / :89 take: this wavefront's share of <Xq, u> and <Xq, u + f32(w X)> for its neurons.
+                const int64_t tq = t - 1;
+                const float wv[4] = {wq01.x, wq01.z, wq23.x, wq23.z};
+                double eu[4] = {0.0, 0.0, 0.0, 0.0}, ew[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int p = 0; p < PW; ++p)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int i = 2 * (pbase + p * KQ + kq) + e;
+                        float xq = 0.f, xx = 0.f;
+                        if (i < K.m) { xq = K.Xq[tq * K.ld + i]; xx = K.X[tq * K.ld + i]; }
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            eu[n] = fma((double)xq, u[n][2 * p + e], eu[n]);
+                            ew[n] = fma((double)xq, u[n][2 * p + e] + (double)__fmul_rn(wv[n], xx), ew[n]);
+                        }
+                    }
+                const double vu = fold_klanes<G>(eu), vw = fold_klanes<G>(ew);
+                if (writer) lds_st<double2>(lds, o_x2, make_double2(vu, vw));
+                slot_barrier();                                   // partials published
+                slot_barrier();                                   // decisions of step t-1 rewritten
+                wq01 = lds_ld<float4>(lds, o_wq + pb * NB * 8);
+                wq23 = lds_ld<float4>(lds, o_wq + pb * NB * 8 + 16);
+            }
+            const float wv[4] = {wq01.x, wq01.z, wq23.x, wq23.z}, qv[4] = {wq01.y, wq01.w, wq23.y, wq23.w};
+
+            // ---- sweep: u_{t-1} = u_{t-2} + increment of step t-1; acc = share of <Xq_{t+1}, u_{t-1}> ----
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            if (!(K.flags & 4))
+#pragma unroll
+            for (int p = 0; p < PW; ++p) {
+                // operands of the pair: X_{t-1}, Xq_{t-1}, Xq_{t+1} (f64)  (requesting all pairs of the slot up front
+                // needs 40 more registers than the 168 a nine-wavefront workgroup leaves per lane: spills)
+                const float2 x2 = lds_ld<float2>(lds, rb + o_x + 8 * p * KQ), q2 = lds_ld<float2>(lds, rb + o_q + 8 * p * KQ);
+                const double2 d2 = lds_ld<double2>(lds, rb + o_d + 16 * p * KQ);
+                const pk2 xv = {x2.x, x2.y}, qx = {q2.x, q2.y};
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    // f32 products and subtraction on two samples at once (v_pk_mul_f32 / v_pk_add_f32): each half rounds
+                    // exactly as the scalar instruction (no contraction: -ffp-contract=off)
+                    const pk2 d = pk2{wv[n], wv[n]} * xv - pk2{qv[n], qv[n]} * qx;
+                    u[n][2 * p]     += (double)d.x;
+                    u[n][2 * p + 1] += (double)d.y;
+                    acc[n] = fma(d2.x, u[n][2 * p], acc[n]);
+                    acc[n] = fma(d2.y, u[n][2 * p + 1], acc[n]);
+                }
+            }
+            if (t < N) {
+                const double v = fold_klanes<G>(acc);
+                if (writer) lds_st<double>(lds, o_dw + (int)((t + 1) & 1) * kSweepWaves * NB * 8, v);
+            }
+            if (s + 1 == ts) dma_wait();                          // this wavefront's share of the next tile has landed
+            slot_barrier();
+        }
     }
-    u[0] += (double)d01.x; u[1] += (double)d01.y; u[2] += (double)d23.x; u[3] += (double)d23.y;
-    acc[0] = fma(da.x, u[0], acc[0]);
-    acc[1] = fma(da.y, u[1], acc[1]);
-    acc[2] = fma(db.x, u[2], acc[2]);
-    acc[3] = fma(db.y, u[3], acc[3]);
+
+    // ---- epilogue: residual norms through the same partial-sum path, residual vectors straight to memory ----
+    if (K.resid) {
+        double ss[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            double q = 0.0;
+#pragma unroll
+            for (int e = 0; e < 2 * PW; ++e) q = fma(u[n][e], u[n][e], q);
+            ss[n] = q;
+        }
+        const double v = fold_klanes<G>(ss);
+        if (writer) lds_st<double>(lds, o_dw, v);
+    }
+    slot_barrier();
+    if (K.u_out) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int64_t jn = jbase + nloc + n;
+            if (jn < K.C) {
+#pragma unroll
+                for (int p = 0; p < PW; ++p)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int i = 2 * (pbase + p * KQ + kq) + e;
+                        if (i < K.m) K.u_out[jn * (int64_t)K.m + i] = u[n][2 * p + e];
+                    }
+            }
+        }
+    }
+}
+
+// ---- decision wavefront ------------------------------------------------------------------------------
+template <int G, int MP>
+__device__ __forceinline__ void decision_role(const PipeK &K, char *lds_generic, const PipeLds &L, int lane)
+{
+    constexpr int NB = 4 * G, R = 64 / NB;
+    constexpr int RB = (int)pipe_rec_bytes(MP);
+    lchar *lds = (lchar *)lds_generic;
+    const int n = lane / R, r = lane % R;                         // neuron of the workgroup, sub-lane
+    const int64_t jn = (int64_t)blockIdx.x * NB + n;
+    const bool active = jn < K.C;
+    const int64_t N = K.N;
+    const int TS = K.TS, M = K.M;
+    const int64_t nrec = N + 1;
+    const int ntiles = (int)((nrec + TS - 1) / TS);
+    const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
+    // per-lane LDS byte offsets that do not change
+    const int o_d   = L.off_d + (r * NB + n) * 8;                 // partial sums of sweep wavefronts r, r + R, ...
+    const int o_x2  = L.off_x2 + (r * NB + n) * 16;
+    const int o_w   = L.off_w + n * TS * 4;
+    const int o_wq  = L.off_wq + n * 8;
+    const int o_out = L.off_out + n * TS * 8;
+
+    // alphabet members r, r + R, ... of this sub-lane (NaN beyond M: never counted); larger alphabets loop over LDS
+    const bool in_regs = M <= 4 * R;
+    double am[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) am[q] = (r + q * R < M) ? lds_ld<double>(lds, L.off_e + 8 * (2 + r + q * R)) : kNaN;
+
+    float wprev = 0.f, qprev = 0.f;
+    bool  redo_prev = false;
+    double nrm_prev = 0.0;
+    unsigned long long n_fallback = 0;
+    int64_t flushed = -1;
+
+    // outputs of a tile wait in LDS until the first slot of the next tile (a flagged step is rewritten before)
+    auto flush = [&](int64_t k) {
+        const int ob = L.off_out + (int)(k & 1) * NB * TS * 8;
+        for (int e = lane; e < NB * TS; e += 64) {
+            const int nn = e / TS, s = e - nn * TS;
+            const int64_t j = (int64_t)blockIdx.x * NB + nn, t = k * TS + s;
+            if (j < K.C && t < N) {
+                const int2 v = lds_ld<int2>(lds, ob + e * 8);
+                if (K.qidx) K.qidx[j * N + t] = (int8_t)v.x;
+                if (K.Qt)   K.Qt[j * N + t]   = __int_as_float(v.y);
+            }
+        }
+    };
+
+    slot_barrier();                                               // (tile 0 landed)
+
+    for (int k = 0; k < ntiles; ++k) {
+        const int tbase = (k & 1) * L.tile_pitch;
+        const int wbase = (k & 1) * NB * TS * 4, obase = (k & 1) * NB * TS * 8;
+        const int ts = (int)((nrec - (int64_t)k * TS) < TS ? (nrec - (int64_t)k * TS) : TS);
+        for (int s = 0; s < ts; ++s) {
+            const int64_t t = (int64_t)k * TS + s;
+            const int pb = (int)((t - 1) & 1), cb = (int)(t & 1);
+            const int flag = lds_ld<int>(lds, L.off_flag + 4 * pb);
+            // requests of the slot that depend on nothing decided here: D_t partials, record t, w_t
+            double part[kSweepWaves / R];
+#pragma unroll
+            for (int q = 0; q < kSweepWaves / R; ++q) part[q] = lds_ld<double>(lds, o_d + (cb * kSweepWaves + q * R) * NB * 8);
+            const int rb = tbase + s * RB;
+            const double2 r01 = lds_ld<double2>(lds, rb), r23 = lds_ld<double2>(lds, rb + 16), r45 = lds_ld<double2>(lds, rb + 32),
+                          r67 = lds_ld<double2>(lds, rb + 48), r89 = lds_ld<double2>(lds, rb + 64);
+            const float wg = lds_ld<float>(lds, o_w + wbase + 4 * s);
+            if (__builtin_amdgcn_readfirstlane(flag) != 0) {
+                // slow path: redo the flagged decisions of step t-1 from the exact dot products (:86, :89)
+                slot_barrier();                                   // partials published
+                double du = 0.0, dw = 0.0;
+#pragma unroll
+                for (int q = 0; q < kSweepWaves / R; ++q) {
+                    const double2 v = lds_ld<double2>(lds, o_x2 + q * R * NB * 16);
+                    du += v.x; dw += v.y;
+                }
+                du = sub_sum<R>(du); dw = sub_sum<R>(dw);
+                if (redo_prev) {
+                    const double te = dw / (nrm_prev * nrm_prev);
+                    const double t2 = fabs(du) < 1e-10 ? (double)wprev : te;
+                    int bi = 0;
+                    double bq = lds_ld<double>(lds, L.off_e + 16), bdist = fabs(bq - t2);
+                    for (int kk = 1; kk < M; ++kk) {
+                        const double ak = lds_ld<double>(lds, L.off_e + 8 * (2 + kk)), dk = fabs(ak - t2);
+                        if (dk < bdist) { bdist = dk; bi = kk; bq = ak; }
+                    }
+                    qprev = (float)bq;
+                    if (r == 0) {
+                        const int64_t tq = t - 1;
+                        lds_st<int2>(lds, o_out + (int)((tq / TS) & 1) * NB * TS * 8 + (int)(tq % TS) * 8, make_int2(bi, __float_as_int(qprev)));
+                        lds_st<float2>(lds, o_wq + pb * NB * 8, make_float2(wprev, qprev));
+                        if (active) ++n_fallback;
+                    }
+                }
+                slot_barrier();                                   // decisions rewritten
+            }
+            if (s == 0 && k >= 1) { flush(k - 1); flushed = k - 1; }   // the previous tile's outputs are final now
+            if (t < N && (K.flags & 2)) {
+                if (r == 0) lds_st<float2>(lds, o_wq + cb * NB * 8, make_float2(wg, 0.f));
+            } else if (t < N) {
+                // ---- D_t: the partial sums of the previous slot ----
+                double D = part[0];
+#pragma unroll
+                for (int q = 1; q < kSweepWaves / R; ++q) D += part[q];
+                D = sub_sum<R>(D);
+
+                // ---- decision t (:83-89, :57) for neuron n; branch-free ----
+                const double rden = r01.x, rG = r01.y, rcb = r23.x, rca = r23.y, rH1 = r45.x, rH2 = r45.y;
+                const double rE1 = r67.x, rE2 = r67.y, rEa = r89.x, nrm = r89.y;
+                const bool rule1 = nrm < 1e-16;                                      // rule (i): literal 0
+                const double wd = (double)wg, wpd = (double)wprev, qpd = (double)qprev;
+                const double corr = fma(wpd, rH1, -(qpd * rH2));
+                const double du = D + corr;                                          // predicted <Xq_t, u_{t-1}>
+                const bool   inc = ((__float_as_uint(wprev) | __float_as_uint(qprev)) << 1) != 0u;
+                const double eps = fma(fabs(wpd), rE1, fabs(qpd) * rE2) + (inc ? rEa : 0.0);
+                const bool   du_exact = eps == 0.0;                                  // increment orthogonal to Xq_t element-wise
+                const bool   msq = du_exact & (fabs(du) < 1e-10);                    // rule (ii), certain
+                const bool   sure = du_exact | (fabs(du) - eps >= 1e-10);            // ... or certainly not rule (ii)
+                const double wG = wd * rG;
+                const double tq = (du + wG) * rden;                                  // predicted quotient
+                const double tt = msq ? wd : tq;
+                // twice the modelling error of the prediction (quotient units) + float64 slack
+                const double delta2 = 2.0 * (fma(fabs(wd), rcb, rca) + eps * rden)
+                                      + 0x1p-43 * (fabs(D) + fabs(corr) + fabs(wG)) * rden;
+                // p = number of members below t (ascending alphabet), counted by the R sub-lanes
+                int c = 0;
+                if (in_regs) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) c += (am[q] < tt) ? 1 : 0;
+                } else {
+                    for (int kk = r; kk < M; kk += R) c += (lds_ld<double>(lds, L.off_e + 8 * (2 + kk)) < tt) ? 1 : 0;
+                }
+                const int p = sub_sumi<R>(c);
+                // neighbours of t in the table -inf, -inf, a_0 .. a_{M-1}, +inf, +inf (all four requested at once)
+                const int oe = L.off_e + 8 * p;
+                const double lolo = lds_ld<double>(lds, oe), lo = lds_ld<double>(lds, oe + 8), hi = lds_ld<double>(lds, oe + 16),
+                             hihi = lds_ld<double>(lds, oe + 24);
+                const double d_lo = fabs(lo - tt), d_hi = fabs(hi - tt), d_ll = fabs(lolo - tt), d_hh = fabs(hihi - tt);
+                const bool at0 = p == 0, atM = p == M;
+                const bool use_hi = at0 | (!atM & !(d_lo <= d_hi));                  // tie -> lower index
+                const int    idx_l = use_hi ? p : p - 1;
+                const double q_l   = use_hi ? hi : lo;
+                // twice the distance of t from the boundary between the winner and the runner-up
+                const double m2_in = fabs(d_hi - d_lo), m2_lo = d_hh - d_hi, m2_hi = d_ll - d_lo;
+                const double m2 = at0 ? m2_lo : (atM ? m2_hi : m2_in);
+                // first-index rule: a lower member at the same distance would win instead (repeated members)
+                const bool plateau = !use_hi & (p >= 2) & !(d_ll > d_lo);
+                const bool cert = !plateau & (msq | (m2 > delta2)) & sure;
+                const float q32 = rule1 ? 0.f : (float)q_l;
+                const int   idx = rule1 ? K.zero_idx : idx_l;
+                const bool  redo = !rule1 & !cert;
+
+                if (r == 0) {
+                    lds_st<float2>(lds, o_wq + cb * NB * 8, make_float2(wg, q32));
+                    lds_st<int2>(lds, o_out + obase + 8 * s, make_int2(idx, __float_as_int(q32)));
+                }
+                const unsigned long long rb_ = __ballot(redo & active & (r == 0));
+                if (lane == 0) lds_st<int>(lds, L.off_flag + 4 * cb, (int)__popcll(rb_));
+                wprev = wg; qprev = q32; redo_prev = redo; nrm_prev = nrm;
+            }
+            slot_barrier();
+        }
+    }
+    if ((N - 1) / TS > flushed) flush((N - 1) / TS);              // the tile of the last step
+
+    if (K.fallback_count && n_fallback) atomicAdd(K.fallback_count, n_fallback);   // rare
+    slot_barrier();                                               // residual-norm partials published
+    if (K.resid) {
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < kSweepWaves / R; ++q) tot += lds_ld<double>(lds, o_d + q * R * NB * 8);
+        tot = sub_sum<R>(tot);
+        if (active && r == 0) K.resid[jn] = sqrt(tot);
+    }
 }
 
 }  // namespace
 
-// NPL neurons per wavefront, EPL samples per lane (row length 64*EPL), NW wavefronts per workgroup.
-// BRANCHY: a neuron whose previous decision was 0 skips the q*Xq half of the increment (scalar branch per neuron).
-template <int NPL, int EPL, int NW, bool BRANCHY>
-__global__ void __launch_bounds__(64 * NW)
-gpfq_pipe_kernel(const char *__restrict__ recs, const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld,
-                 const float *__restrict__ Wt, int64_t ldw, AlphabetArg A, int64_t N, int m, int64_t C, int TS,
-                 int8_t *__restrict__ qidx, float *__restrict__ Qt, double *__restrict__ resid, double *__restrict__ u_out,
-                 unsigned long long *__restrict__ fallback_count)
+// G neuron groups per sweep wavefront (4G neurons per workgroup), S sample pairs per k-lane over the eight sweep
+// wavefronts: rows of MP = (128 / G) * S samples.
+template <int G, int S>
+__global__ void __launch_bounds__(64 * (kSweepWaves + 1))
+gpfq_pipe_kernel(PipeK K, AlphabetArg A)
 {
-    constexpr int MP   = 64 * EPL;
-    constexpr int NCH  = EPL / 4;                  // 256-sample chunks: one float4 (and two double2) per lane each
-    constexpr int GL   = 64 / NPL;                 // lanes of a neuron's decision group
-    constexpr int NEUR = NW * NPL;                 // neurons per workgroup
-    constexpr int64_t RB = kRecBytes + 16 * (int64_t)MP;
-    static_assert(EPL % 4 == 0 && (NPL == 1 || NPL == 2 || NPL == 4), "layout");
-
+    constexpr int NB = 4 * G, KQ = 64 / G, MP = 2 * KQ * S;
+    using PS = PairSplit<S>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tile_bytes = TS * (int)RB;
-    char  *ldsT = lds;                                                            // [2][TS][RB]
-    float *ldsW = reinterpret_cast<float *>(lds + 2 * (size_t)tile_bytes);        // [2][NEUR][TS]
-    double *ldsA = reinterpret_cast<double *>(ldsW + 2 * NEUR * TS);              // [64] alphabet (exact path)
-
-    const unsigned ldsT_addr = lds_addr(ldsT), ldsW_addr = lds_addr(ldsW);
-
+    const PipeLds L = pipe_lds(MP, NB, K.TS);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp  = lane / GL;                    // neuron of this lane's decision group
-    const int ka   = lane % GL;                    // alphabet slot of this lane
-    const int64_t j0 = (int64_t)blockIdx.x * NEUR + (int64_t)wave * NPL;
-    const int64_t jg = j0 + grp;                   // the group's neuron
-    const bool g_active = jg < C;
 
-    const double kInf = __longlong_as_double(0x7ff0000000000000LL);
-    const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
-    const int M = A.M;
-    const double a      = ka < M ? A.a[ka] : kNaN;
-    const double a_next = ka + 1 < M ? A.a[ka + 1] : kInf;
-    const double a_prev = (ka > 0 && ka <= M) ? A.a[ka - 1] : -kInf;
-    const bool ascending = A.ascending != 0;
-    if (tid < 64) ldsA[tid] = tid < M ? A.a[tid] : kNaN;
-    for (int i = tid; i < 2 * NEUR * TS; i += 64 * NW) ldsW[i] = 0.f;
-
-    double u[NPL][EPL];
-#pragma unroll
-    for (int n = 0; n < NPL; ++n)
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) u[n][e] = 0.0;       // zeros(m), :115
-
-    // loop-carried: per-lane partial sums of D_t, the previous step's weight / decision of every neuron
-    double part[NPL];
-    float  wprev[NPL], qprev[NPL];
-#pragma unroll
-    for (int n = 0; n < NPL; ++n) { part[n] = 0.0; wprev[n] = 0.f; qprev[n] = 0.f; }
-    float wg_prev = 0.f, qg_prev = 0.f;            // the same two for this lane's group, as lane values
-
-    int   my_idx = 0;
-    float my_q   = 0.f;
-    unsigned n_fallback = 0;
-
-    const int64_t nrec = N + 1;                    // iterations 0..N (iteration N only applies update N-1)
-    const int ntiles = (int)((nrec + TS - 1) / TS);
-
-    auto load_tile = [&](int k) {
-        const char *src = recs + (int64_t)k * tile_bytes;
-        const unsigned dst = ldsT_addr + (unsigned)(k & 1) * (unsigned)tile_bytes;
-        for (int off = wave * 1024; off < tile_bytes; off += NW * 1024)
-            if (off + lane * 16 < tile_bytes) glds16(src + off + lane * 16, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + off)));
-        const unsigned dw = ldsW_addr + (unsigned)((k & 1) * NEUR * TS * 4);
-        for (int i0 = wave * 64; i0 < NEUR * TS; i0 += NW * 64) {
-            const int i = i0 + lane;
-            const int n = i / TS, s = i - n * TS;
-            const int64_t jn = (int64_t)blockIdx.x * NEUR + n, t = (int64_t)k * TS + s;
-            if (i < NEUR * TS && jn < C && t < N) glds4(Wt + jn * ldw + t, (unsigned)__builtin_amdgcn_readfirstlane((int)(dw + 4 * i0)));
-        }
-    };
-
-    __syncthreads();                               // ldsW zeros before the first DMA lands on top of them
-    load_tile(0);
-    dma_wait();
+    // ---- LDS initialisation: zero weights / partials / (w, q) / flags, alphabet table with sentinels ----
+    for (int i = tid; i < (L.off_e - L.off_w) / 4; i += blockDim.x) reinterpret_cast<int *>(lds + L.off_w)[i] = 0;
+    for (int i = tid; i < (L.total - L.off_out) / 4; i += blockDim.x) reinterpret_cast<int *>(lds + L.off_out)[i] = 0;
+    if (tid < 68) {
+        const double kInf = __longlong_as_double(0x7ff0000000000000LL);
+        const int k = tid - 2;
+        reinterpret_cast<double *>(lds + L.off_e)[tid] = k < 0 ? -kInf : (k < A.M ? A.a[k] : kInf);
+    }
     __syncthreads();
 
-    for (int k = 0; k < ntiles; ++k) {
-        if (k + 1 < ntiles) load_tile(k + 1);      // streams into the other buffer while this tile is worked on
-        const char  *tb = ldsT + (size_t)(k & 1) * tile_bytes;
-        const float *tw = ldsW + (k & 1) * NEUR * TS;
-        const int ts = (int)((nrec - (int64_t)k * TS) < TS ? (nrec - (int64_t)k * TS) : TS);
-        for (int s = 0; s < ts; ++s) {
-            const int64_t t = (int64_t)k * TS + s;
-            const char *rb = tb + (size_t)s * RB;
-            const PipeRec *rec = reinterpret_cast<const PipeRec *>(rb);
-            const float  *bx = reinterpret_cast<const float *>(rb + kRecBytes) + 4 * lane;
-            const float  *bq = bx + MP;
-            const double *bd = reinterpret_cast<const double *>(rb + kRecBytes + 8 * (size_t)MP) + 2 * lane;
-
-            // ---- sweep: u_{t-1} = u_{t-2} + increment of step t-1; next[n] = partial <Xq_{t+1}, u_{t-1}> ----
-            double acc[NPL][4];
+    if (wave < kSweepWaves) {
+        int pbase = 0;
 #pragma unroll
-            for (int n = 0; n < NPL; ++n) { acc[n][0] = 0.0; acc[n][1] = 0.0; acc[n][2] = 0.0; acc[n][3] = 0.0; }
-            if constexpr (BRANCHY) {
-                constexpr int CG = NCH < 4 ? NCH : 4;          // chunks held in registers at a time
-#pragma unroll
-                for (int c0 = 0; c0 < NCH; c0 += CG) {
-                    float4 x4[CG], q4[CG];
-                    double2 da[CG], db[CG];
-#pragma unroll
-                    for (int c = 0; c < CG; ++c) {
-                        x4[c] = *reinterpret_cast<const float4 *>(bx + 256 * (c0 + c));
-                        q4[c] = *reinterpret_cast<const float4 *>(bq + 256 * (c0 + c));
-                        da[c] = *reinterpret_cast<const double2 *>(bd + 256 * (c0 + c));
-                        db[c] = *reinterpret_cast<const double2 *>(bd + 256 * (c0 + c) + 128);
-                    }
-#pragma unroll
-                    for (int n = 0; n < NPL; ++n) {
-                        if ((__float_as_uint(qprev[n]) << 1) == 0u) {
-#pragma unroll
-                            for (int c = 0; c < CG; ++c)
-                                sweep4<true>(&u[n][4 * (c0 + c)], acc[n], wprev[n], qprev[n], x4[c], q4[c], da[c], db[c]);
-                        } else {
-#pragma unroll
-                            for (int c = 0; c < CG; ++c)
-                                sweep4<false>(&u[n][4 * (c0 + c)], acc[n], wprev[n], qprev[n], x4[c], q4[c], da[c], db[c]);
-                        }
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const float4 x4 = *reinterpret_cast<const float4 *>(bx + 256 * c);
-                    const float4 q4 = *reinterpret_cast<const float4 *>(bq + 256 * c);
-                    const double2 da = *reinterpret_cast<const double2 *>(bd + 256 * c);
-                    const double2 db = *reinterpret_cast<const double2 *>(bd + 256 * c + 128);
-#pragma unroll
-                    for (int n = 0; n < NPL; ++n)
-                        sweep4<false>(&u[n][4 * c], acc[n], wprev[n], qprev[n], x4, q4, da, db);
-                }
-            }
-            if (t >= N) break;                                 // iteration N: the last update only
-
-            // ---- D_t for this lane's group: all-reduce of the partial sums of the previous sweep ----
-            const double D = packed_allreduce<NPL>(part);
-#pragma unroll
-            for (int n = 0; n < NPL; ++n) part[n] = (acc[n][0] + acc[n][1]) + (acc[n][2] + acc[n][3]);
-
-            // ---- decision t (:83-89, :57), one copy per 16-lane row of the group; branch-free -----
-            const float wg = tw[(wave * NPL + grp) * TS + s];   // w_t of the group's neuron
-            const double nrm = rec->nrm, rden = rec->rden, rG = rec->G, rcb = rec->cb, rca = rec->ca;
-            const double rH1 = rec->H1, rH2 = rec->H2, rE1 = rec->E1, rE2 = rec->E2, rEa = rec->Ea;
-            const bool rule1 = nrm < 1e-16;                                      // rule (i): literal 0
-            const double wd = (double)wg, wpd = (double)wg_prev, qpd = (double)qg_prev;
-            const double corr = fma(wpd, rH1, -(qpd * rH2));
-            const double du = D + corr;                                          // predicted <Xq_t, u_{t-1}>
-            const bool   inc = ((__float_as_uint(wg_prev) | __float_as_uint(qg_prev)) << 1) != 0u;
-            const double eps = fma(fabs(wpd), rE1, fabs(qpd) * rE2) + (inc ? rEa : 0.0);
-            const bool   du_exact = eps == 0.0;                                  // increment orthogonal to Xq_t element-wise
-            const bool   msq = du_exact & (fabs(du) < 1e-10);                    // rule (ii), certain
-            const bool   sure = du_exact | (fabs(du) - eps >= 1e-10);            // ... or certainly not rule (ii)
-            const double wG = wd * rG;
-            const double tq = (du + wG) * rden;                                  // predicted quotient
-            const double tt = msq ? wd : tq;
-            // twice the modelling error of the prediction (quotient units) + float64 slack
-            const double delta2 = 2.0 * (fma(fabs(wd), rcb, rca) + eps * rden)
-                                  + 0x1p-43 * (fabs(D) + fabs(corr) + fabs(wG)) * rden;
-            const double d  = fabs(a - tt), dn = fabs(a_next - tt), dp = fabs(a_prev - tt);
-            const bool c_lt = a < tt, n_lt = a_next < tt;
-            const bool is_lo = c_lt & !n_lt;                                     // last member below t
-            const bool is_p0 = (ka == 0) & !c_lt;                                // t at or below the whole alphabet (or NaN)
-            const bool use_hi = is_lo & !(d <= dn);                              // tie -> lower index
-            const int    idx_l = ka + (use_hi ? 1 : 0);
-            const double q_l   = use_hi ? a_next : a;
-            const double m2 = (ka + 1 < M) ? fabs(dn - d) : (dp - d);            // twice the distance from the boundary
-            const bool plateau = is_lo & !use_hi & (ka > 0) & !(dp > d);         // first-index rule would pick a lower member
-            const bool cert = !plateau & (msq | (m2 > delta2)) & ascending & sure;
-            const bool decider = (is_lo | is_p0) & !rule1;
-            unsigned w1 = decider ? __float_as_uint((float)q_l) : 0u;
-            unsigned w2 = decider ? ((unsigned)idx_l | (cert ? 0u : 0x100u) | 0x200u) : 0u;
-            w1 = group_or<GL>(w1);
-            w2 = group_or<GL>(w2);
-            float q32 = __uint_as_float(w1);                                     // rule (i): no decider, 0
-            int   idx = rule1 ? A.zero_idx : (int)(w2 & 0xffu);
-            const bool redo = !rule1 & ((w2 & 0x300u) != 0x200u);                // not certified (or no decider)
-            if (__ballot(redo) != 0ull) {
-                // rare: the reference's two dot products on the completed u_{t-1} (:86, :89), plain first-minimum scan
-                double eu[NPL], ew[NPL];
-                float  wn[NPL];
-#pragma unroll
-                for (int n = 0; n < NPL; ++n) {
-                    eu[n] = 0.0; ew[n] = 0.0;
-                    wn[n] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wg), n * GL));
-                }
-#pragma unroll
-                for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = 256 * c + 4 * lane + e;
-                        float xq = 0.f, xx = 0.f;
-                        if (i < m) { xq = Xq[t * ld + i]; xx = X[t * ld + i]; }
-#pragma unroll
-                        for (int n = 0; n < NPL; ++n) {
-                            eu[n] = fma((double)xq, u[n][4 * c + e], eu[n]);
-                            ew[n] = fma((double)xq, u[n][4 * c + e] + (double)__fmul_rn(wn[n], xx), ew[n]);
-                        }
-                    }
-                const double dot_u = packed_allreduce<NPL>(eu);
-                const double dot_w = packed_allreduce<NPL>(ew);
-                const double te = dot_w / (nrm * nrm);
-                const double t2 = fabs(dot_u) < 1e-10 ? (double)wg : te;
-                int bi = 0;
-                double bq2 = ldsA[0], bd2 = fabs(bq2 - t2);
-                for (int kk = 1; kk < M; ++kk) {
-                    const double ak = ldsA[kk], dk = fabs(ak - t2);
-                    if (dk < bd2) { bd2 = dk; bi = kk; bq2 = ak; }
-                }
-                if (redo) { idx = bi; q32 = (float)bq2; }
-                n_fallback += (redo && ka == 0 && g_active) ? 1u : 0u;
-            }
-
-            // ---- hand q_t, w_t to the next sweep (wave-uniform per neuron) and to the next decision (per group) ----
-#pragma unroll
-            for (int n = 0; n < NPL; ++n) {
-                wprev[n] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wg), n * GL));
-                qprev[n] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q32), n * GL));
-            }
-            wg_prev = wg;
-            qg_prev = q32;
-
-            // ---- outputs: lane (t mod 16) of the group keeps step t until the 16-step flush ----
-            const int slot = (int)(t & 15);
-            if (ka == slot) { my_idx = idx; my_q = q32; }
-            if (slot == 15 || t + 1 == N) {
-                const int64_t base = t - slot;
-                if (g_active && ka <= slot) {
-                    if (qidx) qidx[jg * N + base + ka] = (int8_t)my_idx;
-                    if (Qt)   Qt[jg * N + base + ka]   = my_q;
-                }
-            }
-        }
-        dma_wait();                                // this wave's share of the next tile has landed ...
-        __syncthreads();                           // ... everyone's has, and everyone is done with this one
-    }
-
-    if (fallback_count && n_fallback) atomicAdd(fallback_count, (unsigned long long)n_fallback);   // rare
-    if (resid) {
-        double ss[NPL];
-#pragma unroll
-        for (int n = 0; n < NPL; ++n) {
-            double s = 0.0;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) s = fma(u[n][e], u[n][e], s);
-            ss[n] = s;
-        }
-        const double tot = packed_allreduce<NPL>(ss);
-        if (g_active && ka == 0) resid[jg] = sqrt(tot);
-    }
-    if (u_out) {
-#pragma unroll
-        for (int n = 0; n < NPL; ++n) {
-            const int64_t jn = j0 + n;
-            if (jn < C) {
-#pragma unroll
-                for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = 256 * c + 4 * lane + e;
-                        if (i < m) u_out[jn * (int64_t)m + i] = u[n][4 * c + e];
-                    }
-            }
-        }
+        for (int w = 0; w < kSweepWaves; ++w) pbase += (w < wave) ? KQ * PS::pw[w] : 0;
+        const int pw = PS::pw[wave & 7];
+        // one instantiation per distinct pair count of the split
+        if (pw == 1) { if constexpr (S == 16 || S == 24) sweep_role<G, 1, MP>(K, lds, L, wave, lane, pbase); }
+        else if (pw == 2) sweep_role<G, 2, MP>(K, lds, L, wave, lane, pbase);
+        else if (pw == 3) sweep_role<G, 3, MP>(K, lds, L, wave, lane, pbase);
+        else if (pw == 4) { if constexpr (S >= 24) sweep_role<G, 4, MP>(K, lds, L, wave, lane, pbase); }
+        else { if constexpr (S == 32) sweep_role<G, 5, MP>(K, lds, L, wave, lane, pbase); }
+    } else {
+        decision_role<G, MP>(K, lds, L, lane);
     }
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-static int pipe_epl(int64_t m)
+struct PipeShape { int G, S, mp; };
+
+static PipeShape pipe_shape(int64_t m)
 {
-    if (m <= 256) return 4;
-    if (m <= 512) return 8;
-    if (m <= 1024) return 16;
-    if (m <= 2048) return 32;
-    return 0;
+    // smallest padded row that holds m, more neurons per workgroup first
+    static const PipeShape shapes[] = {{16, 16, 128}, {16, 24, 192}, {16, 32, 256}, {8, 24, 384}, {8, 32, 512},
+                                       {4, 24, 768}, {4, 32, 1024}, {2, 24, 1536}, {2, 32, 2048}};
+    for (const PipeShape &s : shapes)
+        if (m <= s.mp) return s;
+    return {0, 0, 0};
 }
 
-static int pipe_tile_steps(int epl, int neur, int64_t N)
+static int pipe_tile_steps(const PipeShape &sh, int64_t N)
 {
-    const int64_t rb = pipe_rec_bytes(epl) + 4 * (int64_t)neur;
-    int ts = (int)((150 * 1024 - 1024) / (2 * rb));
-    if (ts > 16) ts = 16;
+    int ts = 16;
+    while (ts > 1 && pipe_lds(sh.mp, 4 * sh.G, ts).total > 158 * 1024) --ts;
     if (ts > N + 1) ts = (int)(N + 1);
     return ts < 1 ? 1 : ts;
 }
 
 bool pipe_supported(const PipeArgs &a)
 {
-    if (pipe_epl(a.m) == 0 || a.N < 1 || a.m < 1) return false;
-    if (a.A.M > 64) return false;
+    if (pipe_shape(a.m).G == 0 || a.N < 1 || a.m < 1) return false;
+    if (a.A.M > 64 || !a.A.ascending) return false;
     return a.N + 64 < (1LL << 31) / 64;             // tile offsets stay in int range
 }
 
 size_t pipe_workspace_bytes(int64_t N, int64_t m)
 {
-    const int epl = pipe_epl(m);
-    if (!epl) return 0;
-    // iteration records 0..N, padded to whole tiles of up to 16 records
-    return (size_t)(N + 1 + 16) * (size_t)pipe_rec_bytes(epl);
+    const PipeShape sh = pipe_shape(m);
+    if (!sh.G) return 0;
+    // slot records 0..N, padded to whole tiles of up to 16 records
+    return (size_t)(N + 1 + 16) * (size_t)pipe_rec_bytes(sh.mp);
 }
 
-template <int NPL, int EPL, int NW, bool BR>
-static hipError_t launch_pipe_inst(const PipeArgs &a, hipStream_t stream)
+template <int G, int S>
+static hipError_t launch_pipe_inst(const PipeArgs &a, const PipeShape &sh, hipStream_t stream)
 {
-    constexpr int NEUR = NW * NPL;
-    int ts = pipe_tile_steps(EPL, NEUR, a.N);
+    constexpr int NB = 4 * G;
+    int ts = pipe_tile_steps(sh, a.N);
     if (a.ts_override > 0 && a.ts_override < ts) ts = a.ts_override;
-    const size_t lds_bytes = 2 * (size_t)ts * pipe_rec_bytes(EPL) + 2 * (size_t)NEUR * ts * sizeof(float) + 64 * sizeof(double);
-    const unsigned grid = (unsigned)((a.C + NEUR - 1) / NEUR);
-    auto *kern = gpfq_pipe_kernel<NPL, EPL, NW, BR>;
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    const PipeLds L = pipe_lds(sh.mp, NB, ts);
+    const unsigned grid = (unsigned)((a.C + NB - 1) / NB);
+    auto *kern = gpfq_pipe_kernel<G, S>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, stream, static_cast<const char *>(a.workspace), a.X, a.Xq, a.ld,
-                       a.Wt, a.ldw, a.A, a.N, (int)a.m, a.C, ts, a.qidx, a.Qt, a.resid, a.u_out, a.fallback_count);
+    PipeK K;
+    K.recs = static_cast<const char *>(a.workspace); K.X = a.X; K.Xq = a.Xq; K.ld = a.ld; K.Wt = a.Wt; K.ldw = a.ldw;
+    K.N = a.N; K.C = a.C; K.m = (int)a.m; K.TS = ts; K.M = a.A.M; K.zero_idx = a.A.zero_idx; K.flags = a.variant;
+    K.qidx = a.qidx; K.Qt = a.Qt; K.resid = a.resid; K.u_out = a.u_out; K.fallback_count = a.fallback_count;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (kSweepWaves + 1)), (size_t)L.total, stream, K, a.A);
     return hipGetLastError();
-}
-
-template <int NPL, int NW>
-static hipError_t launch_pipe_epl(const PipeArgs &a, int epl, hipStream_t stream)
-{
-    const bool br = !(a.variant & 1);
-    switch (epl) {
-    case 4:  return br ? launch_pipe_inst<NPL, 4, NW, true>(a, stream)  : launch_pipe_inst<NPL, 4, NW, false>(a, stream);
-    case 8:  return br ? launch_pipe_inst<NPL, 8, NW, true>(a, stream)  : launch_pipe_inst<NPL, 8, NW, false>(a, stream);
-    case 16: return br ? launch_pipe_inst<NPL, 16, NW, true>(a, stream) : launch_pipe_inst<NPL, 16, NW, false>(a, stream);
-    default: return br ? launch_pipe_inst<NPL, 32, NW, true>(a, stream) : launch_pipe_inst<NPL, 32, NW, false>(a, stream);
-    }
 }
 
 hipError_t launch_pipe(const PipeArgs &a, hipStream_t stream)
 {
-    const int epl = pipe_epl(a.m);
-    if (!epl) return hipErrorInvalidValue;
-    // pre-pass: iteration records (statistics + padded operand rows), tiles padded with zero records
+    const PipeShape sh = pipe_shape(a.m);
+    if (!sh.G) return hipErrorInvalidValue;
+    // pre-pass: slot records (statistics + padded operand rows), tiles padded with zero records
     const int64_t nrec = a.N + 1 + 16;
-    hipLaunchKernelGGL(gpfq_pipe_prep_kernel, dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, epl,
+    hipLaunchKernelGGL(gpfq_pipe_prep_kernel, dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp,
                        a.nrm32, static_cast<char *>(a.workspace));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    int npl = a.npl;
-    if (npl == 0) npl = a.A.M <= 16 ? 4 : (a.A.M <= 32 ? 2 : 1);
-    if (a.A.M > 16 && npl > 2) npl = 2;
-    if (a.A.M > 32) npl = 1;
-    if (npl == 4) return launch_pipe_epl<4, 4>(a, epl, stream);
-    if (npl == 2) return launch_pipe_epl<2, 8>(a, epl, stream);
-    return launch_pipe_epl<1, 8>(a, epl, stream);
+    switch (sh.G * 100 + sh.S) {
+    case 1616: return launch_pipe_inst<16, 16>(a, sh, stream);
+    case 1624: return launch_pipe_inst<16, 24>(a, sh, stream);
+    case 1632: return launch_pipe_inst<16, 32>(a, sh, stream);
+    case 824:  return launch_pipe_inst<8, 24>(a, sh, stream);
+    case 832:  return launch_pipe_inst<8, 32>(a, sh, stream);
+    case 424:  return launch_pipe_inst<4, 24>(a, sh, stream);
+    case 432:  return launch_pipe_inst<4, 32>(a, sh, stream);
+    case 224:  return launch_pipe_inst<2, 24>(a, sh, stream);
+    default:   return launch_pipe_inst<2, 32>(a, sh, stream);
+    }
 }
 
 }  // namespace gpfq

@@ -67,26 +67,23 @@ def main():
               int((base["idx"][:n_or].cpu().numpy() != io).sum()))
     tmin, tavg = timed(lambda: hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm, want_values=False, path=hip.GPFQ_PATH_ONCHIP))
     print(f"  old kernel: min {tmin:.3f} ms avg {tavg:.3f} ms (incl. pre-pass launches)")
-    for npl in (4, 2, 1):
-        if npl == 4 and M > 16 or npl == 2 and M > 32:
+    variants = [int(v) for v in os.environ.get("PIPE_VARIANTS", "0").split(",")]
+    for variant, ts in [(v, ts) for v in variants for ts in (0, 2, 1)]:
+        try:
+            r = run(pipe=1, tile_steps=ts, variant=16 * variant)
+        except hip.GpfqError as e:
+            print(f"  pipe ts={ts}: {e}")
             continue
-        for variant in (0, 16):
-            for ts in (0, 2, 1):
-                try:
-                    r = run(pipe=npl, variant=variant, tile_steps=ts)
-                except hip.GpfqError as e:
-                    print(f"  pipe npl={npl} variant={variant} ts={ts}: {e}")
-                    continue
-                bad_i = int((r["idx"] != base["idx"]).sum())
-                bad_q = int((r["Q"] != base["Q"]).sum())
-                bad_r = int((r["resid"] != base["resid"]).sum())
-                bad_u = int((r["u"] != base["u"]).sum()) if want_u else -1
-                fb = hip.exact_fallbacks(r)
-                tmin, tavg = timed(lambda: hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm, want_values=False,
-                                                                path=hip.GPFQ_PATH_ONCHIP))
-                print(f"  pipe npl={npl} branchy={0 if variant else 1} ts={ts or 'auto'}: min {tmin:.3f} ms avg {tavg:.3f} ms  "
-                      f"mismatch idx={bad_i} Q={bad_q} resid={bad_r} u={bad_u}  exact fallbacks={fb}")
-    hip.set_option("pipe", -1); hip.set_option("variant", 0); hip.set_option("tile_steps", 0)
+        bad_i = int((r["idx"] != base["idx"]).sum())
+        bad_q = int((r["Q"] != base["Q"]).sum())
+        rel_r = float(((r["resid"] - base["resid"]).abs() / base["resid"].clamp_min(1e-300)).max())
+        bad_u = int((r["u"] != base["u"]).sum()) if want_u else -1
+        fb = hip.exact_fallbacks(r)
+        tmin, tavg = timed(lambda: hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm, want_values=False,
+                                                        path=hip.GPFQ_PATH_ONCHIP))
+        print(f"  pipe variant={variant} ts={ts or 'auto'}: min {tmin:.3f} ms avg {tavg:.3f} ms  "
+              f"mismatch idx={bad_i} Q={bad_q} u={bad_u} max resid rel diff={rel_r:.2e}  exact fallbacks={fb}")
+    hip.set_option("pipe", -1); hip.set_option("tile_steps", 0); hip.set_option("variant", 0)
 
 
 if __name__ == "__main__":
