@@ -11,13 +11,16 @@ One "step" = the whole layer driver on inputs already resident in HBM: alphabet 
 |W|), the row-norm pre-pass, the greedy kernel for every neuron, the all-gather (N > 1) and the
 transposes back to the Keras kernel layout.
 
-N > 1: one process per GPU.  Default "weak" scaling: every rank quantizes its own 4096-neuron shard
-of a Dense(4096 -> 4096*N) layer and one RCCL all-gather reassembles Q; `--scaling strong` splits
-the fixed 4096x4096 layer instead.
+N > 1: one process per GPU.  Default = BASELINE.json's north-star workload: the FIXED 4096 x 4096 layer, its
+neurons split over the N ranks ("strong" scaling) and one RCCL all-gather of the packed indices.  Below about
+1000 neurons per GPU the walk is latency-bound (N sequential steps of ~1 us), so this curve flattens by
+construction; `--scaling weak` gives every rank its own 4096-neuron shard of a Dense(4096 -> 4096*N) layer.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` (dominant kernel,
-live HIP-event timing, algorithmic bytes (8m+8) per weight) and `cpu_baseline` (the C oracle port on
-all host cores over a bounded sample of the same layer).
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  `roofline`      the dominant kernel against the resource that binds it -- FP64-rate vector issue: algorithmic flops
+                  (6 m per weight) / the kernel's HIP-event time / the FP64 vector peak (spec) -- plus,
+                  labelled as secondary, the 8d HBM-equivalent figure, the compulsory traffic and the PMC-measured one;
+  `cpu_baseline`  the C oracle port on all host cores over a bounded sample of the same layer.
 """
 import argparse
 import json
@@ -32,6 +35,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X FP64 vector, spec (= half of the 157.3 TFLOP/s FP32 vector peak of MI355X_MICROARCH.md)
+# what the vector units were measured to issue on this chip (tools/ubench/issue_cycles.hip): a float64-rate
+# wavefront instruction every 5.63 shader cycles per SIMD -> 64 lanes * 2 flop / 5.63 * 1024 SIMDs * 2.4 GHz
+FP64_MEASURED_ISSUE_TFLOPS = 64 * 2 / 5.63 * 1024 * 2.4e9 / 1e12
 
 
 def synthetic_layer(N, m, C, c_lo, c_hi, seed=0):
@@ -53,10 +60,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--n", type=int, default=4096, help="fan-in N (rows of W)")
-    ap.add_argument("--c", type=int, default=4096, help="neurons per GPU (weak) / total (strong)")
-    ap.add_argument("--m", type=int, default=1024, help="calibration samples")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N > 1: strong = the fixed --n x --c layer split over the ranks (north star); weak = --c neurons per rank")
+    ap.add_argument("--n", "--fan-in", dest="n", type=int, default=4096, help="fan-in N (rows of W)")
+    ap.add_argument("--c", "--neurons", dest="c", type=int, default=4096, help="neurons: total (strong, default) / per GPU (weak)")
+    ap.add_argument("--m", "--samples", dest="m", type=int, default=1024, help="calibration samples")
     ap.add_argument("--bits", type=float, default=float(np.log2(3)))
     ap.add_argument("--alphabet-scalar", type=float, default=3.0)
     ap.add_argument("--cpu-sample", type=int, default=512, help="neurons timed on the host cores (0 = skip)")
@@ -103,6 +111,7 @@ def main():
     Wd = torch.from_numpy(W).to(dev)
 
     kernel_ms = []
+    kname = [""]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i_timed=None):
@@ -115,6 +124,7 @@ def main():
         r = hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm, want_values=False)
         if i_timed is not None:
             ev[i_timed][1].record()
+        kname[0] = hip.last_dense_kernel()
         # one all-gather of the indices (packed to 2 bits per weight for the ternary alphabet when N > 1),
         # then values + transpose to the Keras layout in one pass
         if world > 1:
@@ -142,13 +152,19 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    kernel_name = kname[0]
 
     weights_per_step = N * C_total
     value = weights_per_step * args.steps / elapsed
     lo, hi = layer.shard_bounds(C_total, world, rank)
     k_avg_s = float(np.mean(kernel_ms)) / 1e3
-    alg_bytes = (8 * m + 8) * N * (hi - lo)          # per launch on this rank
-    achieved = alg_bytes / k_avg_s / 1e9
+    C_local = hi - lo
+    alg_flops = 6.0 * m * N * C_local                # per launch on this rank: 2m for <Xq, u + wX>, 4m for the update
+    achieved_tf = alg_flops / k_avg_s / 1e12
+    alg_bytes = (8 * m + 8) * N * C_local            # 8d's HBM-equivalent: one f32 row of X and of Xq per weight, w in, q out
+    hbm_equiv = alg_bytes / k_avg_s / 1e9
+    compulsory = (2 * N * m + 2 * N * C_local) * 4   # X, Xq read once; W in, Q out
+    traffic = _recorded_traffic(N, m, C_local, kernel_name)
 
     if rank == 0:
         out = {
@@ -157,21 +173,33 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"Dense({N}->{C_total}) whole-layer GPFQ, m={m} calibration samples, "
-                            f"M={M} alphabet, alphabet_scalar={args.alphabet_scalar:g} (BASELINE cfg2 per GPU)",
-                "N": N, "C": C_total, "m": m, "M": M, "neurons_per_gpu": hi - lo,
-                "sharding": "neurons (columns of W) contiguous over ranks; one all-gather per layer" if world > 1 else "none",
+                "workload": (f"Dense({N}->{C_total}) whole-layer GPFQ, m={m} calibration samples, M={M} alphabet, "
+                             f"alphabet_scalar={args.alphabet_scalar:g}"
+                             + (" (BASELINE.json configs[1], the north-star layer)" if (N, C_total, m, M) == (4096, 4096, 1024, 3) else "")
+                             + (f"; neurons split over {world} GPUs ({args.scaling} scaling)" if world > 1 else "")),
+                "N": N, "C": C_total, "m": m, "M": M, "neurons_per_gpu": C_local,
+                "sharding": "neurons (columns of W) contiguous over ranks; one all-gather of packed indices per layer" if world > 1 else "none",
                 "arithmetic": "f32 products / f64 residual and dot products (reference's mixed flow)",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "gpfq_rows_kernel<32,32,true> (row-group on-chip kernel, 2 neurons per wavefront)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": _recorded_traffic(N, m, hi - lo),
+                "bound": "valu_fp64",
+                "kernel": kernel_name,
+                "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS,
+                "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
                 "kernel_ms_avg": k_avg_s * 1e3, "kernel_ms_min": float(np.min(kernel_ms)),
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "valu_floor": _valu_floor(N, m, hi - lo, k_avg_s),
-                "note": "algorithmic bytes = (8m+8) per weight (SURVEY 8d); the 16 neurons of a workgroup share every "
-                        "LDS-staged row and u stays in VGPRs, so achieved/peak exceeds 1 and the kernel is bound by "
-                        "FP64-rate VALU issue, not HBM (DESIGN.md section 4); `traffic` is the PMC-measured HBM bytes",
+                "algorithmic_flops_per_launch": alg_flops,
+                "frac_of_measured_issue_rate": achieved_tf / FP64_MEASURED_ISSUE_TFLOPS,
+                "measured_issue_rate_tflops": FP64_MEASURED_ISSUE_TFLOPS,
+                "hbm_equiv": {"achieved_gbs": hbm_equiv, "peak_gbs": HBM_PEAK_GBS, "frac": hbm_equiv / HBM_PEAK_GBS,
+                              "algorithmic_bytes_per_launch": alg_bytes,
+                              "note": "SURVEY 8d's (8m+8) B per weight; > 1 means the rows are served on chip, not faster than HBM"},
+                "compulsory_bytes_per_launch": compulsory,
+                "traffic_gbs": (traffic["hbm_bytes_per_launch"] / k_avg_s / 1e9) if traffic else None,
+                "traffic_source": (traffic["source"] if traffic else
+                                   "no committed rocprofv3 --pmc pass for this kernel and shape (profiles/traffic.json)"),
+                "note": "skinny dot products with the residual on chip: the binding resource is FP64-rate vector issue "
+                        "(per weight and sample one f64 fma, one f32->f64 convert, one f64 add, three f32 ops), not HBM; "
+                        "flops per launch = 6 m N C_local (SURVEY 8d); duration = HIP events around the launch on its stream",
             },
         }
         if world == 1 and args.cpu_sample > 0:
@@ -181,29 +209,18 @@ def main():
         dist.destroy_process_group()
 
 
-def _valu_floor(N, m, C_local, k_avg_s):
-    """The bound that actually holds: per (weight, sample) the reference's flow needs one f64 FMA
-    (<Xq_t, u>), one f32->f64 convert and one f64 add (u += d), and f32 mul, mul, sub for d.  A wavefront
-    instruction covers 64 elements; measured issue costs on gfx950 (tools/ubench): 5 cycles per f64-rate
-    instruction, 4 per f32 instruction; 1024 SIMDs at 2.4 GHz."""
-    wave_elems = N * C_local * m / 64.0
-    cycles = wave_elems * (3 * 5 + 3 * 4)
-    floor_s = cycles / (1024 * 2.4e9)
-    return {"bound": "valu_issue", "floor_ms": floor_s * 1e3, "frac": floor_s / k_avg_s,
-            "model": "3 f64-rate (5 cycles) + 3 f32 (4 cycles) wavefront instructions per 64 (weight, sample) elements; "
-                     "1024 SIMDs x 2.4 GHz"}
-
-
-def _recorded_traffic(N, m, C_local):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*.json), if one was
-    recorded for this exact shape; else null."""
+def _recorded_traffic(N, m, C_local, kernel_name):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json: FETCH_SIZE x 2 +
+    WRITE_SIZE, separate --pmc passes of this same command), if one was recorded for this shape AND this kernel
+    family; else None.  The counters cannot be read inside the timed run, so this is a record, and says so."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
         for r in rec.get("records", []):
-            if (r["N"], r["m"], r["C"]) == (N, m, C_local):
-                return r["hbm_bytes_per_launch"]
+            if (r["N"], r["m"], r["C"]) == (N, m, C_local) and r.get("kernel", "").split("<")[0].split(" ")[0] in kernel_name:
+                return {"hbm_bytes_per_launch": r["hbm_bytes_per_launch"],
+                        "source": "profiles/traffic.json (" + r.get("profile", "committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes") + ")"}
     except Exception:
         pass
     return None

@@ -79,10 +79,17 @@ int         gpfq_device_count(void);
 int gpfq_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, float *nrm32, void *stream);
 
 /* Bytes of scratch gpfq_quantize_neurons needs for this shape on this path.  The on-chip path
- * keeps per-row statistics there (32*N + 64 bytes; after the call the first 8 bytes hold, as a
- * uint64, how many decisions were re-derived with the exact dot product -- diagnostics only);
- * without a workspace it still runs, in the reference's verbatim flow (same results, slower). */
+ * keeps per-row statistics there (32*N + 64 bytes, rounded up to 256; after the call the first 8 bytes
+ * hold, as a uint64, how many decisions were re-derived with the exact dot product -- diagnostics
+ * only) and, for rows of up to 2048 samples, the slot records of the pipelined kernel
+ * ((N + 17) * (128 + 16 * padded m) bytes: row statistics + zero-padded operand rows laid out per step);
+ * with less it still runs -- on the row-group kernels, or without any workspace in the reference's
+ * verbatim flow (same results, slower). */
 size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path);
+
+/* Name of the dense kernel family the calling thread's last gpfq_quantize_neurons dispatched ("" before
+ * the first call); diagnostics for benchmarks and tests. */
+const char *gpfq_last_dense_kernel(void);
 
 /*
  * Process-wide tuning/test hooks; results never depend on them.
@@ -93,7 +100,10 @@ size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path);
  *                  1 = wave-per-neuron kernel
  *   "variant"      bit 0: row-group kernel without the float64 copy of Xq in LDS; bit 1: wide kernel with
  *                  LDS-staged rows instead of register prefetch; bit 2: Gram records of walks longer than 64
- *                  steps on the vector units instead of the matrix cores (v_mfma_f64_16x16x4_f64)
+ *                  steps on the vector units instead of the matrix cores (v_mfma_f64_16x16x4_f64);
+ *                  bit 4: pipelined kernel issues its LDS-DMA spread over the steps of a tile
+ *   "pipe"         pipelined dense kernel (rows <= 2048 samples): -1 (default) where measured faster,
+ *                  0 never, 1 whenever it applies
  *   "waves_per_neuron"  2..16: force the wide kernel (one neuron over that many wavefronts), 0 = heuristic
  *                  (rows longer than 2048 samples, and layers too narrow to fill the chip)
  *   "gram_slack_log2"   Gram paths: error bounds multiplied by 2^value (tests force the repair/rerun branches)

@@ -13,6 +13,7 @@
 namespace {
 
 thread_local char g_err[512] = "";
+thread_local const char *g_dense_kernel = "";
 
 int fail(int code, const char *fmt, ...)
 {
@@ -51,9 +52,15 @@ int make_alphabet(const double *alphabet, int M, int zero_idx, gpfq::AlphabetArg
 
 }  // namespace
 
+namespace gpfq {
+void note_dense_kernel(const char *name) { g_dense_kernel = name; }
+}
+
 extern "C" {
 
 int gpfq_version(void) { return 200; }
+
+const char *gpfq_last_dense_kernel(void) { return g_dense_kernel; }
 
 const char *gpfq_last_error(void) { return g_err; }
 
@@ -202,6 +209,7 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
                 workspace_bytes >= onchip_workspace_bytes(N, m)) {
                 pa.workspace = static_cast<char *>(workspace) + onchip_stats_bytes(N);
                 pa.fallback_count = static_cast<unsigned long long *>(workspace);
+                gpfq::note_dense_kernel("gpfq_pipe_kernel (8 sweep wavefronts over the sample axis + 1 decision wavefront per workgroup)");
                 hipError_t e = gpfq::launch_pipe(pa, s);
                 return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_neurons(pipelined)");
             }
@@ -227,6 +235,7 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
     a.X = X; a.Xq = Xq; a.ld = ld; a.nrm32 = nrm32; a.Wt = Wt; a.ldw = ldw; a.A = A;
     a.N = N; a.m = m; a.C = C; a.qidx = qidx; a.Qt = Qt; a.resid = resid; a.u_out = u_out;
     a.workspace = workspace; a.workspace_bytes = workspace_bytes;
+    gpfq::note_dense_kernel("gpfq_stream_step_kernel + gpfq_stream_decide_kernel (residual in HBM)");
     hipError_t e = gpfq::launch_stream(a, s);
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_neurons(stream)");
 }

@@ -78,6 +78,9 @@ bool pipe_supported(const PipeArgs &a);
 size_t pipe_workspace_bytes(int64_t N, int64_t m);
 hipError_t launch_pipe(const PipeArgs &a, hipStream_t stream);
 
+// Which dense kernel family the last gpfq_quantize_neurons call of this thread dispatched (diagnostics: gpfq_last_dense_kernel).
+void note_dense_kernel(const char *name);
+
 hipError_t launch_onchip(const OnchipArgs &a, hipStream_t stream);
 bool rows_supported(const OnchipArgs &a, int lpn);
 hipError_t launch_rows(const OnchipArgs &a, int lpn, hipStream_t stream);

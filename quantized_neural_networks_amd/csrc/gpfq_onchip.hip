@@ -308,15 +308,23 @@ hipError_t launch_onchip(const OnchipArgs &a, hipStream_t stream)
         }
         while (W < 16 && (a.m + 64 * (int64_t)W - 1) / (64 * (int64_t)W) > 16) ++W;
         if (W > 16) W = 16;                          // rows beyond 16384: the long-row form, up to 28 elements per lane
+        note_dense_kernel("gpfq_wide_kernel (one neuron over several wavefronts)");
         return launch_wide(a, W, stream);
     }
     if (a.mode == MODE_CERTIFIED && a.stats) {
         int lpn = a.lpn;
         if (lpn == 0) lpn = 32;                      // measured best on cfg2/cfg3-like layers (tools/sweep_shapes.py)
         while (lpn >= 16 && lpn <= 64 && !rows_supported(a, lpn)) lpn *= 2;
-        if (lpn >= 16 && lpn <= 64) return launch_rows(a, lpn, stream);
+        if (lpn >= 16 && lpn <= 64) {
+            note_dense_kernel(lpn == 16 ? "gpfq_rows_kernel<16> (row-group kernel, 4 neurons per wavefront)"
+                                        : lpn == 32 ? "gpfq_rows_kernel<32> (row-group kernel, 2 neurons per wavefront)"
+                                                    : "gpfq_rows_kernel<64> (row-group kernel, 1 neuron per wavefront)");
+            return launch_rows(a, lpn, stream);
+        }
+        note_dense_kernel("gpfq_onchip_kernel<certified> (wavefront per neuron)");
         return launch_mode<MODE_CERTIFIED>(a, stream);
     }
+    note_dense_kernel("gpfq_onchip_kernel<exact> (wavefront per neuron, verbatim flow)");
     return launch_mode<MODE_EXACT>(a, stream);
 }
 

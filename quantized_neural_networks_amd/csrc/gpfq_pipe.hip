@@ -262,8 +262,8 @@ struct PipeK {
     int64_t ldw;
     int64_t N, C;
     int m, TS, M, zero_idx;
-    int flags;             // tuning / timing experiments: bit 0 = spread the DMA issue over the slots of a tile;
-                           // bits 1, 2 (WRONG RESULTS, timing only) = skip the decision math / the sweep arithmetic
+    int flags;             // tuning: bit 0 = spread the DMA issue over the slots of a tile (measured slower: an LDS-DMA
+                           // piece costs its wavefront 100+ cycles of issue wherever it stands)
     int8_t *qidx;
     float *Qt;
     double *resid, *u_out;
@@ -394,7 +394,6 @@ __device__ __forceinline__ void sweep_role(const PipeK &K, char *lds_generic, co
 
             // ---- sweep: u_{t-1} = u_{t-2} + increment of step t-1; acc = share of <Xq_{t+1}, u_{t-1}> ----
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
-            if (!(K.flags & 4))
 #pragma unroll
             for (int p = 0; p < PW; ++p) {
                 // operands of the pair: X_{t-1}, Xq_{t-1}, Xq_{t+1} (f64)  (requesting all pairs of the slot up front
@@ -549,9 +548,7 @@ __device__ __forceinline__ void decision_role(const PipeK &K, char *lds_generic,
                 slot_barrier();                                   // decisions rewritten
             }
             if (s == 0 && k >= 1) { flush(k - 1); flushed = k - 1; }   // the previous tile's outputs are final now
-            if (t < N && (K.flags & 2)) {
-                if (r == 0) lds_st<float2>(lds, o_wq + cb * NB * 8, make_float2(wg, 0.f));
-            } else if (t < N) {
+            if (t < N) {
                 // ---- D_t: the partial sums of the previous slot ----
                 double D = part[0];
 #pragma unroll
@@ -719,7 +716,7 @@ static hipError_t launch_pipe_inst(const PipeArgs &a, const PipeShape &sh, hipSt
     if (e != hipSuccess) return e;
     PipeK K;
     K.recs = static_cast<const char *>(a.workspace); K.X = a.X; K.Xq = a.Xq; K.ld = a.ld; K.Wt = a.Wt; K.ldw = a.ldw;
-    K.N = a.N; K.C = a.C; K.m = (int)a.m; K.TS = ts; K.M = a.A.M; K.zero_idx = a.A.zero_idx; K.flags = a.variant;
+    K.N = a.N; K.C = a.C; K.m = (int)a.m; K.TS = ts; K.M = a.A.M; K.zero_idx = a.A.zero_idx; K.flags = a.variant & 1;
     K.qidx = a.qidx; K.Qt = a.Qt; K.resid = a.resid; K.u_out = a.u_out; K.fallback_count = a.fallback_count;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (kSweepWaves + 1)), (size_t)L.total, stream, K, a.A);
     return hipGetLastError();

@@ -28,6 +28,7 @@ SYMBOLS = {
     "gpfq_device_count": (_int, []),
     "gpfq_row_norms": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "gpfq_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
+    "gpfq_last_dense_kernel": (ctypes.c_char_p, []),
     "gpfq_set_option": (_int, [ctypes.c_char_p, _int]),
     "gpfq_quantize_neurons": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _int, _int, _i64, _i64, _i64,
                                      _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp]),
@@ -366,6 +367,11 @@ def conv_channels_from_records(records, negflags, act_w_cm, act_q_cm, Wt_all, al
                                                           Wt_all.data_ptr(), arr, M, zero_idx, F, idx.data_ptr(), Q.data_ptr(),
                                                           unc.data_ptr(), ws.data_ptr(), nbytes, _stream())
     _check(rc, "gpfq_quantize_conv_channels_from_records")
+
+
+def last_dense_kernel():
+    """Name of the dense kernel family the last quantize_neurons() call dispatched (diagnostics)."""
+    return load().gpfq_last_dense_kernel().decode()
 
 
 def exact_fallbacks(result):

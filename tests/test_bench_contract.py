@@ -27,9 +27,37 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     roof = out["roofline"]
     for key in ["bound", "achieved", "peak", "unit", "frac", "traffic"]:
         assert key in roof, key
-    assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    # the binding resource of the dominant kernel is named, and the fraction is a fraction
+    assert roof["bound"] in ("valu_fp64", "hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert 0 < roof["frac"] <= 1.0 and roof["unit"] in ("TFLOP/s", "GB/s") and roof["kernel"]
+    assert roof["kernel_ms_avg"] > 0 and roof["algorithmic_flops_per_launch"] == 6.0 * 512 * 256 * 512
+    assert roof["compulsory_bytes_per_launch"] == (2 * 256 * 512 + 2 * 256 * 512) * 4 and "hbm_equiv" in roof
     cpu = out["cpu_baseline"]
     for key in ["value", "unit", "cores", "kind", "sample"]:
         assert key in cpu, key
     assert cpu["kind"] in ("port", "reference") and cpu["value"] > 0
     assert out["parity_sample"]["neurons_with_index_mismatch"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_over_gloo_split_the_fixed_layer():
+    """The N > 1 path of bench.py as the driver launches it (torch.distributed.run, one process per rank), with the
+    collectives on gloo so that two ranks can share this box's one GPU: the default workload is the FIXED layer split
+    over the ranks (strong scaling, the north-star curve), one JSON line from rank 0."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, GPFQ_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--fan-in", "256", "--neurons", "512", "--samples", "512"]      # (the launcher's parser would take "--n" for its own)
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["C"] == 512 and out["config"]["neurons_per_gpu"] == 256 and "split over 2 GPUs" in out["config"]["workload"]
+    assert "cpu_baseline" not in out                     # rank 0 at N = 1 only
+    assert 0 < out["roofline"]["frac"] <= 1.0

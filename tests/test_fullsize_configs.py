@@ -1,0 +1,194 @@
+"""GPU: the BASELINE.json configurations at FULL size, each with (a) size-independent properties over the whole
+layer -- determinism, power-of-two scale, independence of the units under permutation / splitting, fixed point --
+and (b) the C oracle on a sample of the same run (>= 8 neurons / >= 4 (channel, filter) pairs), asserted bit for bit.
+
+  cfg2  Dense(4096 -> 4096), m = 1024, ternary, scalar 3           oracle on 512 neurons (scripts/quantized_network.py:91-121)
+  cfg3  VGG16 fc2 Dense(4096 -> 4096) and fc1 Dense(25088 -> 4096), m = 2048, 16 levels, scalar 5
+  cfg5  ResNet50 conv1 7x7/2 VALID on 4096 x 230 x 230 x 3 (m = 51.4 M columns: int64 indexing, the > 2^18-row
+        error-bound constants, 10 GB patch matrices) and 3x3 64 -> 64 @ 56 x 56 (m = 12.8 M), ternary, scalar 3 (:185-233)
+
+The conv samples are additionally cross-checked against the streaming kernel (the reference's verbatim flow with the
+residual in HBM) on the GPU-built patch matrices -- a second implementation at full size.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from quantized_neural_networks_amd import hip as h
+    h.load()
+    return h
+
+
+def _dense_inputs(N, m, C, dev, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    W = torch.randn((N, C), device=dev, generator=g) / np.sqrt(N)
+    G = torch.randn((N, m), device=dev, generator=g)
+    X = torch.relu(G)
+    Xq = torch.relu(G + 0.1 * torch.randn((N, m), device=dev, generator=g))
+    return W, X, Xq
+
+
+def _dense_oracle_sample(oracle_mod, W, X, Xq, alphabet, out, neurons):
+    """The C oracle on a sample of neurons of the same layer: indices bit for bit, residual norms to 1e-5."""
+    Wh, Xh, Xqh = W.cpu().numpy(), X.cpu().numpy(), Xq.cpu().numpy()
+    for j0, j1 in neurons:
+        _, io, ro = oracle_mod.layer(Wh, Xh, Xqh, alphabet, j0, j1, threads=oracle_mod.num_threads())
+        ig = out["idx"][:, j0:j1].t().cpu().numpy()
+        bad = int((ig != io).any(axis=1).sum())
+        assert bad == 0, f"{bad} of {j1 - j0} neurons differ from the oracle"
+        np.testing.assert_allclose(out["resid"][j0:j1].cpu().numpy(), ro, rtol=1e-5)
+
+
+def _dense_properties(layer, W, X, Xq, alphabet, base, M, fixed_point=True):
+    dev = W.device
+    again = layer.quantize_dense(W, X, Xq, alphabet)
+    assert torch.equal(base["idx"], again["idx"]) and torch.equal(base["resid"], again["resid"])          # determinism
+    a32 = torch.from_numpy(alphabet.astype(np.float32)).to(dev)
+    assert int(base["idx"].min()) >= 0 and int(base["idx"].max()) < M
+    assert torch.equal(base["Q"], a32[base["idx"].long()])
+    s = 2.0 ** -5                                                                                          # scale
+    scaled = layer.quantize_dense(W * s, X, Xq, alphabet * s)
+    assert torch.equal(scaled["idx"], base["idx"]) and torch.equal(scaled["resid"], base["resid"] * s)
+    C = W.shape[1]                                                                                         # independence
+    perm = torch.randperm(C, device=dev, generator=torch.Generator(device=dev).manual_seed(11))
+    permuted = layer.quantize_dense(W[:, perm].contiguous(), X, Xq, alphabet)
+    assert torch.equal(permuted["idx"], base["idx"][:, perm])
+    cut = C // 3
+    lo = layer.quantize_dense(W[:, :cut].contiguous(), X, Xq, alphabet)
+    hi = layer.quantize_dense(W[:, cut:].contiguous(), X, Xq, alphabet)
+    assert torch.equal(torch.cat([lo["idx"], hi["idx"]], dim=1), base["idx"])
+    if fixed_point:                                                                                        # fixed point
+        k = torch.randint(0, M, W.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(12))
+        fixed = layer.quantize_dense(a32[k].contiguous(), X, X, alphabet)
+        assert torch.equal(fixed["idx"].long(), k) and float(fixed["resid"].abs().max()) == 0.0
+
+
+def test_cfg2_dense_oracle_512_neurons(hip, oracle_mod):
+    """The headline layer against the oracle: 512 neurons = 2.1 M decisions (was bench.py's parity_sample)."""
+    from quantized_neural_networks_amd import layer
+    dev = torch.device("cuda")
+    W, X, Xq = _dense_inputs(4096, 1024, 4096, dev, 21)
+    alphabet, rad = layer.layer_alphabet(W, np.linspace(-1, 1, 3), 3)
+    alphabet_o, rad_o = oracle_mod.layer_alphabet(W.cpu().numpy(), np.linspace(-1, 1, 3), 3)
+    assert rad == rad_o and np.array_equal(alphabet, alphabet_o)
+    out = layer.quantize_dense(W, X, Xq, alphabet)
+    assert "gpfq_pipe_kernel" in hip.last_dense_kernel()          # the default kernel of this shape is the one checked
+    _dense_oracle_sample(oracle_mod, W, X, Xq, alphabet, out, [(0, 256), (3840, 4096)])
+
+
+def test_cfg3_vgg16_fc2_full_size(hip, oracle_mod):
+    from quantized_neural_networks_amd import layer
+    dev = torch.device("cuda")
+    W, X, Xq = _dense_inputs(4096, 2048, 4096, dev, 31)
+    alphabet, _ = layer.layer_alphabet(W, np.linspace(-1, 1, 16), 5)
+    out = layer.quantize_dense(W, X, Xq, alphabet)
+    _dense_properties(layer, W, X, Xq, alphabet, out, 16)
+    _dense_oracle_sample(oracle_mod, W, X, Xq, alphabet, out, [(0, 8), (2048, 2056), (4088, 4096)])
+
+
+def test_cfg3_vgg16_fc1_full_size(hip, oracle_mod):
+    """Keras VGG16 `fc1`: 25088 -> 4096 (102.8 M weights, 25088 sequential steps per neuron), m = 2048, 16 levels."""
+    from quantized_neural_networks_amd import layer
+    dev = torch.device("cuda")
+    W, X, Xq = _dense_inputs(25088, 2048, 4096, dev, 32)
+    alphabet, _ = layer.layer_alphabet(W, np.linspace(-1, 1, 16), 5)
+    out = layer.quantize_dense(W, X, Xq, alphabet)
+    _dense_properties(layer, W, X, Xq, alphabet, out, 16)
+    _dense_oracle_sample(oracle_mod, W, X, Xq, alphabet, out, [(0, 4), (4092, 4096)])
+
+
+# ---- conv -------------------------------------------------------------------------------------------------------
+def _conv_inputs(n, H, Wd, cin, cout, k, dev, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    act_w = torch.rand((n, H, Wd, cin), device=dev, generator=g)
+    act_q = torch.relu(act_w + 0.05 * torch.randn((n, H, Wd, cin), device=dev, generator=g))
+    W = torch.randn((k, k, cin, cout), device=dev, generator=g) / k
+    return act_w, act_q, W
+
+
+def _host_gib_available():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / (1 << 20)
+    except OSError:
+        pass
+    return 0.0
+
+
+def _conv_sample(hip, oracle_mod, act_w, act_q, W, alphabet, out, k, stride, padding, pairs, host_gib_needed):
+    """(channel, filter) pairs of the same run against the streaming kernel (verbatim flow, residual in HBM) and
+    against the C oracle, both on the GPU-built patch matrices of the channel."""
+    Wh = W.cpu().numpy()
+    K = k * k
+    for c, filters in pairs:
+        Pw = hip.extract_patches(act_w, c, (k, k), (stride, stride), (1, 1), padding)
+        Pq = hip.extract_patches(act_q, c, (k, k), (stride, stride), (1, 1), padding)
+        Wt = W[:, :, c, :].reshape(K, -1).t()[filters].contiguous()             # [F][K], row-major filters (:215)
+        ref = hip.quantize_neurons(Pw, Pq, Wt, alphabet, path=hip.GPFQ_PATH_STREAM)
+        got = out["idx"][:, :, c, :].reshape(K, -1).t()[filters]
+        assert torch.equal(got, ref["idx"]), f"channel {c}: Gram path differs from the streaming kernel"
+        if _host_gib_available() < host_gib_needed:
+            pytest.skip(f"host has < {host_gib_needed} GiB available for the oracle's copy of the patch matrices")
+        Pwh, Pqh = Pw.cpu().numpy(), Pq.cpu().numpy()
+        del Pw, Pq
+        Wf = np.ascontiguousarray(Wh[:, :, c, :].reshape(K, -1)[:, filters])    # Keras layout [K][F] for oracle.layer
+        _, io, _ = oracle_mod.layer(Wf, Pwh, Pqh, alphabet, 0, len(filters), threads=len(filters))
+        assert np.array_equal(got.cpu().numpy(), io), f"channel {c}: (channel, filter) pairs differ from the oracle"
+        del Pwh, Pqh
+
+
+def _conv_properties(layer, W, act_w, act_q, alphabet, base, M, kw):
+    dev = W.device
+    assert torch.equal(base["idx"], layer.quantize_conv2d(W, act_w, act_q, alphabet, **kw)["idx"])        # determinism
+    s = 2.0 ** 4
+    assert torch.equal(layer.quantize_conv2d(W * s, act_w, act_q, alphabet * s, **kw)["idx"], base["idx"])  # scale
+    cout = W.shape[3]
+    pf = torch.randperm(cout, device=dev, generator=torch.Generator(device=dev).manual_seed(41))
+    perm = layer.quantize_conv2d(W[:, :, :, pf].contiguous(), act_w, act_q, alphabet, **kw)                # independence
+    assert torch.equal(perm["idx"], base["idx"][:, :, :, pf])
+    half = cout // 2
+    lo = layer.quantize_conv2d(W[..., :half].contiguous(), act_w, act_q, alphabet, **kw)
+    hi = layer.quantize_conv2d(W[..., half:].contiguous(), act_w, act_q, alphabet, **kw)
+    assert torch.equal(torch.cat([lo["idx"], hi["idx"]], dim=3), base["idx"])
+    a32 = torch.from_numpy(alphabet.astype(np.float32)).to(dev)                                            # fixed point
+    kk = torch.randint(0, M, W.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(42))
+    fixed = layer.quantize_conv2d(a32[kk].contiguous(), act_w, act_w, alphabet, **kw)
+    assert torch.equal(fixed["idx"].long(), kk)
+
+
+def test_cfg5_resnet50_conv1_full_size(hip, oracle_mod):
+    """ResNet50 conv1: 7x7 / 2, VALID on the zero-padded 230 x 230 input, 3 -> 64, 4096 images: 51.4 M columns."""
+    from quantized_neural_networks_amd import layer
+    dev = torch.device("cuda")
+    act_w, act_q, W = _conv_inputs(4096, 230, 230, 3, 64, 7, dev, 51)
+    alphabet, _ = layer.layer_alphabet(W, np.linspace(-1, 1, 3), 3)
+    kw = dict(strides=(2, 2), padding="VALID", rate=(1, 1), want_resid=False)
+    out = layer.quantize_conv2d(W, act_w, act_q, alphabet, **kw)
+    assert tuple(out["idx"].shape) == (7, 7, 3, 64)
+    assert hip.patch_out_dim(230, 7, 2, 1, False) == 112
+    _conv_properties(layer, W, act_w, act_q, alphabet, out, 3, kw)
+    # 49 x 51.4 M x 4 B = 10 GB per patch matrix: two on the device, two copies on the host for the oracle
+    _conv_sample(hip, oracle_mod, act_w, act_q, W, alphabet, out, 7, 2, "VALID", [(1, [0, 21, 42, 63])], host_gib_needed=48)
+
+
+def test_cfg5_resnet50_conv3x3_56_full_size(hip, oracle_mod):
+    """ResNet50 conv2_x 3x3 SAME 64 -> 64 @ 56 x 56, 4096 images: 12.8 M columns, 4096 (channel, filter) pairs."""
+    from quantized_neural_networks_amd import layer
+    dev = torch.device("cuda")
+    act_w, act_q, W = _conv_inputs(4096, 56, 56, 64, 64, 3, dev, 52)
+    alphabet, _ = layer.layer_alphabet(W, np.linspace(-1, 1, 3), 3)
+    kw = dict(strides=(1, 1), padding="SAME", rate=(1, 1), want_resid=False)
+    out = layer.quantize_conv2d(W, act_w, act_q, alphabet, **kw)
+    assert int(out["reruns"]) <= 4
+    _conv_properties(layer, W, act_w, act_q, alphabet, out, 3, kw)
+    _conv_sample(hip, oracle_mod, act_w, act_q, W, alphabet, out, 3, 1, "SAME", [(0, [0, 1, 62, 63]), (63, [5, 17, 33, 60])],
+                 host_gib_needed=8)
