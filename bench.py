@@ -95,6 +95,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
+        group = dist.group.WORLD           # the layer drivers shard only over an EXPLICIT group
 
     from quantized_neural_networks_amd import hip, layer
 

@@ -12,7 +12,6 @@ accuracy columns hold agreement with the analog network's own predictions (analo
     python examples/quantize_cnn.py [--samples 5000] [--bits 1.585 3] [--scalars 2 3 4] [--csv out.csv]
 """
 import argparse
-import csv
 import os
 import sys
 from collections import namedtuple
@@ -26,8 +25,9 @@ from quantized_network import CIFAR10Sequence, QuantizedCNN, msq_quantize  # noq
 from quantized_neural_networks_amd import keras_shim as keras  # noqa: E402
 
 ParamConfig = namedtuple("ParamConfig", "pretrained_model, data_set, q_train_size, ignore_layers, bits, alphabet_scalar")
-COLUMNS = ["", "data_set", "serialized_model", "q_train_size", "ignore_layers", "bits", "alphabet_scalar",
-           "analog_test_acc", "sd_test_acc", "msq_test_acc", "quantization_time"]
+# columns of the reference's CIFAR10 metrics file, in its order (quantize_pretrained_cnn.py:124-140); the index is the run's time stamp
+METRICS_COLUMNS = ["data_set", "serialized_model", "q_train_size", "ignore_layers", "bits", "alphabet_scalar",
+                   "analog_test_acc", "sd_test_acc", "msq_test_acc", "quantization_time"]
 
 
 def build_model(seed=0):
@@ -69,13 +69,15 @@ def main():
     ap.add_argument("--samples", type=int, default=5000, help="q_train_size (reference: 5000)")
     ap.add_argument("--bits", type=float, nargs="+", default=[np.log2(3)])
     ap.add_argument("--scalars", type=float, nargs="+", default=[2, 3, 4])
-    ap.add_argument("--csv", default=None, help="write the metrics rows here (reference schema)")
+    ap.add_argument("--csv", default=None, help="append the metrics rows here (reference schema and append semantics)")
+    ap.add_argument("--save-dir", default=None, help="save every quantized model there (quantize_pretrained_cnn.py:97-100)")
+    ap.add_argument("--test-samples", type=int, default=2000)
     args = ap.parse_args()
 
     rng = np.random.default_rng(0)
     model = build_model()
     X_train = rng.random((args.samples, 32, 32, 3)).astype(np.float32)
-    X_test = rng.random((2000, 32, 32, 3)).astype(np.float32)
+    X_test = rng.random((args.test_samples, 32, 32, 3)).astype(np.float32)
     y_train = np.zeros((args.samples, 10), dtype=np.float32)
     y_test = model.predict(X_test, batch_size=500)                       # analog network's outputs
     quiet = type("Quiet", (), {"info": staticmethod(lambda m: None)})()
@@ -101,19 +103,25 @@ def main():
                 MSQ_model.layers[layer_idx].set_weights([msq_quantize(W, rad * my_quant_net.alphabet), b])
         MSQ_accuracy = agreement(MSQ_model, y_test, X_test)
 
-        stamp = f"run{idx}"
-        rows.append([stamp, params.data_set, f"quantized_cifar10_scaler{params.alphabet_scalar}_{params.bits}bits_{stamp}",
-                     params.q_train_size, params.ignore_layers, params.bits, params.alphabet_scalar,
-                     1.0, q_accuracy, MSQ_accuracy, quantization_time])
+        import pandas as pd
+        stamp = str(pd.Timestamp.now()).replace(" ", "_").replace(":", "").replace(".", "")
+        model_name = f"quantized_cifar10_scaler{params.alphabet_scalar}_{params.bits}bits_{stamp}"
+        if args.save_dir:
+            os.makedirs(args.save_dir, exist_ok=True)
+            keras.save_model(my_quant_net.quantized_net, os.path.join(args.save_dir, model_name))
+        trial_metrics = pd.DataFrame({
+            "data_set": params.data_set, "serialized_model": model_name, "q_train_size": params.q_train_size,
+            "ignore_layers": [params.ignore_layers], "bits": params.bits, "alphabet_scalar": params.alphabet_scalar,
+            "analog_test_acc": 1.0, "sd_test_acc": q_accuracy, "msq_test_acc": MSQ_accuracy,
+            "quantization_time": quantization_time}, index=[stamp])
+        if args.csv:                                    # header with the first row only, rows appended (:146-159)
+            trial_metrics.to_csv(args.csv, mode="a", header=(idx == 0))
+        rows.append(trial_metrics)
         print(f"bits {params.bits:.3f} scalar {params.alphabet_scalar:g}: quantization_time {quantization_time:.3f} s, "
               f"agreement with the analog net: GPFQ {q_accuracy:.4f}, MSQ {MSQ_accuracy:.4f}", flush=True)
 
     if args.csv:
-        with open(args.csv, "w", newline="") as f:
-            w = csv.writer(f)
-            w.writerow(COLUMNS)
-            w.writerows(rows)
-        print(f"wrote {len(rows)} rows to {args.csv}")
+        print(f"appended {len(rows)} rows to {args.csv}")
 
 
 if __name__ == "__main__":

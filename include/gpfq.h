@@ -57,7 +57,9 @@ extern "C" {
 #define GPFQ_MAX_ALPHABET 64          /* alphabet members per call (bits <= 6)                 */
 
 /* gpfq_quantize_neurons `path` selector */
-#define GPFQ_PATH_AUTO      0   /* on-chip residual when m fits a wavefront's registers, else streaming */
+#define GPFQ_PATH_AUTO      0   /* rows beyond GPFQ_GRAM_MIN_M samples with walks of <= GPFQ_GRAM_MAX_N steps (and no u_out):
+                                   the Gram path + a rerun of what it flags (one stream synchronisation); else on-chip
+                                   residual when m fits the registers, else streaming */
 #define GPFQ_PATH_ONCHIP    1   /* residual u lives in VGPRs (of up to 16 wavefronts per neuron), rows staged through LDS (m <= GPFQ_ONCHIP_MAX_M) */
 #define GPFQ_PATH_STREAM    2   /* residual u lives in HBM (any m; conv patch matrices)          */
 
@@ -277,11 +279,16 @@ int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t 
  * nch * (K*K*2 + K) doubles, K = kh*kw; the flags by maximum) and every GPU finishes from the summed records
  * (gpfq_quantize_conv_channels_from_records on the planes of ALL images, which the repair of uncertified chains
  * reads).  Certified decisions do not depend on the order in which the records were summed, so the results are
- * those of the one-call form.
+ * those of the one-call form -- up to the float32 rounding of a row norm whose float64 square sits within one part in
+ * 10^16 of a rounding boundary (the norm is the rounded square root of a summed record entry).
+ *   gpfq_conv_records_supported: 1 when BOTH halves have a plane kernel for this shape (the halves see different
+ *   image counts: ask for each before committing all GPUs to this form), else 0.
  *   records [device] f64 [nch][K*K*2 + K], negflags [device] i32 [nch]; workspace as for
  *   gpfq_quantize_conv_channels with want_resid = 0 (F = 0 for the records half).
  *   GPFQ_ERR_UNSUPPORTED for kernel shapes that need patch matrices in memory (kh*kw > 256 ...): shard by channel.
  */
+int gpfq_conv_records_supported(int64_t n, int64_t H, int64_t W, int64_t nch, int kh, int kw, int sh, int sw, int rh, int rw,
+                                int same_padding);
 int gpfq_conv_channel_records(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,
                               int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
                               double *records, int32_t *negflags, void *workspace, size_t workspace_bytes, void *stream);

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "../../include/gpfq.h"
 #include "gpfq_launch.hpp"
@@ -92,16 +93,37 @@ static int resolve_path(int64_t m, int path)
     return path;
 }
 
+// GPFQ_PATH_AUTO prefers the Gram path (N x N records + scalar recurrences, gpfq_quantize_neurons_gram) exactly where
+// the Python binding's auto_path does: rows beyond GPFQ_GRAM_MIN_M samples (or half of that with many neurons), walks
+// the records can hold, and no residual vectors requested.
+static bool auto_wants_gram(int64_t N, int64_t m, int64_t C, bool want_u)
+{
+    const bool long_rows = m > GPFQ_GRAM_MIN_M || (m > GPFQ_GRAM_MIN_M / 2 && C * m >= 5000000);
+    return !want_u && long_rows && N <= GPFQ_GRAM_MAX_N && m < (1LL << 30);
+}
+
 // on-chip workspace: [fallback counter, 64 B][RowStats x N][iteration records of the pipelined kernel]
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t onchip_stats_bytes(int64_t N) { return al256(64 + (size_t)N * sizeof(gpfq::RowStats)); }
 static size_t onchip_workspace_bytes(int64_t N, int64_t m) { return onchip_stats_bytes(N) + gpfq::pipe_workspace_bytes(N, m); }
 
+// AUTO -> Gram: [Gram workspace][uncertified flags i32 x C][streaming workspace of ONE neuron, for the rare reruns]
+static size_t auto_gram_workspace_bytes(int64_t N, int64_t m, int64_t C)
+{
+    return al256(gpfq::gram_workspace_bytes(N, m, C)) + al256((size_t)C * sizeof(int32_t)) +
+           gpfq::stream_workspace_bytes(N, m, 1, /*need_u=*/true);
+}
+
 size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path)
 {
     if (N < 0 || m < 0 || C < 0) return 0;
-    if (resolve_path(m, path) == GPFQ_PATH_ONCHIP) return onchip_workspace_bytes(N, m);
-    return gpfq::stream_workspace_bytes(N, m, C, /*need_u=*/true);
+    size_t need = resolve_path(m, path) == GPFQ_PATH_ONCHIP ? onchip_workspace_bytes(N, m)
+                                                             : gpfq::stream_workspace_bytes(N, m, C, /*need_u=*/true);
+    if (path == GPFQ_PATH_AUTO && auto_wants_gram(N, m, C, false)) {
+        const size_t g = auto_gram_workspace_bytes(N, m, C);
+        if (g > need) need = g;
+    }
+    return need;
 }
 
 // Tuning / test hooks (process-wide).  Results never depend on them.
@@ -174,6 +196,41 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
         return fail(GPFQ_ERR_INVALID_ARG, "unknown path %d", path);
     const int p = resolve_path(m, path);
     hipStream_t s = static_cast<hipStream_t>(stream);
+
+    if (path == GPFQ_PATH_AUTO && N > 0 && m > 0 && auto_wants_gram(N, m, C, u_out != nullptr) && workspace &&
+        (uintptr_t)workspace % 16 == 0 && workspace_bytes >= auto_gram_workspace_bytes(N, m, C)) {
+        // Long rows, short walks: Gram records once per layer, the recurrence on scalars with every decision certified,
+        // uncertifiable chains repaired on the device; whatever is still flagged afterwards (practically never) is rerun
+        // here through the streaming kernel, which costs this call ONE stream synchronisation (the flags cross to the host).
+        char *ws = static_cast<char *>(workspace);
+        void *gram_ws = ws;
+        int32_t *unc = reinterpret_cast<int32_t *>(ws + al256(gpfq::gram_workspace_bytes(N, m, C)));
+        char *stream_ws = reinterpret_cast<char *>(unc) + al256((size_t)C * sizeof(int32_t));
+        gpfq::GramArgs g;
+        g.X = X; g.Xq = Xq; g.ld = ld; g.nrm32 = nrm32; g.Wt = Wt; g.ldw = ldw; g.A = A;
+        g.N = N; g.m = m; g.C = C; g.qidx = qidx; g.Qt = Qt; g.resid = resid; g.uncertified = unc;
+        g.workspace = gram_ws;
+        g.slack = std::ldexp(1.0, g_gram_slack_log2);
+        g.variant = g_variant;
+        gpfq::note_dense_kernel("gpfq_gram_* (Gram records + certified scalar recurrence), reruns through gpfq_stream_*");
+        hipError_t e = gpfq::launch_gram(g, s);
+        if (e != hipSuccess) return hip_fail(e, "gpfq_quantize_neurons(auto: gram)");
+        std::vector<int32_t> flags((size_t)C);
+        e = hipMemcpyAsync(flags.data(), unc, (size_t)C * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return hip_fail(e, "gpfq_quantize_neurons(auto: flags)");
+        for (int64_t j = 0; j < C; ++j) {
+            if (!flags[(size_t)j]) continue;
+            gpfq::StreamArgs a;
+            a.X = X; a.Xq = Xq; a.ld = ld; a.nrm32 = nrm32; a.Wt = Wt + j * ldw; a.ldw = ldw; a.A = A;
+            a.N = N; a.m = m; a.C = 1; a.qidx = qidx ? qidx + j * N : nullptr; a.Qt = Qt ? Qt + j * N : nullptr;
+            a.resid = resid ? resid + j : nullptr; a.u_out = nullptr;
+            a.workspace = stream_ws; a.workspace_bytes = gpfq::stream_workspace_bytes(N, m, 1, true);
+            e = gpfq::launch_stream(a, s);
+            if (e != hipSuccess) return hip_fail(e, "gpfq_quantize_neurons(auto: rerun)");
+        }
+        return GPFQ_OK;
+    }
 
     if (p == GPFQ_PATH_ONCHIP) {
         if (m > GPFQ_ONCHIP_MAX_M)
@@ -525,6 +582,17 @@ static int conv_channels_impl(int phase, double *records, int32_t *negflags,
         if (e != hipSuccess) return hip_fail(e, "gpfq_quantize_conv_channels(gram)");
     }
     return GPFQ_OK;
+}
+
+int gpfq_conv_records_supported(int64_t n, int64_t H, int64_t W, int64_t nch, int kh, int kw, int sh, int sw, int rh, int rw,
+                                int same_padding)
+{
+    if (n <= 0 || H <= 0 || W <= 0 || nch <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || rh <= 0 || rw <= 0) return 0;
+    const int64_t oh = gpfq_patch_out_dim(H, kh, sh, rh, same_padding), ow = gpfq_patch_out_dim(W, kw, sw, rw, same_padding);
+    const int64_t cols = n * oh * ow, K = (int64_t)kh * kw;
+    if (cols <= 0 || K > GPFQ_GRAM_MAX_N || cols >= (1LL << 30) || !g_conv_fused) return 0;
+    return (gpfq::gram_image_supported(n, H, W, kh, kw, sh, sw, rh, rw, same_padding) ||
+            gpfq::gram_conv_supported(n, H, W, nch, kh, kw, oh, ow)) ? 1 : 0;
 }
 
 int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,

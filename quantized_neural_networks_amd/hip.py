@@ -39,6 +39,7 @@ SYMBOLS = {
     "gpfq_conv_channels_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _i64, _int]),
     "gpfq_quantize_conv_channels": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int,
                                            _vp, _dp, _int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gpfq_conv_records_supported": (_int, [_i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int]),
     "gpfq_conv_channel_records": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int,
                                          _vp, _vp, _vp, _sz, _vp]),
     "gpfq_quantize_conv_channels_from_records": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int,
@@ -189,7 +190,9 @@ def quantize_neurons(X, Xq, Wt, alphabet, nrm32=None, want_u=False, path=GPFQ_PA
     lib = load()
     nbytes = lib.gpfq_workspace_bytes(N, m, C, path)
     streaming = path == GPFQ_PATH_STREAM or (path == GPFQ_PATH_AUTO and m > GPFQ_ONCHIP_MAX_M)
-    u = torch.empty((C, m), dtype=torch.float64, device=dev) if (want_u or streaming) else None
+    # (the streaming path keeps its residual in the workspace, which gpfq_workspace_bytes sizes for it: a second
+    #  C x m float64 tensor here would double the largest allocation of the call)
+    u = torch.empty((C, m), dtype=torch.float64, device=dev) if want_u else None
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = lib.gpfq_quantize_neurons(xp, xqp, ld, nrm32.data_ptr(), wp, ldw, arr, M, zero_idx, N, m, C,
@@ -309,6 +312,15 @@ def quantize_conv_channels(act_w_cm, act_q_cm, Wt_all, alphabet, kernel_size, st
                                              resid.data_ptr() if resid is not None else None, unc.data_ptr(),
                                              ws.data_ptr(), nbytes, _stream())
     _check(rc, "gpfq_quantize_conv_channels")
+
+
+def conv_records_supported(n, H, W, nch, kernel_size, strides, rate, padding):
+    """Whether conv_channel_records / conv_channels_from_records have a plane kernel for n images of H x W."""
+    kh, kw = kernel_size
+    sh, sw = strides
+    rh, rw = rate if rate else (1, 1)
+    same = 1 if str(padding).upper() == "SAME" else 0
+    return bool(load().gpfq_conv_records_supported(int(n), int(H), int(W), int(nch), kh, kw, sh, sw, rh, rw, same))
 
 
 def conv_channel_records(act_w_cm, act_q_cm, kernel_size, strides, rate, padding):

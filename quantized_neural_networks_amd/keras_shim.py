@@ -38,6 +38,16 @@ class _Node:
         self.inbound_layers = inbound_layers
 
 
+class _FTensor:
+    """Functional-API symbolic tensor: 'the output of `layer`' (Keras' KerasTensor), with its static shape."""
+
+    def __init__(self, layer, shape):
+        self.layer, self.shape = layer, tuple(shape)
+
+
+_creation_counter = [0]
+
+
 def _pair(v):
     return (int(v), int(v)) if np.isscalar(v) else (int(v[0]), int(v[1]))
 
@@ -109,7 +119,29 @@ class Layer:
         return {}
 
     def clone(self):
-        return self.__class__(**self.config())
+        c = self.__class__(**self.config())
+        c.name = self.name
+        return c
+
+    # -- functional API: layer(x) / layer([a, b]) -----------------------------------------
+    def __call__(self, inputs):
+        """Connect the layer to symbolic tensor(s); weights are created when a Model is built over the graph."""
+        multi = isinstance(inputs, (list, tuple))
+        tensors = list(inputs) if multi else [inputs]
+        if not all(isinstance(t, _FTensor) for t in tensors):
+            raise TypeError("functional API: call layers on tensors made by Input() / other layers")
+        if self.inbound_nodes:
+            raise NotImplementedError("the shim connects every layer once (no shared layers)")
+        shapes = [t.shape for t in tensors]
+        self.input_shape = shapes if multi else shapes[0]
+        self.output_shape = self.compute_output_shape(self.input_shape)
+        self.input = tensors if multi else tensors[0]
+        self.output = _FTensor(self, self.output_shape)
+        inbound = [t.layer for t in tensors]
+        self.inbound_nodes = [_Node(inbound if multi else inbound[0])]       # Keras: the layer itself when there is one
+        _creation_counter[0] += 1
+        self._order = _creation_counter[0]
+        return self.output
 
 
 class InputLayer(Layer):
@@ -119,6 +151,38 @@ class InputLayer(Layer):
 
     def config(self):
         return dict(input_shape=self._decl)
+
+
+def Input(shape, name=None):
+    """Functional API entry point: a symbolic input of shape (None,) + shape."""
+    layer = InputLayer(input_shape=tuple(shape), name=name or "input_1")
+    layer.input_shape = layer.output_shape = (None,) + tuple(shape)
+    layer.inbound_nodes = [_Node([])]
+    _creation_counter[0] += 1
+    layer._order = _creation_counter[0]
+    layer.input = layer.output = _FTensor(layer, layer.output_shape)
+    return layer.output
+
+
+class Add(Layer):
+    """Element-wise sum of its inputs (ResNet shortcuts)."""
+
+    def compute_output_shape(self, s):
+        return tuple(s[0])
+
+    def call(self, xs):
+        y = xs[0]
+        for x in xs[1:]:
+            y = y + x
+        return y
+
+
+class GlobalAveragePooling2D(Layer):
+    def compute_output_shape(self, s):
+        return (s[0], s[3])
+
+    def call(self, x):
+        return x.mean(dim=(1, 2))
 
 
 class Dense(Layer):
@@ -438,33 +502,228 @@ class Sequential:
 
 
 class Model:
-    """``Model(inputs=net.layers[0].input, outputs=[layer.output, ...])``: a truncated view."""
+    """``Model(inputs, outputs)`` over symbolic tensors, as the reference uses it:
 
-    def __init__(self, inputs=None, outputs=None):
+    * tensors of a ``Sequential`` (``net.layers[0].input`` / ``layer.output``): a truncated view of that network
+      (scripts/quantized_network.py:456-462);
+    * tensors of the functional API (``Input(...)``, ``layer(x)``, ``Add()([a, b])``): the graph network whose
+      ``layers`` lists, in creation order, every layer between ``inputs`` and ``outputs`` (``InputLayer`` first, as
+      Keras does).  Weights are created the first time a Model is built over unbuilt layers; a second Model over the
+      same tensors (the truncated models of the activation capture) shares them.
+    """
+
+    def __init__(self, inputs=None, outputs=None, device=None, seed=0, name=None):
         self.inputs = inputs
         self._single = not isinstance(outputs, (list, tuple))
         self.outputs = [outputs] if self._single else list(outputs)
+        self.name = name
+        self._functional = all(isinstance(t, _FTensor) for t in self.outputs)
+        if not self._functional:
+            return
+        ins = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
+        if len(ins) != 1 or not isinstance(ins[0], _FTensor):
+            raise NotImplementedError("functional Model: one input tensor")
+        self._input = ins[0]
+        # every layer the outputs depend on, in creation (= topological) order
+        seen, stack = {}, [t.layer for t in self.outputs]
+        while stack:
+            layer = stack.pop()
+            if id(layer) in seen:
+                continue
+            seen[id(layer)] = layer
+            inbound = layer.inbound_nodes[0].inbound_layers
+            stack.extend(inbound if isinstance(inbound, (list, tuple)) else [inbound])
+        self.layers = sorted(seen.values(), key=lambda l: l._order)
+        if self._input.layer not in self.layers:
+            raise ValueError("functional Model: outputs do not depend on the input")
+        self.device = torch.device(device) if device is not None else next(
+            (l.device for l in self.layers if l.built and l.device is not None), _default_device())
+        rng = np.random.default_rng(seed)
+        taken = {l.name for l in self.layers if l.name}
+        for k, layer in enumerate(self.layers):
+            if not layer.built:
+                layer.build(layer.input_shape, self.device, rng)
+            if layer.name is None:
+                base = f"{layer.__class__.__name__.lower()}_{k}"
+                while base in taken:
+                    base += "_"
+                layer.name = base
+                taken.add(base)
+        self._input_shape = tuple(self._input.shape[1:])
+        self.built = True
+
+    # -- Keras surface of a full model ---------------------------------------------------
+    @property
+    def input(self):
+        return self._input if self._functional else self.inputs
+
+    @property
+    def input_shape(self):
+        return (None,) + tuple(self._input_shape)
+
+    def get_weights(self):
+        out = []
+        for layer in self.layers:
+            out += layer.get_weights()
+        return out
+
+    def set_weights(self, weights):
+        i = 0
+        for layer in self.layers:
+            n = len(layer._weights)
+            layer.set_weights(weights[i:i + n])
+            i += n
+        if i != len(weights):
+            raise ValueError("weight list length mismatch")
+
+    def _as_tensor(self, x):
+        if isinstance(x, torch.Tensor):
+            return x.to(device=self.device, dtype=torch.float32)
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.float32)).to(self.device)
+
+    @torch.no_grad()
+    def _run_graph(self, x):
+        """Values of self.outputs for input batch x: one pass over the layers in order, tensors freed after their
+        last consumer."""
+        vals = {id(self._input.layer): self._as_tensor(x)}
+        last_use = {}
+        for k, layer in enumerate(self.layers):
+            inbound = layer.inbound_nodes[0].inbound_layers
+            for p in (inbound if isinstance(inbound, (list, tuple)) else [inbound]):
+                last_use[id(p)] = k
+        keep = {id(t.layer) for t in self.outputs}
+        for k, layer in enumerate(self.layers):
+            if id(layer) in vals:
+                continue
+            inbound = layer.inbound_nodes[0].inbound_layers
+            if isinstance(inbound, (list, tuple)):
+                vals[id(layer)] = layer.call([vals[id(p)] for p in inbound])
+            else:
+                vals[id(layer)] = layer.call(vals[id(inbound)])
+            for p in (inbound if isinstance(inbound, (list, tuple)) else [inbound]):
+                if last_use.get(id(p)) == k and id(p) not in keep:
+                    del vals[id(p)]
+        return [vals[id(t.layer)] for t in self.outputs]
 
     def predict_on_batch(self, x):
-        res = [t.net.forward_upto(x, t.k) for t in self.outputs]
+        if self._functional:
+            res = self._run_graph(x)
+        else:
+            res = [t.net.forward_upto(x, t.k) for t in self.outputs]
         return res[0] if (self._single or len(res) == 1) else res
+
+    def predict(self, x, batch_size=32, verbose=0):
+        outs = [self.predict_on_batch(x[i:i + batch_size]) for i in range(0, len(x), batch_size)]
+        return torch.cat(outs).cpu().numpy()
+
+    def compile(self, *args, **kwargs):
+        return None
+
+    def evaluate(self, x, y, batch_size=256, verbose=0):
+        return Sequential.evaluate(self, x, y, batch_size, verbose)
 
 
 def clone_model(net):
     """Same architecture, freshly initialised weights (Keras semantics); callers copy weights over."""
+    if isinstance(net, Model):
+        if not net._functional:
+            raise NotImplementedError("clone_model of a truncated view")
+        mapping = {}
+        for layer in net.layers:
+            if isinstance(layer, InputLayer):
+                mapping[id(layer)] = Input(layer._decl, name=layer.name)
+                continue
+            inbound = layer.inbound_nodes[0].inbound_layers
+            new = layer.clone()
+            if isinstance(inbound, (list, tuple)):
+                mapping[id(layer)] = new([mapping[id(p)] for p in inbound])
+            else:
+                mapping[id(layer)] = new(mapping[id(inbound)])
+        outs = [mapping[id(t.layer)] for t in net.outputs]
+        return Model(inputs=mapping[id(net._input.layer)], outputs=outs[0] if net._single else outs, device=net.device,
+                     seed=12345, name=net.name)
     clone = Sequential(input_shape=net._input_shape, device=net.device, seed=12345)
     for layer in net.layers:
         clone.add(layer.clone())
     return clone
 
 
+def ResNet50(input_shape=(224, 224, 3), classes=1000, device=None, seed=0):
+    """The topology of ``tf.keras.applications.ResNet50`` (v1, channels-last; the model quantize_pretrained_imagenet.py:10
+    imports): conv1 7x7/2 on the zero-padded input, 3x3/2 max-pool, stages of 3 / 4 / 6 / 3 bottleneck blocks
+    (1x1, 3x3 'same', 1x1 convolutions, BatchNormalization after each, projection shortcut in every stage's first block,
+    stride 2 on the first 1x1 and on the shortcut of stages 3-5), global average pooling, softmax classifier -- 53
+    Conv2D layers and one Dense, with Keras' layer names.  Weights are random (no checkpoints on this image)."""
+    def block(x, filters, stride, conv_shortcut, name):
+        if conv_shortcut:
+            sc = Conv2D(4 * filters, 1, strides=stride, name=name + "_0_conv")(x)
+            sc = BatchNormalization(epsilon=1.001e-5, name=name + "_0_bn")(sc)
+        else:
+            sc = x
+        y = Conv2D(filters, 1, strides=stride, name=name + "_1_conv")(x)
+        y = BatchNormalization(epsilon=1.001e-5, name=name + "_1_bn")(y)
+        y = Activation("relu", name=name + "_1_relu")(y)
+        y = Conv2D(filters, 3, padding="same", name=name + "_2_conv")(y)
+        y = BatchNormalization(epsilon=1.001e-5, name=name + "_2_bn")(y)
+        y = Activation("relu", name=name + "_2_relu")(y)
+        y = Conv2D(4 * filters, 1, name=name + "_3_conv")(y)
+        y = BatchNormalization(epsilon=1.001e-5, name=name + "_3_bn")(y)
+        y = Add(name=name + "_add")([sc, y])
+        return Activation("relu", name=name + "_out")(y)
+
+    def stack(x, filters, blocks, stride1, name):
+        x = block(x, filters, stride1, True, name + "_block1")
+        for i in range(2, blocks + 1):
+            x = block(x, filters, 1, False, f"{name}_block{i}")
+        return x
+
+    inp = Input(input_shape, name="input_1")
+    x = ZeroPadding2D(3, name="conv1_pad")(inp)
+    x = Conv2D(64, 7, strides=2, name="conv1_conv")(x)
+    x = BatchNormalization(epsilon=1.001e-5, name="conv1_bn")(x)
+    x = Activation("relu", name="conv1_relu")(x)
+    x = ZeroPadding2D(1, name="pool1_pad")(x)
+    x = MaxPooling2D(3, strides=2, name="pool1_pool")(x)
+    x = stack(x, 64, 3, 1, "conv2")
+    x = stack(x, 128, 4, 2, "conv3")
+    x = stack(x, 256, 6, 2, "conv4")
+    x = stack(x, 512, 3, 2, "conv5")
+    x = GlobalAveragePooling2D(name="avg_pool")(x)
+    out = Dense(classes, activation="softmax", name="predictions")(x)
+    return Model(inp, out, device=device, seed=seed, name="resnet50")
+
+
+_LAYER_CLASSES = None
+
+
+def _layer_classes():
+    global _LAYER_CLASSES
+    if _LAYER_CLASSES is None:
+        _LAYER_CLASSES = {c.__name__: c for c in (Dense, Conv2D, DepthwiseConv2D, Flatten, MaxPooling2D, AveragePooling2D,
+                                                  ZeroPadding2D, BatchNormalization, Activation, ReLU, Dropout, Add,
+                                                  GlobalAveragePooling2D)}
+    return _LAYER_CLASSES
+
+
 def save_model(model, filepath):
     """Stand-in for ``tf.keras.models.save_model`` as the reference's drivers call it on ``quantized_net``
-    (quantize_pretrained_mlp.py:87-95, _imagenet.py:180-191): architecture (layer classes + configs) and weights
-    in ONE ``.npz`` file (no pickling; ``load_model`` rebuilds the network on the current device)."""
+    (quantize_pretrained_mlp.py:87-95, _imagenet.py:180-191): architecture (layer classes + configs, and for graph
+    networks every layer's inbound layers) and weights in ONE ``.npz`` file (no pickling; ``load_model`` rebuilds the
+    network on the current device)."""
     import json
-    arch = dict(input_shape=list(model._input_shape), layers=[dict(cls=l.__class__.__name__, name=l.name, config=l.config())
-                                                              for l in model.layers])
+    functional = isinstance(model, Model)
+    specs = []
+    for l in model.layers:
+        spec = dict(cls=l.__class__.__name__, name=l.name, config=l.config())
+        if functional:
+            inbound = l.inbound_nodes[0].inbound_layers
+            spec["inbound"] = [p.name for p in inbound] if isinstance(inbound, (list, tuple)) else [inbound.name]
+            spec["multi"] = isinstance(inbound, (list, tuple)) and not isinstance(l, InputLayer)
+        specs.append(spec)
+    arch = dict(input_shape=list(model._input_shape), layers=specs, functional=functional)
+    if functional:
+        arch["outputs"] = [t.layer.name for t in model.outputs]
+        arch["single"] = model._single
     arrays = {"__arch__": np.frombuffer(json.dumps(arch).encode("utf-8"), dtype=np.uint8)}
     for k, layer in enumerate(model.layers):
         for j, w in enumerate(layer.get_weights()):
@@ -478,16 +737,40 @@ def load_model(filepath, device=None):
     """Inverse of ``save_model``."""
     import json
     path = str(filepath)
+
+    def tup(v):
+        return tuple(tup(e) for e in v) if isinstance(v, list) else v
+
     with np.load(path if path.endswith(".npz") else path + ".npz", allow_pickle=False) as z:
         arch = json.loads(bytes(z["__arch__"]).decode("utf-8"))
-        known = {c.__name__: c for c in (Dense, Conv2D, DepthwiseConv2D, Flatten, MaxPooling2D, AveragePooling2D,
-                                         ZeroPadding2D, BatchNormalization, Activation, ReLU, Dropout)}
+        known = _layer_classes()
+        if arch.get("functional"):
+            tensors, layers = {}, []
+            for spec in arch["layers"]:
+                cfg = {key: tup(v) for key, v in spec["config"].items()}
+                if spec["cls"] == "InputLayer":
+                    tensors[spec["name"]] = Input(cfg["input_shape"], name=spec["name"])
+                    layers.append(tensors[spec["name"]].layer)
+                    continue
+                if spec["cls"] not in known:
+                    raise ValueError(f"load_model: unknown layer class {spec['cls']!r}")
+                layer = known[spec["cls"]](**cfg)
+                layer.name = spec["name"]
+                ins = [tensors[n] for n in spec["inbound"]]
+                tensors[spec["name"]] = layer(ins if spec["multi"] else ins[0])
+                layers.append(layer)
+            outs = [tensors[n] for n in arch["outputs"]]
+            net = Model(layers[0].output, outs[0] if arch["single"] else outs, device=device)
+            assert [l.name for l in net.layers] == [s["name"] for s in arch["layers"]]
+            for k, layer in enumerate(net.layers):
+                n = len(layer._weights)
+                if n:
+                    layer.set_weights([z[f"w{k}_{j}"] for j in range(n)])
+            return net
         net = Sequential(input_shape=tuple(arch["input_shape"]), device=device)
         for k, spec in enumerate(arch["layers"]):
             if spec["cls"] not in known:
                 raise ValueError(f"load_model: unknown layer class {spec['cls']!r}")
-            def tup(v):
-                return tuple(tup(e) for e in v) if isinstance(v, list) else v
             cfg = {key: tup(v) for key, v in spec["config"].items()}
             layer = known[spec["cls"]](**cfg)
             layer.name = spec["name"]

@@ -56,9 +56,12 @@ def shard_bounds(n_units, world_size, rank):
 
 
 def _group_info(group):
-    import torch.distributed as dist
-    if group is None and not (dist.is_available() and dist.is_initialized()):
+    """(world, rank) of an EXPLICIT process group; ``None`` means "this process alone" even inside an initialised
+    torch.distributed job (a rank-0-only quantization under torchrun must not wait for collectives the other ranks
+    never enter).  Pass ``dist.group.WORLD`` to shard over all ranks."""
+    if group is None:
         return 1, 0
+    import torch.distributed as dist
     return dist.get_world_size(group), dist.get_rank(group)
 
 
@@ -76,14 +79,6 @@ def all_gather_units(local, n_units, group=None):
     out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, pad, group=group)
     return out[:n_units]
-
-
-# The local worker.  Tests of the collective plumbing (gloo, CPU) substitute a stand-in here; the
-# product never does -- there is no CPU fallback.
-_local_quantize = hip.quantize_neurons
-_extract_patches = hip.extract_patches
-_assemble = hip.assemble_kernel
-_pack = hip.pack_indices
 
 
 # ------------------------------------------------------------------------------------------
@@ -104,18 +99,18 @@ def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True):
     lo, hi = shard_bounds(C, world, rank)
     Wt = W[:, lo:hi].t().contiguous()                        # neuron-major shard [C_local][N]
     if hi > lo:
-        r = _local_quantize(X, Xq, Wt, alphabet, want_values=False, want_resid=want_resid)
+        r = hip.quantize_neurons(X, Xq, Wt, alphabet, want_values=False, want_resid=want_resid)
         i_loc, res_loc = r["idx"], r["resid"]
     else:
         i_loc = torch.empty((0, N), dtype=torch.int8, device=W.device)
         res_loc = torch.empty((0,), dtype=torch.float64, device=W.device)
     # only the indices travel over xGMI -- packed to 2 or 4 bits per weight when the alphabet allows;
     # values are looked up while transposing to the Keras layout
-    if world > 1 and _pack is not None:
-        packed, bits = _pack(i_loc, len(alphabet))
-        Q, idx = _assemble(all_gather_units(packed, C, group).contiguous(), alphabet, bits=bits, N=N)
+    if world > 1:
+        packed, bits = hip.pack_indices(i_loc, len(alphabet))
+        Q, idx = hip.assemble_kernel(all_gather_units(packed, C, group).contiguous(), alphabet, bits=bits, N=N)
     else:
-        Q, idx = _assemble(all_gather_units(i_loc, C, group).contiguous(), alphabet)
+        Q, idx = hip.assemble_kernel(i_loc, alphabet)
     out = dict(Q=Q, idx=idx)
     if want_resid is not False:
         out["resid"] = all_gather_units(res_loc, C, group)
@@ -156,14 +151,16 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
     Each (input channel c, filter f) pair is an independent neuron of kh*kw weights whose data are
     the rows of channel c's patch matrix (:652-727); channels are partitioned over the ranks.  When Cin < world the
     Gram records are formed over image shards and all-reduced (or, where that does not apply, the filters of each
-    channel are partitioned instead).
+    channel are partitioned instead).  Sharded runs exchange ONE all-gather per layer: the alphabet indices of the
+    rank's (channel, filter) pairs, packed to 2 / 4 bits per weight as the dense path's are; values are looked up
+    locally (+ one all-gather of the residual norms when they are requested).
 
     Returns dict(Q f32 [kh][kw][Cin][F], idx i8 same shape, resid f64 [Cin][F]).
     """
     kh, kw, Cin, F = W.shape
     K = kh * kw
     dev = W.device
-    if K == 1 and not want_resid and _local_quantize is hip.quantize_neurons:
+    if K == 1 and not want_resid:
         return _quantize_conv1x1(W, act_q, alphabet, strides)
     world, rank = _group_info(group)
     by_channel = Cin >= world
@@ -177,38 +174,41 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
     # channel-major copies [Cin][n][H][W] of this rank's channels: the per-channel gather then reads
     # contiguous planes instead of one float out of every Cin (one transposing pass per layer)
     same = act_q is act_w
-    if _extract_patches is hip.extract_patches:
-        planes = lambda a: hip.channel_planes(a.contiguous(), c_lo, c_hi)
-    else:                                      # stand-ins of the collective-plumbing tests (CPU tensors)
-        planes = lambda a: a[..., c_lo:c_hi].permute(3, 0, 1, 2).contiguous()
-    cm_w = planes(act_w)
-    cm_q = cm_w if same else planes(act_q)
+    cm_w = hip.channel_planes(act_w.contiguous(), c_lo, c_hi)
+    cm_q = cm_w if same else hip.channel_planes(act_q.contiguous(), c_lo, c_hi)
+
     def patches(c):
         nonlocal Pw, Pq
-        Pw = _extract_patches(cm_w[c - c_lo].unsqueeze(-1), 0, (kh, kw), strides, rate, padding, out=Pw)
-        Pq = Pw if same else _extract_patches(cm_q[c - c_lo].unsqueeze(-1), 0, (kh, kw), strides, rate, padding, out=Pq)
+        Pw = hip.extract_patches(cm_w[c - c_lo].unsqueeze(-1), 0, (kh, kw), strides, rate, padding, out=Pw)
+        Pq = Pw if same else hip.extract_patches(cm_q[c - c_lo].unsqueeze(-1), 0, (kh, kw), strides, rate, padding, out=Pq)
 
     # neuron-major filters [Cin][F][K]: row-major flattening of each kh x kw filter (:215), t = ky*kw + kx
     Wt_all = W.permute(2, 3, 0, 1).reshape(Cin, F, K).contiguous()
-    plan = None
+    rh, rw = rate if rate else (1, 1)
+    same_pad = str(padding).upper() == "SAME"
+    cols = (act_w.shape[0] * hip.patch_out_dim(act_w.shape[1], kh, strides[0], rh, same_pad)
+            * hip.patch_out_dim(act_w.shape[2], kw, strides[1], rw, same_pad))
     replicated = False                         # every rank already holds the whole result (column-sharded records)
-    if (not by_channel and _local_quantize is hip.quantize_neurons and _extract_patches is hip.extract_patches
-            and not want_resid and K <= hip.GPFQ_GRAM_AUTO_MAX_N and act_w.shape[0] >= world):
+    if not by_channel and not want_resid and K <= hip.GPFQ_GRAM_AUTO_MAX_N and act_w.shape[0] >= world:
         # Fewer input channels than ranks (an image input has 3): the Gram records are sums over the patch columns, so
         # every rank forms them over its share of the IMAGES, one all-reduce of Cin * (2 K^2 + K) doubles sums them,
         # and every rank finishes (decide + repair, milliseconds) from the same records -- no gather afterwards.
-        # Certified decisions do not depend on the summation order of the records: same bits as on one GPU.
+        # Certified decisions do not depend on the summation order of the records.  Both phases must have a kernel
+        # for their shape (the first sees this rank's images, the second all of them): all ranks agree on that first.
         import torch.distributed as dist
         n_lo, n_hi = shard_bounds(act_w.shape[0], world, rank)
+        rec = neg = None
         try:
             pw = hip.channel_planes(act_w[n_lo:n_hi].contiguous(), 0, Cin)
             pq = pw if same else hip.channel_planes(act_q[n_lo:n_hi].contiguous(), 0, Cin)
             rec, neg = hip.conv_channel_records(pw, pq, (kh, kw), strides, rate, padding)
-            supported = 1
+            supported = 1 if hip.conv_records_supported(act_w.shape[0], act_w.shape[1], act_w.shape[2], Cin, (kh, kw), strides,
+                                                        rate, padding) else 0
         except hip.GpfqError:
+            supported = 0
+        if rec is None:
             rec = torch.zeros((Cin, K * K * 2 + K), dtype=torch.float64, device=dev)
             neg = torch.zeros((Cin,), dtype=torch.int32, device=dev)
-            supported = 0
         ok = torch.tensor([supported], dtype=torch.int32, device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)          # all ranks take the same branch
         if int(ok.item()):
@@ -222,20 +222,12 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
                 Qc[c, f], Ic[c, f] = r["Q"][0], r["idx"][0]
                 reruns += 1
             replicated = True
-    if replicated:
+    # the whole-shard Gram call for every conv layer (one launch chain instead of a Python loop over the
+    # channels); with residual norms requested it builds patch matrices, which only pays for long ones
+    whole_shard = K <= hip.GPFQ_GRAM_AUTO_MAX_N and cols > (hip.GPFQ_GRAM_MIN_M if want_resid else 0)
+    if replicated or f_hi <= f_lo:
         pass
-    elif _local_quantize is hip.quantize_neurons and _extract_patches is hip.extract_patches and f_hi > f_lo:
-        rh, rw = rate if rate else (1, 1)
-        same_pad = str(padding).upper() == "SAME"
-        cols = (act_w.shape[0] * hip.patch_out_dim(act_w.shape[1], kh, strides[0], rh, same_pad)
-                * hip.patch_out_dim(act_w.shape[2], kw, strides[1], rw, same_pad))
-        # the whole-shard Gram call for every conv layer (one launch chain instead of a Python loop over the
-        # channels); with residual norms requested it builds patch matrices, which only pays for long ones
-        if K <= hip.GPFQ_GRAM_AUTO_MAX_N and cols > (hip.GPFQ_GRAM_MIN_M if want_resid else 0):
-            plan = True
-    if replicated:
-        pass
-    elif plan is not None:
+    elif whole_shard:
         # Gram path, the whole channel loop (:844-860) in one library call: no per-channel allocation,
         # Python or sync; the filters whose decision chain could not be certified are collected once
         Unc = torch.zeros((Cin, F), dtype=torch.int32, device=dev)
@@ -259,22 +251,33 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
             Qc[c, f], Ic[c, f], Rc[c, f] = r["Q"][0], r["idx"][0], r["resid"][0]
     else:
         for c in range(c_lo, c_hi):
-            if f_hi <= f_lo:
-                break
             patches(c)
-            r = _local_quantize(Pw, Pq, Wt_all[c, f_lo:f_hi], alphabet)
+            r = hip.quantize_neurons(Pw, Pq, Wt_all[c, f_lo:f_hi], alphabet)
             Qc[c, f_lo:f_hi] = r["Q"]
             Ic[c, f_lo:f_hi] = r["idx"]
             Rc[c, f_lo:f_hi] = r["resid"]
     if world > 1 and not replicated:
+        # ONE all-gather of the packed alphabet indices ((channel, filter) pairs are rows of K weights); the float32
+        # values never travel: every rank looks them up while laying the kernel out ([K][pairs] is Keras' [kh][kw][Cin][F])
         if by_channel:
-            Qc = all_gather_units(Qc[c_lo:c_hi], Cin, group)
-            Ic = all_gather_units(Ic[c_lo:c_hi], Cin, group)
-            Rc = all_gather_units(Rc[c_lo:c_hi], Cin, group)
+            rows = Ic[c_lo:c_hi].reshape(-1, K).contiguous()                       # (c, f) rows of this rank's channels
+            packed, bits = hip.pack_indices(rows, len(alphabet))
+            g = all_gather_units(packed.reshape(c_hi - c_lo, -1), Cin, group)      # units = channels
+            Qk, Ik = hip.assemble_kernel(g.reshape(Cin * F, -1).contiguous(), alphabet, bits=bits, N=K)
+            Q = Qk.reshape(kh, kw, Cin, F)
+            idx = Ik.reshape(kh, kw, Cin, F)
+            if want_resid:
+                Rc = all_gather_units(Rc[c_lo:c_hi].contiguous(), Cin, group)
         else:
-            Qc = all_gather_units(Qc[:, f_lo:f_hi].transpose(0, 1).contiguous(), F, group).transpose(0, 1)
-            Ic = all_gather_units(Ic[:, f_lo:f_hi].transpose(0, 1).contiguous(), F, group).transpose(0, 1)
-            Rc = all_gather_units(Rc[:, f_lo:f_hi].transpose(0, 1).contiguous(), F, group).transpose(0, 1)
+            rows = Ic[:, f_lo:f_hi].transpose(0, 1).reshape(-1, K).contiguous()    # (f, c) rows of this rank's filters
+            packed, bits = hip.pack_indices(rows, len(alphabet))
+            g = all_gather_units(packed.reshape(f_hi - f_lo, -1), F, group)        # units = filters
+            Qk, Ik = hip.assemble_kernel(g.reshape(F * Cin, -1).contiguous(), alphabet, bits=bits, N=K)
+            Q = Qk.reshape(kh, kw, F, Cin).permute(0, 1, 3, 2).contiguous()
+            idx = Ik.reshape(kh, kw, F, Cin).permute(0, 1, 3, 2).contiguous()
+            if want_resid:
+                Rc = all_gather_units(Rc[:, f_lo:f_hi].transpose(0, 1).contiguous(), F, group).transpose(0, 1)
+        return dict(Q=Q, idx=idx, resid=Rc.contiguous(), reruns=torch.tensor(reruns))
     Q = Qc.reshape(Cin, F, kh, kw).permute(2, 3, 0, 1).contiguous()
     idx = Ic.reshape(Cin, F, kh, kw).permute(2, 3, 0, 1).contiguous()
     return dict(Q=Q, idx=idx, resid=Rc.contiguous(), reruns=torch.tensor(reruns))

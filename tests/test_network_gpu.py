@@ -498,3 +498,55 @@ def test_conv1x1_shortcut_equals_general_path(oracle_mod, stride, bits):
         for f in range(7):
             qo, _, _ = oracle_mod.neuron(W[0, 0, c, f].reshape(1), Pw, Pq, alphabet)
             assert Q[0, 0, c, f] == np.float32(qo[0])
+
+
+# ---- a NumPy-weights Keras (what real tf.keras hands over): the host-side branches on the HIP path -----------------
+@pytest.mark.parametrize("case", ["net_mlp_full", "net_mlp_partial", "net_mlp_nobias_ignore"])
+def test_numpy_weights_keras_reproduces_reference_runs(qn, golden, oracle_mod, case, monkeypatch):
+    """QuantizedNeuralNetwork driven by a duck-typed NumPy Keras (tests/_fake_keras.py) bound the way
+    `from tensorflow.keras.models import Model, clone_model` would bind it: kernels are uploaded from get_weights(),
+    activations arrive as ndarrays from predict_on_batch, Q goes back through set_weights([ndarray, bias]).  The forward
+    passes are NumPy float32 matmuls like the golden run's, so whenever the captured activations equal the reference's,
+    Q equals the reference's bit for bit (scripts/quantized_network.py:504-574)."""
+    import _fake_keras as fk
+    g = golden("network")[case]
+    dims, use_bias = g["dims"], bool(g["use_bias"])
+    layers = [fk.Dense(g[f"W{k}"], g[f"b{k}"] if use_bias else None, "relu" if dims[k + 1] != dims[-1] else "linear")
+              for k in range(len(dims) - 1)]
+    net = fk.Sequential(layers)
+    monkeypatch.setattr(qn, "Model", fk.Model)
+    monkeypatch.setattr(qn, "clone_model", fk.clone_model)
+    batch = int(g["batch"])
+    y = np.zeros((len(g["x"]), 1), dtype=np.float32)
+    logger = ListLogger()
+    q = qn.QuantizedNeuralNetwork(network=net, batch_size=batch, get_data=qn.MNISTSequence(g["x"], y, batch), logger=logger,
+                                  ignore_layers=g["ignore"].tolist(), bits=float(g["bits"]), alphabet_scalar=float(g["scalar"]))
+    assert not q._incremental_capture_possible()                  # the generic Keras path, not the torch shim's
+    assert isinstance(q.quantized_net, fk.Sequential)
+    rec = _record_captures(q)
+    q.quantize_network()
+    ignore = set(g["ignore"].tolist())
+    exact_inputs = True
+    for k in range(len(dims) - 1):
+        Qk = q.quantized_net.layers[k].get_weights()[0]
+        if k in ignore:
+            assert np.array_equal(Qk, g[f"W{k}"])
+            continue
+        # the quantized layer was handed NumPy arrays (a real Keras layer takes nothing else)
+        assert all(t is np.ndarray for t in q.quantized_net.layers[k].set_calls[-1])
+        wX, qX = rec[k]
+        assert wX.shape == g[f"wX{k}"].shape                      # layout incl. the partial-last-batch quirk (:491-495)
+        exact_inputs &= np.array_equal(wX, g[f"wX{k}"]) and np.array_equal(qX, g[f"qX{k}"])
+        # always: the oracle on the activations the class captured
+        alphabet, rad = oracle_mod.layer_alphabet(g[f"W{k}"], g["alphabet"], float(g["scalar"]))
+        assert rad == q.last_layer_stats[k]["rad"]
+        Qo, io, _ = oracle_mod.layer(g[f"W{k}"], wX, qX, alphabet)
+        assert np.array_equal(Qk, Qo.T.astype(np.float32)) and np.array_equal(q.last_layer_stats[k]["idx"], io.T)
+        if use_bias:
+            assert np.array_equal(q.quantized_net.layers[k].get_weights()[1], g[f"b{k}"])      # bias carried over (:517-521)
+        if exact_inputs:
+            assert np.array_equal(Qk, g[f"Q{k}"]), f"layer {k}: same activations as the reference run, different Q"
+        else:
+            np.testing.assert_allclose(wX, g[f"wX{k}"], rtol=1e-5, atol=1e-6)
+            assert np.mean(Qk == g[f"Q{k}"]) > 0.9
+    assert sum("quantized successfully." in l and "Neuron" in l for l in logger.lines) == int(g["n_log_neuron_lines"])

@@ -1,6 +1,8 @@
 """CPU, world_size 2, gloo: the neuron/channel sharding and the single all-gather per layer
-reassemble exactly the unsharded result.  The local worker is replaced by an oracle-backed stand-in
-(the collective plumbing is what is under test; the HIP kernels are covered by the -m gpu tests)."""
+reassemble exactly the unsharded result.  The collective plumbing is what is under test (the HIP kernels are covered
+by the -m gpu tests): THIS TEST replaces the entry points of the HIP binding (`hip.quantize_neurons`, ...) by
+oracle-backed stand-ins on CPU tensors in its own worker processes; the product has no hook for that -- layer.py calls
+the binding directly and the binding refuses CPU tensors."""
 import os
 import socket
 import sys
@@ -25,7 +27,8 @@ def _standin_quantize(X, Xq, Wt, alphabet, **kw):
     return dict(Q=torch.from_numpy(Q.astype(np.float32)), idx=torch.from_numpy(idx), resid=torch.from_numpy(resid), u=None)
 
 
-def _standin_assemble(qidx, alphabet, want_idx=True):
+def _standin_assemble(qidx, alphabet, want_idx=True, bits=8, N=None):
+    assert bits == 8
     a = np.asarray(alphabet, dtype=np.float64)
     k = qidx.numpy().astype(np.int64)
     Q = np.where(k < 0, 0.0, a[np.maximum(k, 0)]).astype(np.float32)
@@ -39,6 +42,26 @@ def _standin_patches(act, channel, kernel_size, strides, rate, padding, out=None
     return torch.from_numpy(patches(act.numpy(), channel, kernel_size[0], kernel_size[1], strides[0], strides[1], rh, rw, padding))
 
 
+def _standin_pack(qidx, M):
+    return qidx, 8                          # "8 bits = plain int8, no packing" (the packing kernel is covered on the GPU)
+
+
+def _standin_planes(act, c_lo, c_hi):
+    return act[..., c_lo:c_hi].permute(3, 0, 1, 2).contiguous()
+
+
+def _install_standins():
+    """Swap the binding's entry points for CPU stand-ins in THIS process; returns the originals."""
+    sys.path.insert(0, ROOT)
+    from quantized_neural_networks_amd import hip
+    names = dict(quantize_neurons=_standin_quantize, extract_patches=_standin_patches, assemble_kernel=_standin_assemble,
+                 pack_indices=_standin_pack, channel_planes=_standin_planes)
+    keep = {k: getattr(hip, k) for k in names}
+    for k, v in names.items():
+        setattr(hip, k, v)
+    return hip, keep
+
+
 def _worker(rank, world, port, case, result_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -46,10 +69,8 @@ def _worker(rank, world, port, case, result_dir):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from quantized_neural_networks_amd import layer
-    layer._local_quantize = _standin_quantize
-    layer._extract_patches = _standin_patches
-    layer._assemble = _standin_assemble
-    layer._pack = None                      # index packing is a HIP kernel; covered by the -m gpu tests
+    _install_standins()
+    group = dist.group.WORLD                # sharding needs an explicit group (None = this process alone)
     r = np.random.default_rng(7)
     if case == "dense":
         N, m, C = 24, 40, 7                                  # 7 neurons over 2 ranks: uneven shards
@@ -58,7 +79,7 @@ def _worker(rank, world, port, case, result_dir):
         X = np.maximum(G, 0).astype(np.float32)
         Xq = np.maximum(G + 0.1 * r.standard_normal((N, m)), 0).astype(np.float32)
         alphabet = 0.3 * np.linspace(-1, 1, 4)
-        out = layer.quantize_dense(torch.from_numpy(W), torch.from_numpy(X), torch.from_numpy(Xq), alphabet)
+        out = layer.quantize_dense(torch.from_numpy(W), torch.from_numpy(X), torch.from_numpy(Xq), alphabet, group=group)
     else:
         Cin = 3 if case == "conv_channels" else 1            # Cin < world -> filters are sharded instead
         act = r.random((4, 6, 6, Cin)).astype(np.float32)
@@ -66,7 +87,7 @@ def _worker(rank, world, port, case, result_dir):
         W = (r.standard_normal((3, 3, Cin, 5)) / 3).astype(np.float32)
         alphabet = 0.25 * np.linspace(-1, 1, 3)
         out = layer.quantize_conv2d(torch.from_numpy(W), torch.from_numpy(act), torch.from_numpy(actq), alphabet,
-                                    strides=(1, 1), padding="SAME", rate=(1, 1))
+                                    strides=(1, 1), padding="SAME", rate=(1, 1), group=group)
     np.savez(os.path.join(result_dir, f"{case}_{rank}.npz"), **{k: v.numpy() for k, v in out.items()})
     dist.barrier()
     dist.destroy_process_group()
@@ -83,8 +104,7 @@ def test_sharded_equals_unsharded(case, tmp_path, oracle_mod):
     # unsharded reference: same stand-ins, no process group
     sys.path.insert(0, ROOT)
     from quantized_neural_networks_amd import layer
-    keep = layer._local_quantize, layer._extract_patches, layer._assemble
-    layer._local_quantize, layer._extract_patches, layer._assemble = _standin_quantize, _standin_patches, _standin_assemble
+    hip, keep = _install_standins()
     try:
         r = np.random.default_rng(7)
         if case == "dense":
@@ -102,6 +122,7 @@ def test_sharded_equals_unsharded(case, tmp_path, oracle_mod):
             out = layer.quantize_conv2d(torch.from_numpy(W), torch.from_numpy(act), torch.from_numpy(actq),
                                         0.25 * np.linspace(-1, 1, 3), strides=(1, 1), padding="SAME", rate=(1, 1))
     finally:
-        layer._local_quantize, layer._extract_patches, layer._assemble = keep
+        for k, v in keep.items():
+            setattr(hip, k, v)
     for k, v in out.items():
         assert np.array_equal(res[0][k], v.numpy()), k
