@@ -262,8 +262,8 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
         if by_channel:
             rows = Ic[c_lo:c_hi].reshape(-1, K).contiguous()                       # (c, f) rows of this rank's channels
             packed, bits = hip.pack_indices(rows, len(alphabet))
-            g = all_gather_units(packed.reshape(c_hi - c_lo, -1), Cin, group)      # units = channels
-            Qk, Ik = hip.assemble_kernel(g.reshape(Cin * F, -1).contiguous(), alphabet, bits=bits, N=K)
+            g = all_gather_units(packed.reshape(c_hi - c_lo, F * packed.shape[1]), Cin, group)   # units = channels (a shard may be empty)
+            Qk, Ik = hip.assemble_kernel(g.reshape(Cin * F, packed.shape[1]).contiguous(), alphabet, bits=bits, N=K)
             Q = Qk.reshape(kh, kw, Cin, F)
             idx = Ik.reshape(kh, kw, Cin, F)
             if want_resid:
@@ -271,8 +271,8 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
         else:
             rows = Ic[:, f_lo:f_hi].transpose(0, 1).reshape(-1, K).contiguous()    # (f, c) rows of this rank's filters
             packed, bits = hip.pack_indices(rows, len(alphabet))
-            g = all_gather_units(packed.reshape(f_hi - f_lo, -1), F, group)        # units = filters
-            Qk, Ik = hip.assemble_kernel(g.reshape(F * Cin, -1).contiguous(), alphabet, bits=bits, N=K)
+            g = all_gather_units(packed.reshape(f_hi - f_lo, Cin * packed.shape[1]), F, group)   # units = filters
+            Qk, Ik = hip.assemble_kernel(g.reshape(F * Cin, packed.shape[1]).contiguous(), alphabet, bits=bits, N=K)
             Q = Qk.reshape(kh, kw, F, Cin).permute(0, 1, 3, 2).contiguous()
             idx = Ik.reshape(kh, kw, F, Cin).permute(0, 1, 3, 2).contiguous()
             if want_resid:

@@ -225,3 +225,18 @@ def test_header_is_plain_c(tmp_path):
     src = tmp_path / "t.c"
     src.write_text('#include "gpfq.h"\nint main(void) { int (*f)(const char *, int) = gpfq_set_option; return f ? GPFQ_MAX_ALPHABET - 64 : 1; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
+
+
+def test_accuracy_regression_entry_point_skips_cleanly_without_data(tmp_path, capsys):
+    """the regression against model_metrics/*.csv needs the data set and the analog weights, which neither
+    the reference checkout nor this image holds: the entry point must say so and exit 0 (no GPU touched)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("accuracy_regression", os.path.join(ROOT, "examples", "accuracy_regression.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    pub = tmp_path / "mnist_model_metrics.csv"
+    pub.write_text(",data_set,analog_model,serialized_quantized_model,q_train_size,bits,alphabet_scalar,analog_test_acc,sd_test_acc,msq_test_acc\n"
+                   "2020-07-15_1,mnist,a,b,25000,1.584962500721156,2,0.9824,0.9548,0.9330\n")
+    assert mod.main(["--published", str(pub), "--dataset", str(tmp_path / "mnist.npz"), "--model", str(tmp_path / "m.npz")]) == 0
+    assert "skipped" in capsys.readouterr().out
+    assert mod.main(["--published", str(tmp_path / "none.csv")]) == 0

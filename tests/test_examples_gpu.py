@@ -75,3 +75,43 @@ def test_cnn_driver_flow_metrics_rows_and_saved_models(tmp_path):
     assert len(convs) == 6 and all(len(np.unique(l.get_weights()[0])) <= 8 for l in convs)     # 3 bits: 8 levels
     y = net.predict_on_batch(np.random.default_rng(1).random((8, 32, 32, 3)).astype(np.float32))
     assert tuple(y.shape) == (8, 10)
+
+
+def test_accuracy_regression_against_a_published_table(tmp_path):
+    """examples/accuracy_regression.py end to end on the GPU: a data set file in Keras' mnist.npz layout, an analog model
+    in the shim's save format and a metrics table in the reference's schema; it must reproduce accuracies it published
+    itself (GPFQ is deterministic) and flag a table that disagrees."""
+    import pandas as pd
+    from quantized_neural_networks_amd import keras_shim as K
+    from quantized_network import MNISTSequence, QuantizedNeuralNetwork
+    r = np.random.default_rng(4)
+    model = K.Sequential(seed=4)
+    model.add(K.Flatten(input_shape=(8, 8)))
+    model.add(K.Dense(64, activation="relu"))
+    model.add(K.Dense(10, activation="softmax"))
+    x_train = (r.random((600, 8, 8)) * 255).astype(np.uint8)
+    x_test = (r.random((300, 8, 8)) * 255).astype(np.uint8)
+    y_train = r.integers(0, 10, 600)
+    y_test = model.predict(x_test.astype(np.float32) / 255.0).argmax(1)             # labels = the analog net's own answers
+    np.savez(tmp_path / "mnist.npz", x_train=x_train, y_train=y_train, x_test=x_test, y_test=y_test)
+    K.save_model(model, tmp_path / "analog")
+    rows = []
+    quiet = type("Quiet", (), {"info": staticmethod(lambda m: None)})()
+    Xf, Yf = x_train.astype(np.float32) / 255.0, np.eye(10, dtype=np.float32)[y_train]
+    for scalar in (2, 3):
+        q = QuantizedNeuralNetwork(network=model, batch_size=400, get_data=MNISTSequence(Xf[:400], Yf[:400], batch_size=400),
+                                   logger=quiet, bits=np.log2(3), alphabet_scalar=scalar)
+        q.quantize_network()
+        _, acc = q.quantized_net.evaluate(x_test.astype(np.float32) / 255.0, np.eye(10, dtype=np.float32)[y_test])
+        rows.append(dict(data_set="mnist", analog_model="analog", serialized_quantized_model=f"q{scalar}", q_train_size=400,
+                         bits=np.log2(3), alphabet_scalar=scalar, analog_test_acc=1.0, sd_test_acc=acc, msq_test_acc=0.0))
+    pd.DataFrame(rows, index=["r0", "r1"]).to_csv(tmp_path / "published.csv")
+    args = ["--published", str(tmp_path / "published.csv"), "--dataset", str(tmp_path / "mnist.npz"), "--model", str(tmp_path / "analog.npz")]
+    out = _run("accuracy_regression.py", *args, "--tolerance", "0.0")
+    assert "accuracy regression passed" in out and out.count("diff +0.0000") == 2
+    bad = pd.read_csv(tmp_path / "published.csv", index_col=0)
+    bad["sd_test_acc"] = (bad["sd_test_acc"] + 0.5) % 1.0
+    bad.to_csv(tmp_path / "published_bad.csv")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "accuracy_regression.py"), "--published",
+                          str(tmp_path / "published_bad.csv"), *args[2:]], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 1 and "FAILED" in res.stdout
