@@ -104,8 +104,9 @@ const char *gpfq_last_dense_kernel(void);
  *                  LDS-staged rows instead of register prefetch; bit 2: Gram records of walks longer than 64
  *                  steps on the vector units instead of the matrix cores (v_mfma_f64_16x16x4_f64);
  *                  bit 4: pipelined kernel issues its LDS-DMA spread over the steps of a tile
- *   "pipe"         pipelined dense kernel (rows <= 2048 samples): -1 (default) where measured faster,
- *                  0 never, 1 whenever it applies
+ *   "pipe"         role-split dense kernels (rows <= 2048 samples): -1 (default) the block form where measured faster,
+ *                  0 never, 1 one step per slot (gpfq_pipe.hip) whenever it applies, 2 blocks of steps per slot
+ *                  (gpfq_blk.hip) whenever it applies
  *   "waves_per_neuron"  2..16: force the wide kernel (one neuron over that many wavefronts), 0 = heuristic
  *                  (rows longer than 2048 samples, and layers too narrow to fill the chip)
  *   "gram_slack_log2"   Gram paths: error bounds multiplied by 2^value (tests force the repair/rerun branches)

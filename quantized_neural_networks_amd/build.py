@@ -18,16 +18,19 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libgpfq_hip.so")
 STAMP = LIB + ".sha"
 OBJDIR = os.path.join(CSRC, "build")
-SOURCES = ["gpfq_capi.hip", "gpfq_onchip.hip", "gpfq_rows.hip", "gpfq_pipe.hip", "gpfq_wide.hip", "gpfq_stream.hip",
+SOURCES = ["gpfq_capi.hip", "gpfq_onchip.hip", "gpfq_rows.hip", "gpfq_pipe.hip", "gpfq_blk.hip", "gpfq_wide.hip", "gpfq_stream.hip",
            "gpfq_gram.hip", "gpfq_gram_image.hip", "gpfq_gram_conv.hip", "gpfq_gram_mfma.hip", "gpfq_misc.hip"]
-HEADERS = ["gpfq_device.hpp", "gpfq_launch.hpp", "gpfq_gram_tile.hpp", os.path.join("..", "..", "include", "gpfq.h")]
+HEADERS = ["gpfq_device.hpp", "gpfq_launch.hpp", "gpfq_gram_tile.hpp", "gpfq_roles.hpp", os.path.join("..", "..", "include", "gpfq.h")]
 
 # -ffp-contract=off: the float32 products/subtraction of the residual update must round
 # separately (reference numerics); float64 accumulations use explicit fma().
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall"]
 # gpfq_pipe.hip writes its packed float32 operations itself; the SLP vectoriser pairs unrelated products
 # through extra register moves there.
-EXTRA_FLAGS = {"gpfq_pipe.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"gpfq_pipe.hip": ["-fno-slp-vectorize"], "gpfq_blk.hip": ["-fno-slp-vectorize"]}
+# diagnostic builds (never the shipped library): GPFQ_DIAG="-DGPFQ_BLK_STAMPS" adds in-kernel phase stamps to gpfq_blk.hip
+if os.environ.get("GPFQ_DIAG"):
+    EXTRA_FLAGS["gpfq_blk.hip"] = EXTRA_FLAGS["gpfq_blk.hip"] + os.environ["GPFQ_DIAG"].split()
 
 
 def _sha(paths, extra=""):

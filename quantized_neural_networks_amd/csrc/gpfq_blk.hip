@@ -1,0 +1,776 @@
+// Block-pipelined GPFQ kernel: gpfq_pipe.hip's roles (eight sweep wavefronts over the sample axis, one decision
+// wavefront per workgroup), with B steps per slot instead of one.
+//
+// Replaces _quantize_neuron_parallel / _quantize_filter2D_parallel_jit (scripts/quantized_network.py:91-121, :185-233);
+// same contract and the same bits as the other dense kernels.
+//
+// Why blocks.  With one step per slot (gpfq_pipe.hip) 45 % of a slot is not arithmetic: the fold of the partial dot
+// products, the LDS hand-off of (w, q) and of the partial sums, and the barrier are paid per STEP and sit on the
+// critical path of every sweep wavefront (profiles/r02: 1375 of 2900 cycles per step with the sweep removed).  Here a
+// slot covers a block of B steps:
+//
+//  * sweep, slot b: applies the B updates of block b-1 to the residual (the reference's element-wise f32/f64 flow,
+//    :119, one after the other) and then accumulates the B dot products <Xq_t, u> of block b+1's rows against the
+//    residual as it stands after block b-1.  One fold sequence per row (pipelined), one hand-off, one barrier per block.
+//  * decision wavefront, slot b: takes the B decisions of block b in order.  Step t = bB + s uses
+//        <Xq_t, u_{t-1}> = D_t + sum over t' in [ (b-1)B, t ) of ( w_t' <Xq_t, X_t'> - q_t' <Xq_t, Xq_t'> )  + roundings,
+//    D_t from the sweep one slot earlier (residual after block b-2), the sum from the pre-pass's Gram BAND of width
+//    2B-1 (<Xq_t, X_t'>, <Xq_t, Xq_t'> and the absolute sums that bound the float32 roundings of those increments:
+//    |d_i - (w x_i - q xq_i)| <= 2^-23 (1 + 2^-24) (|w x_i| + |q xq_i|), subnormal products 2^-149).  A decision whose
+//    predicted quotient is farther from every boundary than the accumulated bound is provably the reference's; the
+//    first one of a neuron that is not stops that neuron's chain for the block.
+//  * slow path (about one decision in 10^6): after the slot's barrier, while any neuron is stopped at step S (the
+//    smallest such S), the sweep wavefronts form the reference's two exact dot products of step bB + S (:86, :89) on the
+//    residual they hold, replaying the block's already decided updates into temporaries (never into u), the decision
+//    wavefront takes the exact decision and resumes the chain; two extra barriers per round.
+//  The residual itself is only ever updated by the exact element-wise flow with final decisions, so u is bit-identical.
+//
+// Layout: slot record t = [statistics of step t + Gram band of row t][X_{t-B}][Xq_{t-B}][Xq_{t+B} as float64],
+// zero-padded; a tile = the B records of a slot, streamed into the other LDS buffer by LDS-DMA during the slot.
+#include "gpfq_device.hpp"
+#include "gpfq_launch.hpp"
+#include "gpfq_roles.hpp"
+
+namespace gpfq {
+
+namespace {
+
+struct BlkStats {          // first 64 bytes of a record header (all float64); see gpfq_pipe.hip's PipeRec
+    double rden, G, cb, ca, Ea, nrm, pad0, pad1;
+};
+struct BandEntry {         // distance d = 1 .. 2B-1 at header offset 64 + 32 (d - 1)
+    double H1, H2, E1, E2; // <Xq_t, X_{t-d}>, <Xq_t, Xq_{t-d}>, 2^-23 (1+2^-20) sum|Xq_t X_{t-d}|, ... sum|Xq_t Xq_{t-d}|
+};
+static_assert(sizeof(BlkStats) == 64 && sizeof(BandEntry) == 32, "header layout");
+
+__host__ __device__ constexpr int blk_hdr_bytes(int B) { return (64 + (2 * B - 1) * 32 + 127) & ~127; }
+__host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B) { return blk_hdr_bytes(B) + 16 * mp; }
+
+// ---- pre-pass ---------------------------------------------------------------------------------
+// One workgroup per slot record t: statistics of row t, its Gram band against rows t-1 .. t-(2B-1), float32 copies
+// of rows t-B, the float64 copy of Xq row t+B; zero-padded to mp samples.
+__global__ void __launch_bounds__(256)
+gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t N, int m, int mp, int B,
+                     const float *__restrict__ nrm32, char *__restrict__ recs)
+{
+    __shared__ double sm[4][4];
+    const int64_t t = blockIdx.x;
+    const int hdr = blk_hdr_bytes(B);
+    char *rb = recs + t * blk_rec_bytes(mp, B);
+    float  *ox = reinterpret_cast<float *>(rb + hdr);
+    float  *oq = ox + mp;
+    double *od = reinterpret_cast<double *>(rb + hdr + 8 * (int64_t)mp);
+    const bool has_prev = t >= B && t - B < N, has_cur = t < N, has_next = t + B < N;
+    const float *px = X + (t - B) * ld, *pq = Xq + (t - B) * ld;
+    const float *cx = X + t * ld, *cq = Xq + t * ld;
+    const float *nq = Xq + (t + B) * ld;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double up = 1.0 + 0x1p-20;
+
+    auto block_sum4 = [&](double (&v)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
+        __syncthreads();
+        if (lane == 0)
+            for (int k = 0; k < 4; ++k) sm[k][wave] = v[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (sm[k][0] + sm[k][1]) + (sm[k][2] + sm[k][3]);
+    };
+
+    double v[4] = {0.0, 0.0, 0.0, 0.0};                       // G, sum|Xq X|, sum|Xq|
+    for (int i = threadIdx.x; i < mp; i += 256) {
+        const bool in = i < m;
+        ox[i] = (has_prev && in) ? px[i] : 0.f;
+        oq[i] = (has_prev && in) ? pq[i] : 0.f;
+        od[i] = (double)((has_next && in) ? nq[i] : 0.f);
+        if (has_cur && in) {
+            const double q = (double)cq[i], pr = q * (double)cx[i];   // products of two f32 are exact in f64
+            v[0] += pr; v[1] += fabs(pr); v[2] += fabs(q);
+        }
+    }
+    block_sum4(v);
+    if (threadIdx.x == 0) {
+        BlkStats st{};
+        const double nrm = has_cur ? (double)nrm32[t] : 0.0;
+        st.nrm = nrm;
+        st.rden = nrm < 1e-16 ? 0.0 : 1.0 / (nrm * nrm);
+        st.G = v[0];
+        st.cb = 0x1p-23 * v[1] * st.rden * up;
+        st.ca = 0x1p-149 * v[2] * st.rden * up;
+        st.Ea = 0x1p-149 * v[2] * up;
+        *reinterpret_cast<BlkStats *>(rb) = st;
+    }
+    for (int d = 1; d <= 2 * B - 1; ++d) {
+        double h[4] = {0.0, 0.0, 0.0, 0.0};
+        if (has_cur && t - d >= 0) {
+            const float *bx = X + (t - d) * ld, *bq = Xq + (t - d) * ld;
+            for (int i = threadIdx.x; i < m; i += 256) {
+                const double q = (double)cq[i];
+                const double p1 = q * (double)bx[i], p2 = q * (double)bq[i];
+                h[0] += p1; h[1] += p2; h[2] += fabs(p1); h[3] += fabs(p2);
+            }
+        }
+        block_sum4(h);
+        if (threadIdx.x == 0) {
+            BandEntry e;
+            e.H1 = h[0]; e.H2 = h[1]; e.E1 = 0x1p-23 * h[2] * up; e.E2 = 0x1p-23 * h[3] * up;
+            *reinterpret_cast<BandEntry *>(rb + 64 + 32 * (d - 1)) = e;
+        }
+    }
+}
+
+// LDS carve-up (byte offsets), shared by host and device.
+struct BlkLds {
+    int tile_bytes, tile_pitch, off_w, off_d, off_wq, off_x2, off_e, off_out, off_ctl, total;
+};
+constexpr int kOutSteps = 32;                                    // steps of outputs staged in LDS between flushes
+
+__host__ __device__ inline BlkLds blk_lds(int mp, int nb, int B)
+{
+    BlkLds L;
+    L.tile_bytes = B * (int)blk_rec_bytes(mp, B);
+    L.tile_pitch = (L.tile_bytes + 1023) & ~1023;               // the DMA moves whole 1 KiB pieces
+    int o = 2 * L.tile_pitch;
+    L.off_w = o;    o += 2 * nb * B * 4;    o = (o + 15) & ~15; // [2][NB][B] f32        weights of the block
+    L.off_d = o;    o += 2 * kSweepWaves * B * nb * 8;          // [2][8][B][NB] f64     partial dot products
+    L.off_wq = o;   o += 2 * nb * B * 8;                        // [2][NB][B] (w, q) f32 decisions of the block
+    L.off_x2 = o;   o += kSweepWaves * nb * 16;                 // [8][NB] (f64, f64)    exact partials (slow path)
+    L.off_e = o;    o += 68 * 8;                                // [2 + 64 + 2] f64      -inf, -inf, alphabet, +inf, +inf
+    L.off_out = o;  o += nb * kOutSteps * 8;                    // [NB][32] (idx i32, q f32) until the flush
+    L.off_ctl = o;  o += 16;                                    // [2] (by slot parity) smallest step a neuron of the block is stopped at, -1: none
+    L.total = o;
+    return L;
+}
+
+struct BlkK {
+    const char *recs;
+    const float *Wt;
+    int64_t ldw;
+    int64_t N, C;
+    int m, M, zero_idx, nblk;   // nblk = ceil(N / B) blocks, nblk + 1 slots
+    int8_t *qidx;
+    float *Qt;
+    double *resid, *u_out;
+    unsigned long long *fallback_count;
+    unsigned long long *stamps;     // diagnostic build only (GPFQ_BLK_STAMPS): per-phase shader cycles of two wavefronts
+};
+
+#ifdef GPFQ_BLK_STAMPS
+#define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
+
+// ---- sweep wavefront -------------------------------------------------------------------------------
+template <int G, int PW, int MP, int B>
+__device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic, const BlkLds &L, int wave, int lane, int pbase)
+{
+    constexpr int NB = 4 * G, KQ = 64 / G;
+    constexpr int HDR = blk_hdr_bytes(B);
+    constexpr int RB = (int)blk_rec_bytes(MP, B);
+    lchar *lds = (lchar *)lds_generic;
+    const int ng = lane & (G - 1), kq = lane / G, row = lane >> 4;
+    const bool writer = (lane & 15 & ~(G - 1)) == 0;             // one lane per (row, ng) publishes the folded sums
+    const int nloc = 4 * ng;                                      // first of this lane's four neurons
+    const int64_t jbase = (int64_t)blockIdx.x * NB;
+    const unsigned ldsT_addr = lds_addr(lds_generic), ldsW_addr = lds_addr(lds_generic + L.off_w);
+    const int64_t N = K.N;
+    const int nslots = K.nblk + 1;
+    const int o_x  = HDR + 8 * (pbase + kq);                      // float2 x   [pair]  (row t - B of record t)
+    const int o_q  = o_x + 4 * MP;                                // float2 xq  [pair]
+    const int o_d  = HDR + 8 * MP + 16 * (pbase + kq);           // double2 xqd[pair]  (row t + B)
+    const int o_wq = L.off_wq + nloc * B * 8;
+    const int o_dw = L.off_d + (wave * B * NB + nloc + row) * 8;
+    const int o_x2 = L.off_x2 + (wave * NB + nloc + row) * 16;
+
+    double u[4][2 * PW];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 2 * PW; ++e) u[i][e] = 0.0;          // zeros(m), :115
+
+    const int npieces = (L.tile_bytes + 1023) >> 10;              // the last piece may run into the next record: harmless
+    auto load_tile = [&](int b) {
+        const char *src = K.recs + (int64_t)b * L.tile_bytes + lane * 16;
+        const unsigned dst = ldsT_addr + (unsigned)(b & 1) * (unsigned)L.tile_pitch;
+        for (int pc = wave; pc < npieces; pc += kSweepWaves) glds16(src + ((size_t)pc << 10), dst + ((unsigned)pc << 10));
+        const unsigned dw = ldsW_addr + (unsigned)((b & 1) * NB * B * 4);
+        for (int i0 = wave * 64; i0 < NB * B; i0 += kSweepWaves * 64) {
+            const int i = i0 + lane;
+            const int n = i / B, s = i - n * B;
+            const int64_t jn = jbase + n, t = (int64_t)b * B + s;
+            if (i < NB * B && jn < K.C && t < N) glds4(K.Wt + jn * K.ldw + t, dw + 4 * (unsigned)i0);
+        }
+    };
+
+    load_tile(0);
+    dma_wait();
+    slot_barrier();
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, acc_dma = 0, acc_u = 0, acc_d = 0, acc_w = 0, acc_b = 0;
+    (void)st0; (void)st1; (void)st2; (void)st3; (void)st4; (void)st5; (void)acc_dma; (void)acc_u; (void)acc_d; (void)acc_w; (void)acc_b;
+
+    for (int b = 0; b < nslots; ++b) {
+        STAMP(st0);
+        if (b + 1 < nslots) load_tile(b + 1);                     // streams into the other buffer meanwhile
+        STAMP(st1);
+        const int tbase = (b & 1) * L.tile_pitch;
+        const int pbq = ((b - 1) & 1) * NB * B * 8;               // (w, q) of block b-1
+
+        // ---- phase U: the B updates of block b-1, in order: u += f32(w x) - f32(q xq)  (:119) ----
+        // Software-pipelined by hand: the operands of the NEXT pair (and the next step's four (w, q)) are requested before
+        // the arithmetic of the current one (sched_barrier keeps hipcc from sinking the requests to their first use,
+        // where every pair would wait out a full LDS round trip).
+        {
+            float2 x2n = lds_ld<float2>(lds, tbase + o_x), q2n = lds_ld<float2>(lds, tbase + o_q);
+            float2 wqn[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) wqn[n] = lds_ld<float2>(lds, o_wq + pbq + (n * B) * 8);
+#pragma unroll 1
+            for (int s = 0; s < B; ++s) {
+                float wv[4], qv[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) { wv[n] = wqn[n].x; qv[n] = wqn[n].y; }
+                const int rb = tbase + s * RB;
+                const int sn = s + 1 < B ? s + 1 : s;             // (the last step re-requests its own: harmless)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) wqn[n] = lds_ld<float2>(lds, o_wq + pbq + (n * B + sn) * 8);
+#pragma unroll
+                for (int p = 0; p < PW; ++p) {
+                    const float2 x2 = x2n, q2 = q2n;
+                    const int rbn = p + 1 < PW ? rb : tbase + sn * RB, pn = p + 1 < PW ? p + 1 : 0;
+                    x2n = lds_ld<float2>(lds, rbn + o_x + 8 * pn * KQ);
+                    q2n = lds_ld<float2>(lds, rbn + o_q + 8 * pn * KQ);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const pk2 xv = {x2.x, x2.y}, qx = {q2.x, q2.y};
+                    // f32 products and subtraction on two samples at once (v_pk_mul_f32 / v_pk_add_f32): each half rounds
+                    // exactly as the scalar instruction (no contraction: -ffp-contract=off).  Written stage by stage over the
+                    // four neurons so that no instruction consumes the result of the one right before it (hipcc pads those
+                    // packed-to-scalar dependences with s_nop, which cost issue slots)
+                    pk2 pr[4], rr[4], dd[4];
+                    double c0[4], c1[4];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) pr[n] = pk2{wv[n], wv[n]} * xv;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) rr[n] = pk2{qv[n], qv[n]} * qx;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) dd[n] = pr[n] - rr[n];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) { c0[n] = (double)dd[n].x; c1[n] = (double)dd[n].y; }
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) { u[n][2 * p] += c0[n]; u[n][2 * p + 1] += c1[n]; }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        STAMP(st2);
+        // ---- phase D: this wavefront's share of <Xq_t, u> for the B rows of block b+1 ----
+        if (b + 1 < nslots) {
+            double2 d2n = lds_ld<double2>(lds, tbase + o_d);
+#pragma unroll 1
+            for (int r = 0; r < B; ++r) {
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                const int rb = tbase + r * RB;
+                const int rn = r + 1 < B ? r + 1 : r;
+#pragma unroll
+                for (int p = 0; p < PW; ++p) {
+                    const double2 d2 = d2n;
+                    const int rbn = p + 1 < PW ? rb : tbase + rn * RB, pn = p + 1 < PW ? p + 1 : 0;
+                    d2n = lds_ld<double2>(lds, rbn + o_d + 16 * pn * KQ);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        acc[n] = fma(d2.x, u[n][2 * p], acc[n]);
+                        acc[n] = fma(d2.y, u[n][2 * p + 1], acc[n]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const double v = fold_klanes<G>(acc);
+                if (writer) lds_st<double>(lds, o_dw + ((((b + 1) & 1) * kSweepWaves) * B + r) * NB * 8, v);
+            }
+        }
+        STAMP(st3);
+        dma_wait();                                               // this wavefront's share of the next tile has landed
+        STAMP(st4);
+        slot_barrier();
+        STAMP(st5);
+#ifdef GPFQ_BLK_STAMPS
+        acc_dma += st1 - st0; acc_u += st2 - st1; acc_d += st3 - st2; acc_w += st4 - st3; acc_b += st5 - st4;
+#endif
+
+        // ---- slow path: neurons of block b stopped at an uncertifiable step (rare) ----
+        for (;;) {
+            const int S = __builtin_amdgcn_readfirstlane(lds_ld<int>(lds, L.off_ctl + 4 * (b & 1)));
+            if (S < 0) break;
+            // u is the residual BEFORE block b.  Exact <Xq_t, u_{t-1}> and <Xq_t, u_{t-1} + f32(w_t X_t)> (:86, :89) for
+            // t = bB + S: the block's first S updates replayed into temporaries; rows of block b are records of tile b+1.
+            const int nb_ = ((b + 1) & 1) * L.tile_pitch;
+            const int cbq = (b & 1) * NB * B * 8;
+            double eu[4] = {0.0, 0.0, 0.0, 0.0}, ew[4] = {0.0, 0.0, 0.0, 0.0};
+            // (one neuron and one pair at a time: the slow path must not cost the hot loop registers)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const float w = lds_ld<float2>(lds, o_wq + cbq + (n * B + S) * 8).x;
+#pragma unroll 1
+                for (int p = 0; p < PW; ++p) {
+                    double t0 = u[n][0], t1 = u[n][1];
+#pragma unroll
+                    for (int pp = 1; pp < PW; ++pp) { t0 = (p == pp) ? u[n][2 * pp] : t0; t1 = (p == pp) ? u[n][2 * pp + 1] : t1; }
+                    for (int j = 0; j < S; ++j) {
+                        const int rb = nb_ + j * RB;
+                        const float2 x2 = lds_ld<float2>(lds, rb + o_x + 8 * p * KQ), q2 = lds_ld<float2>(lds, rb + o_q + 8 * p * KQ);
+                        const float2 wq = lds_ld<float2>(lds, o_wq + cbq + (n * B + j) * 8);
+                        t0 += (double)__fsub_rn(__fmul_rn(wq.x, x2.x), __fmul_rn(wq.y, q2.x));
+                        t1 += (double)__fsub_rn(__fmul_rn(wq.x, x2.y), __fmul_rn(wq.y, q2.y));
+                    }
+                    const int rb = nb_ + S * RB;
+                    const float2 x2 = lds_ld<float2>(lds, rb + o_x + 8 * p * KQ), q2 = lds_ld<float2>(lds, rb + o_q + 8 * p * KQ);
+                    eu[n] = fma((double)q2.x, t0, eu[n]);
+                    eu[n] = fma((double)q2.y, t1, eu[n]);
+                    ew[n] = fma((double)q2.x, t0 + (double)__fmul_rn(w, x2.x), ew[n]);
+                    ew[n] = fma((double)q2.y, t1 + (double)__fmul_rn(w, x2.y), ew[n]);
+                }
+            }
+            const double vu = fold_klanes<G>(eu), vw = fold_klanes<G>(ew);
+            if (writer) lds_st<double2>(lds, o_x2, make_double2(vu, vw));
+            slot_barrier();                                       // partials published
+            slot_barrier();                                       // chains resumed, control word rewritten
+        }
+    }
+
+#ifdef GPFQ_BLK_STAMPS
+    if (K.stamps && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7)) {
+        unsigned long long *o = K.stamps + (wave == 0 ? 0 : 8);
+        o[0] = acc_dma; o[1] = acc_u; o[2] = acc_d; o[3] = acc_w; o[4] = acc_b; o[5] = (unsigned long long)nslots;
+    }
+#endif
+    // ---- epilogue: residual norms through the same partial-sum path, residual vectors straight to memory ----
+    if (K.resid) {
+        double ss[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            double q = 0.0;
+#pragma unroll
+            for (int e = 0; e < 2 * PW; ++e) q = fma(u[n][e], u[n][e], q);
+            ss[n] = q;
+        }
+        const double v = fold_klanes<G>(ss);
+        if (writer) lds_st<double>(lds, o_dw, v);
+    }
+    slot_barrier();
+    if (K.u_out) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int64_t jn = jbase + nloc + n;
+            if (jn < K.C) {
+#pragma unroll
+                for (int p = 0; p < PW; ++p)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int i = 2 * (pbase + p * KQ + kq) + e;
+                        if (i < K.m) K.u_out[jn * (int64_t)K.m + i] = u[n][2 * p + e];
+                    }
+            }
+        }
+    }
+}
+
+// ---- decision wavefront ------------------------------------------------------------------------------
+template <int G, int MP, int B>
+__device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_generic, const BlkLds &L, int lane)
+{
+    constexpr int NB = 4 * G, R = 64 / NB;
+    constexpr int RB = (int)blk_rec_bytes(MP, B);
+    lchar *lds = (lchar *)lds_generic;
+    const int n = lane / R, r = lane % R;                         // neuron of the workgroup, sub-lane
+    const int64_t jn = (int64_t)blockIdx.x * NB + n;
+    const bool active = jn < K.C;
+    const int64_t N = K.N;
+    const int M = K.M;
+    const int nslots = K.nblk + 1;
+    const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
+    const int o_d   = L.off_d + (r * B * NB + n) * 8;             // partial sums of sweep wavefronts r, r + R, ...
+    const int o_x2  = L.off_x2 + (r * NB + n) * 16;
+    const int o_w   = L.off_w + n * B * 4;
+    const int o_wq  = L.off_wq + n * B * 8;
+    const int o_out = L.off_out + n * kOutSteps * 8;
+
+    // alphabet members r, r + R, ... of this sub-lane (NaN beyond M: never counted); larger alphabets loop over LDS
+    const bool in_regs = M <= 4 * R;
+    double am[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) am[q] = (r + q * R < M) ? lds_ld<double>(lds, L.off_e + 8 * (2 + r + q * R)) : kNaN;
+
+    float wprev[B], qprev[B];                                     // block b-1 (final), this neuron
+#pragma unroll
+    for (int j = 0; j < B; ++j) { wprev[j] = 0.f; qprev[j] = 0.f; }
+    unsigned long long n_fallback = 0;
+
+    // Steps [t0, t1) of this workgroup's outputs from the LDS ring to memory: a lane takes 8 consecutive steps of one
+    // neuron (32-byte runs of indices, 128-byte runs of values per neuron)
+    auto flush = [&](int64_t t0, int64_t t1) {
+        for (int e = lane; e < NB * (kOutSteps / 8); e += 64) {
+            const int nn = e / (kOutSteps / 8), c = e % (kOutSteps / 8);
+            const int64_t j = (int64_t)blockIdx.x * NB + nn, ts = t0 + 8 * c;
+            if (j >= K.C || ts >= t1) continue;
+            int idx8[8]; float q8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int2 v = lds_ld<int2>(lds, L.off_out + (nn * kOutSteps + (int)((ts + k) % kOutSteps)) * 8);
+                idx8[k] = v.x; q8[k] = __int_as_float(v.y);
+            }
+            if (ts + 8 <= t1 && ((j * N + ts) & 7) == 0) {
+                if (K.qidx) {
+                    unsigned lo = 0, hi = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { lo |= (unsigned)(idx8[k] & 0xff) << (8 * k); hi |= (unsigned)(idx8[4 + k] & 0xff) << (8 * k); }
+                    *reinterpret_cast<uint2 *>(K.qidx + j * N + ts) = make_uint2(lo, hi);
+                }
+                if (K.Qt) {
+                    float4 *dst = reinterpret_cast<float4 *>(K.Qt + j * N + ts);
+                    if (((uintptr_t)dst & 15) == 0) {
+                        dst[0] = make_float4(q8[0], q8[1], q8[2], q8[3]);
+                        dst[1] = make_float4(q8[4], q8[5], q8[6], q8[7]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) K.Qt[j * N + ts + k] = q8[k];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (ts + k < t1) {
+                        if (K.qidx) K.qidx[j * N + ts + k] = (int8_t)idx8[k];
+                        if (K.Qt)   K.Qt[j * N + ts + k]   = q8[k];
+                    }
+            }
+        }
+    };
+
+    slot_barrier();                                               // (tile 0 landed)
+
+    int64_t flushed = 0;                                          // steps [0, flushed) are in memory
+    unsigned long long dt0 = 0, dt1 = 0, dt2 = 0, dacc_work = 0, dacc_bar = 0;
+    (void)dt0; (void)dt1; (void)dt2; (void)dacc_work; (void)dacc_bar;
+    for (int b = 0; b < nslots; ++b) {
+        STAMP(dt0);
+        const int tbase = (b & 1) * L.tile_pitch;
+        const int cbq = (b & 1) * NB * B * 8;
+        float  wc[B], qc[B];                                      // this block: weights, decisions (as float32 values)
+        double D[B];
+        int stop = B;                                             // first step of the block this neuron could not certify
+        if (b < K.nblk) {
+            // ---- D_t of the B rows: the partial sums of the previous slot; weights of the block ----
+#pragma unroll
+            for (int s = 0; s < B; ++s) {
+                double d = 0.0;
+#pragma unroll
+                for (int q = 0; q < kSweepWaves / R; ++q)
+                    d += lds_ld<double>(lds, o_d + ((((b & 1) * kSweepWaves + q * R) * B) + s) * NB * 8);
+                D[s] = sub_sum<R>(d);
+                wc[s] = lds_ld<float>(lds, o_w + (b & 1) * NB * B * 4 + 4 * s);
+                qc[s] = 0.f;
+                if (r == 0) lds_st<float2>(lds, o_wq + cbq + 8 * s, make_float2(wc[s], 0.f));    // w is known now, q follows
+            }
+        }
+
+        // Contribution of block b-1's increments: independent of this block's decisions, so it is formed before the chain --
+        // and spread over the sub-lanes: sub-lane r (mod B) forms the sums of step r, the chain fetches them by DPP
+        // (R is 4 or 8 and B <= 4: quad_perm broadcasts inside each aligned group of four lanes)
+        double cPm = 0.0, ePm = 0.0;
+        unsigned anyP = 0u;
+#pragma unroll
+        for (int j = 0; j < B; ++j) anyP |= __float_as_uint(wprev[j]) | __float_as_uint(qprev[j]);
+        if (b < K.nblk) {
+            const int sm = lane & (B - 1);                        // this lane's step (B is a power of two <= 4)
+            const int rb = tbase + sm * RB;
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                const int d = B + sm - j;
+                const double2 h = lds_ld<double2>(lds, rb + 64 + 32 * (d - 1)), e = lds_ld<double2>(lds, rb + 64 + 32 * (d - 1) + 16);
+                const double wj = (double)wprev[j], qj = (double)qprev[j];
+                cPm = fma(wj, h.x, cPm); cPm = fma(-qj, h.y, cPm);
+                ePm = fma(fabs(wj), e.x, ePm); ePm = fma(fabs(qj), e.y, ePm);
+            }
+        }
+        auto quad_bcast = [&](double x, int s) -> double {       // value of lane (4 * (lane / 4) + s)
+            int lo = __double2loint(x), hi = __double2hiint(x);
+            if (s == 0) { lo = __builtin_amdgcn_mov_dpp(lo, 0x00, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x00, 0xF, 0xF, true); }
+            if (s == 1) { lo = __builtin_amdgcn_mov_dpp(lo, 0x55, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x55, 0xF, 0xF, true); }
+            if (s == 2) { lo = __builtin_amdgcn_mov_dpp(lo, 0xAA, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xAA, 0xF, 0xF, true); }
+            if (s == 3) { lo = __builtin_amdgcn_mov_dpp(lo, 0xFF, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xFF, 0xF, 0xF, true); }
+            return __hiloint2double(hi, lo);
+        };
+
+        // One decision (:83-89, :57); commit == this lane's chain is still running.  Returns false when not certifiable.
+        auto decide = [&](int s, bool commit) -> bool {
+            const int64_t t = (int64_t)b * B + s;
+            const int rb = tbase + s * RB;
+            const double2 r01 = lds_ld<double2>(lds, rb), r23 = lds_ld<double2>(lds, rb + 16), r45 = lds_ld<double2>(lds, rb + 32);
+            const double rden = r01.x, rG = r01.y, rcb = r23.x, rca = r23.y, rEa = r45.x, nrm = r45.y;
+            const bool rule1 = nrm < 1e-16;                                      // rule (i): literal 0
+            // not yet applied increments: block b-1 (formed above by sub-lane s) and this block's steps before s (distance s - j)
+            double corr = quad_bcast(cPm, s), eps = quad_bcast(ePm, s);
+            unsigned anyinc = anyP;
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                if (j < s) {
+                    const int d = s - j;
+                    const double2 h = lds_ld<double2>(lds, rb + 64 + 32 * (d - 1)), e = lds_ld<double2>(lds, rb + 64 + 32 * (d - 1) + 16);
+                    const double wj = (double)wc[j], qj = (double)qc[j];
+                    corr = fma(wj, h.x, corr); corr = fma(-qj, h.y, corr);
+                    eps = fma(fabs(wj), e.x, eps); eps = fma(fabs(qj), e.y, eps);
+                    anyinc |= __float_as_uint(wc[j]) | __float_as_uint(qc[j]);
+                }
+            }
+            eps += ((anyinc << 1) != 0u) ? rEa : 0.0;
+            const double wd = (double)wc[s];
+            const double du = D[s] + corr;                                       // predicted <Xq_t, u_{t-1}>
+            const bool   du_exact = eps == 0.0;                                  // every pending increment orthogonal to Xq_t element-wise
+            const bool   msq = du_exact & (fabs(du) < 1e-10);                    // rule (ii), certain
+            const bool   sure = du_exact | (fabs(du) - eps >= 1e-10);            // ... or certainly not rule (ii)
+            const double wG = wd * rG;
+            const double tq = (du + wG) * rden;                                  // predicted quotient
+            const double tt = msq ? wd : tq;
+            // twice the modelling error of the prediction (quotient units) + float64 slack
+            const double delta2 = 2.0 * (fma(fabs(wd), rcb, rca) + eps * rden)
+                                  + 0x1p-43 * (fabs(D[s]) + fabs(corr) + fabs(wG)) * rden;
+            int c = 0;                                                           // members below t, counted by the R sub-lanes
+            if (in_regs) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) c += (am[q] < tt) ? 1 : 0;
+            } else {
+                for (int kk = r; kk < M; kk += R) c += (lds_ld<double>(lds, L.off_e + 8 * (2 + kk)) < tt) ? 1 : 0;
+            }
+            const int p = sub_sumi<R>(c);
+            const int oe = L.off_e + 8 * p;
+            const double lolo = lds_ld<double>(lds, oe), lo = lds_ld<double>(lds, oe + 8), hi = lds_ld<double>(lds, oe + 16),
+                         hihi = lds_ld<double>(lds, oe + 24);
+            const double d_lo = fabs(lo - tt), d_hi = fabs(hi - tt), d_ll = fabs(lolo - tt), d_hh = fabs(hihi - tt);
+            const bool at0 = p == 0, atM = p == M;
+            const bool use_hi = at0 | (!atM & !(d_lo <= d_hi));                  // tie -> lower index
+            const int    idx_l = use_hi ? p : p - 1;
+            const double q_l   = use_hi ? hi : lo;
+            const double m2_in = fabs(d_hi - d_lo), m2_lo = d_hh - d_hi, m2_hi = d_ll - d_lo;
+            const double m2 = at0 ? m2_lo : (atM ? m2_hi : m2_in);               // twice the distance from the boundary
+            const bool plateau = !use_hi & (p >= 2) & !(d_ll > d_lo);            // a lower member at the same distance would win
+            const bool cert = !plateau & (msq | (m2 > delta2)) & sure;
+            const bool valid = t < N;                                            // steps beyond N pad the last block: no-ops
+            const float q32 = (rule1 | !valid) ? 0.f : (float)q_l;
+            const int   idx = rule1 ? K.zero_idx : idx_l;
+            const bool ok = rule1 | cert | !valid;
+            if (commit & ok) {
+                qc[s] = q32;
+                if (!valid) wc[s] = 0.f;
+                if (r == 0) {
+                    lds_st<float2>(lds, o_wq + cbq + 8 * s, make_float2(valid ? wc[s] : 0.f, q32));
+                    if (valid) lds_st<int2>(lds, o_out + (int)(t % kOutSteps) * 8, make_int2(idx, __float_as_int(q32)));
+                }
+            }
+            return ok;
+        };
+
+        if (b < K.nblk) {
+#pragma unroll
+            for (int s = 0; s < B; ++s) {
+                const bool ok = decide(s, stop == B);
+                if (stop == B && !ok) stop = s;
+            }
+            // smallest stop over the workgroup's active neurons (B: nobody stopped)
+            int smin = active ? stop : B;
+            smin = min(smin, __builtin_amdgcn_mov_dpp(smin, 0xB1, 0xF, 0xF, true));
+            smin = min(smin, __builtin_amdgcn_mov_dpp(smin, 0x4E, 0xF, 0xF, true));
+#pragma unroll
+            for (int off = 4; off < 64; off <<= 1) smin = min(smin, __shfl_xor(smin, off));
+            if (lane == 0) lds_st<int>(lds, L.off_ctl + 4 * (b & 1), smin < B ? smin : -1);
+        } else if (lane == 0) {
+            lds_st<int>(lds, L.off_ctl + 4 * (b & 1), -1);
+        }
+        STAMP(dt1);
+        slot_barrier();
+        STAMP(dt2);
+#ifdef GPFQ_BLK_STAMPS
+        dacc_work += dt1 - dt0; dacc_bar += dt2 - dt1;
+#endif
+
+        // ---- slow path: exact decision of the stopped step, then the chain resumes ----
+        for (;;) {
+            const int S = __builtin_amdgcn_readfirstlane(lds_ld<int>(lds, L.off_ctl + 4 * (b & 1)));
+            if (S < 0) break;
+            slot_barrier();                                       // exact partials published
+            double du = 0.0, dw = 0.0;
+#pragma unroll
+            for (int q = 0; q < kSweepWaves / R; ++q) {
+                const double2 v = lds_ld<double2>(lds, o_x2 + q * R * NB * 16);
+                du += v.x; dw += v.y;
+            }
+            du = sub_sum<R>(du); dw = sub_sum<R>(dw);
+            const bool mine = active && stop == S;
+            if (mine) {
+                const int64_t t = (int64_t)b * B + S;
+                const double nrm = lds_ld<double2>(lds, tbase + S * RB + 32).y;
+                float wS = 0.f;
+#pragma unroll
+                for (int s = 0; s < B; ++s) wS = (s == S) ? wc[s] : wS;
+                const double te = dw / (nrm * nrm);
+                const double t2 = fabs(du) < 1e-10 ? (double)wS : te;
+                int bi = 0;
+                double bq = lds_ld<double>(lds, L.off_e + 16), bdist = fabs(bq - t2);
+                for (int kk = 1; kk < M; ++kk) {
+                    const double ak = lds_ld<double>(lds, L.off_e + 8 * (2 + kk)), dk = fabs(ak - t2);
+                    if (dk < bdist) { bdist = dk; bi = kk; bq = ak; }
+                }
+                const float q32 = (float)bq;
+#pragma unroll
+                for (int s = 0; s < B; ++s) qc[s] = (s == S) ? q32 : qc[s];
+                if (r == 0) {
+                    lds_st<float2>(lds, o_wq + cbq + 8 * S, make_float2(wS, q32));
+                    lds_st<int2>(lds, o_out + (int)(t % kOutSteps) * 8, make_int2(bi, __float_as_int(q32)));
+                    ++n_fallback;
+                }
+            }
+            // resume the chains that were stopped at S
+            int stop2 = mine ? B : stop;
+#pragma unroll
+            for (int s = 0; s < B; ++s) {
+                if (s > S) {                                      // (uniform)
+                    const bool ok = decide(s, mine && stop2 == B);
+                    if (mine && stop2 == B && !ok) stop2 = s;
+                }
+            }
+            stop = stop2;
+            int smin = active ? stop : B;
+            smin = min(smin, __builtin_amdgcn_mov_dpp(smin, 0xB1, 0xF, 0xF, true));
+            smin = min(smin, __builtin_amdgcn_mov_dpp(smin, 0x4E, 0xF, 0xF, true));
+#pragma unroll
+            for (int off = 4; off < 64; off <<= 1) smin = min(smin, __shfl_xor(smin, off));
+            if (lane == 0) lds_st<int>(lds, L.off_ctl + 4 * (b & 1), smin < B ? smin : -1);
+            slot_barrier();                                       // chains resumed, control word rewritten
+        }
+
+        // block b is final: it becomes "the previous block"; flush the output ring when it is full
+#pragma unroll
+        for (int j = 0; j < B; ++j) { wprev[j] = (b < K.nblk) ? wc[j] : 0.f; qprev[j] = (b < K.nblk) ? qc[j] : 0.f; }
+        const int64_t done = min((int64_t)(b + 1) * B, N);
+        if (b < K.nblk && (done - flushed >= kOutSteps - B + 1 || done == N)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            flush(flushed, done);
+            flushed = done;
+        }
+    }
+
+    if (K.fallback_count && n_fallback) atomicAdd(K.fallback_count, n_fallback);   // rare
+#ifdef GPFQ_BLK_STAMPS
+    if (K.stamps && blockIdx.x == 0 && lane == 0) { K.stamps[16] = dacc_work; K.stamps[17] = dacc_bar; }
+#endif
+    slot_barrier();                                               // residual-norm partials published
+    if (K.resid) {
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < kSweepWaves / R; ++q) tot += lds_ld<double>(lds, o_d + q * R * B * NB * 8);
+        tot = sub_sum<R>(tot);
+        if (active && r == 0) K.resid[jn] = sqrt(tot);
+    }
+}
+
+}  // namespace
+
+// G neuron groups per sweep wavefront (4G neurons per workgroup), S sample pairs per k-lane over the eight sweep
+// wavefronts (rows of MP = (128 / G) * S samples), B steps per slot.
+template <int G, int S, int B>
+__global__ void __launch_bounds__(64 * (kSweepWaves + 1))
+gpfq_blk_kernel(BlkK K, AlphabetArg A)
+{
+    constexpr int NB = 4 * G, KQ = 64 / G, MP = 2 * KQ * S;
+    using PS = PairSplit<S>;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const BlkLds L = blk_lds(MP, NB, B);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- LDS initialisation: zero weights / partials / (w, q) / control, alphabet table with sentinels ----
+    for (int i = tid; i < (L.off_e - L.off_w) / 4; i += blockDim.x) reinterpret_cast<int *>(lds + L.off_w)[i] = 0;
+    for (int i = tid; i < (L.total - L.off_out) / 4; i += blockDim.x) reinterpret_cast<int *>(lds + L.off_out)[i] = 0;
+    if (tid < 68) {
+        const double kInf = __longlong_as_double(0x7ff0000000000000LL);
+        const int k = tid - 2;
+        reinterpret_cast<double *>(lds + L.off_e)[tid] = k < 0 ? -kInf : (k < A.M ? A.a[k] : kInf);
+    }
+    if (tid < 2) reinterpret_cast<int *>(lds + L.off_ctl)[tid] = -1;
+    __syncthreads();
+
+    if (wave < kSweepWaves) {
+        int pbase = 0;
+#pragma unroll
+        for (int w = 0; w < kSweepWaves; ++w) pbase += (w < wave) ? KQ * PS::pw[w] : 0;
+        const int pw = PS::pw[wave & 7];
+        if (pw == 1) { if constexpr (S == 16 || S == 24) blk_sweep_role<G, 1, MP, B>(K, lds, L, wave, lane, pbase); }
+        else if (pw == 2) blk_sweep_role<G, 2, MP, B>(K, lds, L, wave, lane, pbase);
+        else if (pw == 3) blk_sweep_role<G, 3, MP, B>(K, lds, L, wave, lane, pbase);
+        else if (pw == 4) { if constexpr (S >= 24) blk_sweep_role<G, 4, MP, B>(K, lds, L, wave, lane, pbase); }
+        else { if constexpr (S == 32) blk_sweep_role<G, 5, MP, B>(K, lds, L, wave, lane, pbase); }
+    } else {
+        blk_decision_role<G, MP, B>(K, lds, L, lane);
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+struct BlkShape { int G, S, B, mp; };
+
+static BlkShape blk_shape(int64_t m)
+{
+    if (m > 512 && m <= 1024) return {4, 32, 4, 1024};
+    if (m > 1024 && m <= 2048) return {2, 32, 2, 2048};
+    return {0, 0, 0, 0};
+}
+
+bool blk_supported(const PipeArgs &a)
+{
+    const BlkShape sh = blk_shape(a.m);
+    if (sh.G == 0 || a.N < 1 || a.m < 1) return false;
+    if (a.A.M > 64 || !a.A.ascending) return false;
+    return a.N + 64 < (1LL << 31) / 64;
+}
+
+size_t blk_workspace_bytes(int64_t N, int64_t m)
+{
+    const BlkShape sh = blk_shape(m);
+    if (!sh.G) return 0;
+    const int64_t nblk = (N + sh.B - 1) / sh.B;
+    return (size_t)((nblk + 1) * sh.B + 1) * (size_t)blk_rec_bytes(sh.mp, sh.B);   // slots 0..nblk, + one record of DMA over-read
+}
+
+template <int G, int S, int B>
+static hipError_t launch_blk_inst(const PipeArgs &a, const BlkShape &sh, hipStream_t stream)
+{
+    constexpr int NB = 4 * G;
+    const BlkLds L = blk_lds(sh.mp, NB, B);
+    const unsigned grid = (unsigned)((a.C + NB - 1) / NB);
+    auto *kern = gpfq_blk_kernel<G, S, B>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+    if (e != hipSuccess) return e;
+    BlkK K;
+    K.recs = static_cast<const char *>(a.workspace); K.Wt = a.Wt; K.ldw = a.ldw;
+    K.N = a.N; K.C = a.C; K.m = (int)a.m; K.M = a.A.M; K.zero_idx = a.A.zero_idx; K.nblk = (int)((a.N + B - 1) / B);
+    K.qidx = a.qidx; K.Qt = a.Qt; K.resid = a.resid; K.u_out = a.u_out; K.fallback_count = a.fallback_count;
+    K.stamps = a.fallback_count ? a.fallback_count + 8 : nullptr;      // (diagnostic build: the unused row-statistics area behind the counter block)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (kSweepWaves + 1)), (size_t)L.total, stream, K, a.A);
+    return hipGetLastError();
+}
+
+hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
+{
+    const BlkShape sh = blk_shape(a.m);
+    if (!sh.G) return hipErrorInvalidValue;
+    const int64_t nblk = (a.N + sh.B - 1) / sh.B;
+    const int64_t nrec = (nblk + 1) * sh.B + 1;
+    hipLaunchKernelGGL(gpfq_blk_prep_kernel, dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp, sh.B,
+                       a.nrm32, static_cast<char *>(a.workspace));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (sh.G == 4) return launch_blk_inst<4, 32, 4>(a, sh, stream);
+    return launch_blk_inst<2, 32, 2>(a, sh, stream);
+}
+
+}  // namespace gpfq

@@ -105,7 +105,11 @@ static bool auto_wants_gram(int64_t N, int64_t m, int64_t C, bool want_u)
 // on-chip workspace: [fallback counter, 64 B][RowStats x N][iteration records of the pipelined kernel]
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t onchip_stats_bytes(int64_t N) { return al256(64 + (size_t)N * sizeof(gpfq::RowStats)); }
-static size_t onchip_workspace_bytes(int64_t N, int64_t m) { return onchip_stats_bytes(N) + gpfq::pipe_workspace_bytes(N, m); }
+static size_t onchip_workspace_bytes(int64_t N, int64_t m)
+{
+    const size_t p = gpfq::pipe_workspace_bytes(N, m), b = gpfq::blk_workspace_bytes(N, m);
+    return onchip_stats_bytes(N) + (p > b ? p : b);
+}
 
 // AUTO -> Gram: [Gram workspace][uncertified flags i32 x C][streaming workspace of ONE neuron, for the rare reruns]
 static size_t auto_gram_workspace_bytes(int64_t N, int64_t m, int64_t C)
@@ -134,7 +138,8 @@ static int g_lpn = 0;              // 0 = heuristic, 1 = wave-per-neuron kernel,
 static int g_gram_slack_log2 = 0;  // Gram path: error bounds multiplied by 2^this (tests force the uncertified branch)
 static int g_wpn = 0;              // wide kernel: wavefronts per neuron (0 = heuristic: only for rows > 2048)
 static int g_variant = 0;          // bit 0: row-group kernel without the float64 copy of Xq in LDS; bit 1: wide kernel with LDS-staged rows
-static int g_pipe = -1;            // pipelined dense kernel: -1 = heuristic, 0 = never, 1 = whenever it applies
+static int g_pipe = -1;            // pipelined dense kernels: -1 = heuristic, 0 = never, 1 = one step per slot (gpfq_pipe.hip) whenever it
+                                   // applies, 2 = blocks of steps per slot (gpfq_blk.hip) whenever it applies
 static int g_conv_fused = 1;       // conv channel loop: 3x3/stride-1 Gram matrices straight from the planes
 static int g_conv_strip = 0;       // fused conv kernel: forced strip length (0 = heuristic)
 
@@ -152,8 +157,8 @@ int gpfq_set_option(const char *key, int value)
     }
     if (!std::strcmp(key, "variant")) { g_variant = value; return GPFQ_OK; }
     if (!std::strcmp(key, "pipe")) {
-        if (value != -1 && value != 0 && value != 1)
-            return fail(GPFQ_ERR_INVALID_ARG, "pipe must be -1, 0 or 1");
+        if (value != -1 && value != 0 && value != 1 && value != 2)
+            return fail(GPFQ_ERR_INVALID_ARG, "pipe must be -1, 0, 1 or 2");
         g_pipe = value; return GPFQ_OK;
     }
     if (!std::strcmp(key, "waves_per_neuron")) {
@@ -257,11 +262,20 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
             pa.N = N; pa.m = m; pa.C = C; pa.qidx = qidx; pa.Qt = Qt; pa.resid = resid; pa.u_out = u_out;
             pa.ts_override = g_tile_steps; pa.variant = g_variant >> 4;
             const bool forced_old = g_lpn != 0 || g_wpn != 0 || g_onchip_mode != 1 || g_pipe == 0;
-            // measured (tools/pipe_probe.py): ahead of the row-group kernel on wide layers with rows of 513..1024 samples
-            // (16 neurons per workgroup, one round of workgroups: 4096 x 4096, m = 1024: 4.9 vs 5.4 ms); behind it where a
-            // workgroup holds 8 neurons (m > 1024: 11.4 vs 10.0 ms) or the layer is too narrow to fill the chip
+            // measured (tools/pipe_probe.py): the block-pipelined kernel is ahead of the row-group kernel on wide layers with
+            // rows of 513..1024 samples (16 neurons per workgroup, one round of workgroups: 4096 x 4096, m = 1024: 4.7 vs
+            // 5.4 ms; one step per slot: 4.9); behind it where a workgroup holds 8 neurons (m > 1024: 10.6 vs 10.0 ms) or the
+            // layer is too narrow to fill the chip
             const bool fits = m > 512 && m <= 1024 && C >= 2048 && M <= 16;
-            const bool want = g_pipe > 0 || (g_pipe < 0 && !forced_old && fits);
+            const bool want = g_pipe == 1;
+            if ((g_pipe == 2 || (g_pipe < 0 && !forced_old && fits)) && N > 0 && m > 0 && gpfq::blk_supported(pa) && workspace &&
+                (uintptr_t)workspace % 16 == 0 && workspace_bytes >= onchip_workspace_bytes(N, m)) {
+                pa.workspace = static_cast<char *>(workspace) + onchip_stats_bytes(N);
+                pa.fallback_count = static_cast<unsigned long long *>(workspace);
+                gpfq::note_dense_kernel("gpfq_blk_kernel (8 sweep wavefronts + 1 decision wavefront per workgroup, blocks of steps per slot)");
+                hipError_t e = gpfq::launch_blk(pa, s);
+                return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_neurons(block-pipelined)");
+            }
             if (want && N > 0 && m > 0 && gpfq::pipe_supported(pa) && workspace && (uintptr_t)workspace % 16 == 0 &&
                 workspace_bytes >= onchip_workspace_bytes(N, m)) {
                 pa.workspace = static_cast<char *>(workspace) + onchip_stats_bytes(N);

@@ -74,6 +74,10 @@ struct PipeArgs {
     int ts_override = 0;                   // tuning hook (bench/tests); 0 = heuristic
     int variant = 0;                       // tuning / timing experiments (PipeK::flags)
 };
+// Block form (gpfq_blk.hip): B steps per slot; same arguments.
+bool blk_supported(const PipeArgs &a);
+size_t blk_workspace_bytes(int64_t N, int64_t m);
+hipError_t launch_blk(const PipeArgs &a, hipStream_t stream);
 bool pipe_supported(const PipeArgs &a);
 size_t pipe_workspace_bytes(int64_t N, int64_t m);
 hipError_t launch_pipe(const PipeArgs &a, hipStream_t stream);

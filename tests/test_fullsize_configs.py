@@ -79,7 +79,7 @@ def test_cfg2_dense_oracle_512_neurons(hip, oracle_mod):
     alphabet_o, rad_o = oracle_mod.layer_alphabet(W.cpu().numpy(), np.linspace(-1, 1, 3), 3)
     assert rad == rad_o and np.array_equal(alphabet, alphabet_o)
     out = layer.quantize_dense(W, X, Xq, alphabet)
-    assert "gpfq_pipe_kernel" in hip.last_dense_kernel()          # the default kernel of this shape is the one checked
+    assert "gpfq_blk_kernel" in hip.last_dense_kernel()          # the default kernel of this shape is the one checked
     _dense_oracle_sample(oracle_mod, W, X, Xq, alphabet, out, [(0, 256), (3840, 4096)])
 
 

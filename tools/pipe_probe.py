@@ -68,9 +68,10 @@ def main():
     tmin, tavg = timed(lambda: hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm, want_values=False, path=hip.GPFQ_PATH_ONCHIP))
     print(f"  old kernel: min {tmin:.3f} ms avg {tavg:.3f} ms (incl. pre-pass launches)")
     variants = [int(v) for v in os.environ.get("PIPE_VARIANTS", "0").split(",")]
-    for variant, ts in [(v, ts) for v in variants for ts in (0, 2, 1)]:
+    modes = [int(v) for v in os.environ.get("PIPE_MODES", "1,2").split(",")]       # 1: one step per slot, 2: blocks of steps
+    for mode, variant, ts in [(md, v, ts) for md in modes for v in variants for ts in ((0, 2, 1) if md == 1 else (0,))]:
         try:
-            r = run(pipe=1, tile_steps=ts, variant=16 * variant)
+            r = run(pipe=mode, tile_steps=ts, variant=16 * variant)
         except hip.GpfqError as e:
             print(f"  pipe ts={ts}: {e}")
             continue
@@ -79,9 +80,16 @@ def main():
         rel_r = float(((r["resid"] - base["resid"]).abs() / base["resid"].clamp_min(1e-300)).max())
         bad_u = int((r["u"] != base["u"]).sum()) if want_u else -1
         fb = hip.exact_fallbacks(r)
+        if os.environ.get("GPFQ_DIAG") and mode == 2:
+            st = r["workspace"][64:64 + 18 * 8].view(torch.int64).cpu().numpy()
+            ns = max(int(st[5]), 1)
+            for name, o in (("sweep wave 0 (few pairs)", 0), ("sweep wave 7 (most pairs)", 8)):
+                print(f"    {name}: cycles per slot: dma issue {st[o]/ns:.0f}, phase U {st[o+1]/ns:.0f}, phase D+fold {st[o+2]/ns:.0f}, "
+                      f"dma wait {st[o+3]/ns:.0f}, barrier {st[o+4]/ns:.0f}  ({ns} slots)")
+            print(f"    decision wave: work {st[16]/ns:.0f}, barrier {st[17]/ns:.0f} cycles per slot")
         tmin, tavg = timed(lambda: hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm, want_values=False,
                                                         path=hip.GPFQ_PATH_ONCHIP))
-        print(f"  pipe variant={variant} ts={ts or 'auto'}: min {tmin:.3f} ms avg {tavg:.3f} ms  "
+        print(f"  pipe mode={mode} variant={variant} ts={ts or 'auto'} [{hip.last_dense_kernel()[:16]}]: min {tmin:.3f} ms avg {tavg:.3f} ms  "
               f"mismatch idx={bad_i} Q={bad_q} u={bad_u} max resid rel diff={rel_r:.2e}  exact fallbacks={fb}")
     hip.set_option("pipe", -1); hip.set_option("tile_steps", 0); hip.set_option("variant", 0)
 
