@@ -10,7 +10,7 @@ export PYTHONPATH=$ROOT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 $ROOT/bench.py > $OUT/bench.log 2>&1
 cd $ROOT
-KS=gpfq_pipe_kernel
+KS=${KS:-gpfq_blk_kernel}
 summ() {   # average of every counter of the kernels whose name contains $KS
 python3 - "$1" "$KS" <<'PY'
 import csv, glob, sys
