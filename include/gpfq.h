@@ -32,7 +32,10 @@
  *   X, Xq   f32 [N][ld]   row t = direction t of the analog / quantized network's walk over the m
  *                         calibration samples (wX[t,:], qX[t,:]); ld >= m is the row pitch in elements
  *   Wt      f32 [C][ldw]  neuron-major weights: row j = W[:, j] (ldw >= N)
- *   qidx    i8  [C][N]    alphabet index chosen for weight t of neuron j; `zero_idx` semantics below
+ *   qidx    i8  [C][N]    alphabet index chosen for weight t of neuron j; `zero_idx` semantics below.
+ *                         Alphabets of more than 64 members (bits 7 and 8 of the reference's `bits`, :396)
+ *                         have i16 elements instead: every `void *qidx` below is int8_t* for M <= 64 and
+ *                         int16_t* for 64 < M <= GPFQ_MAX_ALPHABET (gpfq_index_bits(M) == 16).
  *   Qt      f32 [C][N]    the quantized weights, (float)alphabet[qidx] (Keras stores float32)
  *   resid   f64 [C]       ||u_final||_2 per neuron (the reference discards u, :121; emitted for parity checks)
  *   u_out   f64 [C][m]    optional final residual vectors (NULL to skip)
@@ -54,7 +57,8 @@ extern "C" {
 #define GPFQ_ERR_LAUNCH        (-4)   /* HIP reported an error; text in gpfq_last_error()      */
 #define GPFQ_ERR_NO_DEVICE     (-5)   /* no gfx950 device visible                              */
 
-#define GPFQ_MAX_ALPHABET 64          /* alphabet members per call (bits <= 6)                 */
+#define GPFQ_MAX_ALPHABET 256         /* alphabet members per call (bits <= 8, scripts/quantized_network.py:396: int(round(2**bits)));
+                                         more than 64 members: int16 indices, the kernels that hold four alphabet registers per lane */
 
 /* gpfq_quantize_neurons `path` selector */
 #define GPFQ_PATH_AUTO      0   /* rows beyond GPFQ_GRAM_MIN_M samples with walks of <= GPFQ_GRAM_MAX_N steps (and no u_out):
@@ -141,7 +145,7 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
                           const float *Wt, int64_t ldw,
                           const double *alphabet, int M, int zero_idx,
                           int64_t N, int64_t m, int64_t C,
-                          int8_t *qidx, float *Qt, double *resid, double *u_out,
+                          void *qidx, float *Qt, double *resid, double *u_out,
                           void *workspace, size_t workspace_bytes, int path, void *stream);
 
 /*
@@ -170,17 +174,17 @@ int gpfq_quantize_neurons_gram(const float *X, const float *Xq, int64_t ld, floa
                                const float *Wt, int64_t ldw,
                                const double *alphabet, int M, int zero_idx,
                                int64_t N, int64_t m, int64_t C,
-                               int8_t *qidx, float *Qt, double *resid, int32_t *uncertified,
+                               void *qidx, float *Qt, double *resid, int32_t *uncertified,
                                void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Memoryless scalar quantization of n weights: Q[i] = (float)alphabet[nearest((double)W[i])].
  * Replaces the per-weight Python loop `[_bit_round_parallel(w, layer_alphabet) for w in W.flatten()]`
  * of the drivers' MSQ baseline (scripts/quantize_pretrained_mlp.py:109, _cnn.py:114, _imagenet.py:219).
- *   W [device] f32 [n]; Q [device] f32 [n] (may be NULL); qidx [device] i8 [n] (may be NULL).
+ *   W [device] f32 [n]; Q [device] f32 [n] (may be NULL); qidx [device] i8 [n] (i16 for M > 64; may be NULL).
  */
 int gpfq_msq_round(const float *W, int64_t n, const double *alphabet, int M,
-                   float *Q, int8_t *qidx, void *stream);
+                   float *Q, void *qidx, void *stream);
 
 /*
  * Assemble the quantized kernel in Keras layout from the neuron-major indices:
@@ -189,14 +193,15 @@ int gpfq_msq_round(const float *W, int64_t n, const double *alphabet, int M,
  * with neurons sharded over GPUs only the indices need to be all-gathered -- packed to 2 or 4 bits per
  * weight by gpfq_pack_indices when the alphabet allows (code = index + 1, 0 = the literal zero; every
  * neuron row padded to whole bytes, ceil(N*bits/8) bytes per row, so shards stay row-aligned).
- *   gpfq_index_bits(M): 2 for M <= 3, 4 for M <= 15, else 8 (plain int8 indices, no packing).
- *   qidx [device] i8 [C][N] (bits = 8) or packed u8 [C][ceil(N*bits/8)];
- *   Q [device] f32 [N][C] (may be NULL); qidx_t [device] i8 [N][C] (may be NULL).
+ *   gpfq_index_bits(M): 2 for M <= 3, 4 for M <= 15, 8 for M <= 64 (plain int8 indices, no packing), 16 beyond
+ *   (plain int16 indices).
+ *   qidx [device] i8 [C][N] (bits = 8), i16 [C][N] (bits = 16) or packed u8 [C][ceil(N*bits/8)];
+ *   Q [device] f32 [N][C] (may be NULL); qidx_t [device] [N][C] of the element type of `bits` (i8 for packed input; may be NULL).
  */
 int gpfq_index_bits(int M);
 int gpfq_pack_indices(const int8_t *qidx, int64_t N, int64_t C, int bits, uint8_t *packed, void *stream);
 int gpfq_assemble_kernel(const void *qidx, int bits, const double *alphabet, int M, int64_t N, int64_t C,
-                         float *Q, int8_t *qidx_t, void *stream);
+                         float *Q, void *qidx_t, void *stream);
 
 /*
  * median(|W|) of n float32 weights with NumPy's semantics (float32 result; even n -> float32 mean of
@@ -270,7 +275,7 @@ size_t gpfq_conv_channels_workspace_bytes(int64_t n, int64_t H, int64_t W, int64
 int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,
                                 int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
                                 const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
-                                int8_t *qidx, float *Qt, double *resid, int32_t *uncertified,
+                                void *qidx, float *Qt, double *resid, int32_t *uncertified,
                                 void *workspace, size_t workspace_bytes, void *stream);
 
 /*
@@ -297,7 +302,7 @@ int gpfq_quantize_conv_channels_from_records(const double *records, const int32_
                                              const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,
                                              int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
                                              const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
-                                             int8_t *qidx, float *Qt, int32_t *uncertified,
+                                             void *qidx, float *Qt, int32_t *uncertified,
                                              void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus

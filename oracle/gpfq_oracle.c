@@ -111,10 +111,10 @@ static int gpfq_oracle_step(float w, double *u, const float *X, const float *Xq,
 
 /* One neuron / one (channel, filter) pair.  w has stride wstride (a column of the Keras
  * [N][C] kernel has stride C).  X, Xq: feature-major [N][ld] f32 rows of length m.
- * Outputs (any may be NULL): q f64[N], idx i8[N], u f64[m] final residual. */
+ * Outputs (any may be NULL): q f64[N], idx i16[N] (alphabets of up to 2^15 members), u f64[m] final residual. */
 void gpfq_oracle_neuron(const float *w, long wstride, const float *X, const float *Xq,
                         long N, long m, long ld, const double *alphabet, int M,
-                        double *q, int8_t *idx, double *u_out)
+                        double *q, int16_t *idx, double *u_out)
 {
     int zi = zero_index(alphabet, M);
     double *u = (double *)calloc((size_t)(m > 0 ? m : 1), sizeof(double));   /* zeros(m) (:115) */
@@ -122,7 +122,7 @@ void gpfq_oracle_neuron(const float *w, long wstride, const float *X, const floa
         double qv;
         int k = gpfq_oracle_step(w[t * wstride], u, X + t * ld, Xq + t * ld, m, alphabet, M, zi, &qv);
         if (q) q[t] = qv;
-        if (idx) idx[t] = (int8_t)k;
+        if (idx) idx[t] = (int16_t)k;
     }
     if (u_out) memcpy(u_out, u, (size_t)m * sizeof(double));
     free(u);
@@ -134,7 +134,7 @@ void gpfq_oracle_neuron(const float *w, long wstride, const float *X, const floa
 void gpfq_oracle_layer(const float *W, long N, long C, long j0, long j1,
                        const float *X, const float *Xq, long m, long ld,
                        const double *alphabet, int M,
-                       double *Q, int8_t *idx, double *resid, int nthreads)
+                       double *Q, int16_t *idx, double *resid, int nthreads)
 {
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -190,11 +190,14 @@ float gpfq_oracle_median_abs(const float *W, long n)
 
 /* Plain memoryless scalar quantization of a whole kernel (drivers' MSQ baseline,
  * quantize_pretrained_mlp.py:109): nearest(alphabet, (double)w) per weight. */
-void gpfq_oracle_msq(const float *W, long n, const double *alphabet, int M, double *Q, int8_t *idx)
+/* Interface revision of this file (2: int16 index outputs); oracle/__init__.py rebuilds a library that reports another. */
+int gpfq_oracle_abi(void) { return 2; }
+
+void gpfq_oracle_msq(const float *W, long n, const double *alphabet, int M, double *Q, int16_t *idx)
 {
     for (long i = 0; i < n; ++i) {
         int k = gpfq_oracle_nearest((double)W[i], alphabet, M);
         if (Q) Q[i] = alphabet[k];
-        if (idx) idx[i] = (int8_t)k;
+        if (idx) idx[i] = (int16_t)k;
     }
 }

@@ -30,24 +30,39 @@ int hip_fail(hipError_t e, const char *what)
     return fail(GPFQ_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
 }
 
-// Copies the host alphabet into the by-value kernel argument and classifies it.
-int make_alphabet(const double *alphabet, int M, int zero_idx, gpfq::AlphabetArg *A)
+// The host alphabet as the by-value kernel arguments: A for up to 64 members (int8 indices, every kernel family), B beyond
+// (65..GPFQ_MAX_ALPHABET members, int16 indices: the wavefront-per-neuron, wide, streaming and thread-per-neuron Gram kernels).
+struct HostAlphabet {
+    gpfq::AlphabetArg A;
+    gpfq::AlphabetBig B;
+    bool is_big = false;
+    const gpfq::AlphabetBig *big() const { return is_big ? &B : nullptr; }
+    size_t idx_bytes() const { return is_big ? 2 : 1; }
+    // element offset into an index array of either width
+    int8_t *at(void *qidx, int64_t elems) const { return qidx ? static_cast<int8_t *>(qidx) + elems * (int64_t)idx_bytes() : nullptr; }
+};
+
+// Copies the host alphabet into the kernel argument of its size class and classifies it.
+int make_alphabet(const double *alphabet, int M, int zero_idx, HostAlphabet *H)
 {
     if (!alphabet) return fail(GPFQ_ERR_INVALID_ARG, "alphabet is NULL");
     if (M < 1) return fail(GPFQ_ERR_INVALID_ARG, "alphabet size M=%d must be >= 1", M);
     if (M > GPFQ_MAX_ALPHABET)
         return fail(GPFQ_ERR_UNSUPPORTED, "alphabet size M=%d exceeds GPFQ_MAX_ALPHABET=%d", M, GPFQ_MAX_ALPHABET);
     if (zero_idx < -1 || zero_idx >= M) return fail(GPFQ_ERR_INVALID_ARG, "zero_idx=%d out of range", zero_idx);
-    std::memset(A, 0, sizeof(*A));
+    std::memset(&H->A, 0, sizeof(H->A));
+    std::memset(&H->B, 0, sizeof(H->B));
+    H->is_big = M > 64;
     bool asc = true;
     for (int k = 0; k < M; ++k) {
-        A->a[k] = alphabet[k];
+        if (H->is_big) H->B.a[k] = alphabet[k];
+        else H->A.a[k] = alphabet[k];
         if (std::isnan(alphabet[k])) asc = false;
         if (k > 0 && !(alphabet[k - 1] <= alphabet[k])) asc = false;
     }
-    A->M = M;
-    A->zero_idx = zero_idx;
-    A->ascending = asc ? 1 : 0;
+    H->A.M = H->B.M = M;
+    H->A.zero_idx = H->B.zero_idx = zero_idx;
+    H->A.ascending = H->B.ascending = asc ? 1 : 0;
     return GPFQ_OK;
 }
 
@@ -59,7 +74,7 @@ void note_dense_kernel(const char *name) { g_dense_kernel = name; }
 
 extern "C" {
 
-int gpfq_version(void) { return 200; }
+int gpfq_version(void) { return 210; }
 
 const char *gpfq_last_dense_kernel(void) { return g_dense_kernel; }
 
@@ -184,14 +199,16 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
                           const float *Wt, int64_t ldw,
                           const double *alphabet, int M, int zero_idx,
                           int64_t N, int64_t m, int64_t C,
-                          int8_t *qidx, float *Qt, double *resid, double *u_out,
+                          void *qidx_v, float *Qt, double *resid, double *u_out,
                           void *workspace, size_t workspace_bytes, int path, void *stream)
 {
     if (N < 0 || m < 0 || C < 0)
         return fail(GPFQ_ERR_INVALID_ARG, "negative size N=%lld m=%lld C=%lld", (long long)N, (long long)m, (long long)C);
-    gpfq::AlphabetArg A;
-    int rc = make_alphabet(alphabet, M, zero_idx, &A);
+    HostAlphabet H;
+    int rc = make_alphabet(alphabet, M, zero_idx, &H);
     if (rc != GPFQ_OK) return rc;
+    const gpfq::AlphabetArg &A = H.A;
+    int8_t *qidx = static_cast<int8_t *>(qidx_v);          // int16 elements when H.is_big
     if (C == 0) return GPFQ_OK;
     if (N > 0 && (!Wt || !nrm32)) return fail(GPFQ_ERR_INVALID_ARG, "Wt/nrm32 is NULL");
     if (N > 0 && m > 0 && (!X || !Xq)) return fail(GPFQ_ERR_INVALID_ARG, "X/Xq is NULL");
@@ -202,7 +219,8 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
     const int p = resolve_path(m, path);
     hipStream_t s = static_cast<hipStream_t>(stream);
 
-    if (path == GPFQ_PATH_AUTO && N > 0 && m > 0 && auto_wants_gram(N, m, C, u_out != nullptr) && workspace &&
+    // (alphabets beyond 64 members have no wavefront-per-neuron chain for walks beyond 64 steps: those stay on the element-wise paths)
+    if (path == GPFQ_PATH_AUTO && N > 0 && m > 0 && auto_wants_gram(N, m, C, u_out != nullptr) && !(H.is_big && N > 64) && workspace &&
         (uintptr_t)workspace % 16 == 0 && workspace_bytes >= auto_gram_workspace_bytes(N, m, C)) {
         // Long rows, short walks: Gram records once per layer, the recurrence on scalars with every decision certified,
         // uncertifiable chains repaired on the device; whatever is still flagged afterwards (practically never) is rerun
@@ -212,7 +230,7 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
         int32_t *unc = reinterpret_cast<int32_t *>(ws + al256(gpfq::gram_workspace_bytes(N, m, C)));
         char *stream_ws = reinterpret_cast<char *>(unc) + al256((size_t)C * sizeof(int32_t));
         gpfq::GramArgs g;
-        g.X = X; g.Xq = Xq; g.ld = ld; g.nrm32 = nrm32; g.Wt = Wt; g.ldw = ldw; g.A = A;
+        g.X = X; g.Xq = Xq; g.ld = ld; g.nrm32 = nrm32; g.Wt = Wt; g.ldw = ldw; g.A = A; g.big = H.big();
         g.N = N; g.m = m; g.C = C; g.qidx = qidx; g.Qt = Qt; g.resid = resid; g.uncertified = unc;
         g.workspace = gram_ws;
         g.slack = std::ldexp(1.0, g_gram_slack_log2);
@@ -227,8 +245,8 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
         for (int64_t j = 0; j < C; ++j) {
             if (!flags[(size_t)j]) continue;
             gpfq::StreamArgs a;
-            a.X = X; a.Xq = Xq; a.ld = ld; a.nrm32 = nrm32; a.Wt = Wt + j * ldw; a.ldw = ldw; a.A = A;
-            a.N = N; a.m = m; a.C = 1; a.qidx = qidx ? qidx + j * N : nullptr; a.Qt = Qt ? Qt + j * N : nullptr;
+            a.X = X; a.Xq = Xq; a.ld = ld; a.nrm32 = nrm32; a.Wt = Wt + j * ldw; a.ldw = ldw; a.A = A; a.big = H.big();
+            a.N = N; a.m = m; a.C = 1; a.qidx = H.at(qidx, j * N); a.Qt = Qt ? Qt + j * N : nullptr;
             a.resid = resid ? resid + j : nullptr; a.u_out = nullptr;
             a.workspace = stream_ws; a.workspace_bytes = gpfq::stream_workspace_bytes(N, m, 1, true);
             e = gpfq::launch_stream(a, s);
@@ -241,7 +259,7 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
         if (m > GPFQ_ONCHIP_MAX_M)
             return fail(GPFQ_ERR_UNSUPPORTED, "on-chip path needs m <= %d (got %lld)", GPFQ_ONCHIP_MAX_M, (long long)m);
         gpfq::OnchipArgs a;
-        a.X = X; a.Xq = Xq; a.ld = ld; a.nrm32 = nrm32; a.Wt = Wt; a.ldw = ldw; a.A = A;
+        a.X = X; a.Xq = Xq; a.ld = ld; a.nrm32 = nrm32; a.Wt = Wt; a.ldw = ldw; a.A = A; a.big = H.big();
         a.N = N; a.m = m; a.C = C; a.qidx = qidx; a.Qt = Qt; a.resid = resid; a.u_out = u_out;
         a.ts_override = g_tile_steps; a.nw_override = g_group_waves;
         a.mode = g_onchip_mode;
@@ -256,7 +274,7 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
         }
         // the pipelined kernel (gpfq_pipe.hip): rows of up to 2048 samples in layers wide enough to fill the chip
         // with 16 neurons per workgroup; narrow layers keep the latency-oriented kernels below
-        {
+        if (!H.is_big) {
             gpfq::PipeArgs pa;
             pa.X = X; pa.Xq = Xq; pa.ld = ld; pa.nrm32 = nrm32; pa.Wt = Wt; pa.ldw = ldw; pa.A = A;
             pa.N = N; pa.m = m; pa.C = C; pa.qidx = qidx; pa.Qt = Qt; pa.resid = resid; pa.u_out = u_out;
@@ -303,7 +321,7 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
         return fail(GPFQ_ERR_WORKSPACE, "streaming path needs %zu workspace bytes, got %zu", need, workspace ? workspace_bytes : (size_t)0);
     if ((uintptr_t)workspace % 16 != 0) return fail(GPFQ_ERR_INVALID_ARG, "workspace must be 16-byte aligned");
     gpfq::StreamArgs a;
-    a.X = X; a.Xq = Xq; a.ld = ld; a.nrm32 = nrm32; a.Wt = Wt; a.ldw = ldw; a.A = A;
+    a.X = X; a.Xq = Xq; a.ld = ld; a.nrm32 = nrm32; a.Wt = Wt; a.ldw = ldw; a.A = A; a.big = H.big();
     a.N = N; a.m = m; a.C = C; a.qidx = qidx; a.Qt = Qt; a.resid = resid; a.u_out = u_out;
     a.workspace = workspace; a.workspace_bytes = workspace_bytes;
     gpfq::note_dense_kernel("gpfq_stream_step_kernel + gpfq_stream_decide_kernel (residual in HBM)");
@@ -321,13 +339,13 @@ int gpfq_quantize_neurons_gram(const float *X, const float *Xq, int64_t ld, floa
                                const float *Wt, int64_t ldw,
                                const double *alphabet, int M, int zero_idx,
                                int64_t N, int64_t m, int64_t C,
-                               int8_t *qidx, float *Qt, double *resid, int32_t *uncertified,
+                               void *qidx, float *Qt, double *resid, int32_t *uncertified,
                                void *workspace, size_t workspace_bytes, void *stream)
 {
     if (N < 0 || m < 0 || C < 0)
         return fail(GPFQ_ERR_INVALID_ARG, "negative size N=%lld m=%lld C=%lld", (long long)N, (long long)m, (long long)C);
-    gpfq::AlphabetArg A;
-    int rc = make_alphabet(alphabet, M, zero_idx, &A);
+    HostAlphabet H;
+    int rc = make_alphabet(alphabet, M, zero_idx, &H);
     if (rc != GPFQ_OK) return rc;
     if (C == 0) return GPFQ_OK;
     if (N > GPFQ_GRAM_MAX_N) return fail(GPFQ_ERR_UNSUPPORTED, "Gram path needs N <= %d (got %lld)", GPFQ_GRAM_MAX_N, (long long)N);
@@ -341,8 +359,8 @@ int gpfq_quantize_neurons_gram(const float *X, const float *Xq, int64_t ld, floa
     if (!workspace || workspace_bytes < need || (uintptr_t)workspace % 16 != 0)
         return fail(GPFQ_ERR_WORKSPACE, "Gram path needs %zu aligned workspace bytes", need);
     gpfq::GramArgs a;
-    a.X = X; a.Xq = Xq; a.ld = ld; a.nrm32 = nrm32; a.Wt = Wt; a.ldw = ldw; a.A = A;
-    a.N = N; a.m = m; a.C = C; a.qidx = qidx; a.Qt = Qt; a.resid = resid; a.uncertified = uncertified;
+    a.X = X; a.Xq = Xq; a.ld = ld; a.nrm32 = nrm32; a.Wt = Wt; a.ldw = ldw; a.A = H.A; a.big = H.big();
+    a.N = N; a.m = m; a.C = C; a.qidx = static_cast<int8_t *>(qidx); a.Qt = Qt; a.resid = resid; a.uncertified = uncertified;
     a.workspace = workspace;
     a.nrm32_out = compute_norms ? nrm32 : nullptr;
     a.slack = std::ldexp(1.0, g_gram_slack_log2);
@@ -351,22 +369,22 @@ int gpfq_quantize_neurons_gram(const float *X, const float *Xq, int64_t ld, floa
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_neurons_gram");
 }
 
-int gpfq_msq_round(const float *W, int64_t n, const double *alphabet, int M, float *Q, int8_t *qidx, void *stream)
+int gpfq_msq_round(const float *W, int64_t n, const double *alphabet, int M, float *Q, void *qidx, void *stream)
 {
     if (n < 0) return fail(GPFQ_ERR_INVALID_ARG, "negative n");
-    gpfq::AlphabetArg A;
-    int rc = make_alphabet(alphabet, M, -1, &A);
+    HostAlphabet H;
+    int rc = make_alphabet(alphabet, M, -1, &H);
     if (rc != GPFQ_OK) return rc;
     if (n == 0) return GPFQ_OK;
     if (!W) return fail(GPFQ_ERR_INVALID_ARG, "W is NULL");
-    hipError_t e = gpfq::launch_msq(W, n, A, Q, qidx, static_cast<hipStream_t>(stream));
+    hipError_t e = gpfq::launch_msq(W, n, H.A, Q, static_cast<int8_t *>(qidx), static_cast<hipStream_t>(stream), H.big());
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_msq_round");
 }
 
 int gpfq_index_bits(int M)
 {
     if (M < 1 || M > GPFQ_MAX_ALPHABET) return 0;
-    return M <= 3 ? 2 : (M <= 15 ? 4 : 8);            // codes 0..M (0 = literal zero)
+    return M <= 3 ? 2 : (M <= 15 ? 4 : (M <= 64 ? 8 : 16));   // packed codes 0..M (0 = literal zero); plain int8 / int16 indices
 }
 
 int gpfq_pack_indices(const int8_t *qidx, int64_t N, int64_t C, int bits, uint8_t *packed, void *stream)
@@ -380,18 +398,21 @@ int gpfq_pack_indices(const int8_t *qidx, int64_t N, int64_t C, int bits, uint8_
 }
 
 int gpfq_assemble_kernel(const void *qidx, int bits, const double *alphabet, int M, int64_t N, int64_t C,
-                         float *Q, int8_t *qidx_t, void *stream)
+                         float *Q, void *qidx_t, void *stream)
 {
     if (N < 0 || C < 0) return fail(GPFQ_ERR_INVALID_ARG, "negative size");
-    if (bits != 2 && bits != 4 && bits != 8) return fail(GPFQ_ERR_INVALID_ARG, "bits must be 2, 4 or 8");
-    gpfq::AlphabetArg A;
-    int rc = make_alphabet(alphabet, M, -1, &A);
+    if (bits != 2 && bits != 4 && bits != 8 && bits != 16) return fail(GPFQ_ERR_INVALID_ARG, "bits must be 2, 4, 8 or 16");
+    HostAlphabet H;
+    int rc = make_alphabet(alphabet, M, -1, &H);
     if (rc != GPFQ_OK) return rc;
     if (bits < 8 && M + 1 > (1 << bits)) return fail(GPFQ_ERR_INVALID_ARG, "%d-bit codes cannot hold an alphabet of %d", bits, M);
+    if ((bits == 16) != H.is_big)
+        return fail(GPFQ_ERR_INVALID_ARG, "alphabets of %d members have %s indices (gpfq_index_bits)", M, H.is_big ? "int16" : "int8 or packed");
     if (N == 0 || C == 0) return GPFQ_OK;
     if (!qidx) return fail(GPFQ_ERR_INVALID_ARG, "qidx is NULL");
     if (N > 2147483647LL * 32 || (C + 31) / 32 > 65535) return fail(GPFQ_ERR_UNSUPPORTED, "kernel too large to assemble in one call");
-    hipError_t e = gpfq::launch_assemble(static_cast<const int8_t *>(qidx), A, N, C, bits, Q, qidx_t, static_cast<hipStream_t>(stream));
+    hipError_t e = gpfq::launch_assemble(static_cast<const int8_t *>(qidx), H.A, N, C, bits, Q, static_cast<int8_t *>(qidx_t),
+                                         static_cast<hipStream_t>(stream), H.big());
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_assemble_kernel");
 }
 
@@ -514,16 +535,18 @@ static int conv_channels_impl(int phase, double *records, int32_t *negflags,
                               const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,
                               int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
                               const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
-                              int8_t *qidx, float *Qt, double *resid, int32_t *uncertified,
+                              void *qidx_v, float *Qt, double *resid, int32_t *uncertified,
                               void *workspace, size_t workspace_bytes, void *stream)
 {
     if (n < 0 || H <= 0 || W <= 0 || nch < 0 || F < 0) return fail(GPFQ_ERR_INVALID_ARG, "bad shape");
     if (kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || rh <= 0 || rw <= 0) return fail(GPFQ_ERR_INVALID_ARG, "bad kernel/stride/rate");
-    gpfq::AlphabetArg A{};
+    HostAlphabet HA;
     if (phase != 1) {
-        int rc = make_alphabet(alphabet, M, zero_idx, &A);
+        int rc = make_alphabet(alphabet, M, zero_idx, &HA);
         if (rc != GPFQ_OK) return rc;
     }
+    const gpfq::AlphabetArg &A = HA.A;
+    int8_t *qidx = static_cast<int8_t *>(qidx_v);          // int16 elements when HA.is_big
     const int64_t oh = gpfq_patch_out_dim(H, kh, sh, rh, same_padding), ow = gpfq_patch_out_dim(W, kw, sw, rw, same_padding);
     const int64_t cols = n * oh * ow, K = (int64_t)kh * kw;
     if (phase && (!records || !negflags)) return fail(GPFQ_ERR_INVALID_ARG, "NULL records / negflags");
@@ -539,7 +562,7 @@ static int conv_channels_impl(int phase, double *records, int32_t *negflags,
         // 3x3 / stride 1: Gram matrices of every channel straight from the planes, one batched decide launch
         gpfq::ImageGramArgs g;
         g.act_w = act_w; g.act_q = act_q; g.n = n; g.H = H; g.W = W; g.nch = nch; g.pad = same_padding ? 1 : 0;
-        g.Wt = Wt; g.A = A; g.F = F; g.qidx = qidx; g.Qt = Qt; g.uncertified = uncertified;
+        g.Wt = Wt; g.A = A; g.big = HA.big(); g.F = F; g.qidx = qidx; g.Qt = Qt; g.uncertified = uncertified;
         g.workspace = workspace;
         g.slack = std::ldexp(1.0, g_gram_slack_log2);
         g.variant = g_conv_strip;
@@ -560,7 +583,7 @@ static int conv_channels_impl(int phase, double *records, int32_t *negflags,
         gpfq::ConvGramArgs g;
         g.act_w = act_w; g.act_q = act_q; g.n = n; g.H = H; g.W = W; g.nch = nch;
         g.kh = kh; g.kw = kw; g.sh = sh; g.sw = sw; g.rh = rh; g.rw = rw; g.pt = pad_top; g.pl = pad_left; g.oh = oh; g.ow = ow;
-        g.Wt = Wt; g.A = A; g.F = F; g.qidx = qidx; g.Qt = Qt; g.uncertified = uncertified;
+        g.Wt = Wt; g.A = A; g.big = HA.big(); g.F = F; g.qidx = qidx; g.Qt = Qt; g.uncertified = uncertified;
         g.workspace = workspace;
         g.slack = std::ldexp(1.0, g_gram_slack_log2);
         g.variant = g_variant;
@@ -586,8 +609,8 @@ static int conv_channels_impl(int phase, double *records, int32_t *negflags,
         if (e != hipSuccess) return hip_fail(e, "gpfq_quantize_conv_channels(patches)");
         gpfq::GramArgs a;
         a.X = Pw; a.Xq = same_act ? Pw : Pq; a.ld = ldp; a.nrm32 = nrm; a.nrm32_out = nrm;
-        a.Wt = Wt + c * F * K; a.ldw = K; a.A = A; a.N = K; a.m = cols; a.C = F;
-        a.qidx = qidx + c * F * K; a.Qt = Qt + c * F * K; a.resid = resid ? resid + c * F : nullptr;
+        a.Wt = Wt + c * F * K; a.ldw = K; a.A = A; a.big = HA.big(); a.N = K; a.m = cols; a.C = F;
+        a.qidx = HA.at(qidx, c * F * K); a.Qt = Qt + c * F * K; a.resid = resid ? resid + c * F : nullptr;
         a.uncertified = uncertified + c * F;
         a.workspace = ws;
         a.slack = std::ldexp(1.0, g_gram_slack_log2);
@@ -612,7 +635,7 @@ int gpfq_conv_records_supported(int64_t n, int64_t H, int64_t W, int64_t nch, in
 int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,
                                 int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
                                 const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
-                                int8_t *qidx, float *Qt, double *resid, int32_t *uncertified,
+                                void *qidx, float *Qt, double *resid, int32_t *uncertified,
                                 void *workspace, size_t workspace_bytes, void *stream)
 {
     return conv_channels_impl(0, nullptr, nullptr, act_w, act_q, n, H, W, nch, kh, kw, sh, sw, rh, rw, same_padding, Wt, alphabet, M,
@@ -631,7 +654,7 @@ int gpfq_quantize_conv_channels_from_records(const double *records, const int32_
                                              const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,
                                              int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
                                              const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
-                                             int8_t *qidx, float *Qt, int32_t *uncertified,
+                                             void *qidx, float *Qt, int32_t *uncertified,
                                              void *workspace, size_t workspace_bytes, void *stream)
 {
     return conv_channels_impl(2, const_cast<double *>(records), const_cast<int32_t *>(negflags), act_w, act_q, n, H, W, nch, kh, kw, sh, sw,

@@ -202,16 +202,130 @@ __device__ __forceinline__ void gram9_add(Gram9 &a, const double (&q)[9], const 
     }
 }
 
-struct AlphabetArg {
-    double a[64];       // GPFQ_MAX_ALPHABET
+template <int CAP>
+struct AlphabetT {
+    double a[CAP];
     int    M;
     int    zero_idx;
     int    ascending;
 };
+using AlphabetArg = AlphabetT<64>;     // by-value kernel argument of every kernel family (bits <= 6)
+using AlphabetBig = AlphabetT<256>;    // GPFQ_MAX_ALPHABET: the kernels that take 65..256 members (bits 7, 8) write int16 indices
 
 __device__ __forceinline__ double alphabet_lane(const AlphabetArg &A, int lane)
 {
     return lane < A.M ? A.a[lane] : __longlong_as_double(0x7ff8000000000000LL);
 }
+
+// ---- alphabets of up to 64 * AR members across the lanes ----------------------------------------------
+// Member k lives in register k / 64 of lane k % 64 (NaN beyond M); AR = 1 is the layout above.  nearest() /
+// nearest_margin() / decide() below are the same procedures with the position count, the two neighbour
+// distances and the first-minimum search taken over AR registers.
+template <int AR>
+struct AlphaLanes {
+    double v[AR];
+};
+template <int AR, int CAP>
+__device__ __forceinline__ AlphaLanes<AR> alpha_lanes(const AlphabetT<CAP> &A, int lane)
+{
+    static_assert(64 * AR <= CAP, "alphabet registers beyond the argument's capacity");
+    AlphaLanes<AR> al;
+#pragma unroll
+    for (int r = 0; r < AR; ++r) al.v[r] = 64 * r + lane < A.M ? A.a[64 * r + lane] : __longlong_as_double(0x7ff8000000000000LL);
+    return al;
+}
+// value of member k (wave-uniform k) of a lane-distributed array
+template <int AR>
+__device__ __forceinline__ double alpha_get(const double (&v)[AR], int k)
+{
+    double x = readlane_f64(v[0], k & 63);
+#pragma unroll
+    for (int r = 1; r < AR; ++r)
+        if ((k >> 6) == r) x = readlane_f64(v[r], k & 63);
+    return x;
+}
+template <int AR>
+__device__ __forceinline__ int first_equal(const double (&d)[AR], double dmin)
+{
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+        const unsigned long long eq = __ballot(d[r] == dmin);
+        if (eq) return 64 * r + (int)__ffsll((long long)eq) - 1;
+    }
+    return 0;                                                   // all-NaN distances: np.argmin -> 0
+}
+template <int AR>
+__device__ __forceinline__ int nearest(double t, const AlphaLanes<AR> &al, int M, bool ascending)
+{
+    double d[AR];
+#pragma unroll
+    for (int r = 0; r < AR; ++r) d[r] = fabs(al.v[r] - t);
+    if (ascending) {
+        int p = 0;
+#pragma unroll
+        for (int r = 0; r < AR; ++r) p += __popcll(__ballot(al.v[r] < t));
+        const int lo = p > 0 ? p - 1 : 0;
+        const int hi = p < M ? p : M - 1;
+        const double dlo = alpha_get<AR>(d, lo);
+        const double dhi = alpha_get<AR>(d, hi);
+        return first_equal<AR>(d, dlo <= dhi ? dlo : dhi);
+    }
+    int best = 0;
+    double dbest = alpha_get<AR>(d, 0);
+    for (int k = 1; k < M; ++k) {
+        const double dk = alpha_get<AR>(d, k);
+        if (dk < dbest) { dbest = dk; best = k; }
+    }
+    return best;
+}
+template <int AR>
+__device__ __forceinline__ int nearest_margin(double t, const AlphaLanes<AR> &al, int M, bool ascending, double &margin)
+{
+    margin = -1.0;
+    if (!ascending) return nearest<AR>(t, al, M, false);
+    double d[AR];
+    int p = 0;
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+        d[r] = fabs(al.v[r] - t);
+        p += __popcll(__ballot(al.v[r] < t));
+    }
+    const int lo = p > 0 ? p - 1 : 0;
+    const int hi = p < M ? p : M - 1;
+    const double dlo = alpha_get<AR>(d, lo);
+    const double dhi = alpha_get<AR>(d, hi);
+    const double dmin = dlo <= dhi ? dlo : dhi;
+    const int idx = first_equal<AR>(d, dmin);
+    if (lo != hi) {
+        if (idx == lo || idx == hi) margin = 0.5 * fabs(dlo - dhi);
+    } else if (M == 1) {
+        margin = __longlong_as_double(0x7ff0000000000000LL);
+    } else if (idx == lo) {
+        const double dn = alpha_get<AR>(d, lo == 0 ? 1 : M - 2);   // t lies outside the alphabet's range
+        margin = 0.5 * (dn - dmin);
+    }
+    return idx;
+}
+template <int AR>
+__device__ __forceinline__ Decision decide(float w, float nrm, double dot_u, double dot_uw,
+                                           const AlphaLanes<AR> &al, int M, int zero_idx, bool ascending)
+{
+    Decision r;
+    if ((double)nrm < 1e-16) {                                  // :83-84
+        r.idx = zero_idx;
+        r.q = 0.0;
+        return r;
+    }
+    double t;
+    if (fabs(dot_u) < 1e-10) t = (double)w;                     // :86-87
+    else t = dot_uw / ((double)nrm * (double)nrm);              // :89 (IEEE f64 division)
+    r.idx = nearest<AR>(t, al, M, ascending);
+    r.q = alpha_get<AR>(al.v, r.idx);
+    return r;
+}
+
+// Index element of the outputs: int8 for alphabets of up to 64 members, int16 beyond (include/gpfq.h: gpfq_index_bits).
+template <int AR> struct IndexOf { using type = int8_t; };
+template <> struct IndexOf<4> { using type = int16_t; };
 
 }  // namespace gpfq

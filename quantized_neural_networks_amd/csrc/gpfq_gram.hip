@@ -199,9 +199,11 @@ gpfq_gram_reduce_few_kernel(const double *__restrict__ part, int nparts, int N, 
 // t0: steps before it take the recorded decisions (qh), step t0 takes the EXACT decision from the two
 // element-wise dot products dot_u = <Xq_t0, u>, dot_uw = <Xq_t0, u + w X_t0> (:86-89), later steps are
 // certified as usual.
+// Alph / Idx: AlphabetArg with int8 indices, or AlphabetBig (65..256 members) with int16 indices.
+template <class Alph, class Idx>
 __device__ __forceinline__ int decide_chain(const double *__restrict__ gram, const float *__restrict__ nrm32,
-                                            const float *__restrict__ w, float *__restrict__ qh, const AlphabetArg &A, int N,
-                                            double slack, int8_t *__restrict__ qidx, float *__restrict__ Qt,
+                                            const float *__restrict__ w, float *__restrict__ qh, const Alph &A, int N,
+                                            double slack, Idx *__restrict__ qidx, float *__restrict__ Qt,
                                             int t0, double dot_u, double dot_uw, bool nonneg)
 {
     const double *nx2 = gram + (int64_t)N * N * 2;
@@ -272,7 +274,7 @@ __device__ __forceinline__ int decide_chain(const double *__restrict__ gram, con
         }
         R += fabs((double)w[t]) * nx + fabs((double)q32) * nq;
         qh[t] = q32;
-        if (qidx) qidx[t] = (int8_t)idx;
+        if (qidx) qidx[t] = (Idx)idx;
         if (Qt) Qt[t] = q32;
     }
     return 0;
@@ -292,10 +294,11 @@ struct FixState {
 };
 
 // One thread per neuron (blockIdx.y = channel of a batched conv launch; all strides 0 for a single problem).
+template <class Alph, class Idx>
 __global__ void __launch_bounds__(64)
 gpfq_gram_decide_kernel(const double *__restrict__ gram, const float *__restrict__ nrm32,
-                        const float *__restrict__ Wt, int64_t ldw, AlphabetArg A, int N, int64_t C,
-                        double slack, int8_t *__restrict__ qidx, float *__restrict__ Qt,
+                        const float *__restrict__ Wt, int64_t ldw, Alph A, int N, int64_t C,
+                        double slack, Idx *__restrict__ qidx, float *__restrict__ Qt,
                         int32_t *__restrict__ uncertified, float *__restrict__ q32_hist, DecideBatch bs,
                         FixState *__restrict__ fix, const int *__restrict__ negflag)
 {
@@ -547,10 +550,11 @@ gpfq_gram_fix_kernel(FixSrc src, const float *__restrict__ Wt, int64_t ldw, int 
 }
 
 // Resume the listed chains from their exact step; chains that stop again are listed for the next round.
+template <class Alph, class Idx>
 __global__ void __launch_bounds__(64)
 gpfq_gram_resume_kernel(const double *__restrict__ gram, const float *__restrict__ nrm32,
-                        const float *__restrict__ Wt, int64_t ldw, AlphabetArg A, int N, int64_t C,
-                        double slack, int8_t *__restrict__ qidx, float *__restrict__ Qt,
+                        const float *__restrict__ Wt, int64_t ldw, Alph A, int N, int64_t C,
+                        double slack, Idx *__restrict__ qidx, float *__restrict__ Qt,
                         int32_t *__restrict__ uncertified, float *__restrict__ q32_hist, DecideBatch bs,
                         FixState *__restrict__ fix, int round, const int *__restrict__ negflag)
 {
@@ -722,7 +726,7 @@ size_t gram_fix_bytes() { return al256(sizeof(FixState)); }
 hipError_t launch_gram_decide(const double *gram, const float *nrm32, const float *Wt, int64_t ldw, const AlphabetArg &A,
                               int N, int64_t C, double slack, int8_t *qidx, float *Qt, int32_t *uncertified,
                               float *q32_hist, const DecideBatch &bs, const FixSrc *src, void *fix_ws, const int *negflag,
-                              hipStream_t stream)
+                              hipStream_t stream, const AlphabetBig *big)
 {
     if (C == 0 || bs.nch == 0) return hipSuccess;
     // The kernels' c = 2^-22 leaves a factor 2 for float64 accumulation chains of any length (m < 2^30).  Rows of up
@@ -738,7 +742,8 @@ hipError_t launch_gram_decide(const double *gram, const float *nrm32, const floa
         if (e != hipSuccess) return e;
     }
     // long walks of a single problem (dense layers with very long rows): one wavefront per neuron
-    const bool wave_chain = N > 64 && N <= kWaveChainMaxN && bs.nch == 1 && A.ascending;
+    // (alphabets beyond 64 members: the thread-per-neuron chain for walks of any length)
+    const bool wave_chain = N > 64 && N <= kWaveChainMaxN && bs.nch == 1 && A.ascending && !big;
     const int per = (N + 63) / 64;
 #define GPFQ_WAVE_CHAIN(KERNEL, GRID, BLOCK, ...)                                                                  \
     do {                                                                                                             \
@@ -750,9 +755,13 @@ hipError_t launch_gram_decide(const double *gram, const float *nrm32, const floa
     if (wave_chain)
         GPFQ_WAVE_CHAIN(gpfq_gram_decide_wave_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256),
                         gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, fix, negflag);
+    else if (big)
+        hipLaunchKernelGGL((gpfq_gram_decide_kernel<AlphabetBig, int16_t>), dim3((unsigned)((C + 63) / 64), (unsigned)bs.nch), dim3(64), 0,
+                           stream, gram, nrm32, Wt, ldw, *big, N, C, slack, reinterpret_cast<int16_t *>(qidx), Qt, uncertified, q32_hist,
+                           bs, fix, negflag);
     else
-        hipLaunchKernelGGL(gpfq_gram_decide_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)bs.nch), dim3(64), 0, stream,
-                           gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, bs, fix, negflag);
+        hipLaunchKernelGGL((gpfq_gram_decide_kernel<AlphabetArg, int8_t>), dim3((unsigned)((C + 63) / 64), (unsigned)bs.nch), dim3(64), 0,
+                           stream, gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, bs, fix, negflag);
     const int rounds = wave_chain ? kFixRoundsLong : kFixRounds;
     for (int round = 0; fix && round < rounds; ++round) {
         hipLaunchKernelGGL(gpfq_gram_fix_kernel, dim3(kFixBlocks, kFixSlots), dim3(256), 0, stream,
@@ -760,8 +769,12 @@ hipError_t launch_gram_decide(const double *gram, const float *nrm32, const floa
         if (wave_chain)
             GPFQ_WAVE_CHAIN(gpfq_gram_resume_wave_kernel, dim3(kFixSlots * 4), dim3(64),
                             gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, fix, round, negflag);
+        else if (big)
+            hipLaunchKernelGGL((gpfq_gram_resume_kernel<AlphabetBig, int16_t>), dim3(kFixMax / 64), dim3(64), 0, stream,
+                               gram, nrm32, Wt, ldw, *big, N, C, slack, reinterpret_cast<int16_t *>(qidx), Qt, uncertified, q32_hist, bs,
+                               fix, round, negflag);
         else
-            hipLaunchKernelGGL(gpfq_gram_resume_kernel, dim3(kFixMax / 64), dim3(64), 0, stream,
+            hipLaunchKernelGGL((gpfq_gram_resume_kernel<AlphabetArg, int8_t>), dim3(kFixMax / 64), dim3(64), 0, stream,
                                gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, bs, fix, round, negflag);
     }
 #undef GPFQ_WAVE_CHAIN
@@ -813,7 +826,7 @@ hipError_t launch_gram(const GramArgs &a, hipStream_t stream)
     FixSrc src{};
     src.X = a.X; src.Xq = a.Xq; src.ld = a.ld; src.m = a.m; src.planes = 0;
     hipError_t e = launch_gram_decide(gram, a.nrm32, a.Wt, a.ldw, a.A, N, a.C, a.slack, a.qidx, a.Qt, a.uncertified, q32h,
-                                      DecideBatch(), &src, fixws, negflag, stream);
+                                      DecideBatch(), &src, fixws, negflag, stream, a.big);
     if (e != hipSuccess) return e;
     if (a.resid) {
         if (a.m > 0 && N > 0) {

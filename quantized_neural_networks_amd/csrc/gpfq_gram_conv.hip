@@ -478,7 +478,7 @@ hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream)
     src.n = (int)a.n; src.H = p.H; src.W = p.W; src.oh = p.oh; src.ow = p.ow;
     src.kw = a.kw; src.sh = a.sh; src.sw = a.sw; src.rh = a.rh; src.rw = a.rw; src.pt = a.pt; src.pl = a.pl;
     return launch_gram_decide(gram, nrm, a.Wt, K, a.A, (int)K, a.F, a.slack, a.qidx, a.Qt, a.uncertified, q32h, bs, &src, fixws, negflag,
-                              stream);
+                              stream, a.big);
 }
 
 }  // namespace gpfq

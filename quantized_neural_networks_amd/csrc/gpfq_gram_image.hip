@@ -316,7 +316,7 @@ hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream)
     src.kw = 3; src.sh = src.sw = src.rh = src.rw = 1; src.pt = src.pl = p.pad;
     src.m = (int64_t)p.grows * src.ow;
     return launch_gram_decide(gram, nrm, a.Wt, 9, a.A, 9, a.F, a.slack, a.qidx, a.Qt, a.uncertified, q32h, bs, &src, fixws, negflag,
-                              stream);
+                              stream, a.big);
 }
 
 }  // namespace gpfq

@@ -30,6 +30,7 @@ struct OnchipArgs {
     const float *Wt;
     int64_t ldw;
     AlphabetArg A;
+    const AlphabetBig *big = nullptr;   // alphabets of 65..256 members: A is unused and qidx points at int16 elements
     int64_t N, m, C;
     int8_t *qidx;
     float *Qt;
@@ -47,6 +48,7 @@ struct StreamArgs {
     const float *Wt;
     int64_t ldw;
     AlphabetArg A;
+    const AlphabetBig *big = nullptr;   // alphabets of 65..256 members: A is unused and qidx points at int16 elements
     int64_t N, m, C;
     int8_t *qidx;
     float *Qt;
@@ -101,6 +103,7 @@ struct GramArgs {
     const float *Wt;
     int64_t ldw;
     AlphabetArg A;
+    const AlphabetBig *big = nullptr;   // alphabets of 65..256 members: A is unused and qidx points at int16 elements
     int64_t N, m, C;
     int8_t *qidx;
     float *Qt;
@@ -144,7 +147,8 @@ size_t gram_fix_bytes();
 hipError_t launch_gram_decide(const double *gram, const float *nrm32, const float *Wt, int64_t ldw, const AlphabetArg &A,
                               int N, int64_t C, double slack, int8_t *qidx, float *Qt, int32_t *uncertified,
                               float *q32_hist, const DecideBatch &bs, const FixSrc *src, void *fix_ws, const int *negflag,
-                              hipStream_t stream);
+                              hipStream_t stream, const AlphabetBig *big = nullptr);
+// big != NULL: alphabets of 65..256 members -- A is unused, qidx points at int16 elements.
 // negflag (may be NULL): one int per channel, zeroed by the caller before its Gram kernel runs and set by
 // that kernel when it meets a negative element of X or Xq; 0 lets the decide step use the Gram entries
 // themselves as the absolute inner products of its error bound (post-ReLU inputs) instead of Cauchy-Schwarz.
@@ -157,6 +161,7 @@ struct ImageGramArgs {
     int pad;                      // 1 = SAME (one ring of zeros), 0 = VALID
     const float *Wt;              // [nch][F][9]
     AlphabetArg A;
+    const AlphabetBig *big = nullptr;   // as GramArgs
     int64_t F;
     int8_t *qidx;                 // [nch][F][9]
     float *Qt;                    // [nch][F][9]
@@ -179,6 +184,7 @@ struct ConvGramArgs {
     int64_t oh, ow;
     const float *Wt;              // [nch][F][kh*kw]
     AlphabetArg A;
+    const AlphabetBig *big = nullptr;   // as GramArgs
     int64_t F;
     int8_t *qidx;                 // [nch][F][kh*kw]
     float *Qt;
@@ -201,9 +207,11 @@ hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream);
 hipError_t launch_row_stats(const float *X, const float *Xq, int64_t N, int64_t m, int64_t ld, const float *nrm32,
                             RowStats *stats, hipStream_t stream);
 hipError_t launch_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, float *nrm32, hipStream_t stream);
-hipError_t launch_msq(const float *W, int64_t n, const AlphabetArg &A, float *Q, int8_t *qidx, hipStream_t stream);
+// big != NULL (65..256 members): A is unused, index arrays hold int16 elements (assemble: bits = 16)
+hipError_t launch_msq(const float *W, int64_t n, const AlphabetArg &A, float *Q, int8_t *qidx, hipStream_t stream,
+                      const AlphabetBig *big = nullptr);
 hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, int64_t C, int bits, float *Q, int8_t *idxT,
-                           hipStream_t stream);
+                           hipStream_t stream, const AlphabetBig *big = nullptr);
 hipError_t launch_pack(const int8_t *qidx, int64_t N, int64_t C, int bits, uint8_t *packed, hipStream_t stream);
 size_t median_workspace_bytes();
 hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream);

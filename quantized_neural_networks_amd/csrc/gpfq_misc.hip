@@ -85,8 +85,9 @@ hipError_t launch_row_stats(const float *X, const float *Xq, int64_t N, int64_t 
 // ---- MSQ -----------------------------------------------------------------------------------
 // Q[i] = alphabet[argmin |alphabet - (double)W[i]|], first index on ties
 // (_bit_round_parallel applied per weight, scripts/quantize_pretrained_mlp.py:109).
+template <class Alph, class Idx>
 __global__ void __launch_bounds__(256)
-gpfq_msq_kernel(const float *__restrict__ W, int64_t n, AlphabetArg A, float *__restrict__ Q, int8_t *__restrict__ qidx)
+gpfq_msq_kernel(const float *__restrict__ W, int64_t n, Alph A, float *__restrict__ Q, Idx *__restrict__ qidx)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -98,16 +99,21 @@ gpfq_msq_kernel(const float *__restrict__ W, int64_t n, AlphabetArg A, float *__
             if (d < dbest) { dbest = d; best = k; }
         }
         if (Q) Q[i] = (float)A.a[best];
-        if (qidx) qidx[i] = (int8_t)best;
+        if (qidx) qidx[i] = (Idx)best;
     }
 }
 
-hipError_t launch_msq(const float *W, int64_t n, const AlphabetArg &A, float *Q, int8_t *qidx, hipStream_t stream)
+hipError_t launch_msq(const float *W, int64_t n, const AlphabetArg &A, float *Q, int8_t *qidx, hipStream_t stream,
+                      const AlphabetBig *big)
 {
     if (n == 0) return hipSuccess;
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(gpfq_msq_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, W, n, A, Q, qidx);
+    if (big)
+        hipLaunchKernelGGL((gpfq_msq_kernel<AlphabetBig, int16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, W, n, *big, Q,
+                           reinterpret_cast<int16_t *>(qidx));
+    else
+        hipLaunchKernelGGL((gpfq_msq_kernel<AlphabetArg, int8_t>), dim3((unsigned)blocks), dim3(256), 0, stream, W, n, A, Q, qidx);
     return hipGetLastError();
 }
 
@@ -221,24 +227,25 @@ hipError_t launch_channel_planes(const float *act, int64_t npos, int64_t Cin, in
 // Q[t][j] = (float)alphabet[qidx[j][t]] (0 for the literal-zero index -1), i.e. `Q[:, neuron_idx] =
 // future.result()` for every neuron (scripts/quantized_network.py:562) fused with the transpose from
 // the kernels' neuron-major layout.  32x32 tiles through LDS, both sides coalesced.
-// `bits` = 8: qidx holds one int8 index per weight; 2 or 4: rows packed by gpfq_pack_kernel
-// (code = index + 1, 0 = the literal zero), row pitch NB = ceil(N*bits/8) bytes.
+// `bits` = 8: qidx holds one int8 index per weight (16: one int16, alphabets of 65..256 members); 2 or 4: rows
+// packed by gpfq_pack_kernel (code = index + 1, 0 = the literal zero), row pitch NB = ceil(N*bits/8) bytes.
+template <class Alph, class Idx>
 __global__ void __launch_bounds__(256)
-gpfq_assemble_kernel(const int8_t *__restrict__ qidx, AlphabetArg A, int64_t N, int64_t C, int bits,
-                     float *__restrict__ Q, int8_t *__restrict__ idxT)
+gpfq_assemble_kernel(const Idx *__restrict__ qidx, Alph A, int64_t N, int64_t C, int bits,
+                     float *__restrict__ Q, Idx *__restrict__ idxT)
 {
-    __shared__ int8_t tile[32][33];
+    __shared__ Idx tile[32][33];
     const int64_t t0 = (int64_t)blockIdx.x * 32, j0 = (int64_t)blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
     const int64_t NB = (N * bits + 7) / 8;
     for (int r = ty; r < 32; r += 8) {
         const int64_t j = j0 + r, t = t0 + tx;
-        int8_t k = 0;
+        Idx k = 0;
         if (j < C && t < N) {
-            if (bits == 8) k = qidx[j * N + t];
+            if (bits >= 8) k = qidx[j * N + t];
             else {
-                const unsigned byte = (unsigned char)qidx[j * NB + (t * bits) / 8];
-                k = (int8_t)((int)((byte >> ((t * bits) & 7)) & ((1u << bits) - 1u)) - 1);
+                const unsigned byte = reinterpret_cast<const unsigned char *>(qidx)[j * NB + (t * bits) / 8];
+                k = (Idx)((int)((byte >> ((t * bits) & 7)) & ((1u << bits) - 1u)) - 1);
             }
         }
         tile[r][tx] = k;
@@ -249,17 +256,21 @@ gpfq_assemble_kernel(const int8_t *__restrict__ qidx, AlphabetArg A, int64_t N, 
         if (t < N && j < C) {
             const int k = tile[tx][r];
             if (Q) Q[t * C + j] = (k >= 0 && k < A.M) ? (float)A.a[k] : 0.f;
-            if (idxT) idxT[t * C + j] = (int8_t)k;
+            if (idxT) idxT[t * C + j] = (Idx)k;
         }
     }
 }
 
 hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, int64_t C, int bits, float *Q, int8_t *idxT,
-                           hipStream_t stream)
+                           hipStream_t stream, const AlphabetBig *big)
 {
     if (N == 0 || C == 0) return hipSuccess;
     const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((C + 31) / 32));
-    hipLaunchKernelGGL(gpfq_assemble_kernel, grid, dim3(256), 0, stream, qidx, A, N, C, bits, Q, idxT);
+    if (big)
+        hipLaunchKernelGGL((gpfq_assemble_kernel<AlphabetBig, int16_t>), grid, dim3(256), 0, stream,
+                           reinterpret_cast<const int16_t *>(qidx), *big, N, C, bits, Q, reinterpret_cast<int16_t *>(idxT));
+    else
+        hipLaunchKernelGGL((gpfq_assemble_kernel<AlphabetArg, int8_t>), grid, dim3(256), 0, stream, qidx, A, N, C, bits, Q, idxT);
     return hipGetLastError();
 }
 

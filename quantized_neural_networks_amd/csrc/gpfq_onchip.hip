@@ -84,17 +84,19 @@ __device__ __forceinline__ void stage_rows(const float *__restrict__ G, int64_t 
 enum { MODE_EXACT = 0, MODE_CERTIFIED = 1 };
 
 // EPL = 32 needs ~200 VGPRs: cap the workgroup at 8 waves so the allocator may use 256.
-template <int EPL, int MODE>
+// AR = alphabet registers per lane: 1 (up to 64 members, int8 indices) or 4 (up to 256 members, int16 indices).
+template <int EPL, int MODE, int AR>
 __global__ void __launch_bounds__(EPL >= 32 ? 512 : 1024)
 gpfq_onchip_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld,
                    const float *__restrict__ nrm32, const RowStats *__restrict__ stats,
                    const float *__restrict__ Wt, int64_t ldw,
-                   AlphabetArg A, int64_t N, int m, int64_t C, int TS, int vec4,
-                   int8_t *__restrict__ qidx, float *__restrict__ Qt,
+                   AlphabetT<64 * AR> A, int64_t N, int m, int64_t C, int TS, int vec4,
+                   typename IndexOf<AR>::type *__restrict__ qidx, float *__restrict__ Qt,
                    double *__restrict__ resid, double *__restrict__ u_out,
                    unsigned long long *__restrict__ fallback_count)
 {
     using L = Lanes<EPL>;
+    using Idx = typename IndexOf<AR>::type;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *ldsX  = lds;                  // [TS][MP]
     float *ldsXq = lds + TS * L::MP;     // [TS][MP]
@@ -105,7 +107,7 @@ gpfq_onchip_kernel(const float *__restrict__ X, const float *__restrict__ Xq, in
     const int64_t j = (int64_t)blockIdx.x * (nthreads >> 6) + wave;   // this wave's neuron
     const bool active = j < C;
 
-    const double a_lane = alphabet_lane(A, lane);
+    const AlphaLanes<AR> a_lane = alpha_lanes<AR>(A, lane);
     const bool ascending = A.ascending != 0;
 
     double u[EPL];
@@ -166,7 +168,7 @@ gpfq_onchip_kernel(const float *__restrict__ X, const float *__restrict__ Xq, in
                 }
                 double dot_u, dot_uw;
                 wave_sum2(d0a + d0b, d1a + d1b, dot_u, dot_uw);
-                dec = decide(w, nrm, dot_u, dot_uw, a_lane, A.M, A.zero_idx, ascending);
+                dec = decide<AR>(w, nrm, dot_u, dot_uw, a_lane, A.M, A.zero_idx, ascending);
             } else {
                 double d0a = 0.0, d0b = 0.0;
 #pragma unroll
@@ -182,7 +184,7 @@ gpfq_onchip_kernel(const float *__restrict__ X, const float *__restrict__ Xq, in
                     dec.idx = A.zero_idx; dec.q = 0.0;
                 } else {
                     if (fabs(dot_u) < 1e-10) {                                 // :86-87
-                        dec.idx = nearest((double)w, a_lane, A.M, ascending);
+                        dec.idx = nearest<AR>((double)w, a_lane, A.M, ascending);
                     } else {
                         const double wd = (double)w;
                         const double wg = wd * st.G;
@@ -190,7 +192,7 @@ gpfq_onchip_kernel(const float *__restrict__ X, const float *__restrict__ Xq, in
                         // modelling error of the prediction (in quotient units) + float64 slack
                         const double delta = fabs(wd) * st.cbound + st.cabs + 0x1p-44 * (fabs(dot_u) + fabs(wg)) * st.rden;
                         double margin;
-                        dec.idx = nearest_margin(tq, a_lane, A.M, ascending, margin);
+                        dec.idx = nearest_margin<AR>(tq, a_lane, A.M, ascending, margin);
                         if (!(margin > delta)) {                               // rare: exact :89
                             ++n_fallback;
                             double a = 0.0, b = 0.0;
@@ -201,10 +203,10 @@ gpfq_onchip_kernel(const float *__restrict__ X, const float *__restrict__ Xq, in
                                 else       a = fma((double)xq[e], v, a);
                             }
                             const double te = wave_sum(a + b) / ((double)nrm * (double)nrm);
-                            dec.idx = nearest(te, a_lane, A.M, ascending);
+                            dec.idx = nearest<AR>(te, a_lane, A.M, ascending);
                         }
                     }
-                    dec.q = readlane_f64(a_lane, dec.idx);
+                    dec.q = alpha_get<AR>(a_lane.v, dec.idx);
                 }
             }
 
@@ -227,7 +229,7 @@ gpfq_onchip_kernel(const float *__restrict__ X, const float *__restrict__ Xq, in
             if (((t + 1) & 63) == 0 || t + 1 == N) {
                 const int64_t base = t & ~(int64_t)63;
                 if (lane <= (int)(t & 63)) {
-                    if (qidx) qidx[j * N + base + lane] = (int8_t)my_idx;
+                    if (qidx) qidx[j * N + base + lane] = (Idx)my_idx;
                     if (Qt)   Qt[j * N + base + lane]   = my_q;
                 }
             }
@@ -255,8 +257,8 @@ gpfq_onchip_kernel(const float *__restrict__ X, const float *__restrict__ Xq, in
     }
 }
 
-template <int EPL, int MODE>
-static hipError_t launch_epl(const OnchipArgs &a, hipStream_t stream)
+template <int EPL, int MODE, int AR>
+static hipError_t launch_epl_ar(const OnchipArgs &a, const AlphabetT<64 * AR> &A, hipStream_t stream)
 {
     constexpr int MP = 64 * EPL;
     // neurons (waves) per workgroup: enough workgroups to cover the 256 CUs, at most 16 waves
@@ -271,13 +273,20 @@ static hipError_t launch_epl(const OnchipArgs &a, hipStream_t stream)
     const size_t lds_bytes = (size_t)2 * ts * MP * sizeof(float);
     const bool vec4 = (a.ld % 4 == 0) && (a.m % 4 == 0) && ((uintptr_t)a.X % 16 == 0) && ((uintptr_t)a.Xq % 16 == 0);
     const unsigned grid = (unsigned)((a.C + nw - 1) / nw);
-    hipError_t e = hipFuncSetAttribute((const void *)gpfq_onchip_kernel<EPL, MODE>,
+    hipError_t e = hipFuncSetAttribute((const void *)gpfq_onchip_kernel<EPL, MODE, AR>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((gpfq_onchip_kernel<EPL, MODE>), dim3(grid), dim3(nw * 64), lds_bytes, stream,
-                       a.X, a.Xq, a.ld, a.nrm32, a.stats, a.Wt, a.ldw, a.A, a.N, (int)a.m, a.C, ts, vec4 ? 1 : 0,
-                       a.qidx, a.Qt, a.resid, a.u_out, a.fallback_count);
+    hipLaunchKernelGGL((gpfq_onchip_kernel<EPL, MODE, AR>), dim3(grid), dim3(nw * 64), lds_bytes, stream,
+                       a.X, a.Xq, a.ld, a.nrm32, a.stats, a.Wt, a.ldw, A, a.N, (int)a.m, a.C, ts, vec4 ? 1 : 0,
+                       reinterpret_cast<typename IndexOf<AR>::type *>(a.qidx), a.Qt, a.resid, a.u_out, a.fallback_count);
     return hipGetLastError();
+}
+
+template <int EPL, int MODE>
+static hipError_t launch_epl(const OnchipArgs &a, hipStream_t stream)
+{
+    if (a.big) return launch_epl_ar<EPL, MODE, 4>(a, *a.big, stream);      // 65..256 members: int16 indices
+    return launch_epl_ar<EPL, MODE, 1>(a, a.A, stream);
 }
 
 template <int MODE>
@@ -312,7 +321,7 @@ hipError_t launch_onchip(const OnchipArgs &a, hipStream_t stream)
         return launch_wide(a, W, stream);
     }
     if (a.mode == MODE_CERTIFIED && a.stats) {
-        int lpn = a.lpn;
+        int lpn = a.big ? 1 : a.lpn;         // 65..256 members: the wavefront-per-neuron kernel (4 alphabet registers per lane)
         if (lpn == 0) lpn = 32;                      // measured best on cfg2/cfg3-like layers (tools/sweep_shapes.py)
         while (lpn >= 16 && lpn <= 64 && !rows_supported(a, lpn)) lpn *= 2;
         if (lpn >= 16 && lpn <= 64) {

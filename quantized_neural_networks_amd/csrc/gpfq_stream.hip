@@ -115,11 +115,13 @@ gpfq_stream_step_kernel(const float *__restrict__ X, const float *__restrict__ X
     }
 }
 
+// AR = alphabet registers per lane: 1 (up to 64 members, int8 indices) or 4 (up to 256 members, int16 indices).
+template <int AR>
 __global__ void __launch_bounds__(64)
 gpfq_stream_decide_kernel(const float *__restrict__ nrm32, const float *__restrict__ Wt, int64_t ldw,
-                          AlphabetArg A, int64_t N, int64_t C, int64_t t,
+                          AlphabetT<64 * AR> A, int64_t N, int64_t C, int64_t t,
                           const double *__restrict__ partials, int64_t nchunks,
-                          float *__restrict__ q32_prev, int8_t *__restrict__ qidx, float *__restrict__ Qt,
+                          float *__restrict__ q32_prev, typename IndexOf<AR>::type *__restrict__ qidx, float *__restrict__ Qt,
                           double *__restrict__ resid)
 {
     const int64_t j = blockIdx.x;
@@ -137,11 +139,11 @@ gpfq_stream_decide_kernel(const float *__restrict__ nrm32, const float *__restri
     s1 = wave_sum(s1);
     const float w = Wt[j * ldw + t];
     const float nrm = nrm32[t];
-    const Decision dec = decide(w, nrm, s0, s1, alphabet_lane(A, lane), A.M, A.zero_idx, A.ascending != 0);
+    const Decision dec = decide<AR>(w, nrm, s0, s1, alpha_lanes<AR>(A, lane), A.M, A.zero_idx, A.ascending != 0);
     if (lane == 0) {
         const float q32 = (float)dec.q;
         q32_prev[j] = q32;
-        if (qidx) qidx[j * N + t] = (int8_t)dec.idx;
+        if (qidx) qidx[j * N + t] = (typename IndexOf<AR>::type)dec.idx;
         if (Qt)   Qt[j * N + t] = q32;
     }
 }
@@ -174,9 +176,14 @@ hipError_t launch_stream(const StreamArgs &a, hipStream_t stream)
     for (int64_t t = 0; t <= a.N; ++t) {
         hipLaunchKernelGGL(gpfq_stream_step_kernel, sgrid, dim3(kStreamThreads), 0, stream,
                            a.X, a.Xq, a.ld, a.Wt, a.ldw, a.N, a.m, a.C, t, q32_prev, u, partials, nchunks, vec);
-        hipLaunchKernelGGL(gpfq_stream_decide_kernel, dim3((unsigned)a.C), dim3(64), 0, stream,
-                           a.nrm32, a.Wt, a.ldw, a.A, a.N, a.C, t, partials, nchunks, q32_prev,
-                           a.qidx, a.Qt, a.resid);
+        if (a.big)
+            hipLaunchKernelGGL(gpfq_stream_decide_kernel<4>, dim3((unsigned)a.C), dim3(64), 0, stream,
+                               a.nrm32, a.Wt, a.ldw, *a.big, a.N, a.C, t, partials, nchunks, q32_prev,
+                               reinterpret_cast<int16_t *>(a.qidx), a.Qt, a.resid);
+        else
+            hipLaunchKernelGGL(gpfq_stream_decide_kernel<1>, dim3((unsigned)a.C), dim3(64), 0, stream,
+                               a.nrm32, a.Wt, a.ldw, a.A, a.N, a.C, t, partials, nchunks, q32_prev,
+                               a.qidx, a.Qt, a.resid);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

@@ -35,12 +35,13 @@ __device__ __forceinline__ void wide_read_row(const float *row, int lane, float 
     }
 }
 
-template <int EPL>
+// AR = alphabet registers per lane: 1 (up to 64 members, int8 indices) or 4 (up to 256 members, int16 indices).
+template <int EPL, int AR>
 __global__ void __launch_bounds__(1024)
 gpfq_wide_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld,
                  const float *__restrict__ nrm32, const float *__restrict__ Wt, int64_t ldw,
-                 AlphabetArg A, int64_t N, int m, int64_t C, int TS, int W, int G, int vec4,
-                 int8_t *__restrict__ qidx, float *__restrict__ Qt,
+                 AlphabetT<64 * AR> A, int64_t N, int m, int64_t C, int TS, int W, int G, int vec4,
+                 typename IndexOf<AR>::type *__restrict__ qidx, float *__restrict__ Qt,
                  double *__restrict__ resid, double *__restrict__ u_out)
 {
     constexpr int VW = EPL >= 4 ? 4 : EPL;
@@ -58,7 +59,7 @@ gpfq_wide_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int6
     const bool active = j < C;                            // inactive waves still walk (barriers) but write nothing
     const float *__restrict__ wrow = Wt + (active ? j : 0) * ldw;
 
-    const double a_lane = alphabet_lane(A, lane);
+    const AlphaLanes<AR> a_lane = alpha_lanes<AR>(A, lane);
     const bool ascending = A.ascending != 0;
 
     double u[EPL];
@@ -130,7 +131,7 @@ gpfq_wide_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int6
             dot_u = 0.0; dot_uw = 0.0;
             for (int p2 = 0; p2 < W; ++p2) { dot_u += slot[2 * p2]; dot_uw += slot[2 * p2 + 1]; }   // fixed order
 
-            const Decision dec = decide(w, nrm, dot_u, dot_uw, a_lane, A.M, A.zero_idx, ascending);
+            const Decision dec = decide<AR>(w, nrm, dot_u, dot_uw, a_lane, A.M, A.zero_idx, ascending);
 
             // u += w*X_t - q*Xq_t  (:119)
             const float q32 = (float)dec.q;
@@ -147,7 +148,7 @@ gpfq_wide_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int6
             if (((t + 1) & 63) == 0 || t + 1 == N) {
                 const int64_t base = t & ~(int64_t)63;
                 if (active && part == 0 && lane <= (int)(t & 63)) {
-                    if (qidx) qidx[j * N + base + lane] = (int8_t)my_idx;
+                    if (qidx) qidx[j * N + base + lane] = (typename IndexOf<AR>::type)my_idx;
                     if (Qt)   Qt[j * N + base + lane]   = my_q;
                 }
             }
@@ -236,12 +237,12 @@ __device__ __forceinline__ void wide_fetch1(const float *__restrict__ P, int64_t
     }
 }
 
-template <int EPL, bool PREFETCH>
+template <int EPL, bool PREFETCH, int AR>
 __global__ void __launch_bounds__((!PREFETCH || EPL >= 16) ? 512 : 1024)  // 16+ elements per lane need > 128 VGPRs
 gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld,
                         const float *__restrict__ nrm32, const float *__restrict__ Wt, int64_t ldw,
-                        AlphabetArg A, int64_t N, int m, int64_t C, int W, int aligned,
-                        int8_t *__restrict__ qidx, float *__restrict__ Qt,
+                        AlphabetT<64 * AR> A, int64_t N, int m, int64_t C, int W, int aligned,
+                        typename IndexOf<AR>::type *__restrict__ qidx, float *__restrict__ Qt,
                         double *__restrict__ resid, double *__restrict__ u_out)
 {
     __shared__ double red[2][16][2];                      // [step parity][wave][dot_u, dot_uw]
@@ -251,7 +252,7 @@ gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ X
     const float *__restrict__ wrow = Wt + j * ldw;
     const int base = part * 64 * EPL;
 
-    const double a_lane = alphabet_lane(A, lane);
+    const AlphaLanes<AR> a_lane = alpha_lanes<AR>(A, lane);
     const bool ascending = A.ascending != 0;
 
     double u[EPL];
@@ -324,7 +325,7 @@ gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ X
         dot_u = 0.0; dot_uw = 0.0;
         for (int p2 = 0; p2 < W; ++p2) { dot_u += slot[p2][0]; dot_uw += slot[p2][1]; }   // fixed order
 
-        const Decision dec = decide(w, nrm, dot_u, dot_uw, a_lane, A.M, A.zero_idx, ascending);
+        const Decision dec = decide<AR>(w, nrm, dot_u, dot_uw, a_lane, A.M, A.zero_idx, ascending);
 
         // u += w*X_t - q*Xq_t  (:119)
         const float q32 = (float)dec.q;
@@ -357,7 +358,7 @@ gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ X
         if (((t + 1) & 63) == 0 || t + 1 == N) {
             const int64_t b0 = t & ~(int64_t)63;
             if (part == 0 && lane <= (int)(t & 63)) {
-                if (qidx) qidx[j * N + b0 + lane] = (int8_t)my_idx;
+                if (qidx) qidx[j * N + b0 + lane] = (typename IndexOf<AR>::type)my_idx;
                 if (Qt)   Qt[j * N + b0 + lane]   = my_q;
             }
         }
@@ -388,9 +389,10 @@ gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ X
     }
 }
 
-template <int EPL>
-static hipError_t launch_wide_epl(const OnchipArgs &a, int W, hipStream_t stream)
+template <int EPL, int AR>
+static hipError_t launch_wide_epl_ar(const OnchipArgs &a, const AlphabetT<64 * AR> &A, int W, hipStream_t stream)
 {
+    auto *qidx = reinterpret_cast<typename IndexOf<AR>::type *>(a.qidx);
     const int MP = 64 * EPL * W;
     int G = 16 / W;                                       // neurons per workgroup (<= 16 wavefronts)
     if (G < 1) G = 1;
@@ -400,9 +402,9 @@ static hipError_t launch_wide_epl(const OnchipArgs &a, int W, hipStream_t stream
         // neurons of a workgroup at every shape measured (tools/narrow_quick.py), the rows come from L2 anyway
         const bool aligned = (a.ld % 4 == 0) && (a.m % 4 == 0) && ((uintptr_t)a.X % 16 == 0) && ((uintptr_t)a.Xq % 16 == 0);
         if (aligned && !(a.variant & 2) && (EPL < 16 || W <= 8)) {
-            hipLaunchKernelGGL((gpfq_wide_direct_kernel<EPL, true>), dim3((unsigned)a.C), dim3(64 * W), 0, stream,
-                               a.X, a.Xq, a.ld, a.nrm32, a.Wt, a.ldw, a.A, a.N, (int)a.m, a.C, W, 1,
-                               a.qidx, a.Qt, a.resid, a.u_out);
+            hipLaunchKernelGGL((gpfq_wide_direct_kernel<EPL, true, AR>), dim3((unsigned)a.C), dim3(64 * W), 0, stream,
+                               a.X, a.Xq, a.ld, a.nrm32, a.Wt, a.ldw, A, a.N, (int)a.m, a.C, W, 1,
+                               qidx, a.Qt, a.resid, a.u_out);
             return hipGetLastError();
         }
     }
@@ -412,12 +414,19 @@ static hipError_t launch_wide_epl(const OnchipArgs &a, int W, hipStream_t stream
     const size_t lds_bytes = (size_t)2 * ts * MP * sizeof(float) + (size_t)2 * G * W * 2 * sizeof(double);
     const bool vec4 = (a.ld % 4 == 0) && (a.m % 4 == 0) && ((uintptr_t)a.X % 16 == 0) && ((uintptr_t)a.Xq % 16 == 0);
     const unsigned grid = (unsigned)((a.C + G - 1) / G);
-    hipError_t e = hipFuncSetAttribute((const void *)gpfq_wide_kernel<EPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void *)gpfq_wide_kernel<EPL, AR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((gpfq_wide_kernel<EPL>), dim3(grid), dim3(64 * W * G), lds_bytes, stream,
-                       a.X, a.Xq, a.ld, a.nrm32, a.Wt, a.ldw, a.A, a.N, (int)a.m, a.C, ts, W, G, vec4 ? 1 : 0,
-                       a.qidx, a.Qt, a.resid, a.u_out);
+    hipLaunchKernelGGL((gpfq_wide_kernel<EPL, AR>), dim3(grid), dim3(64 * W * G), lds_bytes, stream,
+                       a.X, a.Xq, a.ld, a.nrm32, a.Wt, a.ldw, A, a.N, (int)a.m, a.C, ts, W, G, vec4 ? 1 : 0,
+                       qidx, a.Qt, a.resid, a.u_out);
     return hipGetLastError();
+}
+
+template <int EPL>
+static hipError_t launch_wide_epl(const OnchipArgs &a, int W, hipStream_t stream)
+{
+    if (a.big) return launch_wide_epl_ar<EPL, 4>(a, *a.big, W, stream);    // 65..256 members: int16 indices
+    return launch_wide_epl_ar<EPL, 1>(a, a.A, W, stream);
 }
 
 // W = wavefronts per neuron (2..16); elements per lane follow from m.
@@ -435,9 +444,16 @@ hipError_t launch_wide(const OnchipArgs &a, int W, hipStream_t stream)
     if (W == 16 && per_lane8 <= 56) {                     // long rows: 8 wavefronts, rows streamed through a register ring
         const int aligned = (a.ld % 4 == 0) && (a.m % 4 == 0) && ((uintptr_t)a.X % 16 == 0) && ((uintptr_t)a.Xq % 16 == 0);
 #define GPFQ_LONG(EPL_)                                                                                                   \
-        hipLaunchKernelGGL((gpfq_wide_direct_kernel<EPL_, false>), dim3((unsigned)a.C), dim3(512), 0, stream,             \
-                           a.X, a.Xq, a.ld, a.nrm32, a.Wt, a.ldw, a.A, a.N, (int)a.m, a.C, 8, aligned,                    \
-                           a.qidx, a.Qt, a.resid, a.u_out)
+        do {                                                                                                              \
+            if (a.big)                                                                                                    \
+                hipLaunchKernelGGL((gpfq_wide_direct_kernel<EPL_, false, 4>), dim3((unsigned)a.C), dim3(512), 0, stream,  \
+                                   a.X, a.Xq, a.ld, a.nrm32, a.Wt, a.ldw, *a.big, a.N, (int)a.m, a.C, 8, aligned,         \
+                                   reinterpret_cast<int16_t *>(a.qidx), a.Qt, a.resid, a.u_out);                          \
+            else                                                                                                          \
+                hipLaunchKernelGGL((gpfq_wide_direct_kernel<EPL_, false, 1>), dim3((unsigned)a.C), dim3(512), 0, stream,  \
+                                   a.X, a.Xq, a.ld, a.nrm32, a.Wt, a.ldw, a.A, a.N, (int)a.m, a.C, 8, aligned,            \
+                                   a.qidx, a.Qt, a.resid, a.u_out);                                                       \
+        } while (0)
         if (per_lane8 <= 36) GPFQ_LONG(36);
         else if (per_lane8 <= 40) GPFQ_LONG(40);
         else if (per_lane8 <= 44) GPFQ_LONG(44);

@@ -15,7 +15,7 @@ GPFQ_PATH_AUTO, GPFQ_PATH_ONCHIP, GPFQ_PATH_STREAM = 0, 1, 2
 GPFQ_PATH_GRAM = 3                 # binding-level selector: gpfq_quantize_neurons_gram + exact rerun of flagged neurons
 GPFQ_GRAM_AUTO_MAX_N = 64          # conv layers with kh*kw up to this take the whole-shard Gram call
 GPFQ_GRAM_MAX_N = 1024             # longest walk the Gram path takes (include/gpfq.h)
-GPFQ_MAX_ALPHABET = 64
+GPFQ_MAX_ALPHABET = 256       # more than 64 members: int16 indices (index_dtype)
 GPFQ_ONCHIP_MAX_M = 28672          # longest row whose residual stays in registers (include/gpfq.h)
 GPFQ_GRAM_MIN_M = 16384
 
@@ -70,7 +70,7 @@ def lib_path():
     return _build.LIB
 
 
-ABI_VERSION = 200                  # gpfq_version() of the library this binding was written against
+ABI_VERSION = 210                  # gpfq_version() of the library this binding was written against
 
 
 def load():
@@ -120,6 +120,11 @@ def _rows(t, name):
     return t.data_ptr(), t.shape[0], t.shape[1], max(pitch, t.shape[1])
 
 
+def index_dtype(M):
+    """Element type of the index outputs for an alphabet of M members: int8 up to 64, int16 up to GPFQ_MAX_ALPHABET."""
+    return torch.int8 if int(M) <= 64 else torch.int16
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -146,7 +151,7 @@ def row_norms(Xq):
     return out
 
 
-def auto_path(N, m, C, want_u=False):
+def auto_path(N, m, C, want_u=False, M=0):
     """What GPFQ_PATH_AUTO resolves to for C neurons of N weights over rows of m samples.
 
     Rows beyond GPFQ_GRAM_MIN_M samples: the Gram path (N x N records + scalar recurrences) beats walking such rows
@@ -156,7 +161,8 @@ def auto_path(N, m, C, want_u=False):
     Otherwise the residual stays on chip up to GPFQ_ONCHIP_MAX_M samples and streams through HBM beyond
     (the library chooses between those two itself)."""
     long_rows = m > GPFQ_GRAM_MIN_M or (m > GPFQ_GRAM_MIN_M // 2 and C * m >= 5_000_000)
-    if not want_u and long_rows and N <= GPFQ_GRAM_MAX_N:
+    # (alphabets beyond 64 members have no wavefront-per-neuron chain for walks beyond 64 steps: they stay element-wise)
+    if not want_u and long_rows and N <= GPFQ_GRAM_MAX_N and not (M > 64 and N > 64):
         return GPFQ_PATH_GRAM
     return GPFQ_PATH_ONCHIP if m <= GPFQ_ONCHIP_MAX_M else GPFQ_PATH_STREAM
 
@@ -179,12 +185,12 @@ def quantize_neurons(X, Xq, Wt, alphabet, nrm32=None, want_u=False, path=GPFQ_PA
         raise GpfqError("X and Xq must share one row pitch")
     arr, M, zero_idx = _alphabet(alphabet)
     dev = X.device
-    if path == GPFQ_PATH_GRAM or (path == GPFQ_PATH_AUTO and auto_path(N, m, C, want_u) == GPFQ_PATH_GRAM):
+    if path == GPFQ_PATH_GRAM or (path == GPFQ_PATH_AUTO and auto_path(N, m, C, want_u, M) == GPFQ_PATH_GRAM):
         return _quantize_neurons_gram(X, Xq, Wt, alphabet, nrm32, want_values, bool(want_resid))
     if nrm32 is None:
         nrm32 = row_norms(Xq)
     _dev(nrm32, torch.float32, "nrm32")
-    idx = torch.empty((C, N), dtype=torch.int8, device=dev)
+    idx = torch.empty((C, N), dtype=index_dtype(M), device=dev)
     Q = torch.empty((C, N), dtype=torch.float32, device=dev) if want_values else None
     resid = torch.empty(C, dtype=torch.float64, device=dev)
     lib = load()
@@ -212,7 +218,7 @@ def _quantize_neurons_gram(X, Xq, Wt, alphabet, nrm32, want_values=True, want_re
     arr, M, zero_idx = _alphabet(alphabet)
     dev = X.device
     lib = load()
-    idx = torch.empty((C, N), dtype=torch.int8, device=dev)
+    idx = torch.empty((C, N), dtype=index_dtype(M), device=dev)
     Q = torch.empty((C, N), dtype=torch.float32, device=dev)
     resid = torch.empty(C, dtype=torch.float64, device=dev) if want_resid else \
         torch.full((C,), float("nan"), dtype=torch.float64, device=dev)
@@ -255,7 +261,7 @@ class GramPlan:
         wp, C, Nw, ldw = _rows(Wt, "Wt")
         if (N, m, C, Nw) != (self.N, self.m, self.C, self.N) or ld2 != ld:
             raise GpfqError("GramPlan.run: shape differs from the plan")
-        for t, dt, shape in ((idx, torch.int8, (C, N)), (Q, torch.float32, (C, N)), (resid, torch.float64, (C,)),
+        for t, dt, shape in ((idx, index_dtype(self.M), (C, N)), (Q, torch.float32, (C, N)), (resid, torch.float64, (C,)),
                              (unc, torch.int32, (C,))):
             if t.dtype != dt or tuple(t.shape) != shape or not t.is_contiguous() or not t.is_cuda:
                 raise GpfqError("GramPlan.run: outputs must be contiguous GPU tensors of the planned shape")
@@ -285,8 +291,8 @@ def quantize_conv_channels(act_w_cm, act_q_cm, Wt_all, alphabet, kernel_size, st
     """All channels of a conv layer shard in one library call (gpfq_quantize_conv_channels).
     act_*_cm: channel-major f32 [nch][n][H][W]; Wt_all f32 [nch][F][K]; outputs are caller tensors
     idx i8 / Q f32 [nch][F][K], resid f64 [nch][F], unc i32 [nch][F].  No sync; returns nothing."""
-    for t, dt in ((act_w_cm, torch.float32), (act_q_cm, torch.float32), (Wt_all, torch.float32), (idx, torch.int8),
-                  (Q, torch.float32), (resid, torch.float64), (unc, torch.int32)):
+    for t, dt in ((act_w_cm, torch.float32), (act_q_cm, torch.float32), (Wt_all, torch.float32),
+                  (idx, index_dtype(len(alphabet))), (Q, torch.float32), (resid, torch.float64), (unc, torch.int32)):
         if t is None:
             continue                                  # resid is optional (skips the exact replay)
         _dev(t, dt, "tensor")
@@ -365,7 +371,7 @@ def conv_channels_from_records(records, negflags, act_w_cm, act_q_cm, Wt_all, al
             or tuple(idx.shape) != (nch, F, K) or tuple(Q.shape) != (nch, F, K) or tuple(unc.shape) != (nch, F)):
         raise GpfqError("conv_channels_from_records: shape mismatch")
     for t, dt in ((records, torch.float64), (negflags, torch.int32), (act_w_cm, torch.float32), (act_q_cm, torch.float32),
-                  (Wt_all, torch.float32), (idx, torch.int8), (Q, torch.float32), (unc, torch.int32)):
+                  (Wt_all, torch.float32), (idx, index_dtype(len(alphabet))), (Q, torch.float32), (unc, torch.int32)):
         _dev(t, dt, "tensor")
         if not t.is_contiguous():
             raise GpfqError("conv_channels_from_records needs contiguous tensors")
@@ -398,12 +404,12 @@ def set_option(key, value):
 
 
 def msq_round(W, alphabet):
-    """Nearest alphabet member of every weight (first index on ties) -> (Q f32, idx i8), W's shape."""
+    """Nearest alphabet member of every weight (first index on ties) -> (Q f32, idx i8 / i16), W's shape."""
     _dev(W, torch.float32, "W")
     Wc = W.contiguous()
     arr, M, _ = _alphabet(alphabet)
     Q = torch.empty_like(Wc)
-    idx = torch.empty(Wc.shape, dtype=torch.int8, device=W.device)
+    idx = torch.empty(Wc.shape, dtype=index_dtype(M), device=W.device)
     with torch.cuda.device(W.device):
         _check(load().gpfq_msq_round(Wc.data_ptr(), Wc.numel(), arr, M, Q.data_ptr(), idx.data_ptr(), _stream()),
                "gpfq_msq_round")
@@ -411,18 +417,18 @@ def msq_round(W, alphabet):
 
 
 def index_bits(M):
-    """Bits per packed index for an alphabet of M members (8 = plain int8, no packing)."""
+    """Bits per index on the wire for an alphabet of M members (8 = plain int8, 16 = plain int16: no packing)."""
     return int(load().gpfq_index_bits(int(M)))
 
 
 def pack_indices(qidx, M):
-    """[C][N] int8 indices -> (packed u8 [C][ceil(N*bits/8)], bits); bits == 8 returns qidx itself."""
-    _dev(qidx, torch.int8, "qidx")
+    """[C][N] indices -> (packed u8 [C][ceil(N*bits/8)], bits); bits == 8 / 16 returns qidx (int8 / int16) itself."""
+    _dev(qidx, index_dtype(M), "qidx")
     if qidx.dim() != 2 or not qidx.is_contiguous():
         raise GpfqError("qidx must be a contiguous [C][N] tensor")
     bits = index_bits(M)
-    if bits == 8:
-        return qidx, 8
+    if bits >= 8:
+        return qidx, bits
     C, N = qidx.shape
     packed = torch.empty((C, (N * bits + 7) // 8), dtype=torch.uint8, device=qidx.device)
     with torch.cuda.device(qidx.device):
@@ -430,20 +436,22 @@ def pack_indices(qidx, M):
     return packed, bits
 
 
-def assemble_kernel(qidx, alphabet, want_idx=True, bits=8, N=None):
-    """[C][N] int8 indices (bits = 8) or rows packed by pack_indices (bits = 2/4, pass N) ->
-    (Q f32 [N][C] in Keras layout, idx i8 [N][C])."""
-    _dev(qidx, torch.int8 if bits == 8 else torch.uint8, "qidx")
+def assemble_kernel(qidx, alphabet, want_idx=True, bits=None, N=None):
+    """[C][N] int8 / int16 indices (bits = 8 / 16; None = by the alphabet) or rows packed by pack_indices (bits = 2/4,
+    pass N) -> (Q f32 [N][C] in Keras layout, idx i8 / i16 [N][C])."""
+    if bits is None:
+        bits = 8 if len(alphabet) <= 64 else 16
+    _dev(qidx, torch.int16 if bits == 16 else torch.int8 if bits == 8 else torch.uint8, "qidx")
     if qidx.dim() != 2 or not qidx.is_contiguous():
         raise GpfqError("qidx must be a contiguous 2-D tensor")
     C = qidx.shape[0]
-    if bits == 8:
+    if bits >= 8:
         N = qidx.shape[1]
     elif N is None or qidx.shape[1] != (N * bits + 7) // 8:
         raise GpfqError("packed indices need N, with ceil(N*bits/8) bytes per row")
     arr, M, _ = _alphabet(alphabet)
     Q = torch.empty((N, C), dtype=torch.float32, device=qidx.device)
-    idx_t = torch.empty((N, C), dtype=torch.int8, device=qidx.device) if want_idx else None
+    idx_t = torch.empty((N, C), dtype=index_dtype(M), device=qidx.device) if want_idx else None
     with torch.cuda.device(qidx.device):
         _check(load().gpfq_assemble_kernel(qidx.data_ptr(), bits, arr, M, N, C, Q.data_ptr(),
                                            idx_t.data_ptr() if idx_t is not None else None, _stream()),

@@ -73,6 +73,9 @@ def all_gather_units(local, n_units, group=None):
     world, rank = _group_info(group)
     if world == 1:
         return local
+    if local.dtype == torch.int16 and local.dim() >= 2:
+        # RCCL (like NCCL and gloo) has no 16-bit integer type: the indices of 65..256-member alphabets travel as bytes
+        return all_gather_units(local.contiguous().view(torch.uint8), n_units, group).view(torch.int16)
     per = -(-n_units // world)
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
@@ -102,7 +105,7 @@ def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True):
         r = hip.quantize_neurons(X, Xq, Wt, alphabet, want_values=False, want_resid=want_resid)
         i_loc, res_loc = r["idx"], r["resid"]
     else:
-        i_loc = torch.empty((0, N), dtype=torch.int8, device=W.device)
+        i_loc = torch.empty((0, N), dtype=hip.index_dtype(len(alphabet)), device=W.device)
         res_loc = torch.empty((0,), dtype=torch.float64, device=W.device)
     # only the indices travel over xGMI -- packed to 2 or 4 bits per weight when the alphabet allows;
     # values are looked up while transposing to the Keras layout
@@ -165,7 +168,7 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
     world, rank = _group_info(group)
     by_channel = Cin >= world
     Qc = torch.zeros((Cin, F, K), dtype=torch.float32, device=dev)
-    Ic = torch.zeros((Cin, F, K), dtype=torch.int8, device=dev)
+    Ic = torch.zeros((Cin, F, K), dtype=hip.index_dtype(len(alphabet)), device=dev)
     Rc = torch.full((Cin, F), 0.0 if want_resid else float("nan"), dtype=torch.float64, device=dev)
     c_lo, c_hi = shard_bounds(Cin, world, rank) if by_channel else (0, Cin)
     f_lo, f_hi = (0, F) if by_channel else shard_bounds(F, world, rank)
@@ -236,7 +239,7 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
                                        Ic[c_lo:c_hi], Qc[c_lo:c_hi], Rc[c_lo:c_hi] if want_resid else None, Unc[c_lo:c_hi])
         else:                                  # filters split over ranks (Cin < world): every rank walks all channels
             Wt_f = Wt_all[:, f_lo:f_hi].contiguous()
-            i_f = torch.empty((Cin, f_hi - f_lo, K), dtype=torch.int8, device=dev)
+            i_f = torch.empty((Cin, f_hi - f_lo, K), dtype=hip.index_dtype(len(alphabet)), device=dev)
             q_f = torch.empty((Cin, f_hi - f_lo, K), dtype=torch.float32, device=dev)
             r_f = torch.full((Cin, f_hi - f_lo), float("nan"), dtype=torch.float64, device=dev)
             u_f = torch.empty((Cin, f_hi - f_lo), dtype=torch.int32, device=dev)

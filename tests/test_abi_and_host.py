@@ -28,14 +28,17 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_errors_without_gpu(lib):
-    assert lib.gpfq_version() == 200
+    assert lib.gpfq_version() == 210
     # argument validation happens before any launch: safe without a device
     a = (ctypes.c_double * 3)(-1.0, 0.0, 1.0)
     rc = lib.gpfq_quantize_neurons(None, None, 4, None, None, 4, a, 3, 1, 4, 8, 2, None, None, None, None, None, 0, 0, None)
     assert rc == -1 and b"NULL" in lib.gpfq_last_error()
-    big = (ctypes.c_double * 65)(*range(65))
-    rc = lib.gpfq_quantize_neurons(None, None, 4, None, None, 4, big, 65, -1, 4, 8, 2, None, None, None, None, None, 0, 0, None)
+    big = (ctypes.c_double * 257)(*range(257))
+    rc = lib.gpfq_quantize_neurons(None, None, 4, None, None, 4, big, 257, -1, 4, 8, 2, None, None, None, None, None, 0, 0, None)
     assert rc == -2 and b"GPFQ_MAX_ALPHABET" in lib.gpfq_last_error()
+    # 65..256 members (bits 7, 8 of the reference, scripts/quantized_network.py:396) are taken, with int16 indices
+    assert lib.gpfq_quantize_neurons(None, None, 8, None, None, 4, big, 256, -1, 4, 8, 0, None, None, None, None, None, 0, 0, None) == 0
+    assert [lib.gpfq_index_bits(M) for M in (1, 3, 4, 15, 16, 64, 65, 256, 257)] == [2, 2, 4, 4, 8, 8, 16, 16, 0]
     rc = lib.gpfq_quantize_neurons(None, None, 2, None, None, 4, a, 3, 1, 4, 8, 2, None, None, None, None, None, 0, 0, None)
     assert rc == -1
     assert lib.gpfq_quantize_neurons(None, None, 8, None, None, 4, a, 3, 1, 4, 8, 0, None, None, None, None, None, 0, 0, None) == 0

@@ -24,22 +24,24 @@ def _free_port():
 
 def _inputs(case, dev):
     g = torch.Generator(device=dev).manual_seed(11)
-    if case == "dense":
+    if case in ("dense", "dense_8bit"):
         N, m, C = 300, 1024, 70                                  # 70 neurons: uneven shards
         W = torch.randn((N, C), device=dev, generator=g) / np.sqrt(N)
         G = torch.randn((N, m), device=dev, generator=g)
-        return dict(W=W, X=torch.relu(G), Xq=torch.relu(G + 0.1 * torch.randn((N, m), device=dev, generator=g)), bits=2)
+        return dict(W=W, X=torch.relu(G), Xq=torch.relu(G + 0.1 * torch.randn((N, m), device=dev, generator=g)),
+                    bits=8 if case == "dense_8bit" else 2)    # 8 bits: int16 indices, gathered as bytes
     if case == "dense_big_median":
         N, m, C = 2100, 256, 2048                                # 4.3 M weights: the sharded median path
         W = torch.randn((N, C), device=dev, generator=g) / np.sqrt(N)
         G = torch.randn((N, m), device=dev, generator=g)
         return dict(W=W[:, :], X=torch.relu(G), Xq=torch.relu(G + 0.1 * torch.randn((N, m), device=dev, generator=g)), bits=np.log2(3),
                     neurons=64)
-    cin, k = {"conv3x3": (5, 3), "conv5x5": (4, 5), "conv_filters": (1, 3), "conv_columns7": (2, 7)}[case]
+    cin, k = {"conv3x3": (5, 3), "conv5x5": (4, 5), "conv_filters": (1, 3), "conv_columns7": (2, 7), "conv3x3_8bit": (5, 3),
+              "conv_filters_8bit": (1, 3)}[case]
     act_w = torch.rand((40, 24, 24, cin), device=dev, generator=g)
     act_q = torch.relu(act_w + 0.05 * torch.randn(act_w.shape, device=dev, generator=g))
     W = torch.randn((k, k, cin, 6), device=dev, generator=g) / k
-    return dict(W=W, act_w=act_w, act_q=act_q, bits=3)
+    return dict(W=W, act_w=act_w, act_q=act_q, bits=8 if case.endswith("8bit") else 3)
 
 
 def _run(case, dev, group):
@@ -72,6 +74,7 @@ def _worker(rank, world, port, case, result_dir):
 
 
 @pytest.mark.parametrize("case,world", [("dense", 2), ("dense", 3), ("dense_big_median", 2), ("conv3x3", 2), ("conv5x5", 3),
+                                        ("dense_8bit", 3), ("conv3x3_8bit", 2), ("conv_filters_8bit", 2),
                                         ("conv_filters", 2), ("conv_columns7", 3)])   # fewer channels than ranks: image shards
 def test_ranks_sharing_one_gpu(case, world, tmp_path):
     import torch.multiprocessing as mp

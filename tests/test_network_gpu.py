@@ -183,16 +183,18 @@ def _cnn(ks):
     ], seed=3)
 
 
-def test_cnn_against_oracle(qn, ks, oracle_mod):
+@pytest.mark.parametrize("bits,scalar", [(3, 4), (8, 6), (7, 5)])
+def test_cnn_against_oracle(qn, ks, oracle_mod, bits, scalar):
     """QuantizedCNN layer by layer: every (channel, filter) pair equals the oracle's recurrence on the
-    independently built patch matrix of the activations the class captured."""
+    independently built patch matrix of the activations the class captured.  bits 7 and 8 (128 / 256 members, which the
+    reference's `int(round(2**bits))` accepts, scripts/quantized_network.py:396) run the int16-index kernels."""
     net = _cnn(ks)
     r = np.random.default_rng(11)
     x = r.random((20, 16, 16, 3)).astype(np.float32)
     y = np.zeros((20, 6), dtype=np.float32)
     logger = ListLogger()
     q = qn.QuantizedCNN(network=net, batch_size=8, get_data=qn.CIFAR10Sequence(x, y, 8), logger=logger,
-                        bits=3, alphabet_scalar=4)                        # 20 % 8 != 0 -> quirk, 24 rows
+                        bits=bits, alphabet_scalar=scalar)                # 20 % 8 != 0 -> quirk, 24 rows
     assert not hasattr(q, "ignore_layers") and not hasattr(q, "layer_dims")
     rec = _record_captures(q)
     analog = [l.get_weights() for l in net.layers]
@@ -204,8 +206,8 @@ def test_cnn_against_oracle(qn, ks, oracle_mod):
         W = analog[k][0]
         Qk = q.quantized_net.layers[k].get_weights()[0]
         wX, qX = rec[k]
-        alphabet, rad = oracle_mod.layer_alphabet(W, q.alphabet, 4)
-        assert rad == q.last_layer_stats[k]["rad"]
+        alphabet, rad = oracle_mod.layer_alphabet(W, q.alphabet, scalar)
+        assert rad == q.last_layer_stats[k]["rad"] and len(alphabet) == 2 ** bits
         if name == "Dense":
             assert wX.shape == (W.shape[0], 24)
             Qo, _, _ = oracle_mod.layer(W, wX, qX, alphabet)
@@ -331,18 +333,20 @@ def test_single_rank_nccl_group(qn, ks):
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("members", [8, 256])
 @pytest.mark.parametrize("slack", [0, 14, 60])
-def test_conv_layer_gram_fast_path(oracle_mod, slack):
+def test_conv_layer_gram_fast_path(oracle_mod, slack, members):
     """layer.quantize_conv2d on patch matrices long enough for the Gram plan (no per-channel sync);
     slack=14 leaves a few chains uncertified (repaired on the device from the exact dot products),
-    slack=60 every step of every filter, exercising the once-per-layer exact rerun too."""
+    slack=60 every step of every filter, exercising the once-per-layer exact rerun too.  256 members: the int16-index
+    forms of the decide / resume kernels and of the streaming rerun."""
     from quantized_neural_networks_amd import hip, layer
     r = np.random.default_rng(21)
     act_w = r.random((36, 24, 24, 2)).astype(np.float32)
     act_q = np.maximum(act_w + 0.05 * r.standard_normal(act_w.shape), 0).astype(np.float32)
     W = (r.standard_normal((3, 3, 2, 3)) / 3).astype(np.float32)
     Wd = torch.from_numpy(W).cuda()
-    alphabet, _ = layer.layer_alphabet(Wd, np.linspace(-1, 1, 8), 4)
+    alphabet, _ = layer.layer_alphabet(Wd, np.linspace(-1, 1, members), 4)
     assert 36 * 24 * 24 > hip.GPFQ_GRAM_MIN_M
     try:
         hip.set_option("gram_slack_log2", slack)
@@ -351,12 +355,15 @@ def test_conv_layer_gram_fast_path(oracle_mod, slack):
     finally:
         hip.set_option("gram_slack_log2", 0)
     Q = out["Q"].cpu().numpy()
+    idx = out["idx"].cpu().numpy()
+    assert idx.dtype == (np.int8 if members <= 64 else np.int16)
     for c in range(2):
         Pw = ref_patches(act_w, c, 3, 3, 1, 1, 1, 1, "SAME")
         Pq = ref_patches(act_q, c, 3, 3, 1, 1, 1, 1, "SAME")
         for f in range(3):
-            qo, _, uo = oracle_mod.neuron(W[:, :, c, f].reshape(-1), Pw, Pq, alphabet)
+            qo, io, uo = oracle_mod.neuron(W[:, :, c, f].reshape(-1), Pw, Pq, alphabet)
             assert np.array_equal(Q[:, :, c, f].reshape(-1), qo.astype(np.float32)), (c, f)
+            assert np.array_equal(idx[:, :, c, f].reshape(-1), io), (c, f)
             np.testing.assert_allclose(out["resid"][c, f].item(), np.linalg.norm(uo), rtol=1e-5)
 
 

@@ -24,11 +24,12 @@ def _standin_quantize(X, Xq, Wt, alphabet, **kw):
     import oracle
     W = Wt.numpy().T.copy()
     Q, idx, resid = oracle.layer(W, X.numpy(), Xq.numpy(), np.asarray(alphabet))
+    idx = idx.astype(np.int8 if len(alphabet) <= 64 else np.int16)         # the binding's index element types
     return dict(Q=torch.from_numpy(Q.astype(np.float32)), idx=torch.from_numpy(idx), resid=torch.from_numpy(resid), u=None)
 
 
-def _standin_assemble(qidx, alphabet, want_idx=True, bits=8, N=None):
-    assert bits == 8
+def _standin_assemble(qidx, alphabet, want_idx=True, bits=None, N=None):
+    assert bits in (None, 8, 16)
     a = np.asarray(alphabet, dtype=np.float64)
     k = qidx.numpy().astype(np.int64)
     Q = np.where(k < 0, 0.0, a[np.maximum(k, 0)]).astype(np.float32)
@@ -43,7 +44,7 @@ def _standin_patches(act, channel, kernel_size, strides, rate, padding, out=None
 
 
 def _standin_pack(qidx, M):
-    return qidx, 8                          # "8 bits = plain int8, no packing" (the packing kernel is covered on the GPU)
+    return qidx, 8 if M <= 64 else 16       # plain int8 / int16 indices, no packing (the packing kernel is covered on the GPU)
 
 
 def _standin_planes(act, c_lo, c_hi):
@@ -72,13 +73,13 @@ def _worker(rank, world, port, case, result_dir):
     _install_standins()
     group = dist.group.WORLD                # sharding needs an explicit group (None = this process alone)
     r = np.random.default_rng(7)
-    if case == "dense":
+    if case.startswith("dense"):
         N, m, C = 24, 40, 7                                  # 7 neurons over 2 ranks: uneven shards
         W = (r.standard_normal((N, C)) / np.sqrt(N)).astype(np.float32)
         G = r.standard_normal((N, m))
         X = np.maximum(G, 0).astype(np.float32)
         Xq = np.maximum(G + 0.1 * r.standard_normal((N, m)), 0).astype(np.float32)
-        alphabet = 0.3 * np.linspace(-1, 1, 4)
+        alphabet = 0.3 * np.linspace(-1, 1, _dense_members(case))
         out = layer.quantize_dense(torch.from_numpy(W), torch.from_numpy(X), torch.from_numpy(Xq), alphabet, group=group)
     else:
         Cin = 3 if case == "conv_channels" else 1            # Cin < world -> filters are sharded instead
@@ -93,7 +94,11 @@ def _worker(rank, world, port, case, result_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["dense", "conv_channels", "conv_filters"])
+def _dense_members(case):
+    return 200 if case == "dense_int16" else 4              # 200 members: int16 indices, gathered as bytes
+
+
+@pytest.mark.parametrize("case", ["dense", "dense_int16", "conv_channels", "conv_filters"])
 def test_sharded_equals_unsharded(case, tmp_path, oracle_mod):
     import torch.multiprocessing as mp
     world = 2
@@ -107,13 +112,14 @@ def test_sharded_equals_unsharded(case, tmp_path, oracle_mod):
     hip, keep = _install_standins()
     try:
         r = np.random.default_rng(7)
-        if case == "dense":
+        if case.startswith("dense"):
             N, m, C = 24, 40, 7
             W = (r.standard_normal((N, C)) / np.sqrt(N)).astype(np.float32)
             G = r.standard_normal((N, m))
             X = np.maximum(G, 0).astype(np.float32)
             Xq = np.maximum(G + 0.1 * r.standard_normal((N, m)), 0).astype(np.float32)
-            out = layer.quantize_dense(torch.from_numpy(W), torch.from_numpy(X), torch.from_numpy(Xq), 0.3 * np.linspace(-1, 1, 4))
+            out = layer.quantize_dense(torch.from_numpy(W), torch.from_numpy(X), torch.from_numpy(Xq),
+                                       0.3 * np.linspace(-1, 1, _dense_members(case)))
         else:
             Cin = 3 if case == "conv_channels" else 1
             act = r.random((4, 6, 6, Cin)).astype(np.float32)
@@ -126,3 +132,5 @@ def test_sharded_equals_unsharded(case, tmp_path, oracle_mod):
             setattr(hip, k, v)
     for k, v in out.items():
         assert np.array_equal(res[0][k], v.numpy()), k
+    if case == "dense_int16":
+        assert out["idx"].dtype == torch.int16 and res[0]["idx"].dtype == np.int16 and int(out["idx"].max()) > 127
