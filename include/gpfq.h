@@ -98,7 +98,9 @@ size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path);
 const char *gpfq_last_dense_kernel(void);
 
 /*
- * Process-wide tuning/test hooks; results never depend on them.
+ * Process-wide tuning/test hooks; results never depend on them, only which kernel family runs.  Each option is one atomic
+ * integer: a call running on another thread sees the old or the new value of each, never a torn one -- the calls stay
+ * re-entrant per stream whatever is set while they run.
  *   "onchip_mode"  1 (default) certified-prediction mode, 0 verbatim reference flow
  *   "tile_steps"   LDS tile height in steps (power of two <= 64), 0 = heuristic
  *   "group_waves"  neurons (wavefronts) per workgroup 1..16 of the wave-per-neuron kernel, 0 = heuristic

@@ -748,7 +748,7 @@ static hipError_t launch_blk_inst(const PipeArgs &a, const BlkShape &sh, hipStre
     const BlkLds L = blk_lds(sh.mp, NB, B);
     const unsigned grid = (unsigned)((a.C + NB - 1) / NB);
     auto *kern = gpfq_blk_kernel<G, S, B>;
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+    hipError_t e = ensure_dynamic_lds((const void *)kern, (size_t)L.total);
     if (e != hipSuccess) return e;
     BlkK K;
     K.recs = static_cast<const char *>(a.workspace); K.Wt = a.Wt; K.ldw = a.ldw;

@@ -5,7 +5,11 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "../../include/gpfq.h"
@@ -70,6 +74,23 @@ int make_alphabet(const double *alphabet, int M, int zero_idx, HostAlphabet *H)
 
 namespace gpfq {
 void note_dense_kernel(const char *name) { g_dense_kernel = name; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): it is raised when a launch needs more than
+// any launch before it on that device, not once per launch.
+hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> granted;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = granted[std::make_pair(kernel, dev)];
+    if (bytes <= have) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
 }
 
 extern "C" {
@@ -145,18 +166,19 @@ size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path)
     return need;
 }
 
-// Tuning / test hooks (process-wide).  Results never depend on them.
-static int g_onchip_mode = 1;      // 1 = certified (default), 0 = exact flow
-static int g_tile_steps = 0;       // 0 = heuristic
-static int g_group_waves = 0;      // 0 = heuristic
-static int g_lpn = 0;              // 0 = heuristic, 1 = wave-per-neuron kernel, 16/32/64 = row-group kernel
-static int g_gram_slack_log2 = 0;  // Gram path: error bounds multiplied by 2^this (tests force the uncertified branch)
-static int g_wpn = 0;              // wide kernel: wavefronts per neuron (0 = heuristic: only for rows > 2048)
-static int g_variant = 0;          // bit 0: row-group kernel without the float64 copy of Xq in LDS; bit 1: wide kernel with LDS-staged rows
-static int g_pipe = -1;            // pipelined dense kernels: -1 = heuristic, 0 = never, 1 = one step per slot (gpfq_pipe.hip) whenever it
+// Tuning / test hooks (process-wide, atomics: a call on another thread sees either the old or the new value of each).
+// Results never depend on them.
+static std::atomic<int> g_onchip_mode{1};      // 1 = certified (default), 0 = exact flow
+static std::atomic<int> g_tile_steps{0};       // 0 = heuristic
+static std::atomic<int> g_group_waves{0};      // 0 = heuristic
+static std::atomic<int> g_lpn{0};              // 0 = heuristic, 1 = wave-per-neuron kernel, 16/32/64 = row-group kernel
+static std::atomic<int> g_gram_slack_log2{0};  // Gram path: error bounds multiplied by 2^this (tests force the uncertified branch)
+static std::atomic<int> g_wpn{0};              // wide kernel: wavefronts per neuron (0 = heuristic: only for rows > 2048)
+static std::atomic<int> g_variant{0};          // bit 0: row-group kernel without the float64 copy of Xq in LDS; bit 1: wide kernel with LDS-staged rows
+static std::atomic<int> g_pipe{-1};            // pipelined dense kernels: -1 = heuristic, 0 = never, 1 = one step per slot (gpfq_pipe.hip) whenever it
                                    // applies, 2 = blocks of steps per slot (gpfq_blk.hip) whenever it applies
-static int g_conv_fused = 1;       // conv channel loop: 3x3/stride-1 Gram matrices straight from the planes
-static int g_conv_strip = 0;       // fused conv kernel: forced strip length (0 = heuristic)
+static std::atomic<int> g_conv_fused{1};       // conv channel loop: 3x3/stride-1 Gram matrices straight from the planes
+static std::atomic<int> g_conv_strip{0};       // fused conv kernel: forced strip length (0 = heuristic)
 
 int gpfq_set_option(const char *key, int value)
 {

@@ -84,6 +84,9 @@ bool pipe_supported(const PipeArgs &a);
 size_t pipe_workspace_bytes(int64_t N, int64_t m);
 hipError_t launch_pipe(const PipeArgs &a, hipStream_t stream);
 
+// Raises `kernel`'s dynamic-LDS limit on the current device to `bytes` unless an earlier launch already did (gpfq_capi.hip).
+hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes);
+
 // Which dense kernel family the last gpfq_quantize_neurons call of this thread dispatched (diagnostics: gpfq_last_dense_kernel).
 void note_dense_kernel(const char *name);
 

@@ -273,8 +273,7 @@ static hipError_t launch_epl_ar(const OnchipArgs &a, const AlphabetT<64 * AR> &A
     const size_t lds_bytes = (size_t)2 * ts * MP * sizeof(float);
     const bool vec4 = (a.ld % 4 == 0) && (a.m % 4 == 0) && ((uintptr_t)a.X % 16 == 0) && ((uintptr_t)a.Xq % 16 == 0);
     const unsigned grid = (unsigned)((a.C + nw - 1) / nw);
-    hipError_t e = hipFuncSetAttribute((const void *)gpfq_onchip_kernel<EPL, MODE, AR>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = ensure_dynamic_lds((const void *)gpfq_onchip_kernel<EPL, MODE, AR>, lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((gpfq_onchip_kernel<EPL, MODE, AR>), dim3(grid), dim3(nw * 64), lds_bytes, stream,
                        a.X, a.Xq, a.ld, a.nrm32, a.stats, a.Wt, a.ldw, A, a.N, (int)a.m, a.C, ts, vec4 ? 1 : 0,

@@ -575,7 +575,7 @@ static hipError_t launch_pipe_inst(const PipeArgs &a, const PipeShape &sh, hipSt
     const PipeLds L = pipe_lds(sh.mp, NB, ts);
     const unsigned grid = (unsigned)((a.C + NB - 1) / NB);
     auto *kern = gpfq_pipe_kernel<G, S>;
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+    hipError_t e = ensure_dynamic_lds((const void *)kern, (size_t)L.total);
     if (e != hipSuccess) return e;
     PipeK K;
     K.recs = static_cast<const char *>(a.workspace); K.X = a.X; K.Xq = a.Xq; K.ld = a.ld; K.Wt = a.Wt; K.ldw = a.ldw;

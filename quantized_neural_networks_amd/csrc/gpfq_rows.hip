@@ -346,8 +346,7 @@ static hipError_t launch_rows_xqd(const OnchipArgs &a, hipStream_t stream)
     if (a.nw_override > 0 && a.nw_override <= 16 && a.nw_override >= 64 / LPN && !(a.nw_override & (a.nw_override - 1))) gs = a.nw_override;
     const bool vec4 = (a.ld % 4 == 0) && (a.m % 4 == 0) && ((uintptr_t)a.X % 16 == 0) && ((uintptr_t)a.Xq % 16 == 0);
     const unsigned grid = (unsigned)((a.C + gs - 1) / gs);
-    hipError_t e = hipFuncSetAttribute((const void *)gpfq_rows_kernel<LPN, EPL, XQD>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = ensure_dynamic_lds((const void *)gpfq_rows_kernel<LPN, EPL, XQD>, lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((gpfq_rows_kernel<LPN, EPL, XQD>), dim3(grid), dim3(LPN * gs), lds_bytes, stream,
                        a.X, a.Xq, a.ld, a.nrm32, a.stats, a.Wt, a.ldw, a.A, a.N, (int)a.m, a.C, ts, gs, vec4 ? 1 : 0,

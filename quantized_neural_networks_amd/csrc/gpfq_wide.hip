@@ -414,7 +414,7 @@ static hipError_t launch_wide_epl_ar(const OnchipArgs &a, const AlphabetT<64 * A
     const size_t lds_bytes = (size_t)2 * ts * MP * sizeof(float) + (size_t)2 * G * W * 2 * sizeof(double);
     const bool vec4 = (a.ld % 4 == 0) && (a.m % 4 == 0) && ((uintptr_t)a.X % 16 == 0) && ((uintptr_t)a.Xq % 16 == 0);
     const unsigned grid = (unsigned)((a.C + G - 1) / G);
-    hipError_t e = hipFuncSetAttribute((const void *)gpfq_wide_kernel<EPL, AR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = ensure_dynamic_lds((const void *)gpfq_wide_kernel<EPL, AR>, lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((gpfq_wide_kernel<EPL, AR>), dim3(grid), dim3(64 * W * G), lds_bytes, stream,
                        a.X, a.Xq, a.ld, a.nrm32, a.Wt, a.ldw, A, a.N, (int)a.m, a.C, ts, W, G, vec4 ? 1 : 0,
