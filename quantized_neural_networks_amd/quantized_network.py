@@ -14,7 +14,7 @@ The network object is only touched through the Keras attribute set of SURVEY A.4
 
 Extra keyword-only constructor arguments (not in the reference): ``device`` (torch device of this
 process' GPU) and ``process_group`` (a ``torch.distributed`` group over which the neurons of every
-layer are sharded), and ``fix_partial_batch`` to opt out of the reference's
+layer -- and the samples of the activation capture in between -- are sharded), and ``fix_partial_batch`` to opt out of the reference's
 partial-last-batch layout quirk (:491-495).
 """
 from collections import namedtuple
@@ -209,7 +209,14 @@ class QuantizedNeuralNetwork:
     # layer by running only the layers in between -- with the weights layer l' has NOW (it was quantized
     # after its inputs were captured).  Samples are pushed through in large chunks; the reference's
     # batch structure only decides where columns land (including the partial-last-batch quirk).
-    _capture_chunk = 2048
+    #
+    # With a process group the SAMPLES are partitioned over the ranks for this part (shard_capture, on by default): every
+    # rank pushes only its block of whole chunks through the layers in between, and the blocks are all-gathered when a
+    # layer's inputs are needed (every rank walks all samples of its neurons / channels).  The chunk grid does not
+    # depend on the number of ranks, so each chunk goes through the same kernels with the same shapes as in a
+    # single-process run and the captured activations -- hence the quantized network -- are the same bits.
+    _capture_chunk = 512
+    shard_capture = True
 
     def _incremental_capture_possible(self):
         return (getattr(self, "incremental_capture", True) and hasattr(self.trained_net, "forward_upto")
@@ -229,11 +236,36 @@ class QuantizedNeuralNetwork:
             return layer.call(x)
         return torch.cat([layer.call(x[i:i + step]) for i in range(0, x.shape[0], step)])
 
+    def _capture_shard(self, n):
+        """(world, lo, hi, per): this rank's block [lo, hi) of the n samples -- whole chunks of the rank-independent grid,
+        `per` samples per rank in the gathered layout; world == 1 when the capture is not sharded."""
+        world, rank = _layer._group_info(self.process_group)
+        if world == 1 or not self.shard_capture:
+            return 1, 0, n, n
+        chunk = self._capture_chunk
+        n_chunks = -(-n // chunk)
+        c_lo, c_hi = _layer.shard_bounds(n_chunks, world, rank)
+        return world, min(c_lo * chunk, n), min(c_hi * chunk, n), -(-n_chunks // world) * chunk
+
+    def _gather_samples(self, x, n, world, per):
+        """The ranks' sample blocks -> all n samples on every rank (one all-gather; blocks padded to `per` samples)."""
+        if world == 1:
+            return x
+        import torch.distributed as dist
+        pad = torch.zeros((per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        pad[:x.shape[0]] = x
+        out = torch.empty((world * per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, pad, group=self.process_group)
+        return out[:n]
+
     def _capture_incremental(self, layer_idx, transpose):
         raw, sizes = self._raw_inputs()
+        n = raw.shape[0]
+        world, lo, hi, per = self._capture_shard(n)
         fr = getattr(self, "_frontier", None)
         if fr is None or fr["k"] > layer_idx - 1:
-            fr = dict(k=-1, w=raw, q=raw)                       # outputs of "layer -1" = the data itself
+            mine = raw[lo:hi]
+            fr = dict(k=-1, w=mine, q=mine)                     # outputs of "layer -1" = the data itself
         tl, ql = self.trained_net.layers, self.quantized_net.layers
         for k in range(fr["k"] + 1, layer_idx):
             same = fr["q"] is fr["w"] and all(torch.equal(a, b) for a, b in zip(tl[k]._weights, ql[k]._weights))
@@ -241,9 +273,12 @@ class QuantizedNeuralNetwork:
             q = w if same else self._advance(ql[k], fr["q"])
             fr = dict(k=k, w=w, q=q)
         self._frontier = fr
-        wX = self._assemble_capture(fr["w"], sizes, transpose)
+        full_w = raw if fr["k"] < 0 else self._gather_samples(fr["w"], n, world, per)
+        wX = self._assemble_capture(full_w, sizes, transpose)
         # both networks still agree up to here (first quantized layer): one tensor, as for layer 0 (:478-481)
-        return wX, (wX if fr["q"] is fr["w"] else self._assemble_capture(fr["q"], sizes, transpose))
+        if fr["q"] is fr["w"]:
+            return wX, wX
+        return wX, self._assemble_capture(self._gather_samples(fr["q"], n, world, per), sizes, transpose)
 
     def _assemble_capture(self, act, sizes, transpose):
         """Columns in the reference's layout (:491-495): batch b lands at offset b*(its own size)."""

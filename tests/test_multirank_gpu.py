@@ -44,8 +44,63 @@ def _inputs(case, dev):
     return dict(W=W, act_w=act_w, act_q=act_q, bits=8 if case.endswith("8bit") else 3)
 
 
+class _Quiet:
+    def info(self, msg):
+        pass
+
+
+def _run_network(case, dev, group):
+    """The class surface over a process group: neurons / channels sharded per layer AND the samples of the activation
+    capture in between (quantized_network.py: shard_capture).  A capture chunk of 8 samples spreads the 44 samples (6
+    chunks, the last one partial, and a partial last batch) over the ranks; the chunk grid does not depend on the
+    number of ranks, so the single-process run must give the same bits."""
+    from quantized_neural_networks_amd import keras_shim as ks, quantized_network as qn
+    r = np.random.default_rng(5)
+    if case == "network_cnn":
+        net = ks.Sequential([
+            ks.Conv2D(4, 3, padding="same", activation="relu", input_shape=(12, 12, 3)),
+            ks.Conv2D(5, 3, strides=2, padding="same", activation="relu"),
+            ks.DepthwiseConv2D(3, padding="valid", depth_multiplier=2, use_bias=False),
+            ks.Conv2D(3, 1, padding="valid"),
+            ks.Flatten(),
+            ks.Dense(6, activation="softmax"),
+        ], seed=3)
+        x = r.random((44, 12, 12, 3)).astype(np.float32)
+        q = qn.QuantizedCNN(network=net, batch_size=16, get_data=qn.CIFAR10Sequence(x, np.zeros((44, 6), np.float32), 16),
+                            logger=_Quiet(), bits=3, alphabet_scalar=4, process_group=group)
+    else:
+        net = ks.Sequential([ks.Dense(40, activation="relu", input_shape=(30,)), ks.Dense(24, activation="relu"), ks.Dense(5)], seed=2)
+        x = r.random((44, 30)).astype(np.float32)
+        q = qn.QuantizedNeuralNetwork(network=net, batch_size=16, get_data=qn.MNISTSequence(x, np.zeros((44, 1)), 16),
+                                      logger=_Quiet(), bits=2, alphabet_scalar=2, process_group=group)
+    q._capture_chunk = 8
+    captured = []
+    orig = q._get_layer_data_generator
+
+    def wrapped(layer_idx, transpose=False):
+        wX, qX = orig(layer_idx, transpose)
+        captured.append((layer_idx, wX.cpu().numpy(), qX.cpu().numpy()))
+        return wX, qX
+
+    q._get_layer_data_generator = wrapped
+    q.quantize_network()
+    res = {}
+    for k, layer in enumerate(q.quantized_net.layers):
+        ws = layer.get_weights()
+        if ws:
+            res[f"Q{k}"] = np.asarray(ws[0])
+    for k, wX, qX in captured:
+        res[f"wX{k}"], res[f"qX{k}"] = wX, qX
+    if group is not None:                                        # this rank really advanced only its block of samples
+        world, lo, hi, per = q._capture_shard(44)
+        assert world > 1 and q._frontier["w"].shape[0] == hi - lo < 44
+    return res
+
+
 def _run(case, dev, group):
     from quantized_neural_networks_amd import layer
+    if case.startswith("network"):
+        return _run_network(case, dev, group)
     d = _inputs(case, dev)
     unit = np.linspace(-1, 1, int(round(2 ** d["bits"])))
     alphabet, rad = layer.layer_alphabet(d["W"], unit, 3, group)
@@ -75,6 +130,7 @@ def _worker(rank, world, port, case, result_dir):
 
 @pytest.mark.parametrize("case,world", [("dense", 2), ("dense", 3), ("dense_big_median", 2), ("conv3x3", 2), ("conv5x5", 3),
                                         ("dense_8bit", 3), ("conv3x3_8bit", 2), ("conv_filters_8bit", 2),
+                                        ("network_mlp", 2), ("network_cnn", 2), ("network_cnn", 3),
                                         ("conv_filters", 2), ("conv_columns7", 3)])   # fewer channels than ranks: image shards
 def test_ranks_sharing_one_gpu(case, world, tmp_path):
     import torch.multiprocessing as mp
