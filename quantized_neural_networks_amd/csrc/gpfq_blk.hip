@@ -190,21 +190,35 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 #pragma unroll
         for (int e = 0; e < 2 * PW; ++e) u[i][e] = 0.0;          // zeros(m), :115
 
-    const int npieces = (L.tile_bytes + 1023) >> 10;              // the last piece may run into the next record: harmless
-    auto load_tile = [&](int b) {
-        const char *src = K.recs + (int64_t)b * L.tile_bytes + lane * 16;
-        const unsigned dst = ldsT_addr + (unsigned)(b & 1) * (unsigned)L.tile_pitch;
-        for (int pc = wave; pc < npieces; pc += kSweepWaves) glds16(src + ((size_t)pc << 10), dst + ((unsigned)pc << 10));
-        const unsigned dw = ldsW_addr + (unsigned)((b & 1) * NB * B * 4);
+    // The record tile of the next slot streams into the other LDS buffer in 1 KiB LDS-DMA pieces, piece k of this wavefront
+    // being piece wave + 8 k of the tile (the last piece may run into the next record: harmless).  The pieces are issued ONE
+    // AT A TIME from inside phase U (two issue points per step), with the base address stepped in scalar registers: a
+    // wavefront that issues its eight or nine pieces back to back waits ~1000 cycles per slot for the vector-memory queue
+    // (the texture addresser moves 64 bytes per clock: 66 KiB per slot), and so does the wavefront it shares its SIMD with --
+    // spread out, the queue never fills and the transfers hide under the arithmetic (measured: 4.86 -> 4.51 ms at
+    // 4096 x 4096 x 1024, and with the decision wavefront's priority raised 4.17).
+    constexpr int NPIECES = (B * RB + 1023) >> 10;
+    constexpr int PER_MIN = NPIECES / kSweepWaves;                // every wavefront has at least this many pieces per tile
+    constexpr int PTS = PW >= 2 ? 2 : 1;                          // issue points per step of phase U (its first pairs)
+    constexpr int PPP = PER_MIN / (PTS * B) > 0 ? PER_MIN / (PTS * B) : 1;   // pieces per issue point
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto issue_piece = [&](int b1, int k) {
+        const int pc = wave + kSweepWaves * k;
+        glds16_s(K.recs + (int64_t)b1 * L.tile_bytes + ((int64_t)pc << 10), lane16,
+                 ldsT_addr + (unsigned)(b1 & 1) * (unsigned)L.tile_pitch + ((unsigned)pc << 10));
+    };
+    auto load_weights = [&](int b1) {
+        const unsigned dw = ldsW_addr + (unsigned)((b1 & 1) * NB * B * 4);
         for (int i0 = wave * 64; i0 < NB * B; i0 += kSweepWaves * 64) {
             const int i = i0 + lane;
             const int n = i / B, s = i - n * B;
-            const int64_t jn = jbase + n, t = (int64_t)b * B + s;
+            const int64_t jn = jbase + n, t = (int64_t)b1 * B + s;
             if (i < NB * B && jn < K.C && t < N) glds4(K.Wt + jn * K.ldw + t, dw + 4 * (unsigned)i0);
         }
     };
 
-    load_tile(0);
+    for (int k = 0; wave + kSweepWaves * k < NPIECES; ++k) issue_piece(0, k);
+    load_weights(0);
     dma_wait();
     slot_barrier();
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, acc_dma = 0, acc_u = 0, acc_d = 0, acc_w = 0, acc_b = 0;
@@ -212,7 +226,8 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 
     for (int b = 0; b < nslots; ++b) {
         STAMP(st0);
-        if (b + 1 < nslots) load_tile(b + 1);                     // streams into the other buffer meanwhile
+        if (b + 1 < nslots) load_weights(b + 1);                  // the block's weights: one piece
+        const int bn = b + 1 < nslots ? b + 1 : b;                // (the last slot rewrites its own tile with the same bytes)
         STAMP(st1);
         const int tbase = (b & 1) * L.tile_pitch;
         const int pbq = ((b - 1) & 1) * NB * B * 8;               // (w, q) of block b-1
@@ -241,6 +256,13 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
                     const int rbn = p + 1 < PW ? rb : tbase + sn * RB, pn = p + 1 < PW ? p + 1 : 0;
                     x2n = lds_ld<float2>(lds, rbn + o_x + 8 * pn * KQ);
                     q2n = lds_ld<float2>(lds, rbn + o_q + 8 * pn * KQ);
+                    if (p < PTS) {
+#pragma unroll
+                        for (int i = 0; i < PPP; ++i) {
+                            const int k = (PTS * s + p) * PPP + i;
+                            if (PTS * B * PPP <= PER_MIN || k < PER_MIN) issue_piece(bn, k);   // (short tiles: fewer pieces than issue points)
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     const pk2 xv = {x2.x, x2.y}, qx = {q2.x, q2.y};
                     // f32 products and subtraction on two samples at once (v_pk_mul_f32 / v_pk_add_f32): each half rounds
@@ -263,6 +285,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
                 }
             }
         }
+        for (int k = PTS * B * PPP < PER_MIN ? PTS * B * PPP : PER_MIN; wave + kSweepWaves * k < NPIECES; ++k) issue_piece(bn, k);   // the rest
         STAMP(st2);
         // ---- phase D: this wavefront's share of <Xq_t, u> for the B rows of block b+1 ----
         if (b + 1 < nslots) {
@@ -448,6 +471,10 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     };
 
     slot_barrier();                                               // (tile 0 landed)
+    // The B dependent decisions of a slot are a latency chain on a SIMD that two sweep wavefronts keep busy: at equal priority
+    // every instruction of the chain waits its turn behind theirs (9640 cycles per slot, the longest path of the workgroup);
+    // ahead of them it takes 6800 and the sweeps, which have the slack, fill the gaps.
+    __builtin_amdgcn_s_setprio(3);
 
     int64_t flushed = 0;                                          // steps [0, flushed) are in memory
     unsigned long long dt0 = 0, dt1 = 0, dt2 = 0, dacc_work = 0, dacc_bar = 0;
@@ -720,8 +747,11 @@ struct BlkShape { int G, S, B, mp; };
 
 static BlkShape blk_shape(int64_t m)
 {
-    if (m > 512 && m <= 1024) return {4, 32, 4, 1024};
-    if (m > 1024 && m <= 2048) return {2, 32, 2, 2048};
+    if (m > 256 && m <= 512) return {4, 16, 4, 512};
+    if (m > 512 && m <= 768) return {4, 24, 4, 768};
+    if (m > 768 && m <= 1024) return {4, 32, 4, 1024};
+    if (m > 1024 && m <= 1536) return {2, 24, 2, 1536};
+    if (m > 1536 && m <= 2048) return {2, 32, 2, 2048};
     return {0, 0, 0, 0};
 }
 
@@ -769,7 +799,12 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
                        a.nrm32, static_cast<char *>(a.workspace));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (sh.G == 4) return launch_blk_inst<4, 32, 4>(a, sh, stream);
+    if (sh.G == 4) {
+        if (sh.S == 16) return launch_blk_inst<4, 16, 4>(a, sh, stream);
+        if (sh.S == 24) return launch_blk_inst<4, 24, 4>(a, sh, stream);
+        return launch_blk_inst<4, 32, 4>(a, sh, stream);
+    }
+    if (sh.S == 24) return launch_blk_inst<2, 24, 2>(a, sh, stream);
     return launch_blk_inst<2, 32, 2>(a, sh, stream);
 }
 

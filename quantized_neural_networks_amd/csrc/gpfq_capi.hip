@@ -302,11 +302,12 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
             pa.N = N; pa.m = m; pa.C = C; pa.qidx = qidx; pa.Qt = Qt; pa.resid = resid; pa.u_out = u_out;
             pa.ts_override = g_tile_steps; pa.variant = g_variant >> 4;
             const bool forced_old = g_lpn != 0 || g_wpn != 0 || g_onchip_mode != 1 || g_pipe == 0;
-            // measured (tools/pipe_probe.py): the block-pipelined kernel is ahead of the row-group kernel on wide layers with
-            // rows of 513..1024 samples (16 neurons per workgroup, one round of workgroups: 4096 x 4096, m = 1024: 4.7 vs
-            // 5.4 ms; one step per slot: 4.9); behind it where a workgroup holds 8 neurons (m > 1024: 10.6 vs 10.0 ms) or the
-            // layer is too narrow to fill the chip
-            const bool fits = m > 512 && m <= 1024 && C >= 2048 && M <= 16;
+            // measured (tools/blk_shapes.sh): the block-pipelined kernel is ahead of the row-group and wavefront-per-neuron kernels
+            // for rows of 257..2048 samples whenever the layer has 512 neurons or more (4096 x 4096, m = 1024: 4.1 vs 5.4 ms;
+            // m = 2048, 16 levels: 8.8 vs 10.0; m = 512: 3.5 vs 3.9; 4096 x 1024, m = 1536: 3.7 vs 6.8; 784 x 4096, m = 512: 0.73
+            // vs 0.85).  Its time per step does not depend on the number of neurons up to one workgroup per CU, so narrower
+            // layers stay with the kernels that split a neuron over several wavefronts (4096 x 256, m = 1024: 3.5 vs 4.0 ms).
+            const bool fits = m > 256 && m <= 2048 && C >= 512 && M <= 64;
             const bool want = g_pipe == 1;
             if ((g_pipe == 2 || (g_pipe < 0 && !forced_old && fits)) && N > 0 && m > 0 && gpfq::blk_supported(pa) && workspace &&
                 (uintptr_t)workspace % 16 == 0 && workspace_bytes >= onchip_workspace_bytes(N, m)) {

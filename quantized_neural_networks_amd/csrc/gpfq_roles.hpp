@@ -55,6 +55,19 @@ __device__ __forceinline__ void glds4(const void *g, unsigned lds_dst_uniform)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
 }
+// The same with a wave-uniform base address in scalar registers and a 32-bit per-lane byte offset (global_load_lds ..., v, s[..]):
+// stepping the base from piece to piece is scalar arithmetic, so an LDS-DMA piece in the middle of a vector-bound loop costs
+// the loop one vector-memory issue and no vector ALU work.
+__device__ __forceinline__ void glds16_s(const void *base_uniform, unsigned lane_off, unsigned lds_dst_uniform)
+{
+    const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst_uniform);
+    const unsigned long long a = (unsigned long long)(uintptr_t)base_uniform;
+    const unsigned long long sa = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(sa), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr(const void *p)
 {
