@@ -177,7 +177,9 @@ def main():
                 "workload": (f"Dense({N}->{C_total}) whole-layer GPFQ, m={m} calibration samples, M={M} alphabet, "
                              f"alphabet_scalar={args.alphabet_scalar:g}"
                              + (" (BASELINE.json configs[1], the north-star layer)" if (N, C_total, m, M) == (4096, 4096, 1024, 3) else "")
-                             + (f"; neurons split over {world} GPUs ({args.scaling} scaling)" if world > 1 else "")),
+                             + (f"; neurons split over {world} GPUs ({args.scaling} scaling"
+                                + ("; a neuron is a chain of N dependent steps of ~1 us, so the fixed layer is latency-bound per GPU: expect a flat curve"
+                                   if args.scaling == "strong" else "") + ")" if world > 1 else "")),
                 "N": N, "C": C_total, "m": m, "M": M, "neurons_per_gpu": C_local,
                 "sharding": "neurons (columns of W) contiguous over ranks; one all-gather of packed indices per layer" if world > 1 else "none",
                 "arithmetic": "f32 products / f64 residual and dot products (reference's mixed flow)",

@@ -303,14 +303,14 @@ hipError_t launch_onchip(const OnchipArgs &a, hipStream_t stream)
 {
     // rows too long for one wavefront (or a forced split): one neuron over several wavefronts
     // ... or a layer too narrow to fill the chip with one or two neurons per wavefront: its steps are
-    // latency-bound, and splitting a neuron over 2-4 wavefronts shortens them (tools/sweep_wide.py:
+    // latency-bound, and splitting a neuron over 2-4 wavefronts shortens them (round-1 sweep:
     // C = 512, m = 1024: 1.41 -> 1.11 ms per 1024 steps; m = 2048: 2.57 -> 1.45 ms)
     const bool narrow = a.wpn == 0 && a.lpn == 0 && a.m >= 512 && a.C <= 1024;
     if (a.wpn > 1 || a.m > 2048 || narrow) {
         int W = a.wpn > 1 ? a.wpn : (int)((a.m + 1023) / 1024);
         if (narrow && a.m <= 2048) {
             // 4 (8 above 512 neurons) elements per lane, 2..4 wavefronts: multiples of 4 elements per lane keep the
-            // register-prefetch mode of the wide kernel (tools/narrow_quick.py: m = 512, C = 128: 0.92 -> 0.77 us/step)
+            // register-prefetch mode of the wide kernel (round-1 sweep: m = 512, C = 128: 0.92 -> 0.77 us/step)
             W = (int)(a.m / (64 * (a.C > 512 ? 8 : 4)));
             W = W < 2 ? 2 : W > 4 ? 4 : W;
         }
@@ -321,7 +321,7 @@ hipError_t launch_onchip(const OnchipArgs &a, hipStream_t stream)
     }
     if (a.mode == MODE_CERTIFIED && a.stats) {
         int lpn = a.big ? 1 : a.lpn;         // 65..256 members: the wavefront-per-neuron kernel (4 alphabet registers per lane)
-        if (lpn == 0) lpn = 32;                      // measured best on cfg2/cfg3-like layers (tools/sweep_shapes.py)
+        if (lpn == 0) lpn = 32;                      // measured best on cfg2/cfg3-like layers (round-1 sweep over shapes)
         while (lpn >= 16 && lpn <= 64 && !rows_supported(a, lpn)) lpn *= 2;
         if (lpn >= 16 && lpn <= 64) {
             note_dense_kernel(lpn == 16 ? "gpfq_rows_kernel<16> (row-group kernel, 4 neurons per wavefront)"

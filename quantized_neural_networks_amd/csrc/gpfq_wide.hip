@@ -399,7 +399,7 @@ static hipError_t launch_wide_epl_ar(const OnchipArgs &a, const AlphabetT<64 * A
     while (G > 1 && (a.C + G - 1) / G < 256) G >>= 1;     // narrow layers: spread the neurons over the CUs
     if constexpr (EPL % 4 == 0) {
         // register-prefetch mode, one neuron per workgroup: faster than sharing LDS-staged rows between the
-        // neurons of a workgroup at every shape measured (tools/narrow_quick.py), the rows come from L2 anyway
+        // neurons of a workgroup at every shape measured (round-1 sweep of narrow layers), the rows come from L2 anyway
         const bool aligned = (a.ld % 4 == 0) && (a.m % 4 == 0) && ((uintptr_t)a.X % 16 == 0) && ((uintptr_t)a.Xq % 16 == 0);
         if (aligned && !(a.variant & 2) && (EPL < 16 || W <= 8)) {
             hipLaunchKernelGGL((gpfq_wide_direct_kernel<EPL, true, AR>), dim3((unsigned)a.C), dim3(64 * W), 0, stream,
