@@ -178,7 +178,8 @@ static std::atomic<int> g_variant{0};          // bit 0: row-group kernel withou
 static std::atomic<int> g_pipe{-1};            // pipelined dense kernels: -1 = heuristic, 0 = never, 1 = one step per slot (gpfq_pipe.hip) whenever it
                                    // applies, 2 = blocks of steps per slot (gpfq_blk.hip) whenever it applies
 static std::atomic<int> g_conv_fused{1};       // conv channel loop: 3x3/stride-1 Gram matrices straight from the planes
-static std::atomic<int> g_conv_strip{0};       // fused conv kernel: forced strip length (0 = heuristic)
+static std::atomic<int> g_conv_strip{0};
+static std::atomic<int> g_conv_shift{1};    // fused 3x3 conv kernel with SAME padding: the shift form (0 = the per-output-position form)       // fused conv kernel: forced strip length (0 = heuristic)
 
 int gpfq_set_option(const char *key, int value)
 {
@@ -204,6 +205,10 @@ int gpfq_set_option(const char *key, int value)
     }
     if (!std::strcmp(key, "gram_slack_log2")) { g_gram_slack_log2 = value; return GPFQ_OK; }
     if (!std::strcmp(key, "conv_fused")) { g_conv_fused = value ? 1 : 0; return GPFQ_OK; }
+    if (!std::strcmp(key, "conv_shift")) {
+        if (value < 0 || value > 2) return fail(GPFQ_ERR_INVALID_ARG, "conv_shift must be 0, 1 or 2");
+        g_conv_shift = value; return GPFQ_OK;
+    }
     if (!std::strcmp(key, "conv_strip")) {
         if (value != 0 && value != 1 && value != 2 && value != 4)
             return fail(GPFQ_ERR_INVALID_ARG, "conv_strip must be 0, 1, 2 or 4");
@@ -589,6 +594,7 @@ static int conv_channels_impl(int phase, double *records, int32_t *negflags,
         g.workspace = workspace;
         g.slack = std::ldexp(1.0, g_gram_slack_log2);
         g.variant = g_conv_strip;
+        g.shift_form = g_conv_shift;
         g.phase = phase; g.records = records; g.negflags = negflags;
         hipError_t e = gpfq::launch_gram_image(g, static_cast<hipStream_t>(stream));
         return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_conv_channels(fused)");

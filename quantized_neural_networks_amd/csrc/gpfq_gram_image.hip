@@ -32,6 +32,7 @@ struct ImgParams {
     const float *act_w, *act_q;
     int64_t plane;        // n*H*W floats per channel
     int n, H, W, pad;
+    int rpad, cpad;       // zero rows above an image / zero columns left of it in the staged band (pad, pad; shift form: 2, 2)
     int PH, oh, SPR;      // padded plane height, output rows per image, strips per output row
     int grows;            // n*oh output rows in total
     int RB, nbands;       // output rows per band
@@ -74,39 +75,23 @@ __device__ __forceinline__ void load_window_row(const float *p, float (&v)[S + 2
     }
 }
 
-template <int S, int G>
-__device__ __forceinline__ void image_gram_body(const ImgParams &p, float *lds)
+// Stage padded rows [v0, v0 + nv) of channel blockIdx.y (both planes) into LDS: row r of image b's padded plane is image row
+// r - rpad (zeros outside), columns shifted by cpad.  Thread role: column piece st_c4 of rows st_row0, st_row0 + st_step, ...
+__device__ __forceinline__ void stage_band(const ImgParams &p, const float *__restrict__ pw, const float *__restrict__ pq,
+                                           float *__restrict__ lw, float *__restrict__ lq, int v0, int nv, unsigned &signs)
 {
-    Gram9 acc;                                       // only the columns of group G are ever touched
-    gram9_zero(acc);
-    const int lane = threadIdx.x & 63, pair = threadIdx.x >> 7;
-    const float *pw = p.act_w + (int64_t)blockIdx.y * p.plane;
-    const float *pq = p.act_q + (int64_t)blockIdx.y * p.plane;
-    float *lw = lds;
-    float *lq = p.same_act ? lds : lds + (size_t)p.lrows * p.LP;
     const int L4 = p.LP >> 2;
-    // staging role of this thread: column piece st_c4 of rows st_row0 + k*st_step
     const int st_c4 = threadIdx.x & ((1 << p.lpr_log2) - 1), st_row0 = threadIdx.x >> p.lpr_log2;
     const int st_step = kImgThreads >> p.lpr_log2;
-    const int st_ix = 4 * st_c4 - p.pad;
+    const int st_ix = 4 * st_c4 - p.cpad;
     const bool st_inside = st_ix >= 0 && st_ix + 3 < p.W;
-    unsigned signs = 0;                                  // neg_track() of everything this thread staged
-
-    for (int band = blockIdx.x; band < p.nbands; band += gridDim.x) {
-        const int g0 = band * p.RB;
-        const int rows = min(p.RB, p.grows - g0);
-        int oy0, oy1;
-        const int b0 = div_small(g0, p.oh, p.inv_oh, oy0);
-        const int b1 = div_small(g0 + rows - 1, p.oh, p.inv_oh, oy1);
-        const int v0 = b0 * p.PH + oy0;
-        const int nv = b1 * p.PH + oy1 + 2 - v0 + 1;
         __syncthreads();                                   // the previous band has been consumed
         if (st_c4 < L4) {
             // this thread's column piece is fixed; walk its rows st_row0, st_row0 + st_step, ... of the band
             int r;
             int b = div_small(v0 + st_row0, p.PH, p.inv_PH, r);
             for (int row = st_row0; row < nv; row += st_step) {
-                const int iy = r - p.pad;
+                const int iy = r - p.rpad;
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
                 if (b < p.n && iy >= 0 && iy < p.H) {
                     const unsigned o = ((unsigned)b * p.H + iy) * p.W + st_ix;      // plane < 2^30 floats
@@ -133,6 +118,29 @@ __device__ __forceinline__ void image_gram_body(const ImgParams &p, float *lds)
                 while (r >= p.PH) { r -= p.PH; ++b; }
             }
         }
+}
+
+template <int S, int G>
+__device__ __forceinline__ void image_gram_body(const ImgParams &p, float *lds)
+{
+    Gram9 acc;                                       // only the columns of group G are ever touched
+    gram9_zero(acc);
+    const int lane = threadIdx.x & 63, pair = threadIdx.x >> 7;
+    const float *pw = p.act_w + (int64_t)blockIdx.y * p.plane;
+    const float *pq = p.act_q + (int64_t)blockIdx.y * p.plane;
+    float *lw = lds;
+    float *lq = p.same_act ? lds : lds + (size_t)p.lrows * p.LP;
+    unsigned signs = 0;                                  // neg_track() of everything this thread staged
+
+    for (int band = blockIdx.x; band < p.nbands; band += gridDim.x) {
+        const int g0 = band * p.RB;
+        const int rows = min(p.RB, p.grows - g0);
+        int oy0, oy1;
+        const int b0 = div_small(g0, p.oh, p.inv_oh, oy0);
+        const int b1 = div_small(g0 + rows - 1, p.oh, p.inv_oh, oy1);
+        const int v0 = b0 * p.PH + oy0;
+        const int nv = b1 * p.PH + oy1 + 2 - v0 + 1;
+        stage_band(p, pw, pq, lw, lq, v0, nv, signs);
         __syncthreads();
         const int nstrips = rows * p.SPR;
         for (int q = pair * 64 + lane; q < nstrips; q += 128) {
@@ -199,6 +207,205 @@ gpfq_gram_image_kernel(ImgParams p)
     else image_gram_body<S, 1>(p, img_lds);
 }
 
+
+// ---- the shift form (SAME padding) ------------------------------------------------------------------------
+// Row t = (ky, kx) of a patch matrix is the plane shifted by (ky - 1, kx - 1), so with A = o + (ky_t - 1, kx_t - 1)
+//
+//     G1[t][s] = sum over output positions o of q[o + offs_t - 1] x[o + offs_s - 1] = sum_A q[A] x[A + d],   d = offs_s - offs_t,
+//
+// over the input positions A whose output position o = A - offs_t + 1 lies in the image (x, q read as zero outside).  For A at
+// least one step away from the border every t qualifies, and the sum depends on (t, s) only through d: the lower triangle s <= t
+// needs the 13 shifts d = (dy, dx) with dy in {-2, -1} (any dx) or dy = 0, dx <= 0, so an interior position costs
+// 13 + 13 + 1 = 27 float64 FMAs (C1[d] += q[A] x[A+d], C2[d] += q[A] q[A+d], C3 += x[A]^2) instead of the 99 of the
+// per-output-position form above.  Border positions (first / last row or column) qualify only for some t -- top row: ky_t <= 1,
+// bottom row: ky_t >= 1, likewise the columns -- so they are accumulated per border CLASS (8 classes: {top, middle, bottom} x
+// {left, middle, right} without the interior) by DEDICATED THREADS of the same kernel, from the band the workgroup has in LDS
+// anyway (a separate pass over the border columns would touch every cache line of the planes again: a row of 56 floats is two
+// lines): a thread keeps one role for the whole launch, so its private sums belong to one class.
+// The record is assembled as
+//
+//     G1[t][s] = sum over the classes c in which t qualifies of C1_c[d(t, s)]      (G2 likewise;  nx2[s]: classes in which s qualifies).
+//
+// Everything is ADDED (never a full sum minus a border): a patch row that is identically zero keeps an exactly zero norm (rule (i),
+// :83-84), and the float32 row norms (float)sqrt(G2[t][t]) come from sums of squares as before.
+constexpr int kShiftN = 27;            // C1[13], C2[13], C3
+
+template <int N>
+__device__ __forceinline__ void load_row_f(const float *p, float (&v)[N])
+{
+    if constexpr (N == 8) {                        // S = 4: 16-byte aligned
+        const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else if constexpr (N == 6) {                 // S = 2: 8-byte aligned
+        const float2 a = *reinterpret_cast<const float2 *>(p), b = *reinterpret_cast<const float2 *>(p + 2),
+                     c = *reinterpret_cast<const float2 *>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = p[i];
+    }
+}
+
+// The staged band has two zero rows above every image and two zero columns on either side.  A band is RB image rows with
+// RB * (SPR + 2) + 2 * (SPR + 2) <= 256, and every thread has ONE role:
+//   [0, RB*SPR)            a strip of S positions of band row t / SPR, middle columns enabled        (class middle-middle; rows
+//   next 2*RB              the strip that holds the first (even) / last (odd) column of band row j/2,  0 and H-1 disabled)
+//                          only that position enabled                                                 (middle-left / -right)
+//   next SPR + 2           the strips of the band's FIRST image rows (y = 0): SPR with the middle columns, then the two corners
+//   next SPR + 2           the same for the band's LAST image rows (y = H - 1)
+// All roles run the same instruction stream on a 3 x (S + 4) window (rows y-2 .. y, columns x0-2 .. x0+S+1); they differ in which
+// positions of the strip are enabled.  Middle rows are one item per thread and band; a band holds rows 0 / H-1 of at most
+// RB / H + 1 images, which their threads loop over.
+template <int S>
+__global__ void __launch_bounds__(kImgThreads, 2)
+gpfq_gram_shift_kernel(ImgParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float img_lds[];
+    double c1[13], c2[13], c3 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) { c1[i] = 0.0; c2[i] = 0.0; }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const float *pw = p.act_w + (int64_t)blockIdx.y * p.plane;
+    const float *pq = p.act_q + (int64_t)blockIdx.y * p.plane;
+    float *lw = img_lds;
+    float *lq = p.same_act ? img_lds : img_lds + (size_t)p.lrows * p.LP;
+    unsigned signs = 0;
+
+    // role of this thread: cls = 3 * cy + cx (cy: 0 first row, 1 middle rows, 2 last row; cx likewise), strip sx, enabled columns
+    const int nI = p.RB * p.SPR, nC = 2 * p.RB, nR = p.SPR + 2;
+    int cy = 1, cx = 1, my_row = 0, sx = 0;
+    bool active = true;
+    if (tid < nI) my_row = div_small(tid, p.SPR, p.inv_SPR, sx);
+    else if (tid < nI + nC) { my_row = (tid - nI) >> 1; cx = ((tid - nI) & 1) ? 2 : 0; }
+    else if (tid < nI + nC + 2 * nR) {
+        int j = tid - nI - nC;
+        cy = j < nR ? 0 : 2;
+        j -= j < nR ? 0 : nR;
+        if (j < p.SPR) sx = j; else cx = j == p.SPR ? 0 : 2;
+    } else active = false;
+    if (cx == 0) sx = 0;
+    if (cx == 2) sx = p.SPR - 1;
+    const int x0 = S * sx;
+    const int xlo = cx == 1 ? 1 : (cx == 0 ? 0 : p.W - 1), xhi = cx == 1 ? p.W - 2 : xlo;
+
+    for (int band = blockIdx.x; band < p.nbands; band += gridDim.x) {
+        const int g0 = band * p.RB;
+        const int rows = min(p.RB, p.grows - g0);
+        int oy0, oy1;
+        const int b0 = div_small(g0, p.oh, p.inv_oh, oy0);
+        const int b1 = div_small(g0 + rows - 1, p.oh, p.inv_oh, oy1);
+        const int v0 = b0 * p.PH + oy0;                     // padded row of image row oy0 - 2
+        const int nv = b1 * p.PH + oy1 + 2 - v0 + 1;
+        stage_band(p, pw, pq, lw, lq, v0, nv, signs);
+        __syncthreads();
+        // band rows of this thread: its own one (middle rows), or every image row 0 / H-1 in the band
+        int r = cy == 1 ? my_row : (cy == 0 ? (oy0 == 0 ? 0 : p.H - oy0) : p.H - 1 - oy0);
+        const int rstep = cy == 1 ? p.RB : p.H;
+        for (; active && r < rows; r += rstep) {
+            int y;
+            const int b = div_small(g0 + r, p.oh, p.inv_oh, y);
+            const int off = (b * p.PH + y - v0) * p.LP + x0;
+            const bool rowin = cy == 1 ? (y >= 1 && y <= p.H - 2) : true;      // (rows 0 / H-1 belong to their own threads)
+            double qa[S];
+            {   // own row (dy = 0): q[A], x[A] and the shifts dx = -2, -1, 0
+                float xr[S + 4], qr[S + 4];
+                load_row_f<S + 4>(lw + off + 2 * p.LP, xr);
+                load_row_f<S + 4>(lq + off + 2 * p.LP, qr);
+                double xd[S + 2], qd[S + 2];
+#pragma unroll
+                for (int i = 0; i < S + 2; ++i) { xd[i] = (double)xr[i]; qd[i] = (double)qr[i]; }
+#pragma unroll
+                for (int e = 0; e < S; ++e) {
+                    const bool in = rowin && x0 + e >= xlo && x0 + e <= xhi;
+                    qa[e] = in ? (double)qr[e + 2] : 0.0;
+                    const double xm = in ? (double)xr[e + 2] : 0.0;
+                    c3 = fma(xm, xm, c3);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        c1[10 + j] = fma(qa[e], xd[e + j], c1[10 + j]);
+                        c2[10 + j] = fma(qa[e], qd[e + j], c2[10 + j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {                   // rows y - 2, y - 1: dx = -2 .. 2
+                float xr[S + 4], qr[S + 4];
+                load_row_f<S + 4>(lw + off + k * p.LP, xr);
+                load_row_f<S + 4>(lq + off + k * p.LP, qr);
+                double xd[S + 4], qd[S + 4];
+#pragma unroll
+                for (int i = 0; i < S + 4; ++i) { xd[i] = (double)xr[i]; qd[i] = (double)qr[i]; }
+#pragma unroll
+                for (int e = 0; e < S; ++e)
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        c1[k * 5 + j] = fma(qa[e], xd[e + j], c1[k * 5 + j]);
+                        c2[k * 5 + j] = fma(qa[e], qd[e + j], c2[k * 5 + j]);
+                    }
+            }
+        }
+    }
+    if (__ballot(neg_seen(signs)) && lane == 0) atomicOr(p.negflag + blockIdx.y, 1);
+    // class sums of this workgroup through the (now idle) band LDS, nine accumulators at a time, summed in thread order
+    double *sc = reinterpret_cast<double *>(img_lds);       // [9 values + the class][256]
+    const int cls = active ? 3 * cy + cx : -1;
+    double acc[kShiftN];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) { acc[i] = c1[i]; acc[13 + i] = c2[i]; }
+    acc[26] = c3;
+    double *out = p.part + ((int64_t)blockIdx.y * p.nbx + blockIdx.x) * 9 * kShiftN;
+#pragma unroll
+    for (int round = 0; round < 3; ++round) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sc[i * kImgThreads + tid] = acc[round * 9 + i];
+        sc[9 * kImgThreads + tid] = (double)cls;
+        __syncthreads();
+        if (tid < 81) {
+            const int c = tid / 9, i = tid - 9 * c;
+            double v = 0.0;
+            for (int l = 0; l < kImgThreads; ++l) v += (int)sc[9 * kImgThreads + l] == c ? sc[i * kImgThreads + l] : 0.0;
+            out[c * kShiftN + round * 9 + i] = v;
+        }
+    }
+}
+
+// Class sums -> the N = 9 Gram record of a channel (layout of gpfq_gram.hip) + the float32 row norms.
+__global__ void __launch_bounds__(256)
+gpfq_gram_shift_combine_kernel(const double *__restrict__ part, int nparts, double *__restrict__ gram, float *__restrict__ nrm32)
+{
+    __shared__ double T[9][kShiftN];
+    const int64_t ch = blockIdx.x;
+    for (int idx = threadIdx.x; idx < 9 * kShiftN; idx += 256) {
+        double v = 0.0;
+        for (int k = 0; k < nparts; ++k) v += part[(ch * nparts + k) * 9 * kShiftN + idx];      // [class][27] per workgroup
+        T[idx / kShiftN][idx % kShiftN] = v;
+    }
+    __syncthreads();
+    // row t = (ky, kx) qualifies in class (cy, cx) unless the class is the top row and ky = 2, the bottom row and ky = 0, ...
+    auto qualifies = [](int c, int t) {
+        const int cy = c / 3, cx = c - 3 * cy, ky = t / 3, kx = t - 3 * ky;
+        return !(cy == 0 && ky == 2) && !(cy == 2 && ky == 0) && !(cx == 0 && kx == 2) && !(cx == 2 && kx == 0);
+    };
+    for (int e = threadIdx.x; e < (int)kRec9; e += 256) {
+        double v = 0.0;
+        int t = -1, s = -1, k = -1;
+        if (e < 162) {
+            k = e & 1; t = (e >> 1) / 9; s = (e >> 1) - 9 * t;
+            if (s <= t) {
+                const int dy = s / 3 - t / 3, dx = s % 3 - t % 3;            // in the lower half-plane
+                const int j = (dy < 0 ? (dy + 2) * 5 + dx + 2 : 10 + dx + 2) + 13 * k;
+                for (int c = 0; c < 9; ++c) v += qualifies(c, t) ? T[c][j] : 0.0;
+            }
+        } else {
+            s = e - 162;
+            for (int c = 0; c < 9; ++c) v += qualifies(c, s) ? T[c][26] : 0.0;
+        }
+        gram[ch * kRec9 + e] = v;
+        if (nrm32 && k == 1 && s == t) nrm32[ch * 9 + t] = (float)sqrt(v);
+    }
+}
+
 static inline size_t al256i(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int image_strip(int64_t ow, int variant)
@@ -207,29 +414,36 @@ static int image_strip(int64_t ow, int variant)
     return ow % 4 == 0 ? 4 : ow % 2 == 0 ? 2 : 1;
 }
 
-static bool image_plan(int64_t n, int64_t H, int64_t W, int pad, int variant, ImgParams *out, int *S_out, size_t *lds_out)
+// shift: the band layout of the shift form (SAME only): two zero rows above every image, none below, two zero columns on either side.
+static bool image_plan(int64_t n, int64_t H, int64_t W, int pad, int variant, ImgParams *out, int *S_out, size_t *lds_out, bool shift = false)
 {
     const int64_t oh = H + 2 * pad - 2, ow = W + 2 * pad - 2;
     if (oh <= 0 || ow <= 0 || n <= 0) return false;
     // div_small() is exact for dividends below 2^24 (float holds them exactly)
     if (n * (H + 2 * pad) >= (1LL << 24) || n * oh * ow >= (1LL << 30) || n * H * W >= (1LL << 30)) return false;
-    if (W + 2 * pad > 1020) return false;                  // a staged row is at most one piece per thread
+    if (shift && (pad != 1 || H < 4 || W < 4)) return false;          // (launch_gram_image asks for it from 12 x 12 up)
+    const int colpad = shift ? 4 : 2 * pad;
+    if (W + colpad > 1020) return false;                   // a staged row is at most one piece per thread
     const int S = image_strip(ow, variant);
     ImgParams p{};
     p.n = (int)n; p.H = (int)H; p.W = (int)W; p.pad = pad;
+    p.rpad = shift ? 2 : pad; p.cpad = shift ? 2 : pad;
     p.plane = n * H * W;
     p.PH = (int)(H + 2 * pad); p.oh = (int)oh; p.SPR = (int)(ow / S);
     p.grows = (int)(n * oh);
-    p.RB = kImgStripsPerBand / p.SPR; if (p.RB < 1) p.RB = 1;
+    p.RB = shift ? kImgThreads / (p.SPR + 2) - 2 : kImgStripsPerBand / p.SPR;       // shift: one item per thread and band (see the kernel)
+    if (shift && p.RB < 1) return false;
+    if (p.RB < 1) p.RB = 1;
     if (p.RB > p.grows) p.RB = p.grows;
     p.nbands = (p.grows + p.RB - 1) / p.RB;
-    p.LP = (int)((W + 2 * pad + 3) & ~(int64_t)3);
+    p.LP = (int)((W + colpad + 3) & ~(int64_t)3);
     p.lrows = p.RB + 2 * ((p.RB - 1) / p.oh + 2);
     int lg = 0; while ((1 << lg) < p.LP / 4) ++lg;
     p.lpr_log2 = lg;
     p.inv_SPR = 1.0f / (float)p.SPR; p.inv_oh = 1.0f / (float)p.oh; p.inv_PH = 1.0f / (float)p.PH;
-    const size_t lds = (size_t)2 * p.lrows * p.LP * sizeof(float);
+    size_t lds = (size_t)2 * p.lrows * p.LP * sizeof(float);
     if (lds > (size_t)kImgMaxLds) return false;
+    if (shift && lds < (size_t)kImgThreads * 10 * sizeof(double)) lds = (size_t)kImgThreads * 10 * sizeof(double);   // the final class sums
     if (out) *out = p;
     if (S_out) *S_out = S;
     if (lds_out) *lds_out = lds;
@@ -260,11 +474,18 @@ hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream)
     ImgParams p;
     int S;
     size_t lds;
-    if (!image_plan(a.n, a.H, a.W, a.pad, a.variant, &p, &S, &lds)) return hipErrorInvalidValue;
+    // SAME padding: the shift form (27 instead of 99 FMAs per position) wherever its band layout fits.  Measured on ResNet50's
+    // 3x3 layers at 4096 images (tools/conv3x3_probe.py, kernel alone): 56 x 56: 6.8 -> 3.1 ms, 28 x 28: 2.8 -> 1.6, 14 x 14: 1.63 ->
+    // 1.57, 7 x 7: 1.5 -> 1.7 (a third of the positions are on the border and the bands are short): from 12 x 12 up.
+    // shift_form = 2 forces it for every size it can take (tests).
+    const bool shift = a.shift_form && (a.shift_form == 2 || (a.H >= 12 && a.W >= 12)) && image_plan(a.n, a.H, a.W, a.pad, a.variant, &p, &S, &lds, true);
+    if (!shift && !image_plan(a.n, a.H, a.W, a.pad, a.variant, &p, &S, &lds)) return hipErrorInvalidValue;
     p.act_w = a.act_w; p.act_q = a.act_q; p.same_act = a.act_w == a.act_q;
     // one round of the chip: as many workgroups as are co-resident
-    const void *fn = S == 4 ? (const void *)gpfq_gram_image_kernel<4> : S == 2 ? (const void *)gpfq_gram_image_kernel<2>
-                                                                       : (const void *)gpfq_gram_image_kernel<1>;
+    const void *fn = shift ? (S == 4 ? (const void *)gpfq_gram_shift_kernel<4> : S == 2 ? (const void *)gpfq_gram_shift_kernel<2>
+                                                                                 : (const void *)gpfq_gram_shift_kernel<1>)
+                           : (S == 4 ? (const void *)gpfq_gram_image_kernel<4> : S == 2 ? (const void *)gpfq_gram_image_kernel<2>
+                                                                                 : (const void *)gpfq_gram_image_kernel<1>);
     int per_cu = 0, dev = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kImgThreads, lds) != hipSuccess || per_cu < 1) per_cu = 2;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
@@ -293,6 +514,17 @@ hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream)
         p.part = part;
         p.negflag = negflag;
         const dim3 grid((unsigned)nbx, (unsigned)a.nch), block(kImgThreads);
+        if (shift) {
+            // partials: [nch][nbx][9 classes][27], inside the area sized for the per-output-position form's records
+            switch (S) {
+            case 4:  hipLaunchKernelGGL(gpfq_gram_shift_kernel<4>, grid, block, lds, stream, p); break;
+            case 2:  hipLaunchKernelGGL(gpfq_gram_shift_kernel<2>, grid, block, lds, stream, p); break;
+            default: hipLaunchKernelGGL(gpfq_gram_shift_kernel<1>, grid, block, lds, stream, p); break;
+            }
+            hipLaunchKernelGGL(gpfq_gram_shift_combine_kernel, dim3((unsigned)a.nch), dim3(256), 0, stream, part, (int)nbx, gram, nrm);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        } else {
         switch (S) {
         case 4:  hipLaunchKernelGGL(gpfq_gram_image_kernel<4>, grid, block, lds, stream, p); break;
         case 2:  hipLaunchKernelGGL(gpfq_gram_image_kernel<2>, grid, block, lds, stream, p); break;
@@ -302,6 +534,7 @@ hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream)
         if (e != hipSuccess) return e;
         e = launch_gram_reduce(part, nbx * 2, 9, gram, nrm, a.nch, stream);
         if (e != hipSuccess) return e;
+        }
         if (a.phase == 1) {
             e = hipMemcpyAsync(a.records, gram, (size_t)a.nch * kRec9 * sizeof(double), hipMemcpyDeviceToDevice, stream);
             if (e != hipSuccess) return e;

@@ -172,6 +172,7 @@ struct ImageGramArgs {
     void *workspace;
     double slack = 1.0;
     int variant = 0;              // tuning hook: forces the strip length (1, 2, 4)
+    int shift_form = 1;           // SAME padding: shift sums (27 FMAs per position) instead of per-output-position records (99); 0 = never
     // phase 1: stop after the Gram records (written to `records` [nch][171] f64 and `negflags` [nch] i32);
     // phase 2: take the records from there instead of forming them (column-sharded multi-GPU runs sum them in between)
     int phase = 0;

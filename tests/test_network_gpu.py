@@ -376,6 +376,10 @@ def test_conv_layer_gram_fast_path(oracle_mod, slack, members):
     (170, 13, 8, 1, 2, "SAME", 2, False),      # forced strips of 2
     (170, 13, 8, 2, 2, "SAME", 1, True),       # first layer (both networks see the same data), strips of 1
     (60, 28, 28, 1, 3, "SAME", 2, False),      # 28 = 4*7: forced strips of 2
+    (500, 5, 7, 2, 3, "SAME", 0, False),       # shift form with single-position strips; 24 of 35 positions on the border
+    (1100, 4, 4, 2, 2, "SAME", 0, False),      # the smallest image the shift form takes (4 interior positions)
+    (30, 33, 18, 2, 2, "SAME", 0, True),       # strips of 2, signed first-layer input
+    (9, 64, 60, 3, 2, "SAME", 0, False),       # strips of 4, three bands per image
 ])
 def test_conv_fused_3x3(oracle_mod, n, H, W, Cin, F, padding, strip, first):
     """3x3 / stride-1 layers never build patch matrices (gpfq_gram_image.hip): the result must equal the
@@ -396,10 +400,26 @@ def test_conv_fused_3x3(oracle_mod, n, H, W, Cin, F, padding, strip, first):
         out = layer.quantize_conv2d(Wd, aw, aq, alphabet, strides=(1, 1), padding=padding, rate=(1, 1), want_resid=False)
         hip.set_option("conv_fused", 0)
         old = layer.quantize_conv2d(Wd, aw, aq, alphabet, strides=(1, 1), padding=padding, rate=(1, 1), want_resid=False)
+        hip.set_option("conv_fused", 1)
+        # SAME layers take the shift form (27 FMAs per position + border classes); conv_shift = 0 is the per-output-position form
+        hip.set_option("conv_shift", 0)
+        direct = layer.quantize_conv2d(Wd, aw, aq, alphabet, strides=(1, 1), padding=padding, rate=(1, 1), want_resid=False)
+        pw, pq = hip.channel_planes(aw, 0, Cin), hip.channel_planes(aq, 0, Cin)
+        rec0, neg0 = hip.conv_channel_records(pw, pq, (3, 3), (1, 1), (1, 1), padding)
+        hip.set_option("conv_shift", 2)                                 # the shift form whatever the image size
+        forced = layer.quantize_conv2d(Wd, aw, aq, alphabet, strides=(1, 1), padding=padding, rate=(1, 1), want_resid=False)
+        rec1, neg1 = hip.conv_channel_records(pw, pq, (3, 3), (1, 1), (1, 1), padding)
     finally:
         hip.set_option("conv_fused", 1)
         hip.set_option("conv_strip", 0)
+        hip.set_option("conv_shift", 1)
     assert torch.equal(out["Q"], old["Q"]) and torch.equal(out["idx"], old["idx"])
+    assert torch.equal(out["Q"], direct["Q"]) and torch.equal(out["idx"], direct["idx"])
+    assert torch.equal(out["Q"], forced["Q"]) and torch.equal(out["idx"], forced["idx"])
+    # the two forms sum the same exact products in different orders: records agree to float64 accumulation accuracy, entries
+    # that are exactly zero (dead channels: rule (i) needs an exactly zero norm) in one are exactly zero in the other
+    assert torch.equal(neg0, neg1) and torch.equal(rec0 == 0, rec1 == 0)
+    torch.testing.assert_close(rec1, rec0, rtol=1e-12, atol=0)
     Q = out["Q"].cpu().numpy()
     for c in range(Cin):
         Pw = ref_patches(act_w, c, 3, 3, 1, 1, 1, 1, padding)
