@@ -173,7 +173,7 @@ gpfq_gram_conv_mfma_kernel(ConvParams p)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float *pw = p.act_w + (int64_t)blockIdx.z * p.plane;
     const float *pq = p.act_q + (int64_t)blockIdx.z * p.plane;
-    const float *zero = p.zero;
+    const int64_t zoff[2] = {p.zero - pw, p.zero - pq};      // the zero word as an element offset from either plane
     const bool same = p.same_act != 0;
     for (int r = threadIdx.x; r < ROWS; r += kGramThreads) {
         const int ky = r < p.K ? r / p.kw : 0, kx = r < p.K ? r - ky * p.kw : 0;
@@ -211,10 +211,13 @@ gpfq_gram_conv_mfma_kernel(ConvParams p)
                 const int off = tap_off[row], yx = tap_yx[row];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    bool ok = row < p.K && cok[e];
-                    if (p.padded)
-                        ok = ok && (unsigned)(iy0[e] + (yx >> 16)) < (unsigned)p.H && (unsigned)(ix0[e] + (yx & 0xffff)) < (unsigned)p.W;
-                    v[set][j][e] = *(ok ? src + (base[e] + off) : zero);
+                    // branch-free and without a predicate that outlives the load: a tap outside the image (or the matrix) reads the
+                    // zero word at p.zero.  (Short-circuit conditions and a pointer select turned every element into a saveexec /
+                    // branch ladder with the 52 predicates spilled to VGPR lanes: ~1500 instructions per chunk and wavefront.)
+                    const bool in = !p.padded || (((unsigned)(iy0[e] + (yx >> 16)) < (unsigned)p.H) & ((unsigned)(ix0[e] + (yx & 0xffff)) < (unsigned)p.W));
+                    const bool ok = (row < p.K) & cok[e] & in;
+                    const int64_t idx = ok ? (int64_t)(base[e] + off) : zoff[set];
+                    v[set][j][e] = src[idx];
                 }
             }
         }
