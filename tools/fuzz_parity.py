@@ -32,12 +32,12 @@ def activations(shape, kind):
 
 
 while time.time() < t_end:
-    bits = rng.choice([np.log2(3), 2, 3, 4, 5])
+    bits = rng.choice([np.log2(3), 2, 3, 4, 5, 6, 7, 8, np.log2(129)])      # up to 256 members (int16 indices beyond 64)
     M = int(round(2 ** bits))
     scalar = float(rng.choice([1, 2, 3, 5]))
     if rng.random() < 0.5:
         # ---- dense ------------------------------------------------------------------------
-        N = int(rng.integers(1, 200)); C = int(rng.integers(1, 60))
+        N = int(rng.integers(1, 200)); C = int(rng.integers(1, 60)) if rng.random() < 0.8 else int(rng.integers(500, 700))
         m = int(rng.choice([rng.integers(1, 300), rng.integers(300, 3000), rng.integers(3000, 30000)]))
         if rng.random() < 0.15:                     # long walks (Gram path: one wavefront per neuron)
             N = int(rng.integers(200, 1025)); m = int(rng.integers(1, 2500))
@@ -55,7 +55,9 @@ while time.time() < t_end:
         if N > 200:
             path = 3
         opts = {}
-        if path == 1:
+        if path in (0, 1) and rng.random() < 0.5:   # the role-split kernels (one step / a block of steps per slot) wherever they apply
+            opts = dict(pipe=int(rng.choice([1, 2])))
+        elif path == 1:
             opts = dict(lanes_per_neuron=int(rng.choice([0, 1, 16, 32, 64])), waves_per_neuron=int(rng.choice([0, 0, 2, 4, 8, 16])),
                         onchip_mode=int(rng.integers(0, 2)))
         try:
@@ -65,11 +67,11 @@ while time.time() < t_end:
                                      alphabet, path=path)
         finally:
             for k in opts:
-                hip.set_option(k, 1 if k == "onchip_mode" else 0)
+                hip.set_option(k, 1 if k == "onchip_mode" else -1 if k == "pipe" else 0)
         ok = np.array_equal(r["idx"].cpu().numpy(), io) and np.allclose(r["resid"].cpu().numpy(), ro, rtol=1e-5, atol=0)
         n_dense += 1
         if not ok:
-            bad.append(("dense", N, m, C, M, scalar, kind, path, opts))
+            bad.append(("dense", N, m, C, M, scalar, kind, path, opts, hip.last_dense_kernel()))
     else:
         # ---- conv ---------------------------------------------------------------------------
         kh = int(rng.choice([1, 2, 3, 3, 3, 4, 5, 6, 7, 8])); kw = kh if rng.random() < 0.7 else int(rng.choice([1, 2, 3, 5, 7, 11, 17]))
@@ -95,6 +97,7 @@ while time.time() < t_end:
         alphabet, _ = layer.layer_alphabet(Wt, np.linspace(-1, 1, M), scalar)
         aw = torch.from_numpy(act_w).to(dev); aq = aw if first else torch.from_numpy(act_q).to(dev)
         want_resid = bool(rng.random() < 0.3)
+        hip.set_option("conv_shift", int(rng.choice([1, 2])))          # 2: the shift form of 3x3 / 1 / SAME layers at every image size
         out = layer.quantize_conv2d(Wt, aw, aq, alphabet, strides=(stride, stride), padding=padding, rate=(rate, rate), want_resid=want_resid)
         Q = out["Q"].cpu().numpy()
         ok = True
