@@ -27,6 +27,8 @@
 //
 // Layout: slot record t = [statistics of step t + Gram band of row t][X_{t-B}][Xq_{t-B}][Xq_{t+B} as float64],
 // zero-padded; a tile = the B records of a slot, streamed into the other LDS buffer by LDS-DMA during the slot.
+#include <type_traits>
+
 #include "gpfq_device.hpp"
 #include "gpfq_launch.hpp"
 #include "gpfq_roles.hpp"
@@ -529,21 +531,59 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             return __hiloint2double(hi, lo);
         };
 
+        // The chain of B dependent decisions is the longest path of a workgroup whenever the sweeps are short (rows of up to 768
+        // samples, alphabets beyond 16 members, few neurons per GPU), and one wavefront issues it alone: what counts is its
+        // instruction count and how early its LDS reads are issued.  So the record of a step (row statistics, the Gram-band entries
+        // of the in-block corrections) is requested one step AHEAD, at the top of the decision before -- the reads do not depend on
+        // any decision, but behind a decision's LDS stores the compiler could not move them -- and a decision is straight-line code:
+        // its outputs are selected, its stores go to a dummy slot when they are not wanted.
+        const int nvalid = (int)min((int64_t)B, N - (int64_t)b * B);            // steps beyond N pad the last block: no-ops
+        const int oslot0 = (int)(((int64_t)b * B) % kOutSteps);
+        const int o_dummy = L.off_ctl + 8;
+        double2 st01, st23, st45;                                               // record header of the step about to be decided
+        double2 bandH[B], bandE[B];                                            // its entries (s, j < s), at j
+        if (b < K.nblk) {
+            st01 = lds_ld<double2>(lds, tbase); st23 = lds_ld<double2>(lds, tbase + 16); st45 = lds_ld<double2>(lds, tbase + 32);
+        }
+
         // One decision (:83-89, :57); commit == this lane's chain is still running.  Returns false when not certifiable.
-        auto decide = [&](int s, bool commit) -> bool {
-            const int64_t t = (int64_t)b * B + s;
+        // fresh: the record values prefetched above (the hot chain); otherwise read here (the slow path's resumed chains).
+        auto decide = [&](int s, bool commit, auto inregs_tag, auto fresh_tag) -> bool {
+            constexpr bool IN_REGS = decltype(inregs_tag)::value, FRESH = decltype(fresh_tag)::value;
             const int rb = tbase + s * RB;
-            const double2 r01 = lds_ld<double2>(lds, rb), r23 = lds_ld<double2>(lds, rb + 16), r45 = lds_ld<double2>(lds, rb + 32);
+            double2 r01, r23, r45;
+            if constexpr (FRESH) { r01 = st01; r23 = st23; r45 = st45; }
+            else { r01 = lds_ld<double2>(lds, rb); r23 = lds_ld<double2>(lds, rb + 16); r45 = lds_ld<double2>(lds, rb + 32); }
             const double rden = r01.x, rG = r01.y, rcb = r23.x, rca = r23.y, rEa = r45.x, nrm = r45.y;
             const bool rule1 = nrm < 1e-16;                                      // rule (i): literal 0
             // not yet applied increments: block b-1 (formed above by sub-lane s) and this block's steps before s (distance s - j)
             double corr = quad_bcast(cPm, s), eps = quad_bcast(ePm, s);
             unsigned anyinc = anyP;
+            double2 hh[B], ee[B];
 #pragma unroll
             for (int j = 0; j < B; ++j) {
                 if (j < s) {
                     const int d = s - j;
-                    const double2 h = lds_ld<double2>(lds, rb + 64 + 32 * (d - 1)), e = lds_ld<double2>(lds, rb + 64 + 32 * (d - 1) + 16);
+                    if constexpr (FRESH) { hh[j] = bandH[j]; ee[j] = bandE[j]; }
+                    else { hh[j] = lds_ld<double2>(lds, rb + 64 + 32 * (d - 1)); ee[j] = lds_ld<double2>(lds, rb + 64 + 32 * (d - 1) + 16); }
+                }
+            }
+            if constexpr (FRESH) {                                               // the next step's record, ahead of this step's stores
+                if (s + 1 < B) {
+                    st01 = lds_ld<double2>(lds, rb + RB); st23 = lds_ld<double2>(lds, rb + RB + 16); st45 = lds_ld<double2>(lds, rb + RB + 32);
+                }
+#pragma unroll
+                for (int j = 0; j < B; ++j)
+                    if (j < s + 1 && s + 1 < B) {
+                        const int d = s + 1 - j;
+                        bandH[j] = lds_ld<double2>(lds, rb + RB + 64 + 32 * (d - 1));
+                        bandE[j] = lds_ld<double2>(lds, rb + RB + 64 + 32 * (d - 1) + 16);
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                if (j < s) {
+                    const double2 h = hh[j], e = ee[j];
                     const double wj = (double)wc[j], qj = (double)qc[j];
                     corr = fma(wj, h.x, corr); corr = fma(-qj, h.y, corr);
                     eps = fma(fabs(wj), e.x, eps); eps = fma(fabs(qj), e.y, eps);
@@ -563,7 +603,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             const double delta2 = 2.0 * (fma(fabs(wd), rcb, rca) + eps * rden)
                                   + 0x1p-43 * (fabs(D[s]) + fabs(corr) + fabs(wG)) * rden;
             int c = 0;                                                           // members below t, counted by the R sub-lanes
-            if (in_regs) {
+            if constexpr (IN_REGS) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) c += (am[q] < tt) ? 1 : 0;
             } else {
@@ -582,26 +622,36 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             const double m2 = at0 ? m2_lo : (atM ? m2_hi : m2_in);               // twice the distance from the boundary
             const bool plateau = !use_hi & (p >= 2) & !(d_ll > d_lo);            // a lower member at the same distance would win
             const bool cert = !plateau & (msq | (m2 > delta2)) & sure;
-            const bool valid = t < N;                                            // steps beyond N pad the last block: no-ops
+            const bool valid = s < nvalid;
             const float q32 = (rule1 | !valid) ? 0.f : (float)q_l;
             const int   idx = rule1 ? K.zero_idx : idx_l;
             const bool ok = rule1 | cert | !valid;
-            if (commit & ok) {
-                qc[s] = q32;
-                if (!valid) wc[s] = 0.f;
-                if (r == 0) {
-                    lds_st<float2>(lds, o_wq + cbq + 8 * s, make_float2(valid ? wc[s] : 0.f, q32));
-                    if (valid) lds_st<int2>(lds, o_out + (int)(t % kOutSteps) * 8, make_int2(idx, __float_as_int(q32)));
-                }
-            }
+            const bool sel = commit & ok;
+            qc[s] = sel ? q32 : qc[s];
+            wc[s] = (sel & !valid) ? 0.f : wc[s];
+            const bool st = sel & (r == 0);                                      // stores that are not wanted land in the dummy slot
+            lds_st<float2>(lds, st ? o_wq + cbq + 8 * s : o_dummy, make_float2(wc[s], q32));
+            lds_st<int2>(lds, (st & valid) ? o_out + ((oslot0 + s) % kOutSteps) * 8 : o_dummy, make_int2(idx, __float_as_int(q32)));
             return ok;
         };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
 
         if (b < K.nblk) {
+            if (in_regs) {
 #pragma unroll
-            for (int s = 0; s < B; ++s) {
-                const bool ok = decide(s, stop == B);
-                if (stop == B && !ok) stop = s;
+                for (int s = 0; s < B; ++s) {
+                    const bool ok = decide(s, stop == B, T_{}, T_{});
+                    stop = (stop == B && !ok) ? s : stop;
+                    __builtin_amdgcn_sched_barrier(0);            // (the next step's reads are already requested: nothing else should move up)
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < B; ++s) {
+                    const bool ok = decide(s, stop == B, F_{}, T_{});
+                    stop = (stop == B && !ok) ? s : stop;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             // smallest stop over the workgroup's active neurons (B: nobody stopped)
             int smin = active ? stop : B;
@@ -661,7 +711,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 #pragma unroll
             for (int s = 0; s < B; ++s) {
                 if (s > S) {                                      // (uniform)
-                    const bool ok = decide(s, mine && stop2 == B);
+                    const bool ok = in_regs ? decide(s, mine && stop2 == B, T_{}, F_{}) : decide(s, mine && stop2 == B, F_{}, F_{});
                     if (mine && stop2 == B && !ok) stop2 = s;
                 }
             }
