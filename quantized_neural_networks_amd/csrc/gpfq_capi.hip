@@ -309,10 +309,12 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
             const bool forced_old = g_lpn != 0 || g_wpn != 0 || g_onchip_mode != 1 || g_pipe == 0;
             // measured (tools/blk_shapes.sh): the block-pipelined kernel is ahead of the row-group and wavefront-per-neuron kernels
             // for rows of 257..2048 samples whenever the layer has 512 neurons or more (4096 x 4096, m = 1024: 4.1 vs 5.4 ms;
-            // m = 2048, 16 levels: 8.8 vs 10.0; m = 512: 3.5 vs 3.9; 4096 x 1024, m = 1536: 3.7 vs 6.8; 784 x 4096, m = 512: 0.73
-            // vs 0.85).  Its time per step does not depend on the number of neurons up to one workgroup per CU, so narrower
-            // layers stay with the kernels that split a neuron over several wavefronts (4096 x 256, m = 1024: 3.5 vs 4.0 ms).
-            const bool fits = m > 256 && m <= 2048 && C >= 512 && M <= 64;
+            // m = 2048, 16 levels: 8.7 vs 10.0; m = 512: 3.2 vs 3.9; 4096 x 1024, m = 1536: 3.7 vs 6.8; 784 x 4096, m = 512: 0.68
+            // vs 0.85).  Its time per step does not depend on the number of neurons up to one workgroup per CU; narrower layers
+            // stay with the kernels that split a neuron over several wavefronts (4096 x 128, m = 512: 3.05 vs 3.16 ms; m = 2048:
+            // 2.06 vs 2.20) -- except for rows of 769..1024 samples, where workgroups of 8 neurons make it the fastest at any
+            // width (4096 x 2048: 2.9 vs 5.4 ms; 4096 x 64: 2.8 vs 3.5).
+            const bool fits = m > 256 && m <= 2048 && M <= 64 && (C >= 512 || (m > 768 && m <= 1024));
             const bool want = g_pipe == 1;
             if ((g_pipe == 2 || (g_pipe < 0 && !forced_old && fits)) && N > 0 && m > 0 && gpfq::blk_supported(pa) && workspace &&
                 (uintptr_t)workspace % 16 == 0 && workspace_bytes >= onchip_workspace_bytes(N, m)) {
