@@ -118,7 +118,7 @@ const char *gpfq_last_dense_kernel(void);
  *   "gram_slack_log2"   Gram paths: error bounds multiplied by 2^value (tests force the repair/rerun branches)
  *   "conv_fused"   1 (default): conv layers read their patch rows from the channel planes; 0: per-channel patch matrices
  *   "conv_strip"   plane-correlation kernel: output positions per lane (0 = heuristic, 1, 2 or 4)
- *   "conv_shift"   1 (default): 3x3 / stride 1 / SAME layers on images of 12 x 12 or more accumulate shift sums (27 FMAs per
+ *   "conv_shift"   1 (default): 3x3 / stride 1 / SAME layers on images of 20 x 20 or more (shards of 8+ channels) accumulate shift sums (27 FMAs per
  *                  position, border classes apart); 0: the per-output-position records (99 FMAs) that VALID layers and small
  *                  images use; 2: the shift form for every image of 4 x 4 or more (tests)
  */

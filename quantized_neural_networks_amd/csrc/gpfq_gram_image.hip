@@ -256,7 +256,8 @@ __device__ __forceinline__ void load_row_f(const float *p, float (&v)[N])
 // All roles run the same instruction stream on a 3 x (S + 4) window (rows y-2 .. y, columns x0-2 .. x0+S+1); they differ in which
 // positions of the strip are enabled.  Middle rows are one item per thread and band; a band holds rows 0 / H-1 of at most
 // RB / H + 1 images, which their threads loop over.
-template <int S>
+// SAME_ACT: both networks see the same planes (a first layer): C2 = C1, only C1 is accumulated.
+template <int S, bool SAME_ACT>
 __global__ void __launch_bounds__(kImgThreads, 2)
 gpfq_gram_shift_kernel(ImgParams p)
 {
@@ -323,7 +324,7 @@ gpfq_gram_shift_kernel(ImgParams p)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
                         c1[10 + j] = fma(qa[e], xd[e + j], c1[10 + j]);
-                        c2[10 + j] = fma(qa[e], qd[e + j], c2[10 + j]);
+                        if (!SAME_ACT) c2[10 + j] = fma(qa[e], qd[e + j], c2[10 + j]);
                     }
                 }
             }
@@ -340,7 +341,7 @@ gpfq_gram_shift_kernel(ImgParams p)
 #pragma unroll
                     for (int j = 0; j < 5; ++j) {
                         c1[k * 5 + j] = fma(qa[e], xd[e + j], c1[k * 5 + j]);
-                        c2[k * 5 + j] = fma(qa[e], qd[e + j], c2[k * 5 + j]);
+                        if (!SAME_ACT) c2[k * 5 + j] = fma(qa[e], qd[e + j], c2[k * 5 + j]);
                     }
             }
         }
@@ -351,7 +352,7 @@ gpfq_gram_shift_kernel(ImgParams p)
     const int cls = active ? 3 * cy + cx : -1;
     double acc[kShiftN];
 #pragma unroll
-    for (int i = 0; i < 13; ++i) { acc[i] = c1[i]; acc[13 + i] = c2[i]; }
+    for (int i = 0; i < 13; ++i) { acc[i] = c1[i]; acc[13 + i] = SAME_ACT ? c1[i] : c2[i]; }
     acc[26] = c3;
     double *out = p.part + ((int64_t)blockIdx.y * p.nbx + blockIdx.x) * 9 * kShiftN;
 #pragma unroll
@@ -376,10 +377,14 @@ gpfq_gram_shift_combine_kernel(const double *__restrict__ part, int nparts, doub
 {
     __shared__ double T[9][kShiftN];
     const int64_t ch = blockIdx.x;
-    for (int idx = threadIdx.x; idx < 9 * kShiftN; idx += 256) {
+    // one wavefront per entry of the workgroups' [class][27] partials (few channels mean hundreds of workgroups per channel);
+    // lane l takes workgroups l, l + 64, ...: a fixed order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int idx = wave; idx < 9 * kShiftN; idx += 4) {
         double v = 0.0;
-        for (int k = 0; k < nparts; ++k) v += part[(ch * nparts + k) * 9 * kShiftN + idx];      // [class][27] per workgroup
-        T[idx / kShiftN][idx % kShiftN] = v;
+        for (int k = lane; k < nparts; k += 64) v += part[(ch * nparts + k) * 9 * kShiftN + idx];
+        v = wave_sum(v);
+        if (lane == 0) T[idx / kShiftN][idx % kShiftN] = v;
     }
     __syncthreads();
     // row t = (ky, kx) qualifies in class (cy, cx) unless the class is the top row and ky = 2, the bottom row and ky = 0, ...
@@ -421,7 +426,7 @@ static bool image_plan(int64_t n, int64_t H, int64_t W, int pad, int variant, Im
     if (oh <= 0 || ow <= 0 || n <= 0) return false;
     // div_small() is exact for dividends below 2^24 (float holds them exactly)
     if (n * (H + 2 * pad) >= (1LL << 24) || n * oh * ow >= (1LL << 30) || n * H * W >= (1LL << 30)) return false;
-    if (shift && (pad != 1 || H < 4 || W < 4)) return false;          // (launch_gram_image asks for it from 12 x 12 up)
+    if (shift && (pad != 1 || H < 4 || W < 4)) return false;          // (launch_gram_image asks for it from 20 x 20 up)
     const int colpad = shift ? 4 : 2 * pad;
     if (W + colpad > 1020) return false;                   // a staged row is at most one piece per thread
     const int S = image_strip(ow, variant);
@@ -476,14 +481,17 @@ hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream)
     size_t lds;
     // SAME padding: the shift form (27 instead of 99 FMAs per position) wherever its band layout fits.  Measured on ResNet50's
     // 3x3 layers at 4096 images (tools/conv3x3_probe.py, kernel alone): 56 x 56: 6.8 -> 3.1 ms, 28 x 28: 2.8 -> 1.6, 14 x 14: 1.63 ->
-    // 1.57, 7 x 7: 1.5 -> 1.7 (a third of the positions are on the border and the bands are short): from 12 x 12 up.
+    // 1.57, 7 x 7: 1.5 -> 1.7 (a third of the positions are on the border and the bands are short); the CIFAR10 CNN's layers at 5008
+    // images (tools/conv3x3_probe.py, whole layer): 32 x 32, 32 channels: 1.93 -> 1.49 ms; 24 x 24: 1.70 -> 1.50; 20 x 20: 2.24 ->
+    // 2.02; 16 x 16 loses; 3 channels at 32 x 32 (hundreds of short workgroups per channel, each with its class sums to reduce):
+    // 0.34 -> 0.50.  So: from 20 x 20 up, with 8 channels or more in the shard.
     // shift_form = 2 forces it for every size it can take (tests).
-    const bool shift = a.shift_form && (a.shift_form == 2 || (a.H >= 12 && a.W >= 12)) && image_plan(a.n, a.H, a.W, a.pad, a.variant, &p, &S, &lds, true);
+    const bool shift = a.shift_form && (a.shift_form == 2 || (a.H >= 20 && a.W >= 20 && a.nch >= 8)) && image_plan(a.n, a.H, a.W, a.pad, a.variant, &p, &S, &lds, true);
     if (!shift && !image_plan(a.n, a.H, a.W, a.pad, a.variant, &p, &S, &lds)) return hipErrorInvalidValue;
     p.act_w = a.act_w; p.act_q = a.act_q; p.same_act = a.act_w == a.act_q;
     // one round of the chip: as many workgroups as are co-resident
-    const void *fn = shift ? (S == 4 ? (const void *)gpfq_gram_shift_kernel<4> : S == 2 ? (const void *)gpfq_gram_shift_kernel<2>
-                                                                                 : (const void *)gpfq_gram_shift_kernel<1>)
+    const void *fn = shift ? (S == 4 ? (const void *)gpfq_gram_shift_kernel<4, false> : S == 2 ? (const void *)gpfq_gram_shift_kernel<2, false>
+                                                                                        : (const void *)gpfq_gram_shift_kernel<1, false>)
                            : (S == 4 ? (const void *)gpfq_gram_image_kernel<4> : S == 2 ? (const void *)gpfq_gram_image_kernel<2>
                                                                                  : (const void *)gpfq_gram_image_kernel<1>);
     int per_cu = 0, dev = 0, cus = 0;
@@ -516,11 +524,17 @@ hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream)
         const dim3 grid((unsigned)nbx, (unsigned)a.nch), block(kImgThreads);
         if (shift) {
             // partials: [nch][nbx][9 classes][27], inside the area sized for the per-output-position form's records
+#define GPFQ_SHIFT(S_)                                                                                                   \
+            do {                                                                                                             \
+                if (p.same_act) hipLaunchKernelGGL((gpfq_gram_shift_kernel<S_, true>), grid, block, lds, stream, p);         \
+                else hipLaunchKernelGGL((gpfq_gram_shift_kernel<S_, false>), grid, block, lds, stream, p);                   \
+            } while (0)
             switch (S) {
-            case 4:  hipLaunchKernelGGL(gpfq_gram_shift_kernel<4>, grid, block, lds, stream, p); break;
-            case 2:  hipLaunchKernelGGL(gpfq_gram_shift_kernel<2>, grid, block, lds, stream, p); break;
-            default: hipLaunchKernelGGL(gpfq_gram_shift_kernel<1>, grid, block, lds, stream, p); break;
+            case 4:  GPFQ_SHIFT(4); break;
+            case 2:  GPFQ_SHIFT(2); break;
+            default: GPFQ_SHIFT(1); break;
             }
+#undef GPFQ_SHIFT
             hipLaunchKernelGGL(gpfq_gram_shift_combine_kernel, dim3((unsigned)a.nch), dim3(256), 0, stream, part, (int)nbx, gram, nrm);
             e = hipGetLastError();
             if (e != hipSuccess) return e;

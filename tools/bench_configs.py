@@ -1,6 +1,6 @@
 """Single-GPU timings of the BASELINE.json configs other than the headline (parity-test cases, not
 bench lines): cfg1 MNIST MLP layer, cfg3 VGG16 fc2/fc1, cfg4 CIFAR10 CNN conv + dense layers, with
-synthetic activations of the right shapes.  Writes profiles/r01/configs.json.
+synthetic activations of the right shapes.  Writes profiles/r02/configs.json.
 
     python tools/bench_configs.py [--skip-fc1]
 """
