@@ -68,7 +68,7 @@ int main()
     const int iters = 20000;
     const char *names[4] = {"v_mfma_f64_16x16x4            ", "v_fma_f64, same multiplicands ", "v_fma_f64, one changing       ",
                             "v_fma_f64, both changing      "};
-    for (int waves = 1; waves <= 2; ++waves) {
+    for (int waves = 1; waves <= 4; ++waves) {
         for (int which = 0; which < 4; ++which) {
             hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
             dim3 grid(256 * waves), block(256);
