@@ -159,7 +159,8 @@ constexpr int kCmSplit = 4;                // partial records per walker (upper 
 
 typedef double cm_acc __attribute__((ext_vector_type(4)));
 
-template <int NB, bool REM1>
+// PADDED: some tap of some column falls outside the image (SAME padding ...): only then are the taps bounds-checked.
+template <int NB, bool REM1, bool PADDED>
 __global__ void __launch_bounds__(kGramThreads, 2)     // two workgroups per CU: one's gathers and LDS traffic under the other's MFMAs
 gpfq_gram_conv_mfma_kernel(ConvParams p)
 {
@@ -214,7 +215,7 @@ gpfq_gram_conv_mfma_kernel(ConvParams p)
                     // branch-free and without a predicate that outlives the load: a tap outside the image (or the matrix) reads the
                     // zero word at p.zero.  (Short-circuit conditions and a pointer select turned every element into a saveexec /
                     // branch ladder with the 52 predicates spilled to VGPR lanes: ~1500 instructions per chunk and wavefront.)
-                    const bool in = !p.padded || (((unsigned)(iy0[e] + (yx >> 16)) < (unsigned)p.H) & ((unsigned)(ix0[e] + (yx & 0xffff)) < (unsigned)p.W));
+                    const bool in = !PADDED || (((unsigned)(iy0[e] + (yx >> 16)) < (unsigned)p.H) & ((unsigned)(ix0[e] + (yx & 0xffff)) < (unsigned)p.W));
                     const bool ok = (row < p.K) & cok[e] & in;
                     const int64_t idx = ok ? (int64_t)(base[e] + off) : zoff[set];
                     v[set][j][e] = src[idx];
@@ -452,13 +453,19 @@ hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream)
     } else {
         if (mfma) {
             const dim3 grid((unsigned)walkers, 1, (unsigned)a.nch);
-            if (K <= 16) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<1, false>), grid, dim3(kGramThreads), 0, stream, p);
-            else if (K == 17) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<1, true>), grid, dim3(kGramThreads), 0, stream, p);
-            else if (K <= 32) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<2, false>), grid, dim3(kGramThreads), 0, stream, p);
-            else if (K == 33) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<2, true>), grid, dim3(kGramThreads), 0, stream, p);
-            else if (K <= 48) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<3, false>), grid, dim3(kGramThreads), 0, stream, p);
-            else if (K == 49) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<3, true>), grid, dim3(kGramThreads), 0, stream, p);
-            else hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<4, false>), grid, dim3(kGramThreads), 0, stream, p);
+#define GPFQ_CM(NB_, REM_)                                                                                                          \
+            do {                                                                                                                    \
+                if (p.padded) hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<NB_, REM_, true>), grid, dim3(kGramThreads), 0, stream, p);  \
+                else hipLaunchKernelGGL((gpfq_gram_conv_mfma_kernel<NB_, REM_, false>), grid, dim3(kGramThreads), 0, stream, p);          \
+            } while (0)
+            if (K <= 16) GPFQ_CM(1, false);
+            else if (K == 17) GPFQ_CM(1, true);
+            else if (K <= 32) GPFQ_CM(2, false);
+            else if (K == 33) GPFQ_CM(2, true);
+            else if (K <= 48) GPFQ_CM(3, false);
+            else if (K == 49) GPFQ_CM(3, true);
+            else GPFQ_CM(4, false);
+#undef GPFQ_CM
         } else {
             hipLaunchKernelGGL((gpfq_gram_conv_kernel<kConvTB, kConvSB>),
                                dim3((unsigned)tile_count<kConvTB, kConvSB>((int)K), (unsigned)nparts, (unsigned)a.nch), dim3(kGramThreads), 0, stream, p);
