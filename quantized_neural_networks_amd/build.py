@@ -28,9 +28,11 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++
 # gpfq_pipe.hip writes its packed float32 operations itself; the SLP vectoriser pairs unrelated products
 # through extra register moves there.
 EXTRA_FLAGS = {"gpfq_pipe.hip": ["-fno-slp-vectorize"], "gpfq_blk.hip": ["-fno-slp-vectorize"]}
-# diagnostic builds (never the shipped library): GPFQ_DIAG="-DGPFQ_BLK_STAMPS" adds in-kernel phase stamps to gpfq_blk.hip
+# diagnostic builds (never the shipped library): GPFQ_DIAG="-DGPFQ_BLK_STAMPS" adds in-kernel phase stamps to gpfq_blk.hip,
+# "-DGPFQ_WIDE_STAMPS" to the several-wavefronts-per-neuron kernel of gpfq_wide.hip (printed from the kernel)
 if os.environ.get("GPFQ_DIAG"):
-    EXTRA_FLAGS["gpfq_blk.hip"] = EXTRA_FLAGS["gpfq_blk.hip"] + os.environ["GPFQ_DIAG"].split()
+    for _src in ("gpfq_blk.hip", "gpfq_wide.hip"):
+        EXTRA_FLAGS[_src] = EXTRA_FLAGS.get(_src, []) + os.environ["GPFQ_DIAG"].split()
 
 
 def _sha(paths, extra=""):

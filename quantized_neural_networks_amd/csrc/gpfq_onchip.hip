@@ -314,6 +314,13 @@ hipError_t launch_onchip(const OnchipArgs &a, hipStream_t stream)
             W = (int)(a.m / (64 * (a.C > 512 ? 8 : 4)));
             W = W < 2 ? 2 : W > 4 ? 4 : W;
         }
+        if (a.wpn == 0 && a.m > 2048 && a.m <= 8192 && a.C <= 512) {
+            // few neurons on long rows leave most of the chip idle and a step is bound by the instructions each wavefront
+            // spends around its sweep: 8 elements per lane over 8..16 wavefronts instead of 16 over half as many
+            // (tools/wide_probe.py, one deciding wavefront per step: 2048 x 128, m = 5008: 3.29 -> 2.76 ms; m = 3000: 2.79 -> 2.32)
+            W = (int)((a.m + 511) / 512);
+            W = W < 8 ? 8 : W;
+        }
         while (W < 16 && (a.m + 64 * (int64_t)W - 1) / (64 * (int64_t)W) > 16) ++W;
         if (W > 16) W = 16;                          // rows beyond 16384: the long-row form, up to 28 elements per lane
         note_dense_kernel("gpfq_wide_kernel (one neuron over several wavefronts)");

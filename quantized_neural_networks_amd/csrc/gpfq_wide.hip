@@ -13,6 +13,7 @@
 // every wave then takes the (identical) decision itself and updates its own elements.
 #include "gpfq_device.hpp"
 #include "gpfq_launch.hpp"
+#include "gpfq_roles.hpp"
 
 namespace gpfq {
 
@@ -127,7 +128,7 @@ gpfq_wide_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int6
             // the W shares meet in LDS; slots alternate with the step parity so one barrier suffices
             double *slot = red + ((size_t)(t & 1) * G + g) * W * 2;
             if (lane == 0) { slot[2 * part] = dot_u; slot[2 * part + 1] = dot_uw; }
-            __syncthreads();
+            slot_barrier();                                    // (LDS only: not the output stores __syncthreads() would wait for)
             dot_u = 0.0; dot_uw = 0.0;
             for (int p2 = 0; p2 < W; ++p2) { dot_u += slot[2 * p2]; dot_uw += slot[2 * p2 + 1]; }   // fixed order
 
@@ -237,6 +238,12 @@ __device__ __forceinline__ void wide_fetch1(const float *__restrict__ P, int64_t
     }
 }
 
+#ifdef GPFQ_WIDE_STAMPS
+#define WSTAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WSTAMP(var) do { } while (0)
+#endif
+
 template <int EPL, bool PREFETCH, int AR>
 __global__ void __launch_bounds__((!PREFETCH || EPL >= 16) ? 512 : 1024)  // 16+ elements per lane need > 128 VGPRs
 gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld,
@@ -246,6 +253,7 @@ gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ X
                         double *__restrict__ resid, double *__restrict__ u_out)
 {
     __shared__ double red[2][16][2];                      // [step parity][wave][dot_u, dot_uw]
+    __shared__ float qdec[2];                             // [step parity] the decision, from wavefront 0
     const int lane = threadIdx.x & 63;
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t j = blockIdx.x;
@@ -267,7 +275,10 @@ gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ X
         w_next = wrow[0]; nrm_next = nrm32[0];
         if constexpr (PREFETCH) wide_fetch<EPL>(X, Xq, ld, 0, base, lane, m, aligned != 0, xn, xqn);
     }
+    unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, a_pf = 0, a_dot = 0, a_red = 0, a_dec = 0, a_upd = 0;
+    (void)w0; (void)w1; (void)w2; (void)w3; (void)w4; (void)w5; (void)a_pf; (void)a_dot; (void)a_red; (void)a_dec; (void)a_upd;
     for (int64_t t = 0; t < N; ++t) {
+        WSTAMP(w0);
         const float w = w_next, nrm = nrm_next;
         // PREFETCH: the step's row slices are already in registers.  Long-row form: the Xq slice is requested whole
         // at the top of the step and kept for both sweeps; the X slice streams through a ring of kRing 4-element
@@ -287,6 +298,7 @@ gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ X
             w_next = wrow[t + 1]; nrm_next = nrm32[t + 1];
             if constexpr (PREFETCH) wide_fetch<EPL>(X, Xq, ld, t + 1, base, lane, m, aligned != 0, xn, xqn);
         }
+        WSTAMP(w1);
         // this wave's share of <Xq_t, u> (:86) and <Xq_t, u + f32(w*X_t)> (:89)
         double d0a = 0.0, d0b = 0.0, d1a = 0.0, d1b = 0.0;
 #pragma unroll
@@ -317,18 +329,29 @@ gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ X
             for (int c = 0; c < kRing; ++c)                        // its first pieces are in flight during the decision
                 wide_fetch1<4>(X2, ld, t, base + 256 * c, lane, m, aligned != 0, *reinterpret_cast<float (*)[4]>(&x[4 * c]));
         }
+        WSTAMP(w2);
         double dot_u, dot_uw;
         wave_sum2(d0a + d0b, d1a + d1b, dot_u, dot_uw);
         double (*slot)[2] = red[t & 1];                   // slots alternate with the step parity: one barrier per step
         if (lane == 0) { slot[part][0] = dot_u; slot[part][1] = dot_uw; }
-        __syncthreads();
-        dot_u = 0.0; dot_uw = 0.0;
-        for (int p2 = 0; p2 < W; ++p2) { dot_u += slot[p2][0]; dot_uw += slot[p2][1]; }   // fixed order
-
-        const Decision dec = decide<AR>(w, nrm, dot_u, dot_uw, a_lane, A.M, A.zero_idx, ascending);
-
+        // s_waitcnt lgkmcnt(0) + s_barrier, NOT __syncthreads(): that also waits for vmcnt(0), i.e. for the NEXT step's rows
+        // requested a few hundred cycles ago -- a full L2 / HBM round trip on the critical path of every step (in-kernel
+        // stamps, Dense(2048->128) on rows of 5008 samples: 1780 of a step's 3520 cycles)
+        slot_barrier();
+        WSTAMP(w3);
+        // ONE wavefront sums the shares and decides; the others wait at the second barrier instead of repeating the ~150
+        // dependent instructions on the SIMDs they share (W / 4 wavefronts per SIMD: the step took W / 4 times the decision)
+        if (part == 0) {
+            dot_u = 0.0; dot_uw = 0.0;
+            for (int p2 = 0; p2 < W; ++p2) { dot_u += slot[p2][0]; dot_uw += slot[p2][1]; }   // fixed order
+            const Decision dec = decide<AR>(w, nrm, dot_u, dot_uw, a_lane, A.M, A.zero_idx, ascending);
+            if (lane == 0) qdec[t & 1] = (float)dec.q;
+            if (lane == (int)(t & 63)) { my_idx = dec.idx; my_q = (float)dec.q; }
+        }
+        slot_barrier();
         // u += w*X_t - q*Xq_t  (:119)
-        const float q32 = (float)dec.q;
+        const float q32 = qdec[t & 1];                    // (slots alternate with the step parity, like the shares')
+        WSTAMP(w4);
         if constexpr (PREFETCH) {
             if (q32 == 0.0f) {
 #pragma unroll
@@ -354,7 +377,10 @@ gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ X
             }
         }
 
-        if (lane == (int)(t & 63)) { my_idx = dec.idx; my_q = q32; }
+        WSTAMP(w5);
+#ifdef GPFQ_WIDE_STAMPS
+        a_pf += w1 - w0; a_dot += w2 - w1; a_red += w3 - w2; a_dec += w4 - w3; a_upd += w5 - w4;
+#endif
         if (((t + 1) & 63) == 0 || t + 1 == N) {
             const int64_t b0 = t & ~(int64_t)63;
             if (part == 0 && lane <= (int)(t & 63)) {
@@ -363,6 +389,11 @@ gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ X
             }
         }
     }
+#ifdef GPFQ_WIDE_STAMPS
+    if (blockIdx.x == 0 && lane == 0 && part == 0 && N > 0)
+        printf("wide direct kernel EPL=%d W=%d: cycles per step: prefetch issue %llu, dot %llu, reduce+barrier %llu, sum+decide %llu, update %llu\n",
+               EPL, W, a_pf / N, a_dot / N, a_red / N, a_dec / N, a_upd / N);
+#endif
 
     if (resid) {
         double ss = 0.0;

@@ -2,7 +2,7 @@ import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 from quantized_neural_networks_amd import hip, layer
-N, C, m = 2048, 128, 5008
+N, C, m = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (2048, 128, 5008)
 g = torch.Generator(device="cuda").manual_seed(1)
 W = torch.randn((N, C), device="cuda", generator=g) / np.sqrt(N)
 G = torch.randn((N, m), device="cuda", generator=g)
@@ -11,7 +11,7 @@ alphabet, _ = layer.layer_alphabet(W, np.linspace(-1, 1, 8), 4)
 Wt = W.t().contiguous()
 nrm = hip.row_norms(Xq)
 ref = None
-for wpn in (0, 6, 8, 10, 12, 16):
+for wpn in (0, 4, 6, 8, 10, 12, 16):
     hip.set_option("waves_per_neuron", wpn)
     best = 1e9
     for it in range(4):
