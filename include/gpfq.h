@@ -110,9 +110,10 @@ const char *gpfq_last_dense_kernel(void);
  *                  LDS-staged rows instead of register prefetch; bit 2: Gram records of walks longer than 64
  *                  steps on the vector units instead of the matrix cores (v_mfma_f64_16x16x4_f64);
  *                  bit 4: pipelined kernel issues its LDS-DMA spread over the steps of a tile
- *   "pipe"         role-split dense kernels (rows <= 2048 samples): -1 (default) the block form where measured faster,
- *                  0 never, 1 one step per slot (gpfq_pipe.hip) whenever it applies, 2 blocks of steps per slot
- *                  (gpfq_blk.hip) whenever it applies
+ *   "pipe"         role-split dense kernels (rows of 257..2048 samples, alphabets <= 64): -1 (default) the block form
+ *                  (gpfq_blk.hip) where measured faster -- layers of 512+ neurons, and any width for rows of 769..1024
+ *                  samples --, 0 never, 1 one step per slot (gpfq_pipe.hip) whenever it applies, 2 the block form whenever
+ *                  it applies
  *   "waves_per_neuron"  2..16: force the wide kernel (one neuron over that many wavefronts), 0 = heuristic
  *                  (rows longer than 2048 samples, and layers too narrow to fill the chip)
  *   "gram_slack_log2"   Gram paths: error bounds multiplied by 2^value (tests force the repair/rerun branches)
