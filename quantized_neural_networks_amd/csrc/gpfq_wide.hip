@@ -339,18 +339,25 @@ gpfq_wide_direct_kernel(const float *__restrict__ X, const float *__restrict__ X
         // stamps, Dense(2048->128) on rows of 5008 samples: 1780 of a step's 3520 cycles)
         slot_barrier();
         WSTAMP(w3);
-        // ONE wavefront sums the shares and decides; the others wait at the second barrier instead of repeating the ~150
-        // dependent instructions on the SIMDs they share (W / 4 wavefronts per SIMD: the step took W / 4 times the decision)
-        if (part == 0) {
+        // From five wavefronts per neuron on (they share SIMDs) ONE of them sums the shares and decides while the others wait at a
+        // second barrier, instead of all repeating the ~150 dependent instructions on the SIMDs they share (W / 4 wavefronts per
+        // SIMD: the step took W / 4 times the decision).  Up to four wavefronts each has a SIMD of its own and the repeated
+        // decision is cheaper than a second barrier (Dense(784->128), m = 512, two wavefronts: 0.80 vs 0.87 ms).
+        float qsel = 0.f;
+        if (W <= 4 || part == 0) {
             dot_u = 0.0; dot_uw = 0.0;
             for (int p2 = 0; p2 < W; ++p2) { dot_u += slot[p2][0]; dot_uw += slot[p2][1]; }   // fixed order
             const Decision dec = decide<AR>(w, nrm, dot_u, dot_uw, a_lane, A.M, A.zero_idx, ascending);
-            if (lane == 0) qdec[t & 1] = (float)dec.q;
-            if (lane == (int)(t & 63)) { my_idx = dec.idx; my_q = (float)dec.q; }
+            qsel = (float)dec.q;
+            if (lane == (int)(t & 63)) { my_idx = dec.idx; my_q = qsel; }
         }
-        slot_barrier();
+        if (W > 4) {
+            if (part == 0 && lane == 0) qdec[t & 1] = qsel;
+            slot_barrier();
+            qsel = qdec[t & 1];                           // (slots alternate with the step parity, like the shares')
+        }
         // u += w*X_t - q*Xq_t  (:119)
-        const float q32 = qdec[t & 1];                    // (slots alternate with the step parity, like the shares')
+        const float q32 = qsel;
         WSTAMP(w4);
         if constexpr (PREFETCH) {
             if (q32 == 0.0f) {
