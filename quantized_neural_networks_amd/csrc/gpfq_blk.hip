@@ -26,7 +26,17 @@
 //  The residual itself is only ever updated by the exact element-wise flow with final decisions, so u is bit-identical.
 //
 // Layout: slot record t = [statistics of step t + Gram band of row t][X_{t-B}][Xq_{t-B}][Xq_{t+B} as float64],
-// zero-padded; a tile = the B records of a slot, streamed into the other LDS buffer by LDS-DMA during the slot.
+// zero-padded; a tile = the B records of a slot, streamed into the other LDS buffer by LDS-DMA during the slot -- one 1 KiB
+// piece at a time from inside the sweep's update phase (scalar addressing): issued back to back at the top of the slot the
+// pieces filled the vector-memory queue and stalled every sweep ~1000 cycles per slot.
+//
+// Shapes (blk_shape): G neuron groups per sweep wavefront (4G neurons per workgroup), S sample pairs per k-lane over the
+// eight sweep wavefronts, B steps per slot -- <4,16|24|32,4> for rows of up to 512 / 768 / 1024 samples, <2,24|32,2> up to
+// 1536 / 2048, and <2,16,4> (8 neurons per workgroup: half the sweep per slot) for rows of 769..1024 samples when the
+// layer has at most 2048 neurons.  What bounds a slot: the sweeps (nine sample pairs on three of the SIMDs) for <4,32,4> and
+// the B = 2 shapes, the decision wavefront's chain everywhere else; it runs at raised priority (s_setprio) because it
+// shares its SIMD with two sweep wavefronts.  profiles/r02/blk_phase_stamps.txt has the per-phase cycle counts
+// (diagnostic build: GPFQ_DIAG="-DGPFQ_BLK_STAMPS").
 #include <type_traits>
 
 #include "gpfq_device.hpp"
