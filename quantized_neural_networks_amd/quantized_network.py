@@ -213,8 +213,9 @@ class QuantizedNeuralNetwork:
     # With a process group the SAMPLES are partitioned over the ranks for this part (shard_capture, on by default): every
     # rank pushes only its block of whole chunks through the layers in between, and the blocks are all-gathered when a
     # layer's inputs are needed (every rank walks all samples of its neurons / channels).  The chunk grid does not
-    # depend on the number of ranks, so each chunk goes through the same kernels with the same shapes as in a
-    # single-process run and the captured activations -- hence the quantized network -- are the same bits.
+    # depend on the number of ranks, so each chunk has the same shape as in a single-process run; the captured
+    # activations are the same bits whenever the forward kernels are deterministic across processes (GEMMs are; MIOpen's
+    # timed solver search per process can change the last bits of a convolution).
     _capture_chunk = 512
     shard_capture = True
 
