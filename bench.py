@@ -118,7 +118,7 @@ def main():
     def step(i_timed=None):
         alphabet, _ = layer.layer_alphabet(Wd, unit_alphabet, args.alphabet_scalar, group)   # N > 1: counting sharded over ranks
         lo, hi = layer.shard_bounds(C_total, world, rank)
-        Wt = Wd[:, lo:hi].t().contiguous()
+        Wt = hip.neuron_major(Wd, lo, hi)
         nrm = hip.row_norms(Xqd)
         if i_timed is not None:
             ev[i_timed][0].record()          # same stream the kernel is launched on (torch current stream)

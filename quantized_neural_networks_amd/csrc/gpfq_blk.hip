@@ -60,14 +60,18 @@ __host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B) { return 
 
 // ---- pre-pass ---------------------------------------------------------------------------------
 // One workgroup per slot record t: statistics of row t, its Gram band against rows t-1 .. t-(2B-1), float32 copies
-// of rows t-B, the float64 copy of Xq row t+B; zero-padded to mp samples.
+// of rows t-B, the float64 copy of Xq row t+B; zero-padded to mp samples.  One pass over the samples with all 3 + 4 (2B-1)
+// sums in registers and ONE workgroup reduction (a reduction per band distance made the launch latency-bound: 16 barriers
+// for two samples per thread at m = 512).
+template <int B>
 __global__ void __launch_bounds__(256)
-gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t N, int m, int mp, int B,
+gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t N, int m, int mp,
                      const float *__restrict__ nrm32, char *__restrict__ recs)
 {
-    __shared__ double sm[4][4];
+    constexpr int ND = 2 * B - 1, NV = 3 + 4 * ND;
+    __shared__ double sm[4][NV + 1];
     const int64_t t = blockIdx.x;
-    const int hdr = blk_hdr_bytes(B);
+    constexpr int hdr = blk_hdr_bytes(B);
     char *rb = recs + t * blk_rec_bytes(mp, B);
     float  *ox = reinterpret_cast<float *>(rb + hdr);
     float  *oq = ox + mp;
@@ -79,18 +83,9 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double up = 1.0 + 0x1p-20;
 
-    auto block_sum4 = [&](double (&v)[4]) {
+    double v[NV];                                             // G, sum|Xq X|, sum|Xq|, then (H1, H2, sum|.|, sum|.|) per distance
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
-        __syncthreads();
-        if (lane == 0)
-            for (int k = 0; k < 4; ++k) sm[k][wave] = v[k];
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (sm[k][0] + sm[k][1]) + (sm[k][2] + sm[k][3]);
-    };
-
-    double v[4] = {0.0, 0.0, 0.0, 0.0};                       // G, sum|Xq X|, sum|Xq|
+    for (int k = 0; k < NV; ++k) v[k] = 0.0;
     for (int i = threadIdx.x; i < mp; i += 256) {
         const bool in = i < m;
         ox[i] = (has_prev && in) ? px[i] : 0.f;
@@ -99,36 +94,39 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
         if (has_cur && in) {
             const double q = (double)cq[i], pr = q * (double)cx[i];   // products of two f32 are exact in f64
             v[0] += pr; v[1] += fabs(pr); v[2] += fabs(q);
+#pragma unroll
+            for (int d = 1; d <= ND; ++d) {
+                if (t - d < 0) break;
+                const double p1 = q * (double)X[(t - d) * ld + i], p2 = q * (double)Xq[(t - d) * ld + i];
+                v[3 + 4 * (d - 1) + 0] += p1;       v[3 + 4 * (d - 1) + 1] += p2;
+                v[3 + 4 * (d - 1) + 2] += fabs(p1); v[3 + 4 * (d - 1) + 3] += fabs(p2);
+            }
         }
     }
-    block_sum4(v);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const double s = wave_sum(v[k]);
+        if (lane == 0) sm[wave][k] = s;
+    }
+    __syncthreads();
+    auto total = [&](int k) { return (sm[0][k] + sm[1][k]) + (sm[2][k] + sm[3][k]); };
     if (threadIdx.x == 0) {
         BlkStats st{};
         const double nrm = has_cur ? (double)nrm32[t] : 0.0;
+        const double s1 = total(1), s2 = total(2);
         st.nrm = nrm;
         st.rden = nrm < 1e-16 ? 0.0 : 1.0 / (nrm * nrm);
-        st.G = v[0];
-        st.cb = 0x1p-23 * v[1] * st.rden * up;
-        st.ca = 0x1p-149 * v[2] * st.rden * up;
-        st.Ea = 0x1p-149 * v[2] * up;
+        st.G = total(0);
+        st.cb = 0x1p-23 * s1 * st.rden * up;
+        st.ca = 0x1p-149 * s2 * st.rden * up;
+        st.Ea = 0x1p-149 * s2 * up;
         *reinterpret_cast<BlkStats *>(rb) = st;
-    }
-    for (int d = 1; d <= 2 * B - 1; ++d) {
-        double h[4] = {0.0, 0.0, 0.0, 0.0};
-        if (has_cur && t - d >= 0) {
-            const float *bx = X + (t - d) * ld, *bq = Xq + (t - d) * ld;
-            for (int i = threadIdx.x; i < m; i += 256) {
-                const double q = (double)cq[i];
-                const double p1 = q * (double)bx[i], p2 = q * (double)bq[i];
-                h[0] += p1; h[1] += p2; h[2] += fabs(p1); h[3] += fabs(p2);
-            }
-        }
-        block_sum4(h);
-        if (threadIdx.x == 0) {
-            BandEntry e;
-            e.H1 = h[0]; e.H2 = h[1]; e.E1 = 0x1p-23 * h[2] * up; e.E2 = 0x1p-23 * h[3] * up;
-            *reinterpret_cast<BandEntry *>(rb + 64 + 32 * (d - 1)) = e;
-        }
+    } else if (threadIdx.x <= ND) {
+        const int d = threadIdx.x;
+        BandEntry e;
+        e.H1 = total(3 + 4 * (d - 1)); e.H2 = total(4 + 4 * (d - 1));
+        e.E1 = 0x1p-23 * total(5 + 4 * (d - 1)) * up; e.E2 = 0x1p-23 * total(6 + 4 * (d - 1)) * up;
+        *reinterpret_cast<BandEntry *>(rb + 64 + 32 * (d - 1)) = e;
     }
 }
 
@@ -858,7 +856,8 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     if (!sh.G) return hipErrorInvalidValue;
     const int64_t nblk = (a.N + sh.B - 1) / sh.B;
     const int64_t nrec = (nblk + 1) * sh.B + 1;
-    hipLaunchKernelGGL(gpfq_blk_prep_kernel, dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp, sh.B,
+    auto *prep = sh.B == 4 ? gpfq_blk_prep_kernel<4> : gpfq_blk_prep_kernel<2>;
+    hipLaunchKernelGGL(prep, dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp,
                        a.nrm32, static_cast<char *>(a.workspace));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

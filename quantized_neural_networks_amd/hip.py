@@ -286,6 +286,23 @@ def channel_planes(act, c_lo, c_hi):
     return out
 
 
+def neuron_major(W, lo=0, hi=None):
+    """Keras kernel W f32 [N][C] -> the neuron-major shard Wt f32 [hi - lo][N] = W[:, lo:hi].T (what the pool hands its workers,
+    scripts/quantized_network.py:553-556).  The same LDS-tiled transposing copy as channel_planes (gpfq_channel_planes with the
+    neurons as "channels"): ~30 us for a 4096 x 4096 kernel against ~65 us for torch's strided copy."""
+    _dev(W, torch.float32, "W")
+    if W.dim() != 2 or not W.is_contiguous():
+        raise GpfqError("neuron_major needs a contiguous [N][C] kernel")
+    N, C = W.shape
+    hi = C if hi is None else hi
+    out = torch.empty((hi - lo, N), dtype=torch.float32, device=W.device)
+    if hi > lo and N > 0:
+        with torch.cuda.device(W.device):
+            rc = load().gpfq_channel_planes(W.data_ptr(), N, C, lo, hi - lo, out.data_ptr(), _stream())
+        _check(rc, "gpfq_channel_planes")
+    return out
+
+
 def quantize_conv_channels(act_w_cm, act_q_cm, Wt_all, alphabet, kernel_size, strides, rate, padding,
                            idx, Q, resid, unc):
     """All channels of a conv layer shard in one library call (gpfq_quantize_conv_channels).

@@ -100,7 +100,7 @@ def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True):
     N, C = W.shape
     world, rank = _group_info(group)
     lo, hi = shard_bounds(C, world, rank)
-    Wt = W[:, lo:hi].t().contiguous()                        # neuron-major shard [C_local][N]
+    Wt = hip.neuron_major(W.contiguous(), lo, hi)            # neuron-major shard [C_local][N]
     if hi > lo:
         r = hip.quantize_neurons(X, Xq, Wt, alphabet, want_values=False, want_resid=want_resid)
         i_loc, res_loc = r["idx"], r["resid"]

@@ -51,12 +51,16 @@ def _standin_planes(act, c_lo, c_hi):
     return act[..., c_lo:c_hi].permute(3, 0, 1, 2).contiguous()
 
 
+def _standin_neuron_major(W, lo=0, hi=None):
+    return W[:, lo:hi].t().contiguous()
+
+
 def _install_standins():
     """Swap the binding's entry points for CPU stand-ins in THIS process; returns the originals."""
     sys.path.insert(0, ROOT)
     from quantized_neural_networks_amd import hip
     names = dict(quantize_neurons=_standin_quantize, extract_patches=_standin_patches, assemble_kernel=_standin_assemble,
-                 pack_indices=_standin_pack, channel_planes=_standin_planes)
+                 pack_indices=_standin_pack, channel_planes=_standin_planes, neuron_major=_standin_neuron_major)
     keep = {k: getattr(hip, k) for k in names}
     for k, v in names.items():
         setattr(hip, k, v)
