@@ -116,10 +116,15 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i_timed=None):
-        alphabet, _ = layer.layer_alphabet(Wd, unit_alphabet, args.alphabet_scalar, group)   # N > 1: counting sharded over ranks
         lo, hi = layer.shard_bounds(C_total, world, rank)
-        Wt = hip.neuron_major(Wd, lo, hi)
-        nrm = hip.row_norms(Xqd)
+        pre = {}
+
+        def alphabet_free_work():            # queued behind the median kernels, runs while the host waits for the radius
+            pre["Wt"] = hip.neuron_major(Wd, lo, hi)
+            pre["nrm"] = hip.row_norms(Xqd)
+
+        alphabet, _ = layer.layer_alphabet(Wd, unit_alphabet, args.alphabet_scalar, group, alphabet_free_work)   # N > 1: counting sharded over ranks
+        Wt, nrm = pre["Wt"], pre["nrm"]
         if i_timed is not None:
             ev[i_timed][0].record()          # same stream the kernel is launched on (torch current stream)
         r = hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm, want_values=False)

@@ -69,7 +69,7 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
                      const float *__restrict__ nrm32, char *__restrict__ recs)
 {
     constexpr int ND = 2 * B - 1, NV = 3 + 4 * ND;
-    __shared__ double sm[4][NV + 1];
+    __shared__ double sm[4][((NV + 3) & ~3) + 1];
     const int64_t t = blockIdx.x;
     constexpr int hdr = blk_hdr_bytes(B);
     char *rb = recs + t * blk_rec_bytes(mp, B);
@@ -83,9 +83,10 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double up = 1.0 + 0x1p-20;
 
-    double v[NV];                                             // G, sum|Xq X|, sum|Xq|, then (H1, H2, sum|.|, sum|.|) per distance
+    constexpr int NP = (NV + 3) & ~3;
+    double v[NP];                                             // G, sum|Xq X|, sum|Xq|, then (H1, H2, sum|.|, sum|.|) per distance
 #pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = 0.0;
+    for (int k = 0; k < NP; ++k) v[k] = 0.0;
     for (int i = threadIdx.x; i < mp; i += 256) {
         const bool in = i < m;
         ox[i] = (has_prev && in) ? px[i] : 0.f;
@@ -103,10 +104,14 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
             }
         }
     }
+    // wavefront sums four values at a time: halves and rows fold by swaps (row r ends up with value r of the group), then
+    // rotations inside the rows -- 7 additions per group instead of 24 for four separate butterflies (the launch is bound by
+    // exactly this arithmetic: ~4 samples per thread against 31 sums)
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const double s = wave_sum(v[k]);
-        if (lane == 0) sm[wave][k] = s;
+    for (int g = 0; g < NP / 4; ++g) {
+        double x = fold16(fold32(v[4 * g], v[4 * g + 2]), fold32(v[4 * g + 1], v[4 * g + 3]));
+        x = ror_add<8>(x); x = ror_add<4>(x); x = ror_add<2>(x); x = ror_add<1>(x);
+        if ((lane & 15) == 0) sm[wave][4 * g + (lane >> 4)] = x;
     }
     __syncthreads();
     auto total = [&](int k) { return (sm[0][k] + sm[1][k]) + (sm[2][k] + sm[3][k]); };

@@ -306,106 +306,112 @@ hipError_t launch_pack(const int8_t *qidx, int64_t N, int64_t C, int bits, uint8
 // ---- median of |W| ---------------------------------------------------------------------------
 // np.median(np.abs(W.flatten())) on float32 data (scripts/quantized_network.py:544, :831) without a
 // sort: exact radix select on the bit patterns of |w| (monotone as unsigned integers), three
-// histogram passes of 11 + 11 + 10 bits per order statistic.  For an even count NumPy returns the
-// float32 mean of the two middle values, so both are selected.
+// histogram passes of 11 + 11 + 10 bits.  For an even count NumPy returns the float32 mean of the two
+// middle values, so both are selected -- in the SAME three passes over the data: the two ranks are
+// adjacent, so they nearly always share the class being refined (one histogram serves both); when
+// they have parted, the pass counts two classes from the one read.
 struct SelState {
     unsigned prefix;            // bits of the answer fixed so far
-    unsigned done;              // 1: already resolved (the second order statistic, from the first one's last pass)
+    unsigned pad;
     unsigned long long k;       // rank still to be resolved inside the prefix class
 };
 
 constexpr int kSelBins = 2048;
+constexpr int kSelThreads = 1024;
 
-__global__ void __launch_bounds__(256)
-gpfq_select_hist_kernel(const float *__restrict__ W, int64_t n, const SelState *__restrict__ st,
+// Few, large workgroups: every workgroup ends with one global atomic per non-empty bin, and in the first pass all of them
+// hit the same ~40 bins (same-address atomics serialise in L2: with 1024 workgroups that tail was two thirds of the pass).
+__global__ void __launch_bounds__(kSelThreads)
+gpfq_select_hist_kernel(const float *__restrict__ W, int64_t n, const SelState *__restrict__ st, int nsel,
                         int shift, int nbits, unsigned *__restrict__ hist)
 {
-    if (st->done) return;
-    __shared__ unsigned h[kSelBins];
-    for (int b = threadIdx.x; b < kSelBins; b += 256) h[b] = 0;
+    __shared__ unsigned h[2][kSelBins];
+    const unsigned p0 = st[0].prefix, p1 = nsel > 1 ? st[1].prefix : p0;
+    const bool split = p1 != p0;
+    for (int b = threadIdx.x; b < kSelBins; b += kSelThreads) { h[0][b] = 0; h[1][b] = 0; }
     __syncthreads();
-    const unsigned prefix = st->prefix;
     const unsigned hi_mask = (shift + nbits >= 32) ? 0u : ~((1u << (shift + nbits)) - 1u);
     const unsigned bin_mask = (1u << nbits) - 1u;
-    const int64_t stride = (int64_t)gridDim.x * 256;
+    auto count = [&](float w) {
+        const unsigned key = __float_as_uint(w) & 0x7fffffffu, cls = key & hi_mask, bin = (key >> shift) & bin_mask;
+        if (cls == p0) atomicAdd(&h[0][bin], 1u);
+        else if (split && cls == p1) atomicAdd(&h[1][bin], 1u);
+    };
+    const int64_t stride = (int64_t)gridDim.x * kSelThreads;
     const int64_t n4 = ((uintptr_t)W % 16 == 0) ? n / 4 : 0;
     const float4 *W4 = reinterpret_cast<const float4 *>(W);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    for (int64_t i = (int64_t)blockIdx.x * kSelThreads + threadIdx.x; i < n4; i += stride) {
         const float4 v = W4[i];
-        const unsigned k0 = __float_as_uint(v.x) & 0x7fffffffu, k1 = __float_as_uint(v.y) & 0x7fffffffu;
-        const unsigned k2 = __float_as_uint(v.z) & 0x7fffffffu, k3 = __float_as_uint(v.w) & 0x7fffffffu;
-        if ((k0 & hi_mask) == prefix) atomicAdd(&h[(k0 >> shift) & bin_mask], 1u);
-        if ((k1 & hi_mask) == prefix) atomicAdd(&h[(k1 >> shift) & bin_mask], 1u);
-        if ((k2 & hi_mask) == prefix) atomicAdd(&h[(k2 >> shift) & bin_mask], 1u);
-        if ((k3 & hi_mask) == prefix) atomicAdd(&h[(k3 >> shift) & bin_mask], 1u);
+        count(v.x); count(v.y); count(v.z); count(v.w);
     }
-    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const unsigned key = __float_as_uint(W[i]) & 0x7fffffffu;
-        if ((key & hi_mask) == prefix) atomicAdd(&h[(key >> shift) & bin_mask], 1u);
-    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * kSelThreads + threadIdx.x; i < n; i += stride) count(W[i]);
     __syncthreads();
-    for (int b = threadIdx.x; b < kSelBins; b += 256)
-        if (h[b]) atomicAdd(&hist[b], h[b]);
+    // (while the two order statistics share their class, the second histogram stays empty and the pick reads the first)
+    for (int b = threadIdx.x; b < kSelBins; b += kSelThreads) {
+        const unsigned c0 = h[0][b], c1 = h[1][b];
+        if (c0) atomicAdd(&hist[b], c0);
+        if (c1) atomicAdd(&hist[kSelBins + b], c1);
+    }
 }
 
-// Locate the bin holding rank k (parallel: 256 threads x 8 bins), fix its bits, clear the histogram.
-// On the last pass of the first order statistic (`next` != NULL) the following order statistic is
-// resolved too when it lies in the same 2^10-value class: the same value if the bin holds more
-// elements beyond rank k, otherwise the next non-empty bin.
+// Locate the bin holding rank k (parallel: 256 threads x 8 bins) for each order statistic in turn, fix its bits, clear the
+// histograms.  `out` != NULL (last pass): the median itself -- for an even count the float32 mean of the two middle values.
 __global__ void __launch_bounds__(256)
-gpfq_select_pick_kernel(unsigned *__restrict__ hist, SelState *__restrict__ st, int shift, int nbits,
-                        SelState *__restrict__ next)
+gpfq_select_pick_kernel(unsigned *__restrict__ hist, SelState *__restrict__ st, int nsel, int shift, int nbits,
+                        float *__restrict__ out)
 {
-    if (st->done) return;
     __shared__ unsigned h[kSelBins];
     __shared__ unsigned long long part[256];
     __shared__ int found_bin;
     __shared__ unsigned long long found_rank;
-    __shared__ unsigned next_bin;
     const int bins = 1 << nbits;
     const int tid = threadIdx.x;
-    for (int b = tid; b < kSelBins; b += 256) { h[b] = b < bins ? hist[b] : 0u; hist[b] = 0u; }
-    if (tid == 0) { found_bin = bins - 1; found_rank = 0; next_bin = 0xffffffffu; }
-    __syncthreads();
-    unsigned long long mine = 0;
-    for (int b = 0; b < 8; ++b) mine += h[tid * 8 + b];
-    part[tid] = mine;
-    __syncthreads();
-    unsigned long long before = 0;
-    for (int i = 0; i < tid; ++i) before += part[i];
-    const unsigned long long k = st->k;
-    if (before <= k && k < before + mine) {               // exactly one thread (or none if k is out of range)
-        unsigned long long acc = before;
-        int b = tid * 8;
-        for (; b < tid * 8 + 7; ++b) {
-            if (acc + h[b] > k) break;
-            acc += h[b];
+    const bool split = nsel > 1 && st[1].prefix != st[0].prefix;
+    __syncthreads();                                          // (everyone has read the prefixes before thread 0 moves them)
+    for (int sel = 0; sel < nsel; ++sel) {
+        const unsigned *src = hist + ((sel && split) ? kSelBins : 0);
+        for (int b = tid; b < kSelBins; b += 256) h[b] = b < bins ? src[b] : 0u;
+        if (tid == 0) { found_bin = bins - 1; found_rank = 0; }
+        __syncthreads();
+        unsigned long long mine = 0;
+        for (int b = 0; b < 8; ++b) mine += h[tid * 8 + b];
+        part[tid] = mine;
+        __syncthreads();
+        unsigned long long before = 0;
+        for (int i = 0; i < tid; ++i) before += part[i];
+        const unsigned long long k = st[sel].k;
+        if (before <= k && k < before + mine) {           // exactly one thread (or none if k is out of range)
+            unsigned long long acc = before;
+            int b = tid * 8;
+            for (; b < tid * 8 + 7; ++b) {
+                if (acc + h[b] > k) break;
+                acc += h[b];
+            }
+            found_bin = b;
+            found_rank = k - acc;
         }
-        found_bin = b;
-        found_rank = k - acc;
-    }
-    __syncthreads();
-    if (next) {
-        const int fb = found_bin;
-        for (int b = tid * 8; b < tid * 8 + 8; ++b)
-            if (b > fb && h[b]) { atomicMin(&next_bin, (unsigned)b); break; }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned prefix = st->prefix | ((unsigned)found_bin << shift);
-        if (next) {
-            if (found_rank + 1 < h[found_bin]) { next->prefix = prefix; next->done = 1; }
-            else if (next_bin != 0xffffffffu) { next->prefix = st->prefix | (next_bin << shift); next->done = 1; }
+        __syncthreads();
+        if (tid == 0) {
+            st[sel].k = found_rank;
+            st[sel].prefix = st[sel].prefix | ((unsigned)found_bin << shift);
         }
-        st->k = found_rank;
-        st->prefix = prefix;
+        __syncthreads();
+    }
+    for (int b = tid; b < 2 * kSelBins; b += 256) hist[b] = 0u;
+    if (out && tid == 0) {
+        const float a = __uint_as_float(st[0].prefix);
+        *out = nsel > 1 ? __fdiv_rn(__fadd_rn(a, __uint_as_float(st[1].prefix)), 2.0f) : a;
     }
 }
 
-__global__ void gpfq_select_init_kernel(SelState *st, unsigned long long k0, unsigned long long k1)
+__global__ void __launch_bounds__(256)
+gpfq_select_init_kernel(SelState *st, unsigned *hist, unsigned long long k0, unsigned long long k1)
 {
-    st[0].prefix = 0; st[0].done = 0; st[0].k = k0;
-    st[1].prefix = 0; st[1].done = 0; st[1].k = k1;
+    for (int b = threadIdx.x; b < 2 * kSelBins; b += 256) hist[b] = 0u;
+    if (threadIdx.x == 0) {
+        st[0].prefix = 0; st[0].pad = 0; st[0].k = k0;
+        st[1].prefix = 0; st[1].pad = 0; st[1].k = k1;
+    }
 }
 
 __global__ void gpfq_select_finish_kernel(const SelState *st, int even, float *out)
@@ -418,76 +424,60 @@ __global__ void gpfq_select_finish_kernel(const SelState *st, int even, float *o
 
 size_t median_workspace_bytes() { return 2 * sizeof(SelState) + 2 * kSelBins * sizeof(unsigned) + 64; }
 
-hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream)
-{
-    SelState *st = static_cast<SelState *>(workspace);
-    unsigned *hist = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + 64);
-    hipError_t e = hipMemsetAsync(hist, 0, 2 * kSelBins * sizeof(unsigned), stream);
-    if (e != hipSuccess) return e;
-    const bool even = (n % 2) == 0;
-    const unsigned long long k0 = even ? (unsigned long long)(n / 2 - 1) : (unsigned long long)(n / 2);
-    hipLaunchKernelGGL(gpfq_select_init_kernel, dim3(1), dim3(1), 0, stream, st, k0, (unsigned long long)(n / 2));
-    int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
-    if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
-    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
-    for (int sel = 0; sel < (even ? 2 : 1); ++sel)
-        for (int p = 0; p < 3; ++p) {
-            hipLaunchKernelGGL(gpfq_select_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
-                               W, n, st + sel, shifts[p], widths[p], hist + sel * kSelBins);
-            hipLaunchKernelGGL(gpfq_select_pick_kernel, dim3(1), dim3(256), 0, stream,
-                               hist + sel * kSelBins, st + sel, shifts[p], widths[p],
-                               (even && sel == 0 && p == 2) ? st + 1 : static_cast<SelState *>(nullptr));
-        }
-    hipLaunchKernelGGL(gpfq_select_finish_kernel, dim3(1), dim3(1), 0, stream, st, even ? 1 : 0, out);
-    return hipGetLastError();
-}
+static const int kSelShifts[3] = {21, 10, 0}, kSelWidths[3] = {11, 11, 10};
 
-// The same select with the elements partitioned over ranks (every rank holds the whole layer, each counts
-// one slice): per pass the ranks histogram their slices for both order statistics, the caller sums the two
-// histograms over the ranks (8 KiB each, one all-reduce), and every rank picks the same bins.
+static SelState *sel_state(void *workspace) { return static_cast<SelState *>(workspace); }
+static unsigned *sel_hist(void *workspace) { return reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + 64); }
+static int sel_count(int64_t n_total) { return (n_total % 2) == 0 ? 2 : 1; }
+
+// The select with the elements partitioned over ranks (every rank holds the whole layer, each counts one slice): per pass
+// the ranks histogram their slices, the caller sums the histograms over the ranks (2 x 8 KiB, one all-reduce), and every
+// rank picks the same bins.  launch_median_abs is the one-rank sequence of the same kernels.
 hipError_t launch_median_begin(int64_t n_total, void *workspace, hipStream_t stream)
 {
-    SelState *st = static_cast<SelState *>(workspace);
-    unsigned *hist = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + 64);
-    hipError_t e = hipMemsetAsync(hist, 0, 2 * kSelBins * sizeof(unsigned), stream);
-    if (e != hipSuccess) return e;
     const bool even = (n_total % 2) == 0;
     const unsigned long long k0 = even ? (unsigned long long)(n_total / 2 - 1) : (unsigned long long)(n_total / 2);
-    hipLaunchKernelGGL(gpfq_select_init_kernel, dim3(1), dim3(1), 0, stream, st, k0, (unsigned long long)(n_total / 2));
+    hipLaunchKernelGGL(gpfq_select_init_kernel, dim3(1), dim3(256), 0, stream, sel_state(workspace), sel_hist(workspace), k0,
+                       (unsigned long long)(n_total / 2));
     return hipGetLastError();
 }
-
-static const int kSelShifts[3] = {21, 10, 0}, kSelWidths[3] = {11, 11, 10};
 
 hipError_t launch_median_count(const float *W_local, int64_t n_local, int64_t n_total, int pass, void *workspace, hipStream_t stream)
 {
-    SelState *st = static_cast<SelState *>(workspace);
-    unsigned *hist = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + 64);
     if (n_local <= 0) return hipSuccess;
-    int64_t blocks = (n_local + 256 * 16 - 1) / (256 * 16);
-    if (blocks > 1024) blocks = 1024;
-    for (int sel = 0; sel < ((n_total % 2) == 0 ? 2 : 1); ++sel)
-        hipLaunchKernelGGL(gpfq_select_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
-                           W_local, n_local, st + sel, kSelShifts[pass], kSelWidths[pass], hist + sel * kSelBins);
+    int64_t blocks = (n_local + kSelThreads * 16 - 1) / (kSelThreads * 16);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(gpfq_select_hist_kernel, dim3((unsigned)blocks), dim3(kSelThreads), 0, stream,
+                       W_local, n_local, sel_state(workspace), sel_count(n_total), kSelShifts[pass], kSelWidths[pass], sel_hist(workspace));
+    return hipGetLastError();
+}
+
+static hipError_t median_pick(int64_t n_total, int pass, void *workspace, float *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(gpfq_select_pick_kernel, dim3(1), dim3(256), 0, stream, sel_hist(workspace), sel_state(workspace),
+                       sel_count(n_total), kSelShifts[pass], kSelWidths[pass], out);
     return hipGetLastError();
 }
 
 hipError_t launch_median_pick(int64_t n_total, int pass, void *workspace, hipStream_t stream)
 {
-    SelState *st = static_cast<SelState *>(workspace);
-    unsigned *hist = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + 64);
-    for (int sel = 0; sel < ((n_total % 2) == 0 ? 2 : 1); ++sel)
-        hipLaunchKernelGGL(gpfq_select_pick_kernel, dim3(1), dim3(256), 0, stream,
-                           hist + sel * kSelBins, st + sel, kSelShifts[pass], kSelWidths[pass], static_cast<SelState *>(nullptr));
-    return hipGetLastError();
+    return median_pick(n_total, pass, workspace, nullptr, stream);
 }
 
 hipError_t launch_median_end(int64_t n_total, void *workspace, float *out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(gpfq_select_finish_kernel, dim3(1), dim3(1), 0, stream, static_cast<SelState *>(workspace),
-                       (n_total % 2) == 0 ? 1 : 0, out);
+    hipLaunchKernelGGL(gpfq_select_finish_kernel, dim3(1), dim3(1), 0, stream, sel_state(workspace), sel_count(n_total) - 1, out);
     return hipGetLastError();
+}
+
+hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream)
+{
+    hipError_t e = launch_median_begin(n, workspace, stream);
+    for (int p = 0; p < 3 && e == hipSuccess; ++p) {
+        e = launch_median_count(W, n, n, p, workspace, stream);
+        if (e == hipSuccess) e = median_pick(n, p, workspace, p == 2 ? out : nullptr, stream);
+    }
+    return e;
 }
 
 }  // namespace gpfq

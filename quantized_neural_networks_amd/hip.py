@@ -476,9 +476,29 @@ def assemble_kernel(qidx, alphabet, want_idx=True, bits=None, N=None):
     return Q, idx_t
 
 
-def median_abs(W):
-    """np.median(np.abs(W.flatten())) of a float32 GPU tensor as a numpy float32 (exact select)."""
+_pinned = {}
+
+
+def _read_scalar(out, meanwhile=None):
+    """The float32 device scalar `out` on the host.  `meanwhile` (a callable, optional) is run after the copy has been queued
+    and before the host waits for it: kernel launches that do not depend on the value (the layer's transposes and row
+    norms) keep the GPU busy while the host wakes up, instead of a launch bubble after every median."""
     import numpy as np
+    key = (out.device.index, torch.cuda.current_stream(out.device).cuda_stream)
+    slot = _pinned.get(key)
+    if slot is None:
+        slot = _pinned[key] = (torch.empty(1, dtype=torch.float32).pin_memory(), torch.cuda.Event())
+    host, ev = slot
+    host.copy_(out, non_blocking=True)
+    ev.record()
+    if meanwhile is not None:
+        meanwhile()
+    ev.synchronize()
+    return np.float32(host[0].item())
+
+
+def median_abs(W, meanwhile=None):
+    """np.median(np.abs(W.flatten())) of a float32 GPU tensor as a numpy float32 (exact select)."""
     _dev(W, torch.float32, "W")
     Wc = W.contiguous()
     lib = load()
@@ -488,13 +508,13 @@ def median_abs(W):
     with torch.cuda.device(W.device):
         _check(lib.gpfq_median_abs(Wc.data_ptr(), Wc.numel(), out.data_ptr(), ws.data_ptr(), nbytes, _stream()),
                "gpfq_median_abs")
-    return np.float32(out.item())
+        return _read_scalar(out, meanwhile)
 
 
 GPFQ_MEDIAN_HIST_OFFSET, GPFQ_MEDIAN_HIST_WORDS = 64, 4096
 
 
-def median_abs_sharded(W_local, n_total, all_reduce_sum):
+def median_abs_sharded(W_local, n_total, all_reduce_sum, meanwhile=None):
     """The same median when every rank counts one slice of the layer's n_total weights (W_local: this rank's
     contiguous float32 slice; slices partition the flattened kernel).  `all_reduce_sum(t)` must sum the int32
     tensor t in place over the ranks (dist.all_reduce): three 16 KiB all-reduces per median."""
@@ -513,7 +533,7 @@ def median_abs_sharded(W_local, n_total, all_reduce_sum):
             all_reduce_sum(hist)
             _check(lib.gpfq_median_abs_pick(n_total, p, ws.data_ptr(), _stream()), "gpfq_median_abs_pick")
         _check(lib.gpfq_median_abs_end(n_total, ws.data_ptr(), out.data_ptr(), _stream()), "gpfq_median_abs_end")
-    return np.float32(out.item())
+        return _read_scalar(out, meanwhile)
 
 
 def patch_out_dim(size, k, stride, rate, same):

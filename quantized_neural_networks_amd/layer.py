@@ -20,28 +20,32 @@ from . import hip
 _SHARDED_MEDIAN_MIN = 1 << 22      # below this many weights one GPU counts faster than three all-reduces take
 
 
-def median_abs(W, group=None):
+def median_abs(W, group=None, meanwhile=None):
     """np.median(np.abs(W.flatten())) for float32 W (:544, :831) as a float32 value: the middle
     element, or for an even count the float32 mean of the two middle elements (NumPy semantics;
     torch.median would return the lower one).  With a process group (every rank holds W) each rank counts
-    one slice of the flattened kernel and the histograms are summed over the ranks -- the same value."""
+    one slice of the flattened kernel and the histograms are summed over the ranks -- the same value.
+    `meanwhile`: see hip.median_abs (called exactly once, also for an empty kernel)."""
     if W.numel() == 0:
+        if meanwhile is not None:
+            meanwhile()
         return np.float32(np.nan)
     flat = W.detach().reshape(-1)
     n = flat.numel()
     world, rank = _group_info(group)
     if world == 1 or n < _SHARDED_MEDIAN_MIN or not flat.is_cuda:
-        return hip.median_abs(flat)
+        return hip.median_abs(flat, meanwhile)
     import torch.distributed as dist
     per = -(-n // (4 * world)) * 4                       # slices start on multiples of 4 elements
     lo, hi = min(rank * per, n), min((rank + 1) * per, n)
-    return hip.median_abs_sharded(flat[lo:hi], n, lambda t: dist.all_reduce(t, group=group))
+    return hip.median_abs_sharded(flat[lo:hi], n, lambda t: dist.all_reduce(t, group=group), meanwhile)
 
 
-def layer_alphabet(W, alphabet, alphabet_scalar, group=None):
+def layer_alphabet(W, alphabet, alphabet_scalar, group=None, meanwhile=None):
     """(rad * alphabet, rad) with the reference's legacy-NumPy typing (:544-545): the python
-    scalar times the float32 median is a float64 product."""
-    rad = np.float64(alphabet_scalar) * np.float64(median_abs(W, group))
+    scalar times the float32 median is a float64 product.  `meanwhile()` may queue GPU work that does not need the
+    alphabet; it runs while the host waits for the median."""
+    rad = np.float64(alphabet_scalar) * np.float64(median_abs(W, group, meanwhile))
     return rad * np.asarray(alphabet, dtype=np.float64), rad
 
 
