@@ -37,6 +37,7 @@
 // the B = 2 shapes, the decision wavefront's chain everywhere else; it runs at raised priority (s_setprio) because it
 // shares its SIMD with two sweep wavefronts.  profiles/r02/blk_phase_stamps.txt has the per-phase cycle counts
 // (diagnostic build: GPFQ_DIAG="-DGPFQ_BLK_STAMPS").
+#include <atomic>
 #include <type_traits>
 
 #include "gpfq_device.hpp"
@@ -141,16 +142,21 @@ struct BlkLds {
 };
 constexpr int kOutSteps = 32;                                    // steps of outputs staged in LDS between flushes
 
-__host__ __device__ inline BlkLds blk_lds(int mp, int nb, int B)
+// Partial sums have one slot per sweep wavefront, rounded up to the decision wavefront's 64 / NB sub-lanes per neuron
+// (sub-lane r adds slots r, r + R, ...; a slot no wavefront writes stays zero).
+__host__ __device__ constexpr int blk_slots(int nsw, int nb) { return (nsw + 64 / nb - 1) / (64 / nb) * (64 / nb); }
+
+__host__ __device__ inline BlkLds blk_lds(int mp, int nb, int B, int nsw)
 {
     BlkLds L;
+    const int nw = blk_slots(nsw, nb);
     L.tile_bytes = B * (int)blk_rec_bytes(mp, B);
     L.tile_pitch = (L.tile_bytes + 1023) & ~1023;               // the DMA moves whole 1 KiB pieces
     int o = 2 * L.tile_pitch;
     L.off_w = o;    o += 2 * nb * B * 4;    o = (o + 15) & ~15; // [2][NB][B] f32        weights of the block
-    L.off_d = o;    o += 2 * kSweepWaves * B * nb * 8;          // [2][8][B][NB] f64     partial dot products
+    L.off_d = o;    o += 2 * nw * B * nb * 8;                   // [2][NW][B][NB] f64    partial dot products
     L.off_wq = o;   o += 2 * nb * B * 8;                        // [2][NB][B] (w, q) f32 decisions of the block
-    L.off_x2 = o;   o += kSweepWaves * nb * 16;                 // [8][NB] (f64, f64)    exact partials (slow path)
+    L.off_x2 = o;   o += nw * nb * 16;                          // [NW][NB] (f64, f64)   exact partials (slow path)
     L.off_e = o;    o += 68 * 8;                                // [2 + 64 + 2] f64      -inf, -inf, alphabet, +inf, +inf
     L.off_out = o;  o += nb * kOutSteps * 8;                    // [NB][32] (idx i32, q f32) until the flush
     L.off_ctl = o;  o += 16;                                    // [2] (by slot parity) smallest step a neuron of the block is stopped at, -1: none
@@ -178,10 +184,10 @@ struct BlkK {
 #endif
 
 // ---- sweep wavefront -------------------------------------------------------------------------------
-template <int G, int PW, int MP, int B>
+template <int G, int PW, int MP, int B, int NSW>
 __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic, const BlkLds &L, int wave, int lane, int pbase)
 {
-    constexpr int NB = 4 * G, KQ = 64 / G;
+    constexpr int NB = 4 * G, KQ = 64 / G, NW = blk_slots(NSW, NB);
     constexpr int HDR = blk_hdr_bytes(B);
     constexpr int RB = (int)blk_rec_bytes(MP, B);
     lchar *lds = (lchar *)lds_generic;
@@ -213,18 +219,18 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     // spread out, the queue never fills and the transfers hide under the arithmetic (measured: 4.86 -> 4.51 ms at
     // 4096 x 4096 x 1024, and with the decision wavefront's priority raised 4.17).
     constexpr int NPIECES = (B * RB + 1023) >> 10;
-    constexpr int PER_MIN = NPIECES / kSweepWaves;                // every wavefront has at least this many pieces per tile
+    constexpr int PER_MIN = NPIECES / NSW;               // every wavefront has at least this many pieces per tile
     constexpr int PTS = PW >= 2 ? 2 : 1;                          // issue points per step of phase U (its first pairs)
     constexpr int PPP = PER_MIN / (PTS * B) > 0 ? PER_MIN / (PTS * B) : 1;   // pieces per issue point
     const unsigned lane16 = (unsigned)lane * 16u;
     auto issue_piece = [&](int b1, int k) {
-        const int pc = wave + kSweepWaves * k;
+        const int pc = wave + NSW * k;
         glds16_s(K.recs + (int64_t)b1 * L.tile_bytes + ((int64_t)pc << 10), lane16,
                  ldsT_addr + (unsigned)(b1 & 1) * (unsigned)L.tile_pitch + ((unsigned)pc << 10));
     };
     auto load_weights = [&](int b1) {
         const unsigned dw = ldsW_addr + (unsigned)((b1 & 1) * NB * B * 4);
-        for (int i0 = wave * 64; i0 < NB * B; i0 += kSweepWaves * 64) {
+        for (int i0 = wave * 64; i0 < NB * B; i0 += NSW * 64) {
             const int i = i0 + lane;
             const int n = i / B, s = i - n * B;
             const int64_t jn = jbase + n, t = (int64_t)b1 * B + s;
@@ -232,7 +238,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         }
     };
 
-    for (int k = 0; wave + kSweepWaves * k < NPIECES; ++k) issue_piece(0, k);
+    for (int k = 0; wave + NSW * k < NPIECES; ++k) issue_piece(0, k);
     load_weights(0);
     dma_wait();
     slot_barrier();
@@ -300,7 +306,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
                 }
             }
         }
-        for (int k = PTS * B * PPP < PER_MIN ? PTS * B * PPP : PER_MIN; wave + kSweepWaves * k < NPIECES; ++k) issue_piece(bn, k);   // the rest
+        for (int k = PTS * B * PPP < PER_MIN ? PTS * B * PPP : PER_MIN; wave + NSW * k < NPIECES; ++k) issue_piece(bn, k);   // the rest
         STAMP(st2);
         // ---- phase D: this wavefront's share of <Xq_t, u> for the B rows of block b+1 ----
         if (b + 1 < nslots) {
@@ -324,7 +330,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const double v = fold_klanes<G>(acc);
-                if (writer) lds_st<double>(lds, o_dw + ((((b + 1) & 1) * kSweepWaves) * B + r) * NB * 8, v);
+                if (writer) lds_st<double>(lds, o_dw + ((((b + 1) & 1) * NW) * B + r) * NB * 8, v);
             }
         }
         STAMP(st3);
@@ -414,10 +420,10 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 }
 
 // ---- decision wavefront ------------------------------------------------------------------------------
-template <int G, int MP, int B>
+template <int G, int MP, int B, int NSW>
 __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_generic, const BlkLds &L, int lane)
 {
-    constexpr int NB = 4 * G, R = 64 / NB;
+    constexpr int NB = 4 * G, R = 64 / NB, NW = blk_slots(NSW, NB);
     constexpr int RB = (int)blk_rec_bytes(MP, B);
     lchar *lds = (lchar *)lds_generic;
     const int n = lane / R, r = lane % R;                         // neuron of the workgroup, sub-lane
@@ -507,8 +513,8 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             for (int s = 0; s < B; ++s) {
                 double d = 0.0;
 #pragma unroll
-                for (int q = 0; q < kSweepWaves / R; ++q)
-                    d += lds_ld<double>(lds, o_d + ((((b & 1) * kSweepWaves + q * R) * B) + s) * NB * 8);
+                for (int q = 0; q < NW / R; ++q)
+                    d += lds_ld<double>(lds, o_d + ((((b & 1) * NW + q * R) * B) + s) * NB * 8);
                 D[s] = sub_sum<R>(d);
                 wc[s] = lds_ld<float>(lds, o_w + (b & 1) * NB * B * 4 + 4 * s);
                 qc[s] = 0.f;
@@ -690,7 +696,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             slot_barrier();                                       // exact partials published
             double du = 0.0, dw = 0.0;
 #pragma unroll
-            for (int q = 0; q < kSweepWaves / R; ++q) {
+            for (int q = 0; q < NW / R; ++q) {
                 const double2 v = lds_ld<double2>(lds, o_x2 + q * R * NB * 16);
                 du += v.x; dw += v.y;
             }
@@ -757,7 +763,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     if (K.resid) {
         double tot = 0.0;
 #pragma unroll
-        for (int q = 0; q < kSweepWaves / R; ++q) tot += lds_ld<double>(lds, o_d + q * R * B * NB * 8);
+        for (int q = 0; q < NW / R; ++q) tot += lds_ld<double>(lds, o_d + q * R * B * NB * 8);
         tot = sub_sum<R>(tot);
         if (active && r == 0) K.resid[jn] = sqrt(tot);
     }
@@ -765,16 +771,23 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 
 }  // namespace
 
-// G neuron groups per sweep wavefront (4G neurons per workgroup), S sample pairs per k-lane over the eight sweep
+// Sample-pair split over the sweep wavefronts: PairSplit for eight of them (the decision wavefront, wavefront 8, shares
+// SIMD 0 with wavefronts 0 and 4); with eleven the twelve wavefronts of a workgroup are three per SIMD.
+template <int S, int NSW> struct BlkSplit { static constexpr const int *pw = PairSplit<S>::pw; };
+template <> struct BlkSplit<32, 11> { static constexpr int pw_[11] = {3, 3, 3, 3, 3, 3, 3, 2, 3, 3, 3}; static constexpr const int *pw = pw_; };
+template <> struct BlkSplit<24, 11> { static constexpr int pw_[11] = {2, 2, 2, 2, 2, 2, 2, 1, 3, 3, 3}; static constexpr const int *pw = pw_; };
+template <> struct BlkSplit<16, 11> { static constexpr int pw_[11] = {2, 2, 1, 1, 2, 2, 1, 1, 1, 1, 2}; static constexpr const int *pw = pw_; };
+
+// G neuron groups per sweep wavefront (4G neurons per workgroup), S sample pairs per k-lane over the NSW sweep
 // wavefronts (rows of MP = (128 / G) * S samples), B steps per slot.
-template <int G, int S, int B>
-__global__ void __launch_bounds__(64 * (kSweepWaves + 1))
+template <int G, int S, int B, int NSW>
+__global__ void __launch_bounds__(64 * (NSW + 1))
 gpfq_blk_kernel(BlkK K, AlphabetArg A)
 {
     constexpr int NB = 4 * G, KQ = 64 / G, MP = 2 * KQ * S;
-    using PS = PairSplit<S>;
+    using PS = BlkSplit<S, NSW>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const BlkLds L = blk_lds(MP, NB, B);
+    const BlkLds L = blk_lds(MP, NB, B, NSW);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -790,35 +803,38 @@ gpfq_blk_kernel(BlkK K, AlphabetArg A)
     if (tid < 2) reinterpret_cast<int *>(lds + L.off_ctl)[tid] = -1;
     __syncthreads();
 
-    if (wave < kSweepWaves) {
-        int pbase = 0;
+    if (wave < NSW) {
+        int pbase = 0, pw = 1;
 #pragma unroll
-        for (int w = 0; w < kSweepWaves; ++w) pbase += (w < wave) ? KQ * PS::pw[w] : 0;
-        const int pw = PS::pw[wave & 7];
-        if (pw == 1) { if constexpr (S == 16 || S == 24) blk_sweep_role<G, 1, MP, B>(K, lds, L, wave, lane, pbase); }
-        else if (pw == 2) blk_sweep_role<G, 2, MP, B>(K, lds, L, wave, lane, pbase);
-        else if (pw == 3) blk_sweep_role<G, 3, MP, B>(K, lds, L, wave, lane, pbase);
-        else if (pw == 4) { if constexpr (S >= 24) blk_sweep_role<G, 4, MP, B>(K, lds, L, wave, lane, pbase); }
-        else { if constexpr (S == 32) blk_sweep_role<G, 5, MP, B>(K, lds, L, wave, lane, pbase); }
+        for (int w = 0; w < NSW; ++w) { pbase += (w < wave) ? KQ * PS::pw[w] : 0; pw = (w == wave) ? PS::pw[w] : pw; }
+        constexpr int PMAX = NSW == 11 ? 3 : (S == 32 ? 5 : (S == 24 ? 4 : 3));
+        if (pw == 1) blk_sweep_role<G, 1, MP, B, NSW>(K, lds, L, wave, lane, pbase);
+        else if (pw == 2) blk_sweep_role<G, 2, MP, B, NSW>(K, lds, L, wave, lane, pbase);
+        else if (pw == 3) blk_sweep_role<G, 3, MP, B, NSW>(K, lds, L, wave, lane, pbase);
+        else if (pw == 4) { if constexpr (PMAX >= 4) blk_sweep_role<G, 4, MP, B, NSW>(K, lds, L, wave, lane, pbase); }
+        else { if constexpr (PMAX >= 5) blk_sweep_role<G, 5, MP, B, NSW>(K, lds, L, wave, lane, pbase); }
     } else {
-        blk_decision_role<G, MP, B>(K, lds, L, lane);
+        blk_decision_role<G, MP, B, NSW>(K, lds, L, lane);
     }
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-struct BlkShape { int G, S, B, mp; };
+struct BlkShape { int G, S, B, mp, NW; };
+static std::atomic<int> g_blk_nw{8};      // sweep wavefronts of the 16-neuron shapes (experiment switch: blk_set_sweep_waves)
+void blk_set_sweep_waves(int nw) { g_blk_nw.store(nw == 11 ? 11 : 8, std::memory_order_relaxed); }
 
 // C: neurons of the call.  Rows of 769..1024 samples are the one shape whose slot is bound by the sweeps (nine sample pairs
 // on three of the SIMDs), not by the chain of decisions: up to 2048 neurons -- one round of 256 workgroups with 8 neurons
 // each -- the sweeps are halved by giving a workgroup 8 neurons instead of 16 (4096 x 2048, m = 1024: 4.0 -> 2.9 ms).
 static BlkShape blk_shape(int64_t m, int64_t C)
 {
-    if (m > 256 && m <= 512) return {4, 16, 4, 512};
-    if (m > 512 && m <= 768) return {4, 24, 4, 768};
-    if (m > 768 && m <= 1024) return C <= 2048 ? BlkShape{2, 16, 4, 1024} : BlkShape{4, 32, 4, 1024};
-    if (m > 1024 && m <= 1536) return {2, 24, 2, 1536};
-    if (m > 1536 && m <= 2048) return {2, 32, 2, 2048};
-    return {0, 0, 0, 0};
+    const int nw4 = g_blk_nw.load(std::memory_order_relaxed);
+    if (m > 256 && m <= 512) return {4, 16, 4, 512, nw4};
+    if (m > 512 && m <= 768) return {4, 24, 4, 768, nw4};
+    if (m > 768 && m <= 1024) return C <= 2048 ? BlkShape{2, 16, 4, 1024, 8} : BlkShape{4, 32, 4, 1024, nw4};
+    if (m > 1024 && m <= 1536) return {2, 24, 2, 1536, 8};
+    if (m > 1536 && m <= 2048) return {2, 32, 2, 2048, 8};
+    return {0, 0, 0, 0, 0};
 }
 
 bool blk_supported(const PipeArgs &a)
@@ -837,13 +853,13 @@ size_t blk_workspace_bytes(int64_t N, int64_t m)
     return (size_t)((nblk + 1) * sh.B + 1) * (size_t)blk_rec_bytes(sh.mp, sh.B);   // slots 0..nblk, + one record of DMA over-read
 }
 
-template <int G, int S, int B>
+template <int G, int S, int B, int NSW = 8>
 static hipError_t launch_blk_inst(const PipeArgs &a, const BlkShape &sh, hipStream_t stream)
 {
     constexpr int NB = 4 * G;
-    const BlkLds L = blk_lds(sh.mp, NB, B);
+    const BlkLds L = blk_lds(sh.mp, NB, B, NSW);
     const unsigned grid = (unsigned)((a.C + NB - 1) / NB);
-    auto *kern = gpfq_blk_kernel<G, S, B>;
+    auto *kern = gpfq_blk_kernel<G, S, B, NSW>;
     hipError_t e = ensure_dynamic_lds((const void *)kern, (size_t)L.total);
     if (e != hipSuccess) return e;
     BlkK K;
@@ -851,7 +867,7 @@ static hipError_t launch_blk_inst(const PipeArgs &a, const BlkShape &sh, hipStre
     K.N = a.N; K.C = a.C; K.m = (int)a.m; K.M = a.A.M; K.zero_idx = a.A.zero_idx; K.nblk = (int)((a.N + B - 1) / B);
     K.qidx = a.qidx; K.Qt = a.Qt; K.resid = a.resid; K.u_out = a.u_out; K.fallback_count = a.fallback_count;
     K.stamps = a.fallback_count ? a.fallback_count + 8 : nullptr;      // (diagnostic build: the unused row-statistics area behind the counter block)
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (kSweepWaves + 1)), (size_t)L.total, stream, K, a.A);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NSW + 1)), (size_t)L.total, stream, K, a.A);
     return hipGetLastError();
 }
 
@@ -866,6 +882,11 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
                        a.nrm32, static_cast<char *>(a.workspace));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (sh.G == 4 && sh.NW == 11) {
+        if (sh.S == 16) return launch_blk_inst<4, 16, 4, 11>(a, sh, stream);
+        if (sh.S == 24) return launch_blk_inst<4, 24, 4, 11>(a, sh, stream);
+        return launch_blk_inst<4, 32, 4, 11>(a, sh, stream);
+    }
     if (sh.G == 4) {
         if (sh.S == 16) return launch_blk_inst<4, 16, 4>(a, sh, stream);
         if (sh.S == 24) return launch_blk_inst<4, 24, 4>(a, sh, stream);

@@ -199,6 +199,10 @@ int gpfq_set_option(const char *key, int value)
             return fail(GPFQ_ERR_INVALID_ARG, "pipe must be -1, 0, 1 or 2");
         g_pipe = value; return GPFQ_OK;
     }
+    if (!std::strcmp(key, "blk_sweep_waves")) {
+        if (value != 8 && value != 11) return fail(GPFQ_ERR_INVALID_ARG, "blk_sweep_waves must be 8 or 11");
+        gpfq::blk_set_sweep_waves(value); return GPFQ_OK;
+    }
     if (!std::strcmp(key, "waves_per_neuron")) {
         if (value < 0 || value > 16) return fail(GPFQ_ERR_INVALID_ARG, "waves_per_neuron must be in [0, 16]");
         g_wpn = value; return GPFQ_OK;

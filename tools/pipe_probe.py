@@ -69,9 +69,11 @@ def main():
     print(f"  old kernel: min {tmin:.3f} ms avg {tavg:.3f} ms (incl. pre-pass launches)")
     variants = [int(v) for v in os.environ.get("PIPE_VARIANTS", "0").split(",")]
     modes = [int(v) for v in os.environ.get("PIPE_MODES", "1,2").split(",")]       # 1: one step per slot, 2: blocks of steps
-    for mode, variant, ts in [(md, v, ts) for md in modes for v in variants for ts in ((0, 2, 1) if md == 1 else (0,))]:
+    sweeps = [int(v) for v in os.environ.get("PIPE_SWEEPS", "11,8").split(",")]  # mode 2: sweep wavefronts of the 16-neuron shapes
+    for mode, variant, ts, sw in [(md, v, ts, sw) for md in modes for v in variants for ts in ((0, 2, 1) if md == 1 else (0,))
+                                  for sw in (sweeps if md == 2 else (11,))]:
         try:
-            r = run(pipe=mode, tile_steps=ts, variant=16 * variant)
+            r = run(pipe=mode, tile_steps=ts, variant=16 * variant, blk_sweep_waves=sw)
         except hip.GpfqError as e:
             print(f"  pipe ts={ts}: {e}")
             continue
@@ -89,9 +91,9 @@ def main():
             print(f"    decision wave: work {st[16]/ns:.0f}, barrier {st[17]/ns:.0f} cycles per slot")
         tmin, tavg = timed(lambda: hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm, want_values=False,
                                                         path=hip.GPFQ_PATH_ONCHIP))
-        print(f"  pipe mode={mode} variant={variant} ts={ts or 'auto'} [{hip.last_dense_kernel()[:16]}]: min {tmin:.3f} ms avg {tavg:.3f} ms  "
+        print(f"  pipe mode={mode} variant={variant} ts={ts or 'auto'} sweeps={sw} [{hip.last_dense_kernel()[:16]}]: min {tmin:.3f} ms avg {tavg:.3f} ms  "
               f"mismatch idx={bad_i} Q={bad_q} u={bad_u} max resid rel diff={rel_r:.2e}  exact fallbacks={fb}")
-    hip.set_option("pipe", -1); hip.set_option("tile_steps", 0); hip.set_option("variant", 0)
+    hip.set_option("pipe", -1); hip.set_option("tile_steps", 0); hip.set_option("variant", 0); hip.set_option("blk_sweep_waves", 11)
 
 
 if __name__ == "__main__":

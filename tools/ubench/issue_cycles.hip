@@ -1,5 +1,5 @@
 // Micro-benchmark: shader-clock cycles per wavefront instruction (s_memtime inside the kernel, so the
-// result does not depend on the clock the chip holds), at 1 and 2 wavefronts per SIMD, for the
+// result does not depend on the clock the chip holds), at 1 to 4 wavefronts per SIMD, for the
 // instructions and the instruction MIX of the GPFQ sweep (csrc/gpfq_pipe.hip).
 // Build + run on the GPU box: hipcc -O3 --offload-arch=gfx950 -o /tmp/issue_cycles issue_cycles.hip && /tmp/issue_cycles
 #include <hip/hip_runtime.h>
@@ -10,7 +10,7 @@
 constexpr int U = 8;   // independent chains per lane
 
 template <int OP>
-__global__ void __launch_bounds__(512) k(unsigned long long *cyc, float *out, int iters, float seed)
+__global__ void __launch_bounds__(1024) k(unsigned long long *cyc, float *out, int iters, float seed)
 {
     float f[2 * U]; double d[U], e[U];
 #pragma unroll
@@ -76,7 +76,7 @@ int main()
     const char *names[] = {"v_mul_f32", "v_add_f64", "v_fma_f64", "v_cvt_f64_f32", "v_pk_mul_f32", "v_mov_b32_dpp",
                            "sweep mix (9 inst / 2 samples)", "cvt->add dependent pairs", "v_add_f64 one chain", "v_cmp_f64+cndmask"};
     const int per[] = {U, U, U, U, U, U, 9 * U, 2 * U, U, 2 * U};
-    for (int w : {1, 2}) {
+    for (int w : {1, 2, 3, 4}) {
         double c[10];
         c[0] = run<0>(w, iters, cyc, out, per[0]); c[1] = run<1>(w, iters, cyc, out, per[1]); c[2] = run<2>(w, iters, cyc, out, per[2]);
         c[3] = run<3>(w, iters, cyc, out, per[3]); c[4] = run<4>(w, iters, cyc, out, per[4]); c[5] = run<5>(w, iters, cyc, out, per[5]);
