@@ -114,6 +114,8 @@ const char *gpfq_last_dense_kernel(void);
  *                  (gpfq_blk.hip) where measured faster -- layers of 512+ neurons, and any width for rows of 769..1024
  *                  samples --, 0 never, 1 one step per slot (gpfq_pipe.hip) whenever it applies, 2 the block form whenever
  *                  it applies
+ *   "blk_sweep_waves"   8 (default) or 11: sweep wavefronts per workgroup of the block form's 16-neuron shapes (with the
+ *                  decision wavefront two or three wavefronts per SIMD; measured equal within 2 %: DESIGN.md)
  *   "waves_per_neuron"  2..16: force the wide kernel (one neuron over that many wavefronts), 0 = heuristic
  *                  (rows longer than 2048 samples, and layers too narrow to fill the chip)
  *   "gram_slack_log2"   Gram paths: error bounds multiplied by 2^value (tests force the repair/rerun branches)

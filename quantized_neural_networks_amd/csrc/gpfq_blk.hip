@@ -264,6 +264,13 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             for (int n = 0; n < 4; ++n) wqn[n] = lds_ld<float2>(lds, o_wq + pbq + (n * B) * 8);
 #pragma unroll 1
             for (int s = 0; s < B; ++s) {
+                // Issue priority falls with progress through the slot (2, 1, 1, 0 over the halves of the two phases; the decision
+                // wavefront keeps 3).  At equal priority the SIMD serves its OLDEST ready wavefront first: the first-launched
+                // sweep ran at full single-wavefront rate, finished early and left the youngest to run the tail of the slot alone,
+                // at half the issue rate (profiles/r02/blk_phase_stamps.txt: phase U of equal shares took 3440 / 5250 / 7200
+                // cycles by age).  With the laggard preferred the wavefronts of a SIMD reach the barrier together.
+                if (s == 0) __builtin_amdgcn_s_setprio(2);
+                if (s == B / 2) __builtin_amdgcn_s_setprio(1);
                 float wv[4], qv[4];
 #pragma unroll
                 for (int n = 0; n < 4; ++n) { wv[n] = wqn[n].x; qv[n] = wqn[n].y; }
@@ -313,6 +320,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             double2 d2n = lds_ld<double2>(lds, tbase + o_d);
 #pragma unroll 1
             for (int r = 0; r < B; ++r) {
+                if (r == B / 2) __builtin_amdgcn_s_setprio(0);
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
                 const int rb = tbase + r * RB;
                 const int rn = r + 1 < B ? r + 1 : r;

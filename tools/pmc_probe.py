@@ -1,5 +1,5 @@
 """Run the cfg2 dense kernel a few times (for rocprofv3 --pmc passes).
-usage: pmc_probe.py M mode lanes_per_neuron variant tile_steps"""
+usage: pmc_probe.py M mode lanes_per_neuron variant tile_steps blk_sweep_waves"""
 import sys
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -14,7 +14,7 @@ rad = 3 * float(np.median(np.abs(W)))
 alphabet = rad * np.linspace(-1, 1, M)
 Xd, Xqd, Wt = torch.from_numpy(X).cuda(), torch.from_numpy(Xq).cuda(), torch.from_numpy(W.T.copy()).cuda()
 hip.set_option("onchip_mode", arg(2, 1)); hip.set_option("lanes_per_neuron", arg(3, 0))
-hip.set_option("variant", arg(4, 0)); hip.set_option("tile_steps", arg(5, 0))
+hip.set_option("variant", arg(4, 0)); hip.set_option("tile_steps", arg(5, 0)); hip.set_option("blk_sweep_waves", arg(6, 8))
 nrm = hip.row_norms(Xqd)
 for _ in range(3):
     r = hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm)
