@@ -38,6 +38,7 @@
 // shares its SIMD with two sweep wavefronts.  profiles/r02/blk_phase_stamps.txt has the per-phase cycle counts
 // (diagnostic build: GPFQ_DIAG="-DGPFQ_BLK_STAMPS").
 #include <atomic>
+#include <cmath>
 #include <type_traits>
 
 #include "gpfq_device.hpp"
@@ -67,7 +68,7 @@ __host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B) { return 
 template <int B>
 __global__ void __launch_bounds__(256)
 gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t N, int m, int mp,
-                     const float *__restrict__ nrm32, char *__restrict__ recs)
+                     const float *__restrict__ nrm32, char *__restrict__ recs, float sym_a)
 {
     constexpr int ND = 2 * B - 1, NV = 3 + 4 * ND;
     __shared__ double sm[4][((NV + 3) & ~3) + 1];
@@ -91,7 +92,7 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
     for (int i = threadIdx.x; i < mp; i += 256) {
         const bool in = i < m;
         ox[i] = (has_prev && in) ? px[i] : 0.f;
-        oq[i] = (has_prev && in) ? pq[i] : 0.f;
+        oq[i] = (has_prev && in) ? (sym_a != 0.f ? __fmul_rn(sym_a, pq[i]) : pq[i]) : 0.f;   // symmetric form: f32(a Xq), see BlkK::sym_a
         od[i] = (double)((has_next && in) ? nq[i] : 0.f);
         if (has_cur && in) {
             const double q = (double)cq[i], pr = q * (double)cx[i];   // products of two f32 are exact in f64
@@ -175,6 +176,14 @@ struct BlkK {
     double *resid, *u_out;
     unsigned long long *fallback_count;
     unsigned long long *stamps;     // diagnostic build only (GPFQ_BLK_STAMPS): per-phase shader cycles of two wavefronts
+    // Symmetric alphabets {-a, 0, a} and {-a, a} (the reference's default, bits = log2(3): quantize_pretrained_mlp.py:40): every
+    // decision is q = sg * a32 with sg in {-1, 0, 1}, so f32(q * xq) = sg * f32(a32 * xq) EXACTLY and the update's
+    // f32(w x) - f32(q xq) is ONE fused multiply-add on the pre-scaled row: fma(-sg, f32(a32 xq), f32(w x)) rounds once, the
+    // subtraction's rounding.  The pre-pass stores f32(a32 * Xq) in place of Xq and the decisions publish -sg in place of q:
+    // 8 instead of 12 packed float32 instructions per sample pair of four neurons.  0: the general form.
+    float sym_a;
+    const float *Xq;                // (symmetric form's slow path)
+    int64_t ldx;
 };
 
 #ifdef GPFQ_BLK_STAMPS
@@ -184,7 +193,7 @@ struct BlkK {
 #endif
 
 // ---- sweep wavefront -------------------------------------------------------------------------------
-template <int G, int PW, int MP, int B, int NSW>
+template <int G, int PW, int MP, int B, int NSW, bool SYM>
 __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic, const BlkLds &L, int wave, int lane, int pbase)
 {
     constexpr int NB = 4 * G, KQ = 64 / G, NW = blk_slots(NSW, NB);
@@ -301,10 +310,15 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
                     double c0[4], c1[4];
 #pragma unroll
                     for (int n = 0; n < 4; ++n) pr[n] = pk2{wv[n], wv[n]} * xv;
+                    if constexpr (SYM) {                              // qv = -sg, qx = f32(a xq): v_pk_fma_f32, one rounding
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) rr[n] = pk2{qv[n], qv[n]} * qx;
+                        for (int n = 0; n < 4; ++n) dd[n] = __builtin_elementwise_fma(pk2{qv[n], qv[n]}, qx, pr[n]);
+                    } else {
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) dd[n] = pr[n] - rr[n];
+                        for (int n = 0; n < 4; ++n) rr[n] = pk2{qv[n], qv[n]} * qx;
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) dd[n] = pr[n] - rr[n];
+                    }
 #pragma unroll
                     for (int n = 0; n < 4; ++n) { c0[n] = (double)dd[n].x; c1[n] = (double)dd[n].y; }
 #pragma unroll
@@ -372,11 +386,25 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
                         const int rb = nb_ + j * RB;
                         const float2 x2 = lds_ld<float2>(lds, rb + o_x + 8 * p * KQ), q2 = lds_ld<float2>(lds, rb + o_q + 8 * p * KQ);
                         const float2 wq = lds_ld<float2>(lds, o_wq + cbq + (n * B + j) * 8);
-                        t0 += (double)__fsub_rn(__fmul_rn(wq.x, x2.x), __fmul_rn(wq.y, q2.x));
-                        t1 += (double)__fsub_rn(__fmul_rn(wq.x, x2.y), __fmul_rn(wq.y, q2.y));
+                        if constexpr (SYM) {
+                            t0 += (double)__fmaf_rn(wq.y, q2.x, __fmul_rn(wq.x, x2.x));
+                            t1 += (double)__fmaf_rn(wq.y, q2.y, __fmul_rn(wq.x, x2.y));
+                        } else {
+                            t0 += (double)__fsub_rn(__fmul_rn(wq.x, x2.x), __fmul_rn(wq.y, q2.x));
+                            t1 += (double)__fsub_rn(__fmul_rn(wq.x, x2.y), __fmul_rn(wq.y, q2.y));
+                        }
                     }
                     const int rb = nb_ + S * RB;
-                    const float2 x2 = lds_ld<float2>(lds, rb + o_x + 8 * p * KQ), q2 = lds_ld<float2>(lds, rb + o_q + 8 * p * KQ);
+                    const float2 x2 = lds_ld<float2>(lds, rb + o_x + 8 * p * KQ);
+                    float2 q2;
+                    if constexpr (SYM) {                              // the record holds a32 * Xq_t: the row itself from memory (rare path)
+                        const int i0 = 2 * (pbase + p * KQ + kq);
+                        const float *xr = K.Xq + ((int64_t)b * B + S) * K.ldx;
+                        q2.x = i0 < K.m ? xr[i0] : 0.f;
+                        q2.y = i0 + 1 < K.m ? xr[i0 + 1] : 0.f;
+                    } else {
+                        q2 = lds_ld<float2>(lds, rb + o_q + 8 * p * KQ);
+                    }
                     eu[n] = fma((double)q2.x, t0, eu[n]);
                     eu[n] = fma((double)q2.y, t1, eu[n]);
                     ew[n] = fma((double)q2.x, t0 + (double)__fmul_rn(w, x2.x), ew[n]);
@@ -428,7 +456,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 }
 
 // ---- decision wavefront ------------------------------------------------------------------------------
-template <int G, int MP, int B, int NSW>
+template <int G, int MP, int B, int NSW, bool SYM>
 __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_generic, const BlkLds &L, int lane)
 {
     constexpr int NB = 4 * G, R = 64 / NB, NW = blk_slots(NSW, NB);
@@ -657,7 +685,9 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             qc[s] = sel ? q32 : qc[s];
             wc[s] = (sel & !valid) ? 0.f : wc[s];
             const bool st = sel & (r == 0);                                      // stores that are not wanted land in the dummy slot
-            lds_st<float2>(lds, st ? o_wq + cbq + 8 * s : o_dummy, make_float2(wc[s], q32));
+            // what the sweeps multiply the (scaled) Xq row with: q, or minus its sign
+            const float qpub = SYM ? (q32 > 0.f ? -1.f : (q32 < 0.f ? 1.f : 0.f)) : q32;
+            lds_st<float2>(lds, st ? o_wq + cbq + 8 * s : o_dummy, make_float2(wc[s], qpub));
             lds_st<int2>(lds, (st & valid) ? o_out + ((oslot0 + s) % kOutSteps) * 8 : o_dummy, make_int2(idx, __float_as_int(q32)));
             return ok;
         };
@@ -728,7 +758,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 #pragma unroll
                 for (int s = 0; s < B; ++s) qc[s] = (s == S) ? q32 : qc[s];
                 if (r == 0) {
-                    lds_st<float2>(lds, o_wq + cbq + 8 * S, make_float2(wS, q32));
+                    lds_st<float2>(lds, o_wq + cbq + 8 * S, make_float2(wS, SYM ? (q32 > 0.f ? -1.f : (q32 < 0.f ? 1.f : 0.f)) : q32));
                     lds_st<int2>(lds, o_out + (int)(t % kOutSteps) * 8, make_int2(bi, __float_as_int(q32)));
                     ++n_fallback;
                 }
@@ -788,7 +818,7 @@ template <> struct BlkSplit<16, 11> { static constexpr int pw_[11] = {2, 2, 1, 1
 
 // G neuron groups per sweep wavefront (4G neurons per workgroup), S sample pairs per k-lane over the NSW sweep
 // wavefronts (rows of MP = (128 / G) * S samples), B steps per slot.
-template <int G, int S, int B, int NSW>
+template <int G, int S, int B, int NSW, bool SYM>
 __global__ void __launch_bounds__(64 * (NSW + 1))
 gpfq_blk_kernel(BlkK K, AlphabetArg A)
 {
@@ -816,13 +846,13 @@ gpfq_blk_kernel(BlkK K, AlphabetArg A)
 #pragma unroll
         for (int w = 0; w < NSW; ++w) { pbase += (w < wave) ? KQ * PS::pw[w] : 0; pw = (w == wave) ? PS::pw[w] : pw; }
         constexpr int PMAX = NSW == 11 ? 3 : (S == 32 ? 5 : (S == 24 ? 4 : 3));
-        if (pw == 1) blk_sweep_role<G, 1, MP, B, NSW>(K, lds, L, wave, lane, pbase);
-        else if (pw == 2) blk_sweep_role<G, 2, MP, B, NSW>(K, lds, L, wave, lane, pbase);
-        else if (pw == 3) blk_sweep_role<G, 3, MP, B, NSW>(K, lds, L, wave, lane, pbase);
-        else if (pw == 4) { if constexpr (PMAX >= 4) blk_sweep_role<G, 4, MP, B, NSW>(K, lds, L, wave, lane, pbase); }
-        else { if constexpr (PMAX >= 5) blk_sweep_role<G, 5, MP, B, NSW>(K, lds, L, wave, lane, pbase); }
+        if (pw == 1) blk_sweep_role<G, 1, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase);
+        else if (pw == 2) blk_sweep_role<G, 2, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase);
+        else if (pw == 3) blk_sweep_role<G, 3, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase);
+        else if (pw == 4) { if constexpr (PMAX >= 4) blk_sweep_role<G, 4, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase); }
+        else { if constexpr (PMAX >= 5) blk_sweep_role<G, 5, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase); }
     } else {
-        blk_decision_role<G, MP, B, NSW>(K, lds, L, lane);
+        blk_decision_role<G, MP, B, NSW, SYM>(K, lds, L, lane);
     }
 }
 
@@ -861,13 +891,24 @@ size_t blk_workspace_bytes(int64_t N, int64_t m)
     return (size_t)((nblk + 1) * sh.B + 1) * (size_t)blk_rec_bytes(sh.mp, sh.B);   // slots 0..nblk, + one record of DMA over-read
 }
 
-template <int G, int S, int B, int NSW = 8>
-static hipError_t launch_blk_inst(const PipeArgs &a, const BlkShape &sh, hipStream_t stream)
+// a32 of a symmetric alphabet {-a, 0, a} or {-a, a} (BlkK::sym_a), else 0.  PipeArgs::variant bit 1 (option "variant" bit 5) keeps the general form (A/B timing).
+static float blk_sym_a(const PipeArgs &a)
+{
+    const int M = a.A.M;
+    if ((a.variant & 2) || (M != 2 && M != 3)) return 0.f;
+    const float hi = (float)a.A.a[M - 1], lo = (float)a.A.a[0];
+    if (!(hi > 0.f) || lo != -hi || !std::isfinite(hi)) return 0.f;
+    if (M == 3 && (float)a.A.a[1] != 0.f) return 0.f;
+    return hi;
+}
+
+template <int G, int S, int B, int NSW, bool SYM>
+static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStream_t stream)
 {
     constexpr int NB = 4 * G;
     const BlkLds L = blk_lds(sh.mp, NB, B, NSW);
     const unsigned grid = (unsigned)((a.C + NB - 1) / NB);
-    auto *kern = gpfq_blk_kernel<G, S, B, NSW>;
+    auto *kern = gpfq_blk_kernel<G, S, B, NSW, SYM>;
     hipError_t e = ensure_dynamic_lds((const void *)kern, (size_t)L.total);
     if (e != hipSuccess) return e;
     BlkK K;
@@ -875,8 +916,20 @@ static hipError_t launch_blk_inst(const PipeArgs &a, const BlkShape &sh, hipStre
     K.N = a.N; K.C = a.C; K.m = (int)a.m; K.M = a.A.M; K.zero_idx = a.A.zero_idx; K.nblk = (int)((a.N + B - 1) / B);
     K.qidx = a.qidx; K.Qt = a.Qt; K.resid = a.resid; K.u_out = a.u_out; K.fallback_count = a.fallback_count;
     K.stamps = a.fallback_count ? a.fallback_count + 8 : nullptr;      // (diagnostic build: the unused row-statistics area behind the counter block)
+    K.sym_a = SYM ? blk_sym_a(a) : 0.f; K.Xq = a.Xq; K.ldx = a.ld;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NSW + 1)), (size_t)L.total, stream, K, a.A);
     return hipGetLastError();
+}
+
+template <int G, int S, int B, int NSW = 8>
+static hipError_t launch_blk_inst(const PipeArgs &a, const BlkShape &sh, hipStream_t stream)
+{
+    // (not where the chain of decisions bounds the slot -- 16 neurons on rows of up to 768 samples: publishing the sign costs the
+    // chain more than the sweeps gain: 3.04 -> 3.2 ms at 512 samples; sweep-bound shapes gain 3-4 %)
+    if constexpr (NSW == 8 && !(G == 4 && S < 32)) {
+        if (blk_sym_a(a) != 0.f) return launch_blk_sym<G, S, B, NSW, true>(a, sh, stream);
+    }
+    return launch_blk_sym<G, S, B, NSW, false>(a, sh, stream);
 }
 
 hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
@@ -886,8 +939,9 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     const int64_t nblk = (a.N + sh.B - 1) / sh.B;
     const int64_t nrec = (nblk + 1) * sh.B + 1;
     auto *prep = sh.B == 4 ? gpfq_blk_prep_kernel<4> : gpfq_blk_prep_kernel<2>;
+    const float sym_a = (sh.NW == 8 && !(sh.G == 4 && sh.S < 32)) ? blk_sym_a(a) : 0.f;   // (exactly the shapes launch_blk_inst gives the symmetric form)
     hipLaunchKernelGGL(prep, dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp,
-                       a.nrm32, static_cast<char *>(a.workspace));
+                       a.nrm32, static_cast<char *>(a.workspace), sym_a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (sh.G == 4 && sh.NW == 11) {
