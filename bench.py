@@ -206,7 +206,7 @@ def main():
                 "traffic_source": (traffic["source"] if traffic else
                                    "no committed rocprofv3 --pmc pass for this kernel and shape (profiles/traffic.json)"),
                 "note": "skinny dot products with the residual on chip: the binding resource is FP64-rate vector issue "
-                        "(per weight and sample one f64 fma, one f32->f64 convert, one f64 add, three f32 ops), not HBM; "
+                        "(per weight and sample one f64 fma, one f32->f64 convert, one f64 add, three f32 ops on two samples each -- two for the symmetric ternary alphabet), not HBM; "
                         "flops per launch = 6 m N C_local (SURVEY 8d); duration = HIP events around the launch on its stream",
             },
         }
