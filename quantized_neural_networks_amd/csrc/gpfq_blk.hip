@@ -530,6 +530,13 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 #pragma unroll
     for (int j = 0; j < B; ++j) { wprev[j] = 0.f; qprev[j] = 0.f; }
     unsigned long long n_fallback = 0;
+    auto wave_min_stop = [&](int v) -> int {                    // min over the wavefront of values in [0, B]
+        int mn = B;
+#pragma unroll
+        for (int k = B - 1; k >= 0; --k)
+            if (__ballot(v == k) != 0ull) mn = k;
+        return mn;
+    };
 
     // Steps [t0, t1) of this workgroup's outputs from the LDS ring to memory: a lane takes 8 consecutive steps of one
     // neuron (32-byte runs of indices, 128-byte runs of values per neuron)
@@ -579,8 +586,8 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     __builtin_amdgcn_s_setprio(3);
 
     int64_t flushed = 0;                                          // steps [0, flushed) are in memory
-    unsigned long long dt0 = 0, dt1 = 0, dt2 = 0, dacc_work = 0, dacc_bar = 0;
-    (void)dt0; (void)dt1; (void)dt2; (void)dacc_work; (void)dacc_bar;
+    unsigned long long dt0 = 0, dt1 = 0, dt2 = 0, dta = 0, dtb = 0, dacc_work = 0, dacc_bar = 0, dacc_pro = 0, dacc_chain = 0;
+    (void)dt0; (void)dt1; (void)dt2; (void)dta; (void)dtb; (void)dacc_work; (void)dacc_bar; (void)dacc_pro; (void)dacc_chain;
     for (int b = 0; b < nslots; ++b) {
         STAMP(dt0);
         const int tbase = (b & 1) * L.tile_pitch;
@@ -588,38 +595,53 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         float  wc[B], qc[B];                                      // this block: weights, decisions (as float32 values)
         double D[B];
         int stop = B;                                             // first step of the block this neuron could not certify
+        // ---- prologue: D_t of the B rows (the partial sums of the previous slot), the weights of the block, and the contribution
+        // of block b-1's increments, which does not depend on this block's decisions and is spread over the sub-lanes: sub-lane
+        // r (mod B) forms the sums of step r, the chain fetches them by DPP (R is 4 or 8 and B <= 4: quad_perm broadcasts inside each
+        // aligned group of four lanes).  Written as: EVERY LDS read first, then the arithmetic, then the stores -- a store between
+        // two reads orders them (the compiler must assume they alias), and step by step this prologue was eight LDS round trips
+        // (2400-2900 cycles per slot, as long as the chain of decisions itself) right after the barrier, when the LDS is busiest.
+        double cPm = 0.0, ePm = 0.0;
+        unsigned anyP = 0u;
+        double2 st01, st23, st45;                                               // record header of the step about to be decided
+#pragma unroll
+        for (int j = 0; j < B; ++j) anyP |= __float_as_uint(wprev[j]) | __float_as_uint(qprev[j]);
         if (b < K.nblk) {
-            // ---- D_t of the B rows: the partial sums of the previous slot; weights of the block ----
+            double dpart[B][NW / R];
+            double2 hb[B], eb[B];
+            const int sm = lane & (B - 1);                        // this lane's step (B is a power of two <= 4)
+            const int rbm = tbase + sm * RB;
+#pragma unroll
+            for (int s = 0; s < B; ++s) {
+#pragma unroll
+                for (int q = 0; q < NW / R; ++q)
+                    dpart[s][q] = lds_ld<double>(lds, o_d + ((((b & 1) * NW + q * R) * B) + s) * NB * 8);
+                wc[s] = lds_ld<float>(lds, o_w + (b & 1) * NB * B * 4 + 4 * s);
+            }
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                const int d = B + sm - j;
+                hb[j] = lds_ld<double2>(lds, rbm + 64 + 32 * (d - 1)); eb[j] = lds_ld<double2>(lds, rbm + 64 + 32 * (d - 1) + 16);
+            }
+            st01 = lds_ld<double2>(lds, tbase); st23 = lds_ld<double2>(lds, tbase + 16); st45 = lds_ld<double2>(lds, tbase + 32);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < B; ++s) {
                 double d = 0.0;
 #pragma unroll
-                for (int q = 0; q < NW / R; ++q)
-                    d += lds_ld<double>(lds, o_d + ((((b & 1) * NW + q * R) * B) + s) * NB * 8);
+                for (int q = 0; q < NW / R; ++q) d += dpart[s][q];
                 D[s] = sub_sum<R>(d);
-                wc[s] = lds_ld<float>(lds, o_w + (b & 1) * NB * B * 4 + 4 * s);
                 qc[s] = 0.f;
-                if (r == 0) lds_st<float2>(lds, o_wq + cbq + 8 * s, make_float2(wc[s], 0.f));    // w is known now, q follows
             }
-        }
-
-        // Contribution of block b-1's increments: independent of this block's decisions, so it is formed before the chain --
-        // and spread over the sub-lanes: sub-lane r (mod B) forms the sums of step r, the chain fetches them by DPP
-        // (R is 4 or 8 and B <= 4: quad_perm broadcasts inside each aligned group of four lanes)
-        double cPm = 0.0, ePm = 0.0;
-        unsigned anyP = 0u;
-#pragma unroll
-        for (int j = 0; j < B; ++j) anyP |= __float_as_uint(wprev[j]) | __float_as_uint(qprev[j]);
-        if (b < K.nblk) {
-            const int sm = lane & (B - 1);                        // this lane's step (B is a power of two <= 4)
-            const int rb = tbase + sm * RB;
 #pragma unroll
             for (int j = 0; j < B; ++j) {
-                const int d = B + sm - j;
-                const double2 h = lds_ld<double2>(lds, rb + 64 + 32 * (d - 1)), e = lds_ld<double2>(lds, rb + 64 + 32 * (d - 1) + 16);
                 const double wj = (double)wprev[j], qj = (double)qprev[j];
-                cPm = fma(wj, h.x, cPm); cPm = fma(-qj, h.y, cPm);
-                ePm = fma(fabs(wj), e.x, ePm); ePm = fma(fabs(qj), e.y, ePm);
+                cPm = fma(wj, hb[j].x, cPm); cPm = fma(-qj, hb[j].y, cPm);
+                ePm = fma(fabs(wj), eb[j].x, ePm); ePm = fma(fabs(qj), eb[j].y, ePm);
+            }
+            if (r == 0) {
+#pragma unroll
+                for (int s = 0; s < B; ++s) lds_st<float2>(lds, o_wq + cbq + 8 * s, make_float2(wc[s], 0.f));   // w is known now, q follows
             }
         }
         auto quad_bcast = [&](double x, int s) -> double {       // value of lane (4 * (lane / 4) + s)
@@ -640,11 +662,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         const int nvalid = (int)min((int64_t)B, N - (int64_t)b * B);            // steps beyond N pad the last block: no-ops
         const int oslot0 = (int)(((int64_t)b * B) % kOutSteps);
         const int o_dummy = L.off_ctl + 8;
-        double2 st01, st23, st45;                                               // record header of the step about to be decided
-        double2 bandH[B], bandE[B];                                            // its entries (s, j < s), at j
-        if (b < K.nblk) {
-            st01 = lds_ld<double2>(lds, tbase); st23 = lds_ld<double2>(lds, tbase + 16); st45 = lds_ld<double2>(lds, tbase + 32);
-        }
+        double2 bandH[B], bandE[B];                                            // the entries (s, j < s) of that step, at j
 
         // One decision (:83-89, :57); commit == this lane's chain is still running.  Returns false when not certifiable.
         // fresh: the record values prefetched above (the hot chain); otherwise read here (the slow path's resumed chains).
@@ -739,6 +757,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         using T_ = std::true_type;
         using F_ = std::false_type;
 
+        STAMP(dta);
         if (b < K.nblk) {
             if (in_regs) {
 #pragma unroll
@@ -755,12 +774,10 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // smallest stop over the workgroup's active neurons (B: nobody stopped)
-            int smin = active ? stop : B;
-            smin = min(smin, __builtin_amdgcn_mov_dpp(smin, 0xB1, 0xF, 0xF, true));
-            smin = min(smin, __builtin_amdgcn_mov_dpp(smin, 0x4E, 0xF, 0xF, true));
-#pragma unroll
-            for (int off = 4; off < 64; off <<= 1) smin = min(smin, __shfl_xor(smin, off));
+            STAMP(dtb);
+            // smallest stop over the workgroup's active neurons (B: nobody stopped): one ballot per step, scalar from there (a
+            // butterfly over the lanes goes through ds_bpermute: four LDS round trips at the end of every slot's chain)
+            const int smin = wave_min_stop(active ? stop : B);
             if (lane == 0) lds_st<int>(lds, L.off_ctl + 4 * (b & 1), smin < B ? smin : -1);
         } else if (lane == 0) {
             lds_st<int>(lds, L.off_ctl + 4 * (b & 1), -1);
@@ -769,7 +786,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         slot_barrier();
         STAMP(dt2);
 #ifdef GPFQ_BLK_STAMPS
-        dacc_work += dt1 - dt0; dacc_bar += dt2 - dt1;
+        dacc_work += dt1 - dt0; dacc_bar += dt2 - dt1; dacc_pro += dta - dt0; dacc_chain += dtb - dta;
 #endif
 
         // ---- slow path: exact decision of the stopped step, then the chain resumes ----
@@ -818,11 +835,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                 }
             }
             stop = stop2;
-            int smin = active ? stop : B;
-            smin = min(smin, __builtin_amdgcn_mov_dpp(smin, 0xB1, 0xF, 0xF, true));
-            smin = min(smin, __builtin_amdgcn_mov_dpp(smin, 0x4E, 0xF, 0xF, true));
-#pragma unroll
-            for (int off = 4; off < 64; off <<= 1) smin = min(smin, __shfl_xor(smin, off));
+            const int smin = wave_min_stop(active ? stop : B);
             if (lane == 0) lds_st<int>(lds, L.off_ctl + 4 * (b & 1), smin < B ? smin : -1);
             slot_barrier();                                       // chains resumed, control word rewritten
         }
@@ -840,7 +853,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 
     if (K.fallback_count && n_fallback) atomicAdd(K.fallback_count, n_fallback);   // rare
 #ifdef GPFQ_BLK_STAMPS
-    if (K.stamps && blockIdx.x == 0 && lane == 0) { K.stamps[16] = dacc_work; K.stamps[17] = dacc_bar; }
+    if (K.stamps && blockIdx.x == 0 && lane == 0) { K.stamps[16] = dacc_work; K.stamps[17] = dacc_bar; K.stamps[18] = dacc_pro; K.stamps[19] = dacc_chain; }
 #endif
     slot_barrier();                                               // residual-norm partials published
     if (K.resid) {
@@ -969,9 +982,8 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
 template <int G, int S, int B, int NSW = 8>
 static hipError_t launch_blk_inst(const PipeArgs &a, const BlkShape &sh, hipStream_t stream)
 {
-    // (not where the chain of decisions bounds the slot -- 16 neurons on rows of up to 768 samples: publishing the sign costs the
-    // chain more than the sweeps gain: 3.04 -> 3.2 ms at 512 samples; sweep-bound shapes gain 3-4 %)
-    if constexpr (NSW == 8 && !(G == 4 && S < 32)) {
+    // (sweep-bound shapes gain 3-4 %, the others nothing)
+    if constexpr (NSW == 8) {
         if (blk_sym_a(a) != 0.f) return launch_blk_sym<G, S, B, NSW, true>(a, sh, stream);
     }
     return launch_blk_sym<G, S, B, NSW, false>(a, sh, stream);
@@ -984,7 +996,7 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     const int64_t nblk = (a.N + sh.B - 1) / sh.B;
     const int64_t nrec = (nblk + 1) * sh.B + 1;
     auto *prep = sh.B == 4 ? gpfq_blk_prep_kernel<4> : gpfq_blk_prep_kernel<2>;
-    const float sym_a = (sh.NW == 8 && !(sh.G == 4 && sh.S < 32)) ? blk_sym_a(a) : 0.f;   // (exactly the shapes launch_blk_inst gives the symmetric form)
+    const float sym_a = sh.NW == 8 ? blk_sym_a(a) : 0.f;   // (exactly the launches launch_blk_inst gives the symmetric form)
     hipLaunchKernelGGL(prep, dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp,
                        a.nrm32, static_cast<char *>(a.workspace), sym_a);
     hipError_t e = hipGetLastError();
