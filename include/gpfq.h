@@ -259,6 +259,17 @@ int gpfq_extract_patches(const float *act, int64_t n, int64_t H, int64_t W, int6
 int gpfq_channel_planes(const float *act, int64_t npos, int64_t Cin, int64_t c_lo, int64_t nch, float *planes, void *stream);
 
 /*
+ * Squared channel norms of NHWC activations over the positions a (1, 1) kernel with strides (sh, sw) visits:
+ * sumsq[c] = sum over img, y % sh == 0, x % sw == 0 of act[img][y][x][c]^2 in float64 -- the squared norm of the single row
+ * of channel c's patch matrix for kernel_size (1, 1) (scripts/quantized_network.py:769-797, :83).  All a 1 x 1 conv layer
+ * needs from its activations: its (channel, filter) walks have one step, u = 0, so the decision is nearest(alphabet, w)
+ * unless that norm is below 1e-16 (:83-87).  act [device] f32 [n][H][W][Cin]; sumsq [device] f64 [Cin]; one pass.
+ */
+size_t gpfq_channel_sumsq_workspace_bytes(int64_t Cin);
+int gpfq_channel_sumsq(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int sh, int sw, double *sumsq,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * The channel loop of a conv layer in one call: for each of `nch` input channels build the two patch
  * matrices and run gpfq_quantize_neurons_gram for that channel's F filters -- the body of
  * `for channel_idx in range(num_channels)` in _quantize_conv2D_layer_parallel_jit

@@ -547,6 +547,19 @@ int gpfq_channel_planes(const float *act, int64_t npos, int64_t Cin, int64_t c_l
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_channel_planes");
 }
 
+size_t gpfq_channel_sumsq_workspace_bytes(int64_t Cin) { return Cin > 0 ? gpfq::channel_sumsq_workspace_bytes(Cin) : 0; }
+
+int gpfq_channel_sumsq(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int sh, int sw, double *sumsq,
+                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (n < 0 || H <= 0 || W <= 0 || Cin <= 0 || sh <= 0 || sw <= 0) return fail(GPFQ_ERR_INVALID_ARG, "bad shape or stride");
+    if (!sumsq) return fail(GPFQ_ERR_INVALID_ARG, "NULL output");
+    if (workspace_bytes < gpfq_channel_sumsq_workspace_bytes(Cin) || !workspace) return fail(GPFQ_ERR_WORKSPACE, "workspace too small");
+    if (n > 0 && !act) return fail(GPFQ_ERR_INVALID_ARG, "NULL activations");
+    hipError_t e = gpfq::launch_channel_sumsq(act, n, H, W, Cin, sh, sw, sumsq, workspace, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_channel_sumsq");
+}
+
 static size_t al256c(size_t x) { return (x + 255) & ~(size_t)255; }
 
 size_t gpfq_conv_channels_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t nch, int kh, int kw, int sh, int sw,

@@ -219,6 +219,9 @@ hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, 
                            hipStream_t stream, const AlphabetBig *big = nullptr);
 hipError_t launch_pack(const int8_t *qidx, int64_t N, int64_t C, int bits, uint8_t *packed, hipStream_t stream);
 size_t median_workspace_bytes();
+size_t channel_sumsq_workspace_bytes(int64_t Cin);
+hipError_t launch_channel_sumsq(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int sh, int sw, double *out,
+                                void *workspace, hipStream_t stream);
 hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream);
 hipError_t launch_median_begin(int64_t n_total, void *workspace, hipStream_t stream);
 hipError_t launch_median_count(const float *W_local, int64_t n_local, int64_t n_total, int pass, void *workspace, hipStream_t stream);

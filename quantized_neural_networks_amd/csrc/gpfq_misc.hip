@@ -44,6 +44,100 @@ hipError_t launch_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, f
     return hipGetLastError();
 }
 
+// ---- channel norms straight from NHWC activations (1x1 conv layers) -----------------------------
+// sumsq[c] = sum over the sampled positions (img, y, x) with y % sh == 0, x % sw == 0 of (double)act[img][y][x][c]^2: the
+// squared row norm of channel c's 1 x 1 patch matrix (scripts/quantized_network.py:769-797 with kernel_size (1, 1): one row
+// per channel, one column per output position) without building it.  A 1 x 1 layer needs nothing else from its activations
+// (layer.py: _quantize_conv1x1); the channel-major copy + one workgroup per row that did this before read the tensor three
+// times at 0.6 TB/s (64 rows of 12.8 M samples: 64 busy CUs).  Here the positions are split over the workgroups, a thread owns
+// the same four (or one) channels at every position it visits, and the per-workgroup partial sums are added in a fixed order.
+template <int VEC>
+__global__ void __launch_bounds__(256)
+gpfq_channel_sumsq_kernel(const float *__restrict__ act, int64_t n, int64_t H, int64_t W, int64_t Cin, int sh, int sw,
+                          int64_t oh, int64_t ow, double *__restrict__ partial)
+{
+    __shared__ double sm[256][VEC];
+    const int64_t G = Cin / VEC;                                  // channel groups of a position
+    const int64_t g0 = (int64_t)blockIdx.y * 256;                 // this workgroup's first group (G > 256: chunks of 256)
+    const int gw = (int)(G - g0 < 256 ? G - g0 : 256);            // groups of this chunk
+    const int pp = 256 / gw;                                      // positions in flight per pass
+    const int g = threadIdx.x % gw, slot = threadIdx.x / gw;
+    const int64_t P = n * oh * ow;
+    const int64_t per = (P + gridDim.x - 1) / gridDim.x;
+    const int64_t p_lo = (int64_t)blockIdx.x * per, p_hi = p_lo + per < P ? p_lo + per : P;
+    double acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.0;
+    if (slot < pp) {
+        for (int64_t p = p_lo + slot; p < p_hi; p += pp) {
+            int64_t pix = p;                                      // stride 1: the positions are the pixels, in order
+            if (sh != 1 || sw != 1) {
+                const int64_t img = p / (oh * ow);
+                const unsigned rem = (unsigned)(p - img * oh * ow), y = rem / (unsigned)ow, x = rem - y * (unsigned)ow;
+                pix = (img * H + (int64_t)y * sh) * W + (int64_t)x * sw;
+            }
+            const float *src = act + pix * Cin + (g0 + g) * VEC;
+            if constexpr (VEC == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(src);
+                acc[0] = fma((double)v.x, (double)v.x, acc[0]); acc[1] = fma((double)v.y, (double)v.y, acc[1]);
+                acc[2] = fma((double)v.z, (double)v.z, acc[2]); acc[3] = fma((double)v.w, (double)v.w, acc[3]);
+            } else {
+                acc[0] = fma((double)src[0], (double)src[0], acc[0]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) sm[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < gw) {                                       // slots of a group, in order
+        double tot[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) tot[k] = 0.0;
+        for (int q = 0; q < pp; ++q)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) tot[k] += sm[q * gw + threadIdx.x][k];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) partial[(int64_t)blockIdx.x * Cin + (g0 + threadIdx.x) * VEC + k] = tot[k];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+gpfq_channel_sumsq_final_kernel(const double *__restrict__ partial, int64_t Cin, int nblocks, double *__restrict__ out)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= Cin) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * Cin + c];
+    out[c] = s;
+}
+
+constexpr int kSumsqBlocks = 1024;
+size_t channel_sumsq_workspace_bytes(int64_t Cin) { return (size_t)kSumsqBlocks * (size_t)Cin * sizeof(double); }
+
+hipError_t launch_channel_sumsq(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int sh, int sw, double *out,
+                                void *workspace, hipStream_t stream)
+{
+    const int64_t oh = (H + sh - 1) / sh, ow = (W + sw - 1) / sw, P = n * oh * ow;
+    const bool vec = (Cin % 4 == 0) && ((uintptr_t)act % 16 == 0);
+    const int64_t G = vec ? Cin / 4 : Cin;
+    int64_t nb = (P + 63) / 64;                                   // at least 64 positions per workgroup
+    const int64_t chunks = (G + 255) / 256;
+    const int64_t cap = kSumsqBlocks / chunks > 0 ? kSumsqBlocks / chunks : 1;
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    double *partial = static_cast<double *>(workspace);
+    if (vec)
+        hipLaunchKernelGGL(gpfq_channel_sumsq_kernel<4>, dim3((unsigned)nb, (unsigned)chunks), dim3(256), 0, stream, act, n, H, W, Cin, sh, sw,
+                           oh, ow, partial);
+    else
+        hipLaunchKernelGGL(gpfq_channel_sumsq_kernel<1>, dim3((unsigned)nb, (unsigned)chunks), dim3(256), 0, stream, act, n, H, W, Cin, sh, sw,
+                           oh, ow, partial);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gpfq_channel_sumsq_final_kernel, dim3((unsigned)((Cin + 255) / 256)), dim3(256), 0, stream, partial, Cin, (int)nb, out);
+    return hipGetLastError();
+}
+
 // ---- row statistics of the certified mode (see RowStats) -----------------------------------
 __global__ void __launch_bounds__(256)
 gpfq_row_stats_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t m, int64_t ld,

@@ -36,6 +36,8 @@ SYMBOLS = {
     "gpfq_quantize_neurons_gram": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _i64, _dp, _int, _int, _i64, _i64, _i64,
                                           _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpfq_channel_planes": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "gpfq_channel_sumsq_workspace_bytes": (_sz, [_i64]),
+    "gpfq_channel_sumsq": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _vp, _sz, _vp]),
     "gpfq_conv_channels_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _i64, _int]),
     "gpfq_quantize_conv_channels": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int,
                                            _vp, _dp, _int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -283,6 +285,23 @@ def channel_planes(act, c_lo, c_hi):
     with torch.cuda.device(act.device):
         rc = load().gpfq_channel_planes(act.data_ptr(), n * H * W, Cin, c_lo, c_hi - c_lo, out.data_ptr(), _stream())
     _check(rc, "gpfq_channel_planes")
+    return out
+
+
+def channel_sumsq(act, strides=(1, 1)):
+    """f64 [Cin]: squared norms of the channels of NHWC f32 activations over the positions a (1, 1) kernel with these strides
+    visits (gpfq_channel_sumsq): one pass over the tensor, no channel-major copy."""
+    _dev(act, torch.float32, "act")
+    if act.dim() != 4 or not act.is_contiguous():
+        raise GpfqError("channel_sumsq needs a contiguous NHWC tensor")
+    n, H, W, Cin = act.shape
+    lib = load()
+    nbytes = lib.gpfq_channel_sumsq_workspace_bytes(Cin)
+    ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=act.device)
+    out = torch.empty(Cin, dtype=torch.float64, device=act.device)
+    with torch.cuda.device(act.device):
+        rc = lib.gpfq_channel_sumsq(act.data_ptr(), n, H, W, Cin, int(strides[0]), int(strides[1]), out.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    _check(rc, "gpfq_channel_sumsq")
     return out
 
 

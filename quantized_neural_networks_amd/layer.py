@@ -136,8 +136,9 @@ def _quantize_conv1x1(W, act_q, alphabet, strides):
     dead code, :835-842.)  The residual norms are not formed (NaN)."""
     _, _, Cin, F = W.shape
     sh, sw = strides
-    planes = act_q.permute(3, 0, 1, 2)[:, :, ::sh, ::sw].reshape(Cin, -1).contiguous()   # SAME == VALID for k = 1
-    nrm = hip.row_norms(planes)
+    # the row norm of each channel's one-row patch matrix, float32-rounded as the norm pre-pass of the other paths
+    # (SAME == VALID for k = 1); one pass over the NHWC tensor
+    nrm = hip.channel_sumsq(act_q.contiguous(), (sh, sw)).sqrt().float()
     Q, idx = hip.msq_round(W.reshape(Cin, F), alphabet)
     dead = nrm.double() < 1e-16
     zero_idx = -1
