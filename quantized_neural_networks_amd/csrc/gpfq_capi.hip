@@ -95,7 +95,7 @@ hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes)
 
 extern "C" {
 
-int gpfq_version(void) { return 210; }
+int gpfq_version(void) { return 211; }
 
 const char *gpfq_last_dense_kernel(void) { return g_dense_kernel; }
 

@@ -72,7 +72,7 @@ def lib_path():
     return _build.LIB
 
 
-ABI_VERSION = 210                  # gpfq_version() of the library this binding was written against
+ABI_VERSION = 211                  # gpfq_version() of the library this binding was written against
 
 
 def load():

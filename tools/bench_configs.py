@@ -100,9 +100,21 @@ def main():
         n = 4096
         recs.append(time_conv("cfg5 ResNet50 conv1 7x7/2 VALID (3->64 @230x230 padded input), 4096 images, ternary, scalar 3",
                               3, 64, 230, n, np.log2(3), 3, dev, k=7, stride=2, padding="VALID", reps=2))
-        for cin, hw in [(64, 56), (128, 28), (256, 14), (512, 7)]:
-            recs.append(time_conv(f"cfg5 ResNet50 3x3 conv ({cin}->{cin} @{hw}x{hw}), 4096 images, ternary, scalar 3",
-                                  cin, cin, hw, n, np.log2(3), 3, dev, reps=3))
+        # every other conv layer of the net by distinct shape (cin, cout, input size, kernel, stride) x how often it occurs:
+        # 16 3x3 layers, 36 1x1 layers (four of them the stride-2 first convolutions of a stage, four the stride-2 shortcuts)
+        inventory = [(64, 64, 56, 1, 1, 1), (64, 64, 56, 3, 1, 3), (64, 256, 56, 1, 1, 4), (256, 64, 56, 1, 1, 2),
+                     (256, 128, 56, 1, 2, 1), (256, 512, 56, 1, 2, 1), (128, 128, 28, 3, 1, 4), (128, 512, 28, 1, 1, 4), (512, 128, 28, 1, 1, 3),
+                     (512, 256, 28, 1, 2, 1), (512, 1024, 28, 1, 2, 1), (256, 256, 14, 3, 1, 6), (256, 1024, 14, 1, 1, 6), (1024, 256, 14, 1, 1, 5),
+                     (1024, 512, 14, 1, 2, 1), (1024, 2048, 14, 1, 2, 1), (512, 512, 7, 3, 1, 3), (512, 2048, 7, 1, 1, 3), (2048, 512, 7, 1, 1, 2)]
+        total5, count5 = recs[-1]["ms"], 1
+        for cin, cout, hw, k, stride, times in inventory:
+            r = time_conv(f"cfg5 ResNet50 {k}x{k}/{stride} conv ({cin}->{cout} @{hw}x{hw}) x{times}, 4096 images, ternary, scalar 3",
+                          cin, cout, hw, n, np.log2(3), 3, dev, k=k, stride=stride, reps=3)
+            r["occurrences"] = times
+            total5 += times * r["ms"]; count5 += times
+            recs.append(r)
+        recs.append(dict(config=f"cfg5 ResNet50, all {count5} conv layers (quantization only, synthetic activations of each layer's shape, one GPU)", ms=total5))
+        print(json.dumps(recs[-1]))
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(dict(note="tools/bench_configs.py on one MI355X; best of 2-3 runs per layer; whole layer driver "
                         "(median, norms, kernel, assemble) with inputs resident in HBM", records=recs),
