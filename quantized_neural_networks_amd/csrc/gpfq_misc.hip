@@ -355,10 +355,51 @@ gpfq_assemble_kernel(const Idx *__restrict__ qidx, Alph A, int64_t N, int64_t C,
     }
 }
 
+// The common case -- one int8 index per weight, N and C multiples of four -- in 64 x 64 tiles with 4-byte index reads and
+// 16-byte value writes (the 32 x 32 form reads single bytes: 43 -> 27 us for 4096 x 4096).
+__global__ void __launch_bounds__(256)
+gpfq_assemble64_kernel(const int8_t *__restrict__ qidx, AlphabetArg A, int64_t N, int64_t C, float *__restrict__ Q, int8_t *__restrict__ idxT)
+{
+    __shared__ int8_t tile[64][68];                               // [neuron][step], rows 4-byte aligned
+    const int64_t t0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;
+    const int c4 = threadIdx.x & 15, r0 = threadIdx.x >> 4;       // 16 x 16
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int r = r0 + 16 * pass;
+        const int64_t j = j0 + r, t = t0 + 4 * c4;
+        unsigned w = 0;
+        if (j < C && t < N) w = *reinterpret_cast<const unsigned *>(qidx + j * N + t);
+        *reinterpret_cast<unsigned *>(&tile[r][4 * c4]) = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int tt = r0 + 16 * pass;
+        const int64_t t = t0 + tt, j = j0 + 4 * c4;
+        if (t < N && j < C) {
+            int k[4];
+            float q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                k[e] = tile[4 * c4 + e][tt];
+                q[e] = (k[e] >= 0 && k[e] < A.M) ? (float)A.a[k[e]] : 0.f;
+            }
+            if (Q) *reinterpret_cast<float4 *>(Q + t * C + j) = make_float4(q[0], q[1], q[2], q[3]);
+            if (idxT) *reinterpret_cast<unsigned *>(idxT + t * C + j) = (unsigned)(k[0] & 0xff) | ((unsigned)(k[1] & 0xff) << 8) |
+                                                                       ((unsigned)(k[2] & 0xff) << 16) | ((unsigned)(k[3] & 0xff) << 24);
+        }
+    }
+}
+
 hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, int64_t C, int bits, float *Q, int8_t *idxT,
                            hipStream_t stream, const AlphabetBig *big)
 {
     if (N == 0 || C == 0) return hipSuccess;
+    if (!big && bits == 8 && N % 4 == 0 && C % 4 == 0 && (uintptr_t)qidx % 4 == 0 && (uintptr_t)Q % 16 == 0 && (uintptr_t)idxT % 4 == 0) {
+        hipLaunchKernelGGL(gpfq_assemble64_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, stream,
+                           qidx, A, N, C, Q, idxT);
+        return hipGetLastError();
+    }
     const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((C + 31) / 32));
     if (big)
         hipLaunchKernelGGL((gpfq_assemble_kernel<AlphabetBig, int16_t>), grid, dim3(256), 0, stream,
