@@ -510,10 +510,17 @@ gpfq_select_pick_kernel(unsigned *__restrict__ hist, SelState *__restrict__ st, 
         __syncthreads();
         unsigned long long mine = 0;
         for (int b = 0; b < 8; ++b) mine += h[tid * 8 + b];
-        part[tid] = mine;
+        // exclusive prefix of `mine` over the 256 threads: shuffles inside each wavefront, the four wavefront totals through LDS
+        unsigned long long incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long up = __shfl_up(incl, off);
+            if ((tid & 63) >= off) incl += up;
+        }
+        if ((tid & 63) == 63) part[tid >> 6] = incl;
         __syncthreads();
-        unsigned long long before = 0;
-        for (int i = 0; i < tid; ++i) before += part[i];
+        unsigned long long before = incl - mine;
+        for (int w = 0; w < (tid >> 6); ++w) before += part[w];
         const unsigned long long k = st[sel].k;
         if (before <= k && k < before + mine) {           // exactly one thread (or none if k is out of range)
             unsigned long long acc = before;
