@@ -872,6 +872,8 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 template <int S, int NSW> struct BlkSplit { static constexpr const int *pw = PairSplit<S>::pw; };
 template <> struct BlkSplit<32, 11> { static constexpr int pw_[11] = {3, 3, 3, 3, 3, 3, 3, 2, 3, 3, 3}; static constexpr const int *pw = pw_; };
 template <> struct BlkSplit<24, 11> { static constexpr int pw_[11] = {2, 2, 2, 2, 2, 2, 2, 1, 3, 3, 3}; static constexpr const int *pw = pw_; };
+template <> struct BlkSplit<64, 11> { static constexpr int pw_[11] = {6, 6, 6, 6, 6, 6, 6, 4, 6, 6, 6}; static constexpr const int *pw = pw_; };
+template <> struct BlkSplit<48, 11> { static constexpr int pw_[11] = {5, 4, 4, 4, 5, 4, 4, 4, 5, 5, 4}; static constexpr const int *pw = pw_; };
 template <> struct BlkSplit<16, 11> { static constexpr int pw_[11] = {2, 2, 1, 1, 2, 2, 1, 1, 1, 1, 2}; static constexpr const int *pw = pw_; };
 
 // G neuron groups per sweep wavefront (4G neurons per workgroup), S sample pairs per k-lane over the NSW sweep
@@ -903,12 +905,13 @@ gpfq_blk_kernel(BlkK K, AlphabetArg A)
         int pbase = 0, pw = 1;
 #pragma unroll
         for (int w = 0; w < NSW; ++w) { pbase += (w < wave) ? KQ * PS::pw[w] : 0; pw = (w == wave) ? PS::pw[w] : pw; }
-        constexpr int PMAX = NSW == 11 ? 3 : (S == 32 ? 5 : (S == 24 ? 4 : 3));
+        constexpr int PMAX = S == 64 ? 6 : (S == 48 ? 5 : (NSW == 11 ? 3 : (S == 32 ? 5 : (S == 24 ? 4 : 3))));
         if (pw == 1) blk_sweep_role<G, 1, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase);
         else if (pw == 2) blk_sweep_role<G, 2, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase);
         else if (pw == 3) blk_sweep_role<G, 3, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase);
         else if (pw == 4) { if constexpr (PMAX >= 4) blk_sweep_role<G, 4, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase); }
-        else { if constexpr (PMAX >= 5) blk_sweep_role<G, 5, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase); }
+        else if (pw == 5) { if constexpr (PMAX >= 5) blk_sweep_role<G, 5, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase); }
+        else { if constexpr (PMAX >= 6) blk_sweep_role<G, 6, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase); }
     } else {
         blk_decision_role<G, MP, B, NSW, SYM>(K, lds, L, lane);
     }
@@ -917,6 +920,8 @@ gpfq_blk_kernel(BlkK K, AlphabetArg A)
 // ---- host side ------------------------------------------------------------------------------------
 struct BlkShape { int G, S, B, mp, NW; };
 static std::atomic<int> g_blk_nw{8};      // sweep wavefronts of the 16-neuron shapes (experiment switch: blk_set_sweep_waves)
+static std::atomic<int> g_blk_wide{1};    // 16-neuron workgroups for rows beyond 1024 samples in layers wider than 2048 neurons
+void blk_set_wide_groups(int on) { g_blk_wide.store(on ? 1 : 0, std::memory_order_relaxed); }
 void blk_set_sweep_waves(int nw) { g_blk_nw.store(nw == 11 ? 11 : 8, std::memory_order_relaxed); }
 
 // C: neurons of the call.  Rows of 769..1024 samples are the one shape whose slot is bound by the sweeps (nine sample pairs
@@ -928,8 +933,13 @@ static BlkShape blk_shape(int64_t m, int64_t C)
     if (m > 256 && m <= 512) return {4, 16, 4, 512, nw4};
     if (m > 512 && m <= 768) return {4, 24, 4, 768, nw4};
     if (m > 768 && m <= 1024) return C <= 2048 ? BlkShape{2, 16, 4, 1024, 8} : BlkShape{4, 32, 4, 1024, nw4};
-    if (m > 1024 && m <= 1536) return {2, 24, 2, 1536, 8};
-    if (m > 1536 && m <= 2048) return {2, 32, 2, 2048, 8};
+    // rows beyond 1024 samples: 8 neurons per workgroup and eight sweep wavefronts -- or, in layers of more than 2048 neurons (where
+    // that takes two rounds of workgroups), 16 neurons over eleven sweep wavefronts: one round, half the decisions and folds per weight
+    // (a 16-neuron workgroup takes 1.6 x as long as an 8-neuron one: 6.5 against 4.1 ms for 4096 steps of 2048 samples; rounds of 256)
+    const int64_t rounds16 = (C + 4095) / 4096, rounds8 = (C + 2047) / 2048;
+    const bool wide = C > 2048 && 8 * rounds16 <= 5 * rounds8 && g_blk_wide.load(std::memory_order_relaxed) != 0;
+    if (m > 1024 && m <= 1536) return wide ? BlkShape{4, 48, 2, 1536, 11} : BlkShape{2, 24, 2, 1536, 8};
+    if (m > 1536 && m <= 2048) return wide ? BlkShape{4, 64, 2, 2048, 11} : BlkShape{2, 32, 2, 2048, 8};
     return {0, 0, 0, 0, 0};
 }
 
@@ -979,11 +989,14 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
     return hipGetLastError();
 }
 
+// (the eleven-wavefront variants of the shapes that also exist with eight are kept in the general form only: an experiment switch)
+constexpr bool blk_has_sym(int S, int NSW) { return NSW == 8 || S > 32; }
+
 template <int G, int S, int B, int NSW = 8>
 static hipError_t launch_blk_inst(const PipeArgs &a, const BlkShape &sh, hipStream_t stream)
 {
     // (sweep-bound shapes gain 3-4 %, the others nothing)
-    if constexpr (NSW == 8) {
+    if constexpr (blk_has_sym(S, NSW)) {
         if (blk_sym_a(a) != 0.f) return launch_blk_sym<G, S, B, NSW, true>(a, sh, stream);
     }
     return launch_blk_sym<G, S, B, NSW, false>(a, sh, stream);
@@ -996,11 +1009,13 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     const int64_t nblk = (a.N + sh.B - 1) / sh.B;
     const int64_t nrec = (nblk + 1) * sh.B + 1;
     auto *prep = sh.B == 4 ? gpfq_blk_prep_kernel<4> : gpfq_blk_prep_kernel<2>;
-    const float sym_a = sh.NW == 8 ? blk_sym_a(a) : 0.f;   // (exactly the launches launch_blk_inst gives the symmetric form)
+    const float sym_a = blk_has_sym(sh.S, sh.NW) ? blk_sym_a(a) : 0.f;   // (exactly the launches launch_blk_inst gives the symmetric form)
     hipLaunchKernelGGL(prep, dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp,
                        a.nrm32, static_cast<char *>(a.workspace), sym_a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (sh.G == 4 && sh.S == 64) return launch_blk_inst<4, 64, 2, 11>(a, sh, stream);
+    if (sh.G == 4 && sh.S == 48) return launch_blk_inst<4, 48, 2, 11>(a, sh, stream);
     if (sh.G == 4 && sh.NW == 11) {
         if (sh.S == 16) return launch_blk_inst<4, 16, 4, 11>(a, sh, stream);
         if (sh.S == 24) return launch_blk_inst<4, 24, 4, 11>(a, sh, stream);
