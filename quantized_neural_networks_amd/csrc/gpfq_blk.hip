@@ -31,12 +31,15 @@
 // pieces filled the vector-memory queue and stalled every sweep ~1000 cycles per slot.
 //
 // Shapes (blk_shape): G neuron groups per sweep wavefront (4G neurons per workgroup), S sample pairs per k-lane over the
-// eight sweep wavefronts, B steps per slot -- <4,16|24|32,4> for rows of up to 512 / 768 / 1024 samples, <2,24|32,2> up to
-// 1536 / 2048, and <2,16,4> (8 neurons per workgroup: half the sweep per slot) for rows of 769..1024 samples when the
-// layer has at most 2048 neurons.  What bounds a slot: the sweeps (nine sample pairs on three of the SIMDs) for <4,32,4> and
-// the B = 2 shapes, the decision wavefront's chain everywhere else; it runs at raised priority (s_setprio) because it
-// shares its SIMD with two sweep wavefronts.  profiles/r02/blk_phase_stamps.txt has the per-phase cycle counts
-// (diagnostic build: GPFQ_DIAG="-DGPFQ_BLK_STAMPS").
+// sweep wavefronts, B steps per slot, NSW sweep wavefronts -- <4,16|24|32,4> x 8 for rows of up to 512 / 768 / 1024 samples,
+// <2,24|32,2> x 8 up to 1536 / 2048 (8 neurons per workgroup), <4,48|64,2> x 11 for the same rows in layers of more than
+// 2048 neurons (16 neurons per workgroup: one round of workgroups instead of two, half the folds and decisions per weight:
+// 8.2 -> 6.5 ms at 4096 x 4096 x 2048), and <2,16,4> x 8 (8 neurons per workgroup: half the sweep per slot) for rows of
+// 769..1024 samples when the layer has at most 2048 neurons.  What bounds a slot: the sweeps (nine sample pairs on three of
+// the SIMDs) for <4,32,4> and the B = 2 shapes, the decision wavefront's chain everywhere else; it runs at raised priority
+// (s_setprio) because it shares its SIMD with two sweep wavefronts, and the sweeps lower theirs as they progress through the
+// slot.  Symmetric alphabets take the SYM instantiation (BlkK::sym_a).  profiles/r02/blk_phase_stamps.txt has the per-phase
+// cycle counts (diagnostic build: GPFQ_DIAG="-DGPFQ_BLK_STAMPS").
 #include <atomic>
 #include <cmath>
 #include <type_traits>
