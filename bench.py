@@ -115,7 +115,10 @@ def main():
     kname = [""]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
+    st = {"C_total": C_total, "Wd": Wd}      # the layer being stepped (the weak-scaling companion swaps in its own)
+
     def step(i_timed=None):
+        C_total, Wd = st["C_total"], st["Wd"]
         lo, hi = layer.shard_bounds(C_total, world, rank)
         pre = {}
 
@@ -159,6 +162,28 @@ def main():
         elapsed = float(tmax.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     kernel_name = kname[0]
+
+    # N > 1, strong scaling (the default: the north-star layer is fixed): the same run also steps the weak-scaling layer --
+    # args.c neurons PER GPU -- so that one launch of the driver's command shows both regimes.  `value` stays the strong one.
+    weak = None
+    if world > 1 and args.scaling == "strong":
+        Cw = args.c * world
+        Ww = np.concatenate([weight_block(N, b, args.c) for b in range(world)], axis=1)
+        st["C_total"], st["Wd"] = Cw, torch.from_numpy(Ww).to(dev)
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0w = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        ew = time.perf_counter() - t0w
+        tw = torch.tensor([ew], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        ew = float(tw.item())
+        weak = {"value": N * Cw * args.steps / ew, "unit": "weights/s", "ms_per_step": ew / args.steps * 1e3, "scaling": "weak",
+                "workload": f"Dense({N}->{Cw}): {args.c} neurons per GPU, same samples and alphabet (whole-job aggregate over {world} GPUs)"}
+        st["C_total"], st["Wd"] = C_total, Wd
 
     weights_per_step = N * C_total
     value = weights_per_step * args.steps / elapsed
@@ -210,6 +235,8 @@ def main():
                         "flops per launch = 6 m N C_local (SURVEY 8d); duration = HIP events around the launch on its stream",
             },
         }
+        if weak is not None:
+            out["weak_scaling_companion"] = weak
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"], out["parity_sample"] = _cpu_baseline(W, X, Xq, unit_alphabet, args, idx, last)
         print(json.dumps(out))

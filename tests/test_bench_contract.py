@@ -61,3 +61,5 @@ def test_bench_two_ranks_over_gloo_split_the_fixed_layer():
     assert out["config"]["C"] == 512 and out["config"]["neurons_per_gpu"] == 256 and "split over 2 GPUs" in out["config"]["workload"]
     assert "cpu_baseline" not in out                     # rank 0 at N = 1 only
     assert 0 < out["roofline"]["frac"] <= 1.0
+    weak = out["weak_scaling_companion"]                 # the same launch also steps --neurons per GPU (weak scaling)
+    assert weak["scaling"] == "weak" and weak["value"] > 0 and "Dense(256->1024)" in weak["workload"]
