@@ -32,7 +32,7 @@ def activations(shape, kind):
 
 
 while time.time() < t_end:
-    bits = rng.choice([np.log2(3), 2, 3, 4, 5, 6, 7, 8, np.log2(129)])      # up to 256 members (int16 indices beyond 64)
+    bits = rng.choice([1, np.log2(3), np.log2(3), 2, 3, 4, 5, 6, 7, 8, np.log2(129)])   # up to 256 members (int16 indices beyond 64); 1 and log2(3): symmetric forms
     M = int(round(2 ** bits))
     scalar = float(rng.choice([1, 2, 3, 5]))
     if rng.random() < 0.5:
@@ -41,6 +41,8 @@ while time.time() < t_end:
         m = int(rng.choice([rng.integers(1, 300), rng.integers(300, 3000), rng.integers(3000, 30000)]))
         if rng.random() < 0.15:                     # long walks (Gram path: one wavefront per neuron)
             N = int(rng.integers(200, 1025)); m = int(rng.integers(1, 2500))
+        if rng.random() < 0.12:                     # wide layers on long rows: 16 neurons per workgroup over eleven sweep wavefronts
+            N = int(rng.integers(1, 40)); C = int(rng.integers(2049, 2400)); m = int(rng.integers(1025, 2049))
         kind = rng.choice(["relu", "sparse", "signed", "uniform"])
         X = activations((N, m), kind)
         Xq = X if rng.random() < 0.2 else (X + 0.1 * rng.standard_normal((N, m)).astype(np.float32) * (X != 0 if kind == "sparse" else 1)).astype(np.float32)
@@ -56,7 +58,8 @@ while time.time() < t_end:
             path = 3
         opts = {}
         if path in (0, 1) and rng.random() < 0.5:   # the role-split kernels (one step / a block of steps per slot) wherever they apply
-            opts = dict(pipe=int(rng.choice([1, 2])))
+            opts = dict(pipe=int(rng.choice([1, 2])), blk_sweep_waves=int(rng.choice([8, 8, 11])), blk_wide_groups=int(rng.choice([1, 1, 0])),
+                        variant=int(rng.choice([0, 0, 32])))
         elif path == 1:
             opts = dict(lanes_per_neuron=int(rng.choice([0, 1, 16, 32, 64])), waves_per_neuron=int(rng.choice([0, 0, 2, 4, 8, 16])),
                         onchip_mode=int(rng.integers(0, 2)))
@@ -67,7 +70,7 @@ while time.time() < t_end:
                                      alphabet, path=path)
         finally:
             for k in opts:
-                hip.set_option(k, 1 if k == "onchip_mode" else -1 if k == "pipe" else 0)
+                hip.set_option(k, {"onchip_mode": 1, "pipe": -1, "blk_sweep_waves": 8, "blk_wide_groups": 1}.get(k, 0))
         ok = np.array_equal(r["idx"].cpu().numpy(), io) and np.allclose(r["resid"].cpu().numpy(), ro, rtol=1e-5, atol=0)
         n_dense += 1
         if not ok:
