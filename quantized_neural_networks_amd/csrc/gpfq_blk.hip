@@ -35,7 +35,8 @@
 // <2,24|32,2> x 8 up to 1536 / 2048 (8 neurons per workgroup), <4,48|64,2> x 11 for the same rows in layers of more than
 // 2048 neurons (16 neurons per workgroup: one round of workgroups instead of two, half the folds and decisions per weight:
 // 8.2 -> 6.5 ms at 4096 x 4096 x 2048), and <2,16,4> x 8 (8 neurons per workgroup: half the sweep per slot) for rows of
-// 769..1024 samples when the layer has at most 2048 neurons.  What bounds a slot: the sweeps (nine sample pairs on three of
+// 769..1024 samples when the layer has at most 2048 neurons, <1,8,4> / <1,12|16,2> x 8 (4 neurons per workgroup) for rows of 769..2048
+// samples when it has at most 1024.  What bounds a slot: the sweeps (nine sample pairs on three of
 // the SIMDs) for <4,32,4> and the B = 2 shapes, the decision wavefront's chain everywhere else; it runs at raised priority
 // (s_setprio) because it shares its SIMD with two sweep wavefronts, and the sweeps lower theirs as they progress through the
 // slot.  Symmetric alphabets take the SYM instantiation (BlkK::sym_a).  profiles/r02/blk_phase_stamps.txt has the per-phase
@@ -193,7 +194,8 @@ constexpr int kOutSteps = 32;                                    // steps of out
 
 // Partial sums have one slot per sweep wavefront, rounded up to the decision wavefront's 64 / NB sub-lanes per neuron
 // (sub-lane r adds slots r, r + R, ...; a slot no wavefront writes stays zero).
-__host__ __device__ constexpr int blk_slots(int nsw, int nb) { return (nsw + 64 / nb - 1) / (64 / nb) * (64 / nb); }
+__host__ __device__ constexpr int blk_sublanes(int nb) { return 64 / nb > 8 ? 8 : 64 / nb; }   // R: lanes of the decision wavefront per neuron
+__host__ __device__ constexpr int blk_slots(int nsw, int nb) { return (nsw + blk_sublanes(nb) - 1) / blk_sublanes(nb) * blk_sublanes(nb); }
 
 __host__ __device__ inline BlkLds blk_lds(int mp, int nb, int B, int nsw)
 {
@@ -510,10 +512,13 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 template <int G, int MP, int B, int NSW, bool SYM>
 __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_generic, const BlkLds &L, int lane)
 {
-    constexpr int NB = 4 * G, R = 64 / NB, NW = blk_slots(NSW, NB);
+    constexpr int NB = 4 * G, R = blk_sublanes(NB), NW = blk_slots(NSW, NB);
     constexpr int RB = (int)blk_rec_bytes(MP, B);
     lchar *lds = (lchar *)lds_generic;
-    const int n = lane / R, r = lane % R;                         // neuron of the workgroup, sub-lane
+    // neuron of the workgroup, sub-lane.  Four-neuron workgroups use 32 lanes; the other half shadows the last neuron (same reads,
+    // same decisions, same stores to the same addresses) and is left out of the counters
+    const bool shadow = lane / R >= NB;
+    const int n = shadow ? NB - 1 : lane / R, r = lane % R;
     const int64_t jn = (int64_t)blockIdx.x * NB + n;
     const bool active = jn < K.C;
     const int64_t N = K.N;
@@ -828,7 +833,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                 if (r == 0) {
                     lds_st<float2>(lds, o_wq + cbq + 8 * S, make_float2(wS, SYM ? (q32 > 0.f ? -1.f : (q32 < 0.f ? 1.f : 0.f)) : q32));
                     lds_st<int2>(lds, o_out + (int)(t % kOutSteps) * 8, make_int2(bi, __float_as_int(q32)));
-                    ++n_fallback;
+                    if (!shadow) ++n_fallback;
                 }
             }
             // resume the chains that were stopped at S
@@ -926,6 +931,8 @@ gpfq_blk_kernel(BlkK K, AlphabetArg A)
 // ---- host side ------------------------------------------------------------------------------------
 struct BlkShape { int G, S, B, mp, NW; };
 static std::atomic<int> g_blk_nw{8};      // sweep wavefronts of the 16-neuron shapes (experiment switch: blk_set_sweep_waves)
+static std::atomic<int> g_blk_four{1};    // 4-neuron workgroups for layers of at most 1024 neurons on rows of 769..2048 samples
+void blk_set_four_groups(int on) { g_blk_four.store(on ? 1 : 0, std::memory_order_relaxed); }
 static std::atomic<int> g_blk_wide{1};    // 16-neuron workgroups for rows beyond 1024 samples in layers wider than 2048 neurons
 void blk_set_wide_groups(int on) { g_blk_wide.store(on ? 1 : 0, std::memory_order_relaxed); }
 void blk_set_sweep_waves(int nw) { g_blk_nw.store(nw == 11 ? 11 : 8, std::memory_order_relaxed); }
@@ -938,6 +945,12 @@ static BlkShape blk_shape(int64_t m, int64_t C)
     const int nw4 = g_blk_nw.load(std::memory_order_relaxed);
     if (m > 256 && m <= 512) return {4, 16, 4, 512, nw4};
     if (m > 512 && m <= 768) return {4, 24, 4, 768, nw4};
+    // layers of at most 1024 neurons on rows of 769+ samples: FOUR neurons per workgroup (a quarter of the 16-neuron sweep per slot;
+    // 256 workgroups hold 1024 neurons) -- the slot is then the chain of decisions
+    const bool four = C <= 1024 && g_blk_four.load(std::memory_order_relaxed) != 0;
+    if (four && m > 768 && m <= 1024) return {1, 8, 4, 1024, 8};
+    if (four && m > 1024 && m <= 1536) return {1, 12, 2, 1536, 8};
+    if (four && m > 1536 && m <= 2048) return {1, 16, 2, 2048, 8};
     if (m > 768 && m <= 1024) return C <= 2048 ? BlkShape{2, 16, 4, 1024, 8} : BlkShape{4, 32, 4, 1024, nw4};
     // rows beyond 1024 samples: 8 neurons per workgroup and eight sweep wavefronts -- or, in layers of more than 2048 neurons (where
     // that takes two rounds of workgroups), 16 neurons over eleven sweep wavefronts: one round, half the decisions and folds per weight
@@ -1031,6 +1044,11 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
         if (sh.S == 16) return launch_blk_inst<4, 16, 4>(a, sh, stream);
         if (sh.S == 24) return launch_blk_inst<4, 24, 4>(a, sh, stream);
         return launch_blk_inst<4, 32, 4>(a, sh, stream);
+    }
+    if (sh.G == 1) {
+        if (sh.S == 8) return launch_blk_inst<1, 8, 4>(a, sh, stream);
+        if (sh.S == 12) return launch_blk_inst<1, 12, 2>(a, sh, stream);
+        return launch_blk_inst<1, 16, 2>(a, sh, stream);
     }
     if (sh.B == 4) return launch_blk_inst<2, 16, 4>(a, sh, stream);
     if (sh.S == 24) return launch_blk_inst<2, 24, 2>(a, sh, stream);

@@ -199,6 +199,7 @@ int gpfq_set_option(const char *key, int value)
             return fail(GPFQ_ERR_INVALID_ARG, "pipe must be -1, 0, 1 or 2");
         g_pipe = value; return GPFQ_OK;
     }
+    if (!std::strcmp(key, "blk_four_groups")) { gpfq::blk_set_four_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_wide_groups")) { gpfq::blk_set_wide_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_sweep_waves")) {
         if (value != 8 && value != 11) return fail(GPFQ_ERR_INVALID_ARG, "blk_sweep_waves must be 8 or 11");

@@ -87,6 +87,7 @@ __device__ __forceinline__ double fold_klanes(const double (&a)[4])
     if constexpr (G <= 8) x = ror_add<8>(x);
     if constexpr (G <= 4) x = ror_add<4>(x);
     if constexpr (G <= 2) x = ror_add<2>(x);
+    if constexpr (G <= 1) x = ror_add<1>(x);
     return x;
 }
 
@@ -129,6 +130,8 @@ template <int S> struct PairSplit;
 template <> struct PairSplit<32> { static constexpr int pw[8] = {2, 4, 4, 4, 3, 5, 5, 5}; };
 template <> struct PairSplit<24> { static constexpr int pw[8] = {1, 3, 3, 3, 2, 4, 4, 4}; };
 template <> struct PairSplit<16> { static constexpr int pw[8] = {1, 2, 2, 2, 1, 3, 3, 2}; };
+template <> struct PairSplit<12> { static constexpr int pw[8] = {1, 2, 2, 1, 1, 2, 2, 1}; };
+template <> struct PairSplit<8>  { static constexpr int pw[8] = {1, 1, 1, 1, 1, 1, 1, 1}; };
 
 // LDS through 32-bit address-space-3 pointers: offsets stay 32-bit integer arithmetic (generic pointers into the
 // dynamic LDS array cost 64-bit adds and multiplies per access in the hot loop).
