@@ -537,6 +537,8 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 #pragma unroll
     for (int q = 0; q < 4; ++q) am[q] = (r + q * R < M) ? lds_ld<double>(lds, L.off_e + 8 * (2 + r + q * R)) : kNaN;
 
+    const double sym_top = SYM ? lds_ld<double>(lds, L.off_e + 8 * (2 + M - 1)) : 0.0;      // a;  a / 2 (0 for {-a, a})
+    const double sym_hb = (SYM && M == 3) ? 0.5 * sym_top : 0.0;
     float wprev[B], qprev[B];                                     // block b-1 (final), this neuron
 #pragma unroll
     for (int j = 0; j < B; ++j) { wprev[j] = 0.f; qprev[j] = 0.f; }
@@ -731,6 +733,20 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             // twice the modelling error of the prediction (quotient units) + float64 slack
             const double delta2 = 2.0 * (fma(fabs(wd), rcb, rca) + eps * rden)
                                   + 0x1p-43 * (fabs(D[s]) + fabs(corr) + fabs(wG)) * rden;
+            int idx_l;
+            double q_l;
+            bool cert;
+            if constexpr (SYM) {
+                // {-a, 0, a} / {-a, a}, exactly symmetric in float64 (blk_sym_a): the boundaries are -a/2 and a/2 (or 0), exact, and
+                // the nearest member follows from two comparisons -- a tie goes to the lower index as argmin does (:57), though a
+                // decision that close is never certified.  Twice the distance from the nearer boundary is the margin.  No table
+                // look-up, no LDS round trip in the chain.
+                const bool up = tt > sym_hb, mid = tt > -sym_hb;
+                idx_l = up ? M - 1 : (mid ? 1 : 0);
+                q_l = up ? sym_top : (mid ? 0.0 : -sym_top);
+                const double m2 = 2.0 * fmin(fabs(tt - sym_hb), fabs(tt + sym_hb));
+                cert = (msq | (m2 > delta2)) & sure;
+            } else {
             int c = 0;                                                           // members below t, counted by the R sub-lanes
             if constexpr (IN_REGS) {
 #pragma unroll
@@ -745,12 +761,13 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             const double d_lo = fabs(lo - tt), d_hi = fabs(hi - tt), d_ll = fabs(lolo - tt), d_hh = fabs(hihi - tt);
             const bool at0 = p == 0, atM = p == M;
             const bool use_hi = at0 | (!atM & !(d_lo <= d_hi));                  // tie -> lower index
-            const int    idx_l = use_hi ? p : p - 1;
-            const double q_l   = use_hi ? hi : lo;
+            idx_l = use_hi ? p : p - 1;
+            q_l   = use_hi ? hi : lo;
             const double m2_in = fabs(d_hi - d_lo), m2_lo = d_hh - d_hi, m2_hi = d_ll - d_lo;
             const double m2 = at0 ? m2_lo : (atM ? m2_hi : m2_in);               // twice the distance from the boundary
             const bool plateau = !use_hi & (p >= 2) & !(d_ll > d_lo);            // a lower member at the same distance would win
-            const bool cert = !plateau & (msq | (m2 > delta2)) & sure;
+            cert = !plateau & (msq | (m2 > delta2)) & sure;
+            }
             const bool valid = s < nvalid;
             const float q32 = (rule1 | !valid) ? 0.f : (float)q_l;
             const int   idx = rule1 ? K.zero_idx : idx_l;
@@ -983,9 +1000,10 @@ static float blk_sym_a(const PipeArgs &a)
 {
     const int M = a.A.M;
     if ((a.variant & 2) || (M != 2 && M != 3)) return 0.f;
-    const float hi = (float)a.A.a[M - 1], lo = (float)a.A.a[0];
-    if (!(hi > 0.f) || lo != -hi || !std::isfinite(hi)) return 0.f;
-    if (M == 3 && (float)a.A.a[1] != 0.f) return 0.f;
+    // (exactly symmetric as float64 too: the decisions' nearest-member search takes its boundaries as -a/2 and a/2)
+    if (a.A.a[0] != -a.A.a[M - 1] || (M == 3 && a.A.a[1] != 0.0)) return 0.f;
+    const float hi = (float)a.A.a[M - 1];
+    if (!(hi > 0.f) || !std::isfinite(hi)) return 0.f;
     return hi;
 }
 
