@@ -312,10 +312,75 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         const int tbase = (b & 1) * L.tile_pitch;
         const int pbq = ((b - 1) & 1) * NB * B * 8;               // (w, q) of block b-1
 
+        // one sample pair of one step: f32 products and subtraction on two samples at once (v_pk_mul_f32 / v_pk_add_f32 or, for
+        // symmetric alphabets, v_pk_fma_f32), conversions, float64 additions
+        auto update_pair = [&](int p, const float2 &x2, const float2 &q2, const float (&wv)[4], const float (&qv)[4]) {
+            const pk2 xv = {x2.x, x2.y}, qx = {q2.x, q2.y};
+            // f32 products and subtraction on two samples at once (v_pk_mul_f32 / v_pk_add_f32): each half rounds
+            // exactly as the scalar instruction (no contraction: -ffp-contract=off).  Written stage by stage over the
+            // four neurons so that no instruction consumes the result of the one right before it (hipcc pads those
+            // packed-to-scalar dependences with s_nop, which cost issue slots)
+            pk2 pr[4], rr[4], dd[4];
+            double c0[4], c1[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) pr[n] = pk2{wv[n], wv[n]} * xv;
+            if constexpr (SYM) {                      // qv = -sg, qx = f32(a xq): v_pk_fma_f32, one rounding
+#pragma unroll
+                for (int n = 0; n < 4; ++n) dd[n] = __builtin_elementwise_fma(pk2{qv[n], qv[n]}, qx, pr[n]);
+            } else {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) rr[n] = pk2{qv[n], qv[n]} * qx;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) dd[n] = pr[n] - rr[n];
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) { c0[n] = (double)dd[n].x; c1[n] = (double)dd[n].y; }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) { u[n][2 * p] += c0[n]; u[n][2 * p + 1] += c1[n]; }
+        };
+        constexpr bool kPreloadAll = PW * B <= 8;                  // few pairs per step: see below
         // ---- phase U: the B updates of block b-1, in order: u += f32(w x) - f32(q xq)  (:119) ----
         // Software-pipelined by hand: the operands of the NEXT pair (and the next step's four (w, q)) are requested before
         // the arithmetic of the current one (sched_barrier keeps hipcc from sinking the requests to their first use,
         // where every pair would wait out a full LDS round trip).
+        if constexpr (kPreloadAll) {
+            // One or two pairs per step: the pipelined loop below keeps ONE pair of operands in flight, and a step's arithmetic
+            // (32 instructions per pair) is shorter than an LDS round trip with twelve wavefronts on the LDS -- the sweep of a
+            // 4-neuron workgroup took 600 cycles per (pair, step) against 316 for the arithmetic.  So every operand of the slot is
+            // requested up front (at most 8 pairs + the block's (w, q): 64 registers) and the steps run back to back.
+            float2 xs[B][PW], qs[B][PW], wqa[B][4];
+#pragma unroll
+            for (int s = 0; s < B; ++s) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) wqa[s][n] = lds_ld<float2>(lds, o_wq + pbq + (n * B + s) * 8);
+#pragma unroll
+                for (int p = 0; p < PW; ++p) {
+                    xs[s][p] = lds_ld<float2>(lds, tbase + s * RB + o_x + 8 * p * KQ);
+                    qs[s][p] = lds_ld<float2>(lds, tbase + s * RB + o_q + 8 * p * KQ);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < B; ++s) {
+                if (s == 0) __builtin_amdgcn_s_setprio(2);
+                if (s == B / 2) __builtin_amdgcn_s_setprio(1);
+                float wv[4], qv[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) { wv[n] = wqa[s][n].x; qv[n] = wqa[s][n].y; }
+#pragma unroll
+                for (int p = 0; p < PW; ++p) {
+                    if (p < PTS) {
+#pragma unroll
+                        for (int i = 0; i < PPP; ++i) {
+                            const int k = (PTS * s + p) * PPP + i;
+                            if (PTS * B * PPP <= PER_MIN || k < PER_MIN) issue_piece(bn, k);
+                        }
+                    }
+                    update_pair(p, xs[s][p], qs[s][p], wv, qv);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else
         {
             float2 x2n = lds_ld<float2>(lds, tbase + o_x), q2n = lds_ld<float2>(lds, tbase + o_q);
             float2 wqn[4];
@@ -354,28 +419,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    const pk2 xv = {x2.x, x2.y}, qx = {q2.x, q2.y};
-                    // f32 products and subtraction on two samples at once (v_pk_mul_f32 / v_pk_add_f32): each half rounds
-                    // exactly as the scalar instruction (no contraction: -ffp-contract=off).  Written stage by stage over the
-                    // four neurons so that no instruction consumes the result of the one right before it (hipcc pads those
-                    // packed-to-scalar dependences with s_nop, which cost issue slots)
-                    pk2 pr[4], rr[4], dd[4];
-                    double c0[4], c1[4];
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) pr[n] = pk2{wv[n], wv[n]} * xv;
-                    if constexpr (SYM) {                              // qv = -sg, qx = f32(a xq): v_pk_fma_f32, one rounding
-#pragma unroll
-                        for (int n = 0; n < 4; ++n) dd[n] = __builtin_elementwise_fma(pk2{qv[n], qv[n]}, qx, pr[n]);
-                    } else {
-#pragma unroll
-                        for (int n = 0; n < 4; ++n) rr[n] = pk2{qv[n], qv[n]} * qx;
-#pragma unroll
-                        for (int n = 0; n < 4; ++n) dd[n] = pr[n] - rr[n];
-                    }
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) { c0[n] = (double)dd[n].x; c1[n] = (double)dd[n].y; }
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) { u[n][2 * p] += c0[n]; u[n][2 * p + 1] += c1[n]; }
+                    update_pair(p, x2, q2, wv, qv);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -383,6 +427,28 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         for (int k = PTS * B * PPP < PER_MIN ? PTS * B * PPP : PER_MIN; wave + NSW * k < NPIECES; ++k) issue_piece(bn, k);   // the rest
         STAMP(st2);
         // ---- phase D: this wavefront's share of <Xq_t, u> for the B rows of block b+1 ----
+        if (b + 1 < nslots && kPreloadAll) {
+            double2 ds[B][PW];
+#pragma unroll
+            for (int r = 0; r < B; ++r)
+#pragma unroll
+                for (int p = 0; p < PW; ++p) ds[r][p] = lds_ld<double2>(lds, tbase + r * RB + o_d + 16 * p * KQ);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                if (r == B / 2) __builtin_amdgcn_s_setprio(0);
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int p = 0; p < PW; ++p)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        acc[n] = fma(ds[r][p].x, u[n][2 * p], acc[n]);
+                        acc[n] = fma(ds[r][p].y, u[n][2 * p + 1], acc[n]);
+                    }
+                const double v = fold_klanes<G>(acc);
+                if (writer) lds_st<double>(lds, o_dw + ((((b + 1) & 1) * NW) * B + r) * NB * 8, v);
+            }
+        } else
         if (b + 1 < nslots) {
             double2 d2n = lds_ld<double2>(lds, tbase + o_d);
 #pragma clang loop unroll_count(B == 4 ? 2 : 1)
