@@ -110,10 +110,10 @@ const char *gpfq_last_dense_kernel(void);
  *                  LDS-staged rows instead of register prefetch; bit 2: Gram records of walks longer than 64
  *                  steps on the vector units instead of the matrix cores (v_mfma_f64_16x16x4_f64);
  *                  bit 4: pipelined kernel issues its LDS-DMA spread over the steps of a tile
- *   "pipe"         role-split dense kernels (rows of 257..2048 samples, alphabets <= 64): -1 (default) the block form
- *                  (gpfq_blk.hip) where measured faster -- layers of 512+ neurons, and any width for rows of 769..1024
- *                  samples --, 0 never, 1 one step per slot (gpfq_pipe.hip) whenever it applies, 2 the block form whenever
- *                  it applies
+ *   "pipe"         role-split dense kernels (alphabets <= 64): -1 (default) the block form (gpfq_blk.hip; rows of 257..4096
+ *                  samples) where measured faster -- layers of 512+ neurons, and any width for rows of 769+ samples --,
+ *                  0 never, 1 one step per slot (gpfq_pipe.hip, rows up to 2048) whenever it applies, 2 the block form
+ *                  whenever it applies
  *   "blk_sweep_waves"   8 (default) or 11: sweep wavefronts per workgroup of the block form's 16-neuron shapes (with the
  *                  decision wavefront two or three wavefronts per SIMD; measured equal within 2 %: DESIGN.md)
  *   "blk_four_groups"   1 (default): layers of at most 1024 neurons on rows of 769..2048 samples take 4 neurons per workgroup; 0: 8

@@ -36,7 +36,8 @@
 // 2048 neurons (16 neurons per workgroup: one round of workgroups instead of two, half the folds and decisions per weight:
 // 8.2 -> 6.5 ms at 4096 x 4096 x 2048), and <2,16,4> x 8 (8 neurons per workgroup: half the sweep per slot) for rows of
 // 769..1024 samples when the layer has at most 2048 neurons, <1,8,4> / <1,12|16,2> x 8 (4 neurons per workgroup) for rows of 769..2048
-// samples when it has at most 1024.  What bounds a slot: the sweeps (nine sample pairs on three of
+// samples when it has at most 1024, and one step per slot -- <2,48|64,1> x 11, <1,24|32,1> x 8 -- for rows of 2049..4096 samples.
+// What bounds a slot: the sweeps (nine sample pairs on three of
 // the SIMDs) for <4,32,4> and the B = 2 shapes, the decision wavefront's chain everywhere else; it runs at raised priority
 // (s_setprio) because it shares its SIMD with two sweep wavefronts, and the sweeps lower theirs as they progress through the
 // slot.  Symmetric alphabets take the SYM instantiation (BlkK::sym_a).  profiles/r02/blk_phase_stamps.txt has the per-phase
@@ -338,7 +339,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 #pragma unroll
             for (int n = 0; n < 4; ++n) { u[n][2 * p] += c0[n]; u[n][2 * p + 1] += c1[n]; }
         };
-        constexpr bool kPreloadAll = PW * B <= 8;                  // few pairs per step: see below
+        constexpr bool kPreloadAll = PW * B <= 8 && PW <= 5;      // few pairs per slot: see below
         // ---- phase U: the B updates of block b-1, in order: u += f32(w x) - f32(q xq)  (:119) ----
         // Software-pipelined by hand: the operands of the NEXT pair (and the next step's four (w, q)) are requested before
         // the arithmetic of the current one (sched_barrier keeps hipcc from sinking the requests to their first use,
@@ -1042,6 +1043,11 @@ static BlkShape blk_shape(int64_t m, int64_t C)
     const bool wide = C > 2048 && 8 * rounds16 <= 5 * rounds8 && g_blk_wide.load(std::memory_order_relaxed) != 0;
     if (m > 1024 && m <= 1536) return wide ? BlkShape{4, 48, 2, 1536, 11} : BlkShape{2, 24, 2, 1536, 8};
     if (m > 1536 && m <= 2048) return wide ? BlkShape{4, 64, 2, 2048, 11} : BlkShape{2, 32, 2, 2048, 8};
+    // rows of 2049..4096 samples: a record is 48 / 64 KiB, so a slot is ONE step (B = 1) -- 8 neurons over eleven sweep wavefronts
+    // (six 64-sample pairs each), or 4 neurons over eight for layers of at most 1024 neurons.  Still four to five times the
+    // several-wavefronts-per-neuron kernel these rows had (4096 x 4096 x 4096: 38 ms)
+    if (m > 2048 && m <= 3072) return four ? BlkShape{1, 24, 1, 3072, 8} : BlkShape{2, 48, 1, 3072, 11};
+    if (m > 3072 && m <= 4096) return four ? BlkShape{1, 32, 1, 4096, 8} : BlkShape{2, 64, 1, 4096, 11};
     return {0, 0, 0, 0, 0};
 }
 
@@ -1111,12 +1117,16 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     if (!sh.G) return hipErrorInvalidValue;
     const int64_t nblk = (a.N + sh.B - 1) / sh.B;
     const int64_t nrec = (nblk + 1) * sh.B + 1;
-    auto *prep = sh.B == 4 ? gpfq_blk_prep_kernel<4> : gpfq_blk_prep_kernel<2>;
+    auto *prep = sh.B == 4 ? gpfq_blk_prep_kernel<4> : (sh.B == 2 ? gpfq_blk_prep_kernel<2> : gpfq_blk_prep_kernel<1>);
     const float sym_a = blk_has_sym(sh.S, sh.NW) ? blk_sym_a(a) : 0.f;   // (exactly the launches launch_blk_inst gives the symmetric form)
     hipLaunchKernelGGL(prep, dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp,
                        a.nrm32, static_cast<char *>(a.workspace), sym_a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (sh.B == 1) {
+        if (sh.G == 2) return sh.S == 64 ? launch_blk_inst<2, 64, 1, 11>(a, sh, stream) : launch_blk_inst<2, 48, 1, 11>(a, sh, stream);
+        return sh.S == 32 ? launch_blk_inst<1, 32, 1>(a, sh, stream) : launch_blk_inst<1, 24, 1>(a, sh, stream);
+    }
     if (sh.G == 4 && sh.S == 64) return launch_blk_inst<4, 64, 2, 11>(a, sh, stream);
     if (sh.G == 4 && sh.S == 48) return launch_blk_inst<4, 48, 2, 11>(a, sh, stream);
     if (sh.G == 4 && sh.NW == 11) {

@@ -314,13 +314,13 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
             pa.ts_override = g_tile_steps; pa.variant = g_variant >> 4;
             const bool forced_old = g_lpn != 0 || g_wpn != 0 || g_onchip_mode != 1 || g_pipe == 0;
             // measured (tools/blk_shapes.sh): the block-pipelined kernel is ahead of the row-group and wavefront-per-neuron kernels
-            // for rows of 257..2048 samples whenever the layer has 512 neurons or more (4096 x 4096, m = 1024: 4.1 vs 5.4 ms;
+            // for rows of 257..4096 samples (2049+: one step per slot; 4096 x 4096 x 4096: 16.6 vs 38 ms) whenever the layer has 512 neurons or more (4096 x 4096, m = 1024: 4.1 vs 5.4 ms;
             // m = 2048, 16 levels: 8.7 vs 10.0; m = 512: 3.2 vs 3.9; 4096 x 1024, m = 1536: 3.7 vs 6.8; 784 x 4096, m = 512: 0.68
             // vs 0.85).  Its time per step does not depend on the number of neurons up to one workgroup per CU; narrower layers
             // stay with the kernels that split a neuron over several wavefronts (4096 x 128, m = 512: 3.05 vs 3.16 ms; m = 2048:
-            // 2.06 vs 2.20) -- except for rows of 769..1024 samples, where workgroups of 8 neurons make it the fastest at any
-            // width (4096 x 2048: 2.9 vs 5.4 ms; 4096 x 64: 2.8 vs 3.5).
-            const bool fits = m > 256 && m <= 2048 && M <= 64 && (C >= 512 || (m > 768 && m <= 1024));
+            // 2.06 vs 2.20) -- except for rows of 769+ samples, where workgroups of 8 and of 4 neurons make it the fastest at any
+            // width (4096 x 2048, m = 1024: 2.5 vs 5.4 ms; 4096 x 128, m = 2048: 2.9 vs 4.5; 2048 x 128, m = 4096: 2.3 vs 2.5).
+            const bool fits = m > 256 && m <= 4096 && M <= 64 && (C >= 512 || m > 768);
             const bool want = g_pipe == 1;
             if ((g_pipe == 2 || (g_pipe < 0 && !forced_old && fits)) && N > 0 && m > 0 && gpfq::blk_supported(pa) && workspace &&
                 (uintptr_t)workspace % 16 == 0 && workspace_bytes >= onchip_workspace_bytes(N, m)) {
