@@ -63,7 +63,10 @@ struct BandEntry {         // distance d = 1 .. 2B-1 at header offset 64 + 32 (d
 static_assert(sizeof(BlkStats) == 64 && sizeof(BandEntry) == 32, "header layout");
 
 __host__ __device__ constexpr int blk_hdr_bytes(int B) { return (64 + (2 * B - 1) * 32 + 127) & ~127; }
-__host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B) { return blk_hdr_bytes(B) + 16 * mp; }
+// The row t + B travels as float64 (the sweep's dot products then need no conversion) -- except in the one-step-per-slot shapes,
+// which are bound by the record stream itself: there it stays float32 (12 instead of 16 bytes per sample) and is converted in the sweep.
+__host__ __device__ constexpr bool blk_row64(int B) { return B > 1; }
+__host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B) { return blk_hdr_bytes(B) + (blk_row64(B) ? 16 : 12) * mp; }
 
 // ---- pre-pass ---------------------------------------------------------------------------------
 // One workgroup per slot record t: statistics of row t, its Gram band against rows t-1 .. t-(2B-1), float32 copies
@@ -123,8 +126,12 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
             for (int d = 1; d <= ND; ++d) { bx4[d - 1] = row(X, t - d); bq4[d - 1] = row(Xq, t - d); }
             *reinterpret_cast<float4 *>(ox + i) = xp;
             *reinterpret_cast<float4 *>(oq + i) = sym_a != 0.f ? make_float4(__fmul_rn(sym_a, qp.x), __fmul_rn(sym_a, qp.y), __fmul_rn(sym_a, qp.z), __fmul_rn(sym_a, qp.w)) : qp;
-            *reinterpret_cast<double2 *>(od + i) = make_double2((double)qn.x, (double)qn.y);
-            *reinterpret_cast<double2 *>(od + i + 2) = make_double2((double)qn.z, (double)qn.w);
+            if constexpr (blk_row64(B)) {
+                *reinterpret_cast<double2 *>(od + i) = make_double2((double)qn.x, (double)qn.y);
+                *reinterpret_cast<double2 *>(od + i + 2) = make_double2((double)qn.z, (double)qn.w);
+            } else {
+                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(od) + i) = qn;
+            }
             float b1[ND], b2[ND];
 #pragma unroll
             for (int d = 0; d < ND; ++d) { b1[d] = bx4[d].x; b2[d] = bq4[d].x; }
@@ -144,7 +151,8 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
             const bool in = i < m;
             ox[i] = (has_prev && in) ? px[i] : 0.f;
             oq[i] = (has_prev && in) ? (sym_a != 0.f ? __fmul_rn(sym_a, pq[i]) : pq[i]) : 0.f;   // symmetric form: f32(a Xq), see BlkK::sym_a
-            od[i] = (double)((has_next && in) ? nq[i] : 0.f);
+            if constexpr (blk_row64(B)) od[i] = (double)((has_next && in) ? nq[i] : 0.f);
+            else reinterpret_cast<float *>(od)[i] = (has_next && in) ? nq[i] : 0.f;
             if (has_cur && in) {
                 float b1[ND], b2[ND];
 #pragma unroll
@@ -260,7 +268,11 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     const int nslots = K.nblk + 1;
     const int o_x  = HDR + 8 * (pbase + kq);                      // float2 x   [pair]  (row t - B of record t)
     const int o_q  = o_x + 4 * MP;                                // float2 xq  [pair]
-    const int o_d  = HDR + 8 * MP + 16 * (pbase + kq);           // double2 xqd[pair]  (row t + B)
+    constexpr int DB = blk_row64(B) ? 16 : 8;                     // bytes of a sample pair of row t + B
+    const int o_d  = HDR + 8 * MP + DB * (pbase + kq);           // double2 (float2) xqd[pair]  (row t + B)
+    using DRaw = std::conditional_t<blk_row64(B), double2, float2>;   // as it sits in the record; converted where it is consumed
+    auto ld_d = [&](int off) -> DRaw { return lds_ld<DRaw>(lds, off); };
+    auto to_d2 = [](const DRaw &v) -> double2 { return make_double2((double)v.x, (double)v.y); };
     const int o_wq = L.off_wq + nloc * B * 8;
     const int o_dw = L.off_d + (wave * B * NB + nloc + row) * 8;
     const int o_x2 = L.off_x2 + (wave * NB + nloc + row) * 16;
@@ -429,29 +441,31 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         STAMP(st2);
         // ---- phase D: this wavefront's share of <Xq_t, u> for the B rows of block b+1 ----
         if (b + 1 < nslots && kPreloadAll) {
-            double2 ds[B][PW];
+            DRaw ds[B][PW];
 #pragma unroll
             for (int r = 0; r < B; ++r)
 #pragma unroll
-                for (int p = 0; p < PW; ++p) ds[r][p] = lds_ld<double2>(lds, tbase + r * RB + o_d + 16 * p * KQ);
+                for (int p = 0; p < PW; ++p) ds[r][p] = ld_d(tbase + r * RB + o_d + DB * p * KQ);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < B; ++r) {
                 if (r == B / 2) __builtin_amdgcn_s_setprio(0);
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int p = 0; p < PW; ++p)
+                for (int p = 0; p < PW; ++p) {
+                    const double2 d2 = to_d2(ds[r][p]);
 #pragma unroll
                     for (int n = 0; n < 4; ++n) {
-                        acc[n] = fma(ds[r][p].x, u[n][2 * p], acc[n]);
-                        acc[n] = fma(ds[r][p].y, u[n][2 * p + 1], acc[n]);
+                        acc[n] = fma(d2.x, u[n][2 * p], acc[n]);
+                        acc[n] = fma(d2.y, u[n][2 * p + 1], acc[n]);
                     }
+                }
                 const double v = fold_klanes<G>(acc);
                 if (writer) lds_st<double>(lds, o_dw + ((((b + 1) & 1) * NW) * B + r) * NB * 8, v);
             }
         } else
         if (b + 1 < nslots) {
-            double2 d2n = lds_ld<double2>(lds, tbase + o_d);
+            DRaw d2n = ld_d(tbase + o_d);
 #pragma clang loop unroll_count(B == 4 ? 2 : 1)
             for (int r = 0; r < B; ++r) {
                 if (r == B / 2) __builtin_amdgcn_s_setprio(0);
@@ -460,9 +474,9 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
                 const int rn = r + 1 < B ? r + 1 : r;
 #pragma unroll
                 for (int p = 0; p < PW; ++p) {
-                    const double2 d2 = d2n;
+                    const double2 d2 = to_d2(d2n);
                     const int rbn = p + 1 < PW ? rb : tbase + rn * RB, pn = p + 1 < PW ? p + 1 : 0;
-                    d2n = lds_ld<double2>(lds, rbn + o_d + 16 * pn * KQ);
+                    d2n = ld_d(rbn + o_d + DB * pn * KQ);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int n = 0; n < 4; ++n) {
