@@ -123,6 +123,8 @@ const char *gpfq_last_dense_kernel(void);
  *                  (rows longer than 2048 samples, and layers too narrow to fill the chip)
  *   "gram_slack_log2"   Gram paths: error bounds multiplied by 2^value (tests force the repair/rerun branches)
  *   "conv_fused"   1 (default): conv layers read their patch rows from the channel planes; 0: per-channel patch matrices
+ *   "conv_nhwc"    1 (default): 3x3 / stride 1 / SAME layers with 64+ channels per shard read the NHWC activations directly
+ *                  (gpfq_quantize_conv3x3_nhwc); 0: channel planes first
  *   "conv_strip"   plane-correlation kernel: output positions per lane (0 = heuristic, 1, 2 or 4)
  *   "conv_shift"   1 (default): 3x3 / stride 1 / SAME layers on images of 20 x 20 or more (shards of 8+ channels) accumulate shift sums (27 FMAs per
  *                  position, border classes apart); 0: the per-output-position records (99 FMAs) that VALID layers and small
@@ -299,6 +301,21 @@ int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t 
                                 const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
                                 void *qidx, float *Qt, double *resid, int32_t *uncertified,
                                 void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * The channel loop of a 3 x 3 / stride 1 / SAME conv layer straight from the NHWC activations Keras hands over
+ * (`layer_data[..., channel_idx]`, scripts/quantized_network.py:769-770, without the channel-major copy): the shift-form Gram
+ * records with the lanes along the channels, then the batched decide of gpfq_quantize_conv_channels.  Same results.
+ *   act_w, act_q [device] f32 NHWC [n][H][W][Cin]; the call takes channels [c_lo, c_lo + nch) (a rank's shard);
+ *   Wt [nch][F][9], outputs qidx / Qt [nch][F][9], uncertified [nch][F] as gpfq_quantize_conv_channels (no residual norms).
+ *   gpfq_conv3x3_nhwc_supported: 1 if this form takes the shape (images of 4 x 4 or more, 64+ channels in the shard,
+ *   options "conv_fused" and "conv_nhwc" on), else 0: use gpfq_channel_planes + gpfq_quantize_conv_channels.
+ */
+int gpfq_conv3x3_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t nch);
+size_t gpfq_conv3x3_nhwc_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t nch, int64_t F);
+int gpfq_quantize_conv3x3_nhwc(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t c_lo, int64_t nch,
+                               const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
+                               void *qidx, float *Qt, int32_t *uncertified, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * The same call in two halves, for layers with fewer input channels than GPUs (an image input has 3): the Gram

@@ -95,7 +95,7 @@ hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes)
 
 extern "C" {
 
-int gpfq_version(void) { return 211; }
+int gpfq_version(void) { return 212; }
 
 const char *gpfq_last_dense_kernel(void) { return g_dense_kernel; }
 
@@ -178,6 +178,7 @@ static std::atomic<int> g_variant{0};          // bit 0: row-group kernel withou
 static std::atomic<int> g_pipe{-1};            // pipelined dense kernels: -1 = heuristic, 0 = never, 1 = one step per slot (gpfq_pipe.hip) whenever it
                                    // applies, 2 = blocks of steps per slot (gpfq_blk.hip) whenever it applies
 static std::atomic<int> g_conv_fused{1};       // conv channel loop: 3x3/stride-1 Gram matrices straight from the planes
+static std::atomic<int> g_conv_nhwc{1};        // 3x3 / stride 1 / SAME layers straight from the NHWC activations (no channel-major copy)
 static std::atomic<int> g_conv_strip{0};
 static std::atomic<int> g_conv_shift{1};    // fused 3x3 conv kernel with SAME padding: the shift form (0 = the per-output-position form)       // fused conv kernel: forced strip length (0 = heuristic)
 
@@ -211,6 +212,7 @@ int gpfq_set_option(const char *key, int value)
     }
     if (!std::strcmp(key, "gram_slack_log2")) { g_gram_slack_log2 = value; return GPFQ_OK; }
     if (!std::strcmp(key, "conv_fused")) { g_conv_fused = value ? 1 : 0; return GPFQ_OK; }
+    if (!std::strcmp(key, "conv_nhwc")) { g_conv_nhwc = value ? 1 : 0; return GPFQ_OK; }
     if (!std::strcmp(key, "conv_shift")) {
         if (value < 0 || value > 2) return fail(GPFQ_ERR_INVALID_ARG, "conv_shift must be 0, 1 or 2");
         g_conv_shift = value; return GPFQ_OK;
@@ -669,6 +671,41 @@ static int conv_channels_impl(int phase, double *records, int32_t *negflags,
         if (e != hipSuccess) return hip_fail(e, "gpfq_quantize_conv_channels(gram)");
     }
     return GPFQ_OK;
+}
+
+int gpfq_conv3x3_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t nch)
+{
+    return g_conv_fused && g_conv_nhwc && gpfq::gram_image_nhwc_supported(n, H, W, nch) ? 1 : 0;
+}
+
+size_t gpfq_conv3x3_nhwc_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t nch, int64_t F)
+{
+    if (!gpfq::gram_image_nhwc_supported(n, H, W, nch) || F < 0) return 0;
+    return gpfq::gram_image_nhwc_workspace_bytes(n, H, W, nch, F);
+}
+
+int gpfq_quantize_conv3x3_nhwc(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t c_lo, int64_t nch,
+                               const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
+                               void *qidx, float *Qt, int32_t *uncertified, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (n <= 0 || H <= 0 || W <= 0 || Cin <= 0 || c_lo < 0 || nch < 0 || c_lo + nch > Cin || F < 0) return fail(GPFQ_ERR_INVALID_ARG, "bad shape");
+    HostAlphabet HA;
+    int rc = make_alphabet(alphabet, M, zero_idx, &HA);
+    if (rc != GPFQ_OK) return rc;
+    if (nch == 0 || F == 0) return GPFQ_OK;
+    if (!gpfq::gram_image_nhwc_supported(n, H, W, nch)) return fail(GPFQ_ERR_UNSUPPORTED, "NHWC form needs images of 4 x 4 or more and 64+ channels");
+    if (!act_w || !act_q || !Wt || !qidx || !Qt || !uncertified) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    const size_t need = gpfq_conv3x3_nhwc_workspace_bytes(n, H, W, nch, F);
+    if (!workspace || workspace_bytes < need || (uintptr_t)workspace % 16 != 0)
+        return fail(GPFQ_ERR_WORKSPACE, "NHWC conv call needs %zu aligned workspace bytes", need);
+    gpfq::ImageGramArgs g;
+    g.act_w = act_w + c_lo; g.act_q = act_q + c_lo; g.nhwc_cin = Cin;
+    g.n = n; g.H = H; g.W = W; g.nch = nch; g.pad = 1;
+    g.Wt = Wt; g.A = HA.A; g.big = HA.big(); g.F = F; g.qidx = static_cast<int8_t *>(qidx); g.Qt = Qt; g.uncertified = uncertified;
+    g.workspace = workspace;
+    g.slack = std::ldexp(1.0, g_gram_slack_log2);
+    hipError_t e = gpfq::launch_gram_image_nhwc(g, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_conv3x3_nhwc");
 }
 
 int gpfq_conv_records_supported(int64_t n, int64_t H, int64_t W, int64_t nch, int kh, int kw, int sh, int sw, int rh, int rw,

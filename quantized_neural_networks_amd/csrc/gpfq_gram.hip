@@ -495,7 +495,7 @@ __device__ __forceinline__ void fix_fetch(const FixSrc &src, int64_t ch, int s, 
     const int iy = oy * src.sh + ky * src.rh - src.pt, ix = ox * src.sw + kx * src.rw - src.pl;
     x = 0.f; xq = 0.f;
     if (iy >= 0 && iy < src.H && ix >= 0 && ix < src.W) {
-        const int64_t o = ch * src.plane + (b * src.H + iy) * src.W + ix;
+        const int64_t o = ch * src.plane + ((b * src.H + iy) * src.W + ix) * src.pix;
         x = src.X[o];
         xq = src.Xq[o];
     }

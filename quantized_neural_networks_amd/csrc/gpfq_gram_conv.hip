@@ -484,7 +484,7 @@ hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream)
     bs.nch = a.nch; bs.gram_cs = gram_record(K); bs.nrm_cs = K; bs.w_cs = a.F * K; bs.out_cs = a.F * K; bs.unc_cs = a.F;
     bs.hist_cs = a.F * K;
     FixSrc src{};
-    src.X = a.act_w; src.Xq = a.act_q; src.ld = 0; src.m = m; src.planes = 1; src.plane = p.plane;
+    src.X = a.act_w; src.Xq = a.act_q; src.ld = 0; src.m = m; src.planes = 1; src.plane = p.plane; src.pix = 1;
     src.n = (int)a.n; src.H = p.H; src.W = p.W; src.oh = p.oh; src.ow = p.ow;
     src.kw = a.kw; src.sh = a.sh; src.sw = a.sw; src.rh = a.rh; src.rw = a.rw; src.pt = a.pt; src.pl = a.pl;
     return launch_gram_decide(gram, nrm, a.Wt, K, a.A, (int)K, a.F, a.slack, a.qidx, a.Qt, a.uncertified, q32h, bs, &src, fixws, negflag,

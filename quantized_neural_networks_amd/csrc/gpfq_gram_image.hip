@@ -17,8 +17,11 @@
 // consecutive output positions of one row from a 3 x (S+2) register window, and the two wavefronts of a
 // pair own the columns s in {0,3,5,7,8} and {1,2,4,6} of the record (49 + 50 sums), which keeps a wavefront
 // under 128 accumulator registers and two of them resident per SIMD.
+#include <type_traits>
+
 #include "gpfq_device.hpp"
 #include "gpfq_launch.hpp"
+#include "gpfq_roles.hpp"
 
 namespace gpfq {
 
@@ -411,6 +414,184 @@ gpfq_gram_shift_combine_kernel(const double *__restrict__ part, int nparts, doub
     }
 }
 
+// ---- the shift form straight from NHWC activations ------------------------------------------------------------
+// The same 27 sums per input position and the same nine classes, with the LANES along the channels: a wavefront (a workgroup of
+// 64 threads) holds one position of 64 channels at a time (256 contiguous bytes per access) and belongs to ONE class for the whole
+// launch -- which positions a class holds is the same for every channel, so the class logic is scalar.  An item is one image x
+// one strip of kNhwcStrip columns, walked DOWN the rows with the 3 x (strip + 4) neighbourhood of both tensors in registers as
+// float64: the two rows above a position were the wavefront's own rows a moment ago, so an element is requested once per strip
+// (+ the halo columns).  That window and the 27 accumulators leave two wavefronts per SIMD, too few to cover HBM latency with
+// register loads (the first version: 8.5 ms for a layer the planes form does in 5.9): the rows come through an LDS RING filled
+// by LDS-DMA (global_load_lds_dword: no registers), kNhwcDepth - 1 rows ahead of the arithmetic.
+// Partial sums: [channel][slot][27], slots grouped by class (NhwcParams::slot_off), added per class in slot order.
+struct NhwcParams {
+    const float *act_w, *act_q;           // NHWC, offset to the first channel of the shard
+    int64_t cin;                          // channels of the tensor (the pixel stride)
+    int n, H, W, nch;
+    int nslots, slot_off[10];             // slots of class c: [slot_off[c], slot_off[c + 1])
+    double *part;
+    int *negflag;
+};
+constexpr int kNhwcStrip = 5;             // positions of an image row per item (the window is kNhwcStrip + 4 columns wide)
+constexpr int kNhwcDepth = 4;             // rows of the LDS ring
+
+template <bool SAME_ACT>
+__global__ void __launch_bounds__(64)
+gpfq_gram_shift_nhwc_kernel(NhwcParams p)
+{
+    constexpr int SW = kNhwcStrip, NC = SW + 4, D = kNhwcDepth, NT = SAME_ACT ? 1 : 2;
+    __shared__ float ring[D][NT][NC][64];
+    const int lane = threadIdx.x;
+    const int64_t ch = (int64_t)blockIdx.y * 64 + lane;
+    const bool live = ch < p.nch;
+    int cls = 0;
+    while ((int)blockIdx.x >= p.slot_off[cls + 1]) ++cls;
+    const int k = blockIdx.x - p.slot_off[cls], nk = p.slot_off[cls + 1] - p.slot_off[cls];
+    const int cy = cls / 3, cx = cls - 3 * cy;
+    const int H = p.H, W = p.W;
+    const int ya = cy == 1 ? 1 : (cy == 0 ? 0 : H - 1), yb = cy == 1 ? H - 2 : ya;
+    const int xlo = cx == 1 ? 1 : (cx == 0 ? 0 : W - 1), xhi = cx == 1 ? W - 2 : xlo;
+    const int ns = (xhi - xlo + SW) / SW;
+    const int64_t nitems = (int64_t)p.n * ns;
+    const float *bw = p.act_w + (live ? ch : 0), *bq = p.act_q + (live ? ch : 0);
+    const unsigned ring_addr = lds_addr(&ring[0][0][0][0]);
+
+    double c1[13], c2[13], c3 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) { c1[i] = 0.0; c2[i] = 0.0; }
+    bool neg = false;
+
+    // items k, k + nk, ...: the slots that run side by side hold neighbouring strips of the same images
+    for (int64_t item = k; item < nitems; item += nk) {
+        const int64_t img = item / ns;
+        const int xa = xlo + SW * (int)(item - img * ns);          // first position; window columns xa - 2 .. xa + SW + 1
+        const int64_t ibase = img * H * (int64_t)W * p.cin;
+        const int nr = yb - ya + 3;                                 // rows ya - 2 .. yb of the walk, j = 0 .. nr - 1
+        // request row j of the walk into ring slot j % D (rows / columns outside the image are requested from a clamped address
+        // and read as zeros by the consumer: every row is then exactly 2 * NC requests, which keeps the wait counts static)
+        auto request = [&](int j) {
+            int y = ya - 2 + j;
+            y = y < 0 ? 0 : y;
+            const int64_t rb = ibase + (int64_t)y * W * p.cin;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                int col = xa - 2 + i;
+                col = col < 0 ? 0 : (col >= W ? W - 1 : col);
+                glds4(bw + rb + (int64_t)col * p.cin, ring_addr + (unsigned)((((j % D) * NT + 0) * NC + i) * 256));
+                if (!SAME_ACT) glds4(bq + rb + (int64_t)col * p.cin, ring_addr + (unsigned)((((j % D) * NT + 1) * NC + i) * 256));
+            }
+        };
+        float rx[NC], rq[NC];
+        auto consume = [&](int j) {                                 // wait for row j, read it (zeros outside the image)
+            const int ahead = nr - 1 - j < D - 2 ? nr - 1 - j : D - 2;              // rows requested after it so far (row j + D - 1 follows this read)
+            if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NC * NT) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 * NC * NT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const bool vy = ya - 2 + j >= 0;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const int col = xa - 2 + i;
+                const bool ok = vy && col >= 0 && col < W && live;
+                const float a = ring[j % D][0][i][lane];
+                rx[i] = ok ? a : 0.f;
+                if (!SAME_ACT) { const float b = ring[j % D][NT - 1][i][lane]; rq[i] = ok ? b : 0.f; }
+            }
+        };
+        static_assert(D == 4, "the wait counts above are written for a ring of four rows");
+#pragma unroll
+        for (int j = 0; j < D - 1; ++j)
+            if (j < nr) request(j);
+        double Bx[3][NC], Bq[3][NC];
+        // rows ya - 2, ya - 1 (j = 0, 1) fill the two buffers above; each consumed row frees its ring slot for row j + D
+        consume(0); if (3 < nr) request(3);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) { Bx[1][i] = (double)rx[i]; Bq[1][i] = SAME_ACT ? Bx[1][i] : (double)rq[i]; }
+        consume(1); if (4 < nr) request(4);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) { Bx[2][i] = (double)rx[i]; Bq[2][i] = SAME_ACT ? Bx[2][i] : (double)rq[i]; }
+        // one row: ROT names the buffers (row y in B[ROT], y - 1 in B[ROT + 2], y - 2 in B[ROT + 1], indices mod 3)
+        auto step = [&](int j, auto rot_tag) {
+            constexpr int R0 = decltype(rot_tag)::value, R1 = (R0 + 2) % 3, R2 = (R0 + 1) % 3;
+            consume(j);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the ring slot is read before it is requested again
+            if (j + D - 1 < nr) request(j + D - 1);
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                Bx[R0][i] = (double)rx[i];
+                Bq[R0][i] = SAME_ACT ? Bx[R0][i] : (double)rq[i];
+                neg |= (rx[i] < 0.f) | (!SAME_ACT && rq[i] < 0.f);
+            }
+#pragma unroll
+            for (int e = 0; e < SW; ++e) {
+                const bool in = xa + e <= xhi;
+                const double qa = in ? Bq[R0][e + 2] : 0.0, xm = in ? Bx[R0][e + 2] : 0.0;
+                c3 = fma(xm, xm, c3);
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {                     // dy = 0, dx = jj - 2
+                    c1[10 + jj] = fma(qa, Bx[R0][e + jj], c1[10 + jj]);
+                    if (!SAME_ACT) c2[10 + jj] = fma(qa, Bq[R0][e + jj], c2[10 + jj]);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 5; ++jj) {                     // dy = -2, -1, dx = jj - 2
+                    c1[jj] = fma(qa, Bx[R2][e + jj], c1[jj]);
+                    c1[5 + jj] = fma(qa, Bx[R1][e + jj], c1[5 + jj]);
+                    if (!SAME_ACT) { c2[jj] = fma(qa, Bq[R2][e + jj], c2[jj]); c2[5 + jj] = fma(qa, Bq[R1][e + jj], c2[5 + jj]); }
+                }
+            }
+        };
+        for (int j = 2; j < nr; j += 3) {
+            step(j, std::integral_constant<int, 0>{});
+            if (j + 1 < nr) step(j + 1, std::integral_constant<int, 1>{});
+            if (j + 2 < nr) step(j + 2, std::integral_constant<int, 2>{});
+        }
+    }
+    if (live) {
+        if (neg) atomicOr(p.negflag + ch, 1);
+        double *out = p.part + (ch * p.nslots + blockIdx.x) * kShiftN;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) { out[i] = c1[i]; out[13 + i] = SAME_ACT ? c1[i] : c2[i]; }
+        out[26] = c3;
+    }
+}
+
+// Class sums of the NHWC form -> the N = 9 Gram record of a channel + the float32 row norms (as gpfq_gram_shift_combine_kernel).
+__global__ void __launch_bounds__(256)
+gpfq_gram_shift_combine_nhwc_kernel(NhwcParams p, double *__restrict__ gram, float *__restrict__ nrm32)
+{
+    __shared__ double T[9][kShiftN];
+    const int64_t ch = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int idx = wave; idx < 9 * kShiftN; idx += 4) {
+        const int c = idx / kShiftN, i = idx - c * kShiftN;
+        double v = 0.0;
+        for (int k = p.slot_off[c] + lane; k < p.slot_off[c + 1]; k += 64) v += p.part[(ch * p.nslots + k) * kShiftN + i];
+        v = wave_sum(v);
+        if (lane == 0) T[c][i] = v;
+    }
+    __syncthreads();
+    auto qualifies = [](int c, int t) {
+        const int cy = c / 3, cx = c - 3 * cy, ky = t / 3, kx = t - 3 * ky;
+        return !(cy == 0 && ky == 2) && !(cy == 2 && ky == 0) && !(cx == 0 && kx == 2) && !(cx == 2 && kx == 0);
+    };
+    for (int e = threadIdx.x; e < (int)kRec9; e += 256) {
+        double v = 0.0;
+        int t = -1, s = -1, k = -1;
+        if (e < 162) {
+            k = e & 1; t = (e >> 1) / 9; s = (e >> 1) - 9 * t;
+            if (s <= t) {
+                const int dy = s / 3 - t / 3, dx = s % 3 - t % 3;
+                const int j = (dy < 0 ? (dy + 2) * 5 + dx + 2 : 10 + dx + 2) + 13 * k;
+                for (int c = 0; c < 9; ++c) v += qualifies(c, t) ? T[c][j] : 0.0;
+            }
+        } else {
+            s = e - 162;
+            for (int c = 0; c < 9; ++c) v += qualifies(c, s) ? T[c][26] : 0.0;
+        }
+        gram[ch * kRec9 + e] = v;
+        if (nrm32 && k == 1 && s == t) nrm32[ch * 9 + t] = (float)sqrt(v);
+    }
+}
+
 static inline size_t al256i(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int image_strip(int64_t ow, int variant)
@@ -558,10 +739,93 @@ hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream)
     DecideBatch bs;
     bs.nch = a.nch; bs.gram_cs = kRec9; bs.nrm_cs = 9; bs.w_cs = a.F * 9; bs.out_cs = a.F * 9; bs.unc_cs = a.F; bs.hist_cs = a.F * 9;
     FixSrc src{};
-    src.X = a.act_w; src.Xq = a.act_q; src.ld = 0; src.planes = 1; src.plane = p.plane;
+    src.X = a.act_w; src.Xq = a.act_q; src.ld = 0; src.planes = 1; src.plane = p.plane; src.pix = 1;
     src.n = p.n; src.H = p.H; src.W = p.W; src.oh = p.oh; src.ow = p.SPR * S;
     src.kw = 3; src.sh = src.sw = src.rh = src.rw = 1; src.pt = src.pl = p.pad;
     src.m = (int64_t)p.grows * src.ow;
+    return launch_gram_decide(gram, nrm, a.Wt, 9, a.A, 9, a.F, a.slack, a.qidx, a.Qt, a.uncertified, q32h, bs, &src, fixws, negflag,
+                              stream, a.big);
+}
+
+// ---- NHWC entry: 3 x 3, stride 1, SAME, all channels of the shard in one launch chain ----
+static void nhwc_slots(int64_t n, int64_t H, int64_t W, int64_t nch, NhwcParams &p)
+{
+    // slots per class in proportion to its work (items x rows per item), about 4096 wavefronts per 64 channels in all
+    const int64_t groups = (nch + 63) / 64;
+    int64_t total = 4096 / groups;
+    if (total < 256) total = 256;
+    const int64_t ns_mid = (W - 2 + kNhwcStrip - 1) / kNhwcStrip;
+    double work[9];
+    int64_t items[9];
+    double wsum = 0.0;
+    for (int c = 0; c < 9; ++c) {
+        const int cy = c / 3, cx = c % 3;
+        const int64_t rows = cy == 1 ? H - 2 : 1, strips = cx == 1 ? ns_mid : 1;
+        items[c] = n * strips;
+        work[c] = (double)items[c] * (double)(rows + 2);
+        wsum += work[c];
+    }
+    p.slot_off[0] = 0;
+    for (int c = 0; c < 9; ++c) {
+        int64_t nb = (int64_t)((double)total * work[c] / wsum + 0.5);
+        if (nb < 1) nb = 1;
+        if (nb > items[c]) nb = items[c];
+        p.slot_off[c + 1] = p.slot_off[c] + (int)nb;
+    }
+    p.nslots = p.slot_off[9];
+}
+
+bool gram_image_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t nch)
+{
+    // (64 channels fill the lanes of a wavefront; with 32 the planes form is as fast or faster: CIFAR10 CNN layers, tools/bench_configs.py)
+    return n > 0 && H >= 4 && W >= 4 && nch >= 64 && n * H * W < (1LL << 30) && H < 32768 && W < 32768;
+}
+
+size_t gram_image_nhwc_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t nch, int64_t F)
+{
+    NhwcParams p{};
+    nhwc_slots(n, H, W, nch, p);
+    size_t b = 0;
+    b += al256i((size_t)nch * p.nslots * kShiftN * sizeof(double));
+    b += al256i((size_t)nch * kRec9 * sizeof(double));
+    b += al256i((size_t)nch * 9 * sizeof(float));
+    b += al256i((size_t)nch * F * 9 * sizeof(float));
+    b += gram_fix_bytes();
+    b += al256i((size_t)nch * sizeof(int));
+    return b;
+}
+
+hipError_t launch_gram_image_nhwc(const ImageGramArgs &a, hipStream_t stream)
+{
+    if (a.nch == 0 || a.F == 0) return hipSuccess;
+    if (!gram_image_nhwc_supported(a.n, a.H, a.W, a.nch) || a.pad != 1 || a.nhwc_cin < a.nch) return hipErrorInvalidValue;
+    NhwcParams p{};
+    p.act_w = a.act_w; p.act_q = a.act_q; p.cin = a.nhwc_cin;
+    p.n = (int)a.n; p.H = (int)a.H; p.W = (int)a.W; p.nch = (int)a.nch;
+    nhwc_slots(a.n, a.H, a.W, a.nch, p);
+    char *ws = static_cast<char *>(a.workspace);
+    p.part = reinterpret_cast<double *>(ws);        ws += al256i((size_t)a.nch * p.nslots * kShiftN * sizeof(double));
+    double *gram = reinterpret_cast<double *>(ws);  ws += al256i((size_t)a.nch * kRec9 * sizeof(double));
+    float *nrm = reinterpret_cast<float *>(ws);     ws += al256i((size_t)a.nch * 9 * sizeof(float));
+    float *q32h = reinterpret_cast<float *>(ws);    ws += al256i((size_t)a.nch * a.F * 9 * sizeof(float));
+    void *fixws = ws;                               ws += gram_fix_bytes();
+    int *negflag = reinterpret_cast<int *>(ws);
+    p.negflag = negflag;
+    hipError_t e = hipMemsetAsync(negflag, 0, (size_t)a.nch * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    const dim3 grid((unsigned)p.nslots, (unsigned)((a.nch + 63) / 64));
+    if (a.act_w == a.act_q) hipLaunchKernelGGL((gpfq_gram_shift_nhwc_kernel<true>), grid, dim3(64), 0, stream, p);
+    else hipLaunchKernelGGL((gpfq_gram_shift_nhwc_kernel<false>), grid, dim3(64), 0, stream, p);
+    hipLaunchKernelGGL(gpfq_gram_shift_combine_nhwc_kernel, dim3((unsigned)a.nch), dim3(256), 0, stream, p, gram, nrm);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    DecideBatch bs;
+    bs.nch = a.nch; bs.gram_cs = kRec9; bs.nrm_cs = 9; bs.w_cs = a.F * 9; bs.out_cs = a.F * 9; bs.unc_cs = a.F; bs.hist_cs = a.F * 9;
+    FixSrc src{};
+    src.X = a.act_w; src.Xq = a.act_q; src.ld = 0; src.planes = 1; src.plane = 1; src.pix = a.nhwc_cin;   // channel stride 1, pixel stride Cin
+    src.n = p.n; src.H = p.H; src.W = p.W; src.oh = p.H; src.ow = p.W;
+    src.kw = 3; src.sh = src.sw = src.rh = src.rw = 1; src.pt = src.pl = 1;
+    src.m = (int64_t)a.n * a.H * a.W;
     return launch_gram_decide(gram, nrm, a.Wt, 9, a.A, 9, a.F, a.slack, a.qidx, a.Qt, a.uncertified, q32h, bs, &src, fixws, negflag,
                               stream, a.big);
 }

@@ -142,8 +142,9 @@ hipError_t launch_gram_reduce(const double *part, int64_t nparts, int N, double 
 struct FixSrc {
     const float *X, *Xq;
     int64_t ld, m;               // m = columns (n*oh*ow for planes)
-    int planes;                  // 0: X/Xq are [N][ld] patch rows; 1: [nch][n][H][W] channel planes
-    int64_t plane;               // floats per channel plane
+    int planes;                  // 0: X/Xq are [N][ld] patch rows; 1: channel images, element (ch, img, y, x) at ch * plane + ((img * H + y) * W + x) * pix
+    int64_t plane;               // channel stride: floats per channel plane ([nch][n][H][W]), or 1 for NHWC
+    int64_t pix;                 // pixel stride: 1 for channel planes, Cin for NHWC
     int n, H, W, oh, ow;
     int kw, sh, sw, rh, rw, pt, pl;
 };
@@ -175,6 +176,7 @@ struct ImageGramArgs {
     void *workspace;
     double slack = 1.0;
     int variant = 0;              // tuning hook: forces the strip length (1, 2, 4)
+    int64_t nhwc_cin = 0;         // launch_gram_image_nhwc: act_w / act_q are NHWC tensors (offset to the shard's first channel) of this many channels
     int shift_form = 1;           // SAME padding: shift sums (27 FMAs per position) instead of per-output-position records (99); 0 = never
     // phase 1: stop after the Gram records (written to `records` [nch][171] f64 and `negflags` [nch] i32);
     // phase 2: take the records from there instead of forming them (column-sharded multi-GPU runs sum them in between)
@@ -210,6 +212,10 @@ hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream);
 bool gram_image_supported(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw, int rh, int rw, int same_padding);
 size_t gram_image_workspace_bytes(int64_t nch, int64_t F);
 hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream);
+// The same from NHWC activations (ImageGramArgs::nhwc_cin; 3 x 3 / stride 1 / SAME, phase 0 only): no channel-major copy
+bool gram_image_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t nch);
+size_t gram_image_nhwc_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t nch, int64_t F);
+hipError_t launch_gram_image_nhwc(const ImageGramArgs &a, hipStream_t stream);
 
 hipError_t launch_row_stats(const float *X, const float *Xq, int64_t N, int64_t m, int64_t ld, const float *nrm32,
                             RowStats *stats, hipStream_t stream);

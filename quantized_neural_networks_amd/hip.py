@@ -36,6 +36,9 @@ SYMBOLS = {
     "gpfq_quantize_neurons_gram": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _i64, _dp, _int, _int, _i64, _i64, _i64,
                                           _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpfq_channel_planes": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "gpfq_conv3x3_nhwc_supported": (_int, [_i64, _i64, _i64, _i64]),
+    "gpfq_conv3x3_nhwc_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
+    "gpfq_quantize_conv3x3_nhwc": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _dp, _int, _int, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpfq_channel_sumsq_workspace_bytes": (_sz, [_i64]),
     "gpfq_channel_sumsq": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _vp, _sz, _vp]),
     "gpfq_conv_channels_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _i64, _int]),
@@ -72,7 +75,7 @@ def lib_path():
     return _build.LIB
 
 
-ABI_VERSION = 211                  # gpfq_version() of the library this binding was written against
+ABI_VERSION = 212                  # gpfq_version() of the library this binding was written against
 
 
 def load():
@@ -354,6 +357,36 @@ def quantize_conv_channels(act_w_cm, act_q_cm, Wt_all, alphabet, kernel_size, st
                                              resid.data_ptr() if resid is not None else None, unc.data_ptr(),
                                              ws.data_ptr(), nbytes, _stream())
     _check(rc, "gpfq_quantize_conv_channels")
+
+
+def conv3x3_nhwc_supported(n, H, W, nch):
+    """Whether quantize_conv3x3_nhwc takes a shard of nch channels of n images of H x W."""
+    return bool(load().gpfq_conv3x3_nhwc_supported(int(n), int(H), int(W), int(nch)))
+
+
+def quantize_conv3x3_nhwc(act_w, act_q, c_lo, c_hi, Wt_all, alphabet, idx, Q, unc):
+    """Channels [c_lo, c_hi) of a 3 x 3 / stride 1 / SAME conv layer straight from the NHWC activations
+    (gpfq_quantize_conv3x3_nhwc): no channel-major copy.  act_* f32 [n][H][W][Cin]; Wt_all f32 [nch][F][9]; outputs are caller
+    tensors idx / Q [nch][F][9], unc i32 [nch][F].  No sync; returns nothing."""
+    for t, dt in ((act_w, torch.float32), (act_q, torch.float32), (Wt_all, torch.float32), (idx, index_dtype(len(alphabet))),
+                  (Q, torch.float32), (unc, torch.int32)):
+        _dev(t, dt, "tensor")
+        if not t.is_contiguous():
+            raise GpfqError("quantize_conv3x3_nhwc needs contiguous tensors")
+    n, H, W, Cin = act_w.shape
+    nch = c_hi - c_lo
+    F = Wt_all.shape[1]
+    if (tuple(act_q.shape) != (n, H, W, Cin) or tuple(Wt_all.shape) != (nch, F, 9) or tuple(idx.shape) != (nch, F, 9)
+            or tuple(Q.shape) != (nch, F, 9) or tuple(unc.shape) != (nch, F)):
+        raise GpfqError("quantize_conv3x3_nhwc: shape mismatch")
+    arr, M, zero_idx = _alphabet(alphabet)
+    lib = load()
+    nbytes = lib.gpfq_conv3x3_nhwc_workspace_bytes(n, H, W, nch, F)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=act_w.device)
+    with torch.cuda.device(act_w.device):
+        rc = lib.gpfq_quantize_conv3x3_nhwc(act_w.data_ptr(), act_q.data_ptr(), n, H, W, Cin, c_lo, nch, Wt_all.data_ptr(), arr, M, zero_idx,
+                                            F, idx.data_ptr(), Q.data_ptr(), unc.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    _check(rc, "gpfq_quantize_conv3x3_nhwc")
 
 
 def conv_records_supported(n, H, W, nch, kernel_size, strides, rate, padding):

@@ -182,11 +182,27 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
     # channel-major copies [Cin][n][H][W] of this rank's channels: the per-channel gather then reads
     # contiguous planes instead of one float out of every Cin (one transposing pass per layer)
     same = act_q is act_w
-    cm_w = hip.channel_planes(act_w.contiguous(), c_lo, c_hi)
-    cm_q = cm_w if same else hip.channel_planes(act_q.contiguous(), c_lo, c_hi)
+    act_w = act_w.contiguous()
+    act_q = act_w if same else act_q.contiguous()
+    # 3 x 3 / stride 1 / SAME shards of 64+ channels read the NHWC tensors directly; everything else goes through the planes
+    nhwc = (not want_resid and by_channel and (kh, kw) == (3, 3) and tuple(strides) == (1, 1) and tuple(rate or (1, 1)) == (1, 1)
+            and str(padding).upper() == "SAME" and len(alphabet) <= hip.GPFQ_MAX_ALPHABET
+            and hip.conv3x3_nhwc_supported(act_w.shape[0], act_w.shape[1], act_w.shape[2], c_hi - c_lo))
+    cm = {}
+
+    def planes():
+        if not cm:
+            cm["w"] = hip.channel_planes(act_w, c_lo, c_hi)
+            cm["q"] = cm["w"] if same else hip.channel_planes(act_q, c_lo, c_hi)
+        return cm["w"], cm["q"]
 
     def patches(c):
         nonlocal Pw, Pq
+        if nhwc:                                                       # (rare reruns: that channel's slice alone)
+            Pw = hip.extract_patches(act_w[..., c:c + 1].contiguous(), 0, (kh, kw), strides, rate, padding, out=Pw)
+            Pq = Pw if same else hip.extract_patches(act_q[..., c:c + 1].contiguous(), 0, (kh, kw), strides, rate, padding, out=Pq)
+            return
+        cm_w, cm_q = planes()
         Pw = hip.extract_patches(cm_w[c - c_lo].unsqueeze(-1), 0, (kh, kw), strides, rate, padding, out=Pw)
         Pq = Pw if same else hip.extract_patches(cm_q[c - c_lo].unsqueeze(-1), 0, (kh, kw), strides, rate, padding, out=Pq)
 
@@ -223,7 +239,7 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
             dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=group)
             dist.all_reduce(neg, op=dist.ReduceOp.MAX, group=group)
             Unc = torch.zeros((Cin, F), dtype=torch.int32, device=dev)
-            hip.conv_channels_from_records(rec, neg, cm_w, cm_q, Wt_all, alphabet, (kh, kw), strides, rate, padding, Ic, Qc, Unc)
+            hip.conv_channels_from_records(rec, neg, *planes(), Wt_all, alphabet, (kh, kw), strides, rate, padding, Ic, Qc, Unc)
             for c, f in torch.nonzero(Unc).tolist():                       # the same (rare) pairs on every rank
                 patches(c)
                 r = hip.quantize_neurons(Pw, Pq, Wt_all[c, f:f + 1], alphabet, path=hip.GPFQ_PATH_STREAM)
@@ -239,8 +255,10 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
         # Gram path, the whole channel loop (:844-860) in one library call: no per-channel allocation,
         # Python or sync; the filters whose decision chain could not be certified are collected once
         Unc = torch.zeros((Cin, F), dtype=torch.int32, device=dev)
-        if (f_lo, f_hi) == (0, F):
-            hip.quantize_conv_channels(cm_w, cm_q, Wt_all[c_lo:c_hi], alphabet, (kh, kw), strides, rate, padding,
+        if (f_lo, f_hi) == (0, F) and nhwc:
+            hip.quantize_conv3x3_nhwc(act_w, act_q, c_lo, c_hi, Wt_all[c_lo:c_hi], alphabet, Ic[c_lo:c_hi], Qc[c_lo:c_hi], Unc[c_lo:c_hi])
+        elif (f_lo, f_hi) == (0, F):
+            hip.quantize_conv_channels(*planes(), Wt_all[c_lo:c_hi], alphabet, (kh, kw), strides, rate, padding,
                                        Ic[c_lo:c_hi], Qc[c_lo:c_hi], Rc[c_lo:c_hi] if want_resid else None, Unc[c_lo:c_hi])
         else:                                  # filters split over ranks (Cin < world): every rank walks all channels
             Wt_f = Wt_all[:, f_lo:f_hi].contiguous()
@@ -248,7 +266,7 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
             q_f = torch.empty((Cin, f_hi - f_lo, K), dtype=torch.float32, device=dev)
             r_f = torch.full((Cin, f_hi - f_lo), float("nan"), dtype=torch.float64, device=dev)
             u_f = torch.empty((Cin, f_hi - f_lo), dtype=torch.int32, device=dev)
-            hip.quantize_conv_channels(cm_w, cm_q, Wt_f, alphabet, (kh, kw), strides, rate, padding, i_f, q_f,
+            hip.quantize_conv_channels(*planes(), Wt_f, alphabet, (kh, kw), strides, rate, padding, i_f, q_f,
                                        r_f if want_resid else None, u_f)
             Ic[:, f_lo:f_hi], Qc[:, f_lo:f_hi], Rc[:, f_lo:f_hi], Unc[:, f_lo:f_hi] = i_f, q_f, r_f, u_f
         flagged = torch.nonzero(Unc).tolist()                         # one sync per layer; ~1 filter in 10^4

@@ -367,6 +367,53 @@ def test_conv_layer_gram_fast_path(oracle_mod, slack, members):
             np.testing.assert_allclose(out["resid"][c, f].item(), np.linalg.norm(uo), rtol=1e-5)
 
 
+@pytest.mark.parametrize("n,H,W,Cin,F,first", [(6, 9, 11, 70, 3, False), (3, 4, 4, 64, 2, False), (5, 13, 6, 130, 2, True), (2, 20, 23, 64, 2, False)])
+def test_conv_3x3_from_nhwc(oracle_mod, n, H, W, Cin, F, first):
+    """3 x 3 / stride 1 / SAME shards of 64+ channels take the shift form straight from the NHWC activations (lanes along the
+    channels, rows through an LDS ring; no channel-major copy): the same bits as the planes form (conv_nhwc = 0), a shard that
+    starts in the middle of the channels, a dead channel, signed first-layer input, and the oracle on some (channel, filter) pairs."""
+    from quantized_neural_networks_amd import hip, layer
+    r = np.random.default_rng(n + W + Cin)
+    act_w = (r.random((n, H, W, Cin)) - (0.3 if first else 0.0)).astype(np.float32)
+    act_q = act_w if first else np.maximum(act_w + 0.05 * r.standard_normal(act_w.shape), 0).astype(np.float32)
+    if not first:
+        act_q[..., 5] = 0.0                                              # dead channel: rule (i) everywhere
+    Wk = (r.standard_normal((3, 3, Cin, F)) / 3).astype(np.float32)
+    Wd = torch.from_numpy(Wk).cuda()
+    alphabet, _ = layer.layer_alphabet(Wd, np.linspace(-1, 1, 3), 3)
+    aw = torch.from_numpy(act_w).cuda()
+    aq = aw if first else torch.from_numpy(act_q).cuda()
+    assert hip.conv3x3_nhwc_supported(n, H, W, Cin)
+    out = layer.quantize_conv2d(Wd, aw, aq, alphabet, strides=(1, 1), padding="SAME", rate=(1, 1), want_resid=False)
+    try:
+        hip.set_option("conv_nhwc", 0)
+        assert not hip.conv3x3_nhwc_supported(n, H, W, Cin)
+        planes = layer.quantize_conv2d(Wd, aw, aq, alphabet, strides=(1, 1), padding="SAME", rate=(1, 1), want_resid=False)
+    finally:
+        hip.set_option("conv_nhwc", 1)
+    assert torch.equal(out["Q"], planes["Q"]) and torch.equal(out["idx"], planes["idx"])
+    Q = out["Q"].cpu().numpy()
+    for c in (0, 5, Cin // 2, Cin - 1):
+        Pw = ref_patches(act_w, c, 3, 3, 1, 1, 1, 1, "SAME")
+        Pq = ref_patches(act_q, c, 3, 3, 1, 1, 1, 1, "SAME")
+        for f in range(F):
+            qo, _, _ = oracle_mod.neuron(Wk[:, :, c, f].reshape(-1), Pw, Pq, alphabet)
+            assert np.array_equal(Q[:, :, c, f].reshape(-1), qo.astype(np.float32)), (c, f)
+    if not first:
+        assert (Q[:, :, 5] == 0).all()
+    # a shard of channels that starts inside the tensor (what a rank of a multi-GPU run holds): the C entry directly
+    c_lo, c_hi = 3, 3 + 64
+    Wt = Wd.permute(2, 3, 0, 1).reshape(Cin, F, 9).contiguous()[c_lo:c_hi].contiguous()
+    idx = torch.empty((64, F, 9), dtype=hip.index_dtype(3), device="cuda")
+    Qs = torch.empty((64, F, 9), dtype=torch.float32, device="cuda")
+    unc = torch.zeros((64, F), dtype=torch.int32, device="cuda")
+    if Cin >= c_hi:
+        hip.quantize_conv3x3_nhwc(aw, aq, c_lo, c_hi, Wt, alphabet, idx, Qs, unc)
+        assert int(unc.sum()) == 0
+        want = out["Q"].permute(2, 3, 0, 1).reshape(Cin, F, 9)[c_lo:c_hi]
+        assert torch.equal(Qs, want)
+
+
 @pytest.mark.parametrize("n,H,W,Cin,F,padding,strip,first", [
     (36, 24, 24, 2, 3, "SAME", 0, False),      # strips of 4, one image per band
     (100, 14, 14, 3, 4, "SAME", 0, False),     # strips of 2, bands straddle images
