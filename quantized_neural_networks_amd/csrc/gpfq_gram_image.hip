@@ -555,13 +555,13 @@ gpfq_gram_shift_nhwc_kernel(NhwcParams p)
 }
 
 // Class sums of the NHWC form -> the N = 9 Gram record of a channel + the float32 row norms (as gpfq_gram_shift_combine_kernel).
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 gpfq_gram_shift_combine_nhwc_kernel(NhwcParams p, double *__restrict__ gram, float *__restrict__ nrm32)
 {
     __shared__ double T[9][kShiftN];
     const int64_t ch = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int idx = wave; idx < 9 * kShiftN; idx += 4) {
+    for (int idx = wave; idx < 9 * kShiftN; idx += (int)(blockDim.x >> 6)) {      // sixteen wavefronts: few channels are few workgroups
         const int c = idx / kShiftN, i = idx - c * kShiftN;
         double v = 0.0;
         for (int k = p.slot_off[c] + lane; k < p.slot_off[c + 1]; k += 64) v += p.part[(ch * p.nslots + k) * kShiftN + i];
@@ -573,7 +573,7 @@ gpfq_gram_shift_combine_nhwc_kernel(NhwcParams p, double *__restrict__ gram, flo
         const int cy = c / 3, cx = c - 3 * cy, ky = t / 3, kx = t - 3 * ky;
         return !(cy == 0 && ky == 2) && !(cy == 2 && ky == 0) && !(cx == 0 && kx == 2) && !(cx == 2 && kx == 0);
     };
-    for (int e = threadIdx.x; e < (int)kRec9; e += 256) {
+    for (int e = threadIdx.x; e < (int)kRec9; e += (int)blockDim.x) {
         double v = 0.0;
         int t = -1, s = -1, k = -1;
         if (e < 162) {
@@ -816,7 +816,7 @@ hipError_t launch_gram_image_nhwc(const ImageGramArgs &a, hipStream_t stream)
     const dim3 grid((unsigned)p.nslots, (unsigned)((a.nch + 63) / 64));
     if (a.act_w == a.act_q) hipLaunchKernelGGL((gpfq_gram_shift_nhwc_kernel<true>), grid, dim3(64), 0, stream, p);
     else hipLaunchKernelGGL((gpfq_gram_shift_nhwc_kernel<false>), grid, dim3(64), 0, stream, p);
-    hipLaunchKernelGGL(gpfq_gram_shift_combine_nhwc_kernel, dim3((unsigned)a.nch), dim3(256), 0, stream, p, gram, nrm);
+    hipLaunchKernelGGL(gpfq_gram_shift_combine_nhwc_kernel, dim3((unsigned)a.nch), dim3(1024), 0, stream, p, gram, nrm);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     DecideBatch bs;
