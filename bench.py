@@ -114,6 +114,7 @@ def main():
     kernel_ms = []
     kname = [""]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev_ag = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]   # N > 1: the all-gather
 
     st = {"C_total": C_total, "Wd": Wd}      # the layer being stepped (the weak-scaling companion swaps in its own)
 
@@ -138,7 +139,13 @@ def main():
         # then values + transpose to the Keras layout in one pass
         if world > 1:
             packed, bits = hip.pack_indices(r["idx"], M)
-            Q, idx = hip.assemble_kernel(layer.all_gather_units(packed, C_total, group).contiguous(), alphabet, bits=bits, N=N)
+            if i_timed is not None:
+                ev_ag[i_timed][0].record()
+            gathered = layer.all_gather_units(packed, C_total, group)
+            if i_timed is not None:
+                ev_ag[i_timed][1].record()
+                st["gather_bytes"] = gathered.numel() * gathered.element_size()
+            Q, idx = hip.assemble_kernel(gathered.contiguous(), alphabet, bits=bits, N=N)
         else:
             Q, idx = hip.assemble_kernel(r["idx"], alphabet)
         return Q, idx, r
@@ -162,6 +169,23 @@ def main():
         elapsed = float(tmax.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     kernel_name = kname[0]
+    # N > 1: what the collective saw -- backend, the world size of the group the all-gather ran on, the all-gather's own
+    # duration (HIP events around it on its stream; it waits for the slowest rank's kernel, so rank 0's figure includes the
+    # skew) and every rank's kernel time, gathered over the same group
+    collective = None
+    if world > 1:
+        ag_ms = [a.elapsed_time(b) for a, b in ev_ag]
+        mine = torch.tensor([float(np.mean(kernel_ms)), float(np.mean(ag_ms)), float(np.min(ag_ms))], dtype=torch.float64, device=dev)
+        every = torch.empty((dist.get_world_size(group), 3), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(every, mine, group=group)
+        every = every.cpu().numpy()
+        collective = {"backend": dist.get_backend(group) + (" (RCCL over xGMI)" if dist.get_backend(group) == "nccl" else ""),
+                      "world_size": dist.get_world_size(group), "op": "all_gather_into_tensor of packed alphabet indices, one per layer",
+                      "gathered_bytes_per_rank": int(st.get("gather_bytes", 0)),
+                      "allgather_ms": float(every[:, 1].max()), "allgather_ms_min_over_steps_per_rank": [float(v) for v in every[:, 2]],
+                      "allgather_ms_per_rank": [float(v) for v in every[:, 1]],
+                      "kernel_ms_per_rank": [float(v) for v in every[:, 0]],
+                      "devices": sorted({torch.cuda.get_device_name(dev)})}
 
     # N > 1, strong scaling (the default: the north-star layer is fixed): the same run also steps the weak-scaling layer --
     # args.c neurons PER GPU -- so that one launch of the driver's command shows both regimes.  `value` stays the strong one.
@@ -235,6 +259,8 @@ def main():
                         "flops per launch = 6 m N C_local (SURVEY 8d); duration = HIP events around the launch on its stream",
             },
         }
+        if collective is not None:
+            out["collective"] = collective
         if weak is not None:
             out["weak_scaling_companion"] = weak
         if world == 1 and args.cpu_sample > 0:

@@ -275,6 +275,19 @@ int gpfq_channel_sumsq(const float *act, int64_t n, int64_t H, int64_t W, int64_
                        void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * The one bit per channel a 1 x 1 conv layer consumes of its activations: dead[c] = 1 iff the float32-rounded norm of
+ * channel c over the positions a (1, 1) kernel with strides (sh, sw) visits is below 1e-16 (rule (i),
+ * scripts/quantized_network.py:83-84) -- the comparison gpfq_channel_sumsq's output would be put to, without reading the
+ * whole tensor: sums of squares only grow, so a channel whose sum over the first `prefix_positions` positions
+ * (0 = about 8 MiB worth) already exceeds 4e-32 is live; only the channels still undecided after the prefix get their
+ * full sum (a strided pass over those channels alone; skipped on the device when there are none).  No host round trip.
+ * act [device] f32 [n][H][W][Cin]; dead [device] i32 [Cin].
+ */
+size_t gpfq_channel_dead_workspace_bytes(int64_t Cin);
+int gpfq_channel_dead(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int sh, int sw, int64_t prefix_positions,
+                      int32_t *dead, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * The channel loop of a conv layer in one call: for each of `nch` input channels build the two patch
  * matrices and run gpfq_quantize_neurons_gram for that channel's F filters -- the body of
  * `for channel_idx in range(num_channels)` in _quantize_conv2D_layer_parallel_jit

@@ -95,7 +95,7 @@ hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes)
 
 extern "C" {
 
-int gpfq_version(void) { return 212; }
+int gpfq_version(void) { return 300; }
 
 const char *gpfq_last_dense_kernel(void) { return g_dense_kernel; }
 
@@ -562,6 +562,20 @@ int gpfq_channel_sumsq(const float *act, int64_t n, int64_t H, int64_t W, int64_
     if (n > 0 && !act) return fail(GPFQ_ERR_INVALID_ARG, "NULL activations");
     hipError_t e = gpfq::launch_channel_sumsq(act, n, H, W, Cin, sh, sw, sumsq, workspace, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_channel_sumsq");
+}
+
+size_t gpfq_channel_dead_workspace_bytes(int64_t Cin) { return Cin > 0 ? gpfq::channel_dead_workspace_bytes(Cin) : 0; }
+
+int gpfq_channel_dead(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int sh, int sw, int64_t prefix_positions,
+                      int32_t *dead, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (n < 0 || H <= 0 || W <= 0 || Cin <= 0 || sh <= 0 || sw <= 0 || prefix_positions < 0) return fail(GPFQ_ERR_INVALID_ARG, "bad shape, stride or prefix");
+    if (!dead) return fail(GPFQ_ERR_INVALID_ARG, "NULL output");
+    if (workspace_bytes < gpfq_channel_dead_workspace_bytes(Cin) || !workspace || (uintptr_t)workspace % 16 != 0)
+        return fail(GPFQ_ERR_WORKSPACE, "workspace too small or misaligned");
+    if (n > 0 && !act) return fail(GPFQ_ERR_INVALID_ARG, "NULL activations");
+    hipError_t e = gpfq::launch_channel_dead(act, n, H, W, Cin, sh, sw, dead, workspace, prefix_positions, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_channel_dead");
 }
 
 static size_t al256c(size_t x) { return (x + 255) & ~(size_t)255; }

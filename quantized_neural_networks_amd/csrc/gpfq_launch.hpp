@@ -230,6 +230,9 @@ size_t median_workspace_bytes();
 size_t channel_sumsq_workspace_bytes(int64_t Cin);
 hipError_t launch_channel_sumsq(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int sh, int sw, double *out,
                                 void *workspace, hipStream_t stream);
+size_t channel_dead_workspace_bytes(int64_t Cin);
+hipError_t launch_channel_dead(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int sh, int sw, int32_t *dead,
+                               void *workspace, int64_t prefix_positions, hipStream_t stream);
 hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream);
 hipError_t launch_median_begin(int64_t n_total, void *workspace, hipStream_t stream);
 hipError_t launch_median_count(const float *W_local, int64_t n_local, int64_t n_total, int pass, void *workspace, hipStream_t stream);

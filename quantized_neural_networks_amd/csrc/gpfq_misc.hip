@@ -54,7 +54,7 @@ hipError_t launch_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, f
 template <int VEC>
 __global__ void __launch_bounds__(256)
 gpfq_channel_sumsq_kernel(const float *__restrict__ act, int64_t n, int64_t H, int64_t W, int64_t Cin, int sh, int sw,
-                          int64_t oh, int64_t ow, double *__restrict__ partial)
+                          int64_t oh, int64_t ow, int64_t p_limit, double *__restrict__ partial)
 {
     __shared__ double sm[256][VEC];
     const int64_t G = Cin / VEC;                                  // channel groups of a position
@@ -62,7 +62,7 @@ gpfq_channel_sumsq_kernel(const float *__restrict__ act, int64_t n, int64_t H, i
     const int gw = (int)(G - g0 < 256 ? G - g0 : 256);            // groups of this chunk
     const int pp = 256 / gw;                                      // positions in flight per pass
     const int g = threadIdx.x % gw, slot = threadIdx.x / gw;
-    const int64_t P = n * oh * ow;
+    const int64_t P = n * oh * ow < p_limit ? n * oh * ow : p_limit;   // (p_limit: the first positions only, gpfq_channel_dead)
     const int64_t per = (P + gridDim.x - 1) / gridDim.x;
     const int64_t p_lo = (int64_t)blockIdx.x * per, p_hi = p_lo + per < P ? p_lo + per : P;
     double acc[VEC];
@@ -128,13 +128,162 @@ hipError_t launch_channel_sumsq(const float *act, int64_t n, int64_t H, int64_t 
     double *partial = static_cast<double *>(workspace);
     if (vec)
         hipLaunchKernelGGL(gpfq_channel_sumsq_kernel<4>, dim3((unsigned)nb, (unsigned)chunks), dim3(256), 0, stream, act, n, H, W, Cin, sh, sw,
-                           oh, ow, partial);
+                           oh, ow, P, partial);
     else
         hipLaunchKernelGGL(gpfq_channel_sumsq_kernel<1>, dim3((unsigned)nb, (unsigned)chunks), dim3(256), 0, stream, act, n, H, W, Cin, sh, sw,
-                           oh, ow, partial);
+                           oh, ow, P, partial);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gpfq_channel_sumsq_final_kernel, dim3((unsigned)((Cin + 255) / 256)), dim3(256), 0, stream, partial, Cin, (int)nb, out);
+    return hipGetLastError();
+}
+
+// ---- dead channels of a 1x1 conv layer without reading the whole tensor -----------------------------
+// A 1 x 1 layer consumes ONE bit per channel of its activations: whether the float32-rounded norm of the channel's one-row
+// patch matrix is below 1e-16 (rule (i), scripts/quantized_network.py:83-84).  Partial sums of squares only grow, so a channel
+// whose sum over the FIRST positions already exceeds kLiveSumsq = 4e-32 (norm 2e-16: beyond 1e-16 by more than any rounding of
+// the float64 sum, the square root or the float32 conversion) is live whatever follows.  Phase 1 sums a prefix of the
+// positions (gpfq_channel_sumsq_kernel with a position limit: <= 8 MiB read), phase 2 lists the channels still undecided,
+// phase 3 -- only when the list is not empty -- forms the full sums of the listed channels alone (positions over the
+// workgroups, a strided 4-byte read per position and listed channel), phase 4 compares.  Same bits as comparing the full
+// norms: only the comparison is consumed.  36 of ResNet50's 53 conv layers are 1 x 1: 33 ms of full passes -> launch latency.
+constexpr double kLiveSumsq = 4e-32;
+constexpr int kDeadBlocks = 512;         // workgroups of phase 3 (a partial sum per workgroup and listed channel)
+constexpr int kDeadGroup = 8;            // listed channels accumulated together in one pass over the positions
+
+struct DeadCtl { int n_undecided; int pad[15]; };
+
+__global__ void __launch_bounds__(256)
+gpfq_channel_dead_list_kernel(const double *__restrict__ partial, int64_t Cin, int nblocks, bool complete,
+                              int32_t *__restrict__ dead, DeadCtl *__restrict__ ctl, int32_t *__restrict__ list)
+{
+    // one workgroup: the list keeps the channels in ascending order (fixed summation order downstream: deterministic)
+    __shared__ int base;
+    __shared__ int wcount[4];
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < Cin; c0 += 256) {
+        const int64_t c = c0 + threadIdx.x;
+        bool und = false;
+        if (c < Cin) {
+            double s = 0.0;
+            for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * Cin + c];
+            const bool live = s >= kLiveSumsq;
+            // the prefix was the whole tensor: decide here with the norm pre-pass's rounding, float32(sqrt(sum)) (:83)
+            if (complete) dead[c] = ((double)(float)sqrt(s) < 1e-16) ? 1 : 0;
+            else { dead[c] = 0; und = !live; }
+        }
+        const unsigned long long bal = __ballot(und);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) wcount[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wcount[w];
+        if (und) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)c;
+        __syncthreads();
+        if (threadIdx.x == 0) base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ctl->n_undecided = base;
+}
+
+__global__ void __launch_bounds__(256)
+gpfq_channel_dead_scan_kernel(const float *__restrict__ act, int64_t n, int64_t H, int64_t W, int64_t Cin, int sh, int sw,
+                              int64_t oh, int64_t ow, const DeadCtl *__restrict__ ctl, const int32_t *__restrict__ list,
+                              double *__restrict__ partial2)
+{
+    const int nu = ctl->n_undecided;
+    if (nu == 0) return;                                          // (the usual case: every channel was live in the prefix)
+    __shared__ double sm[4][kDeadGroup];
+    const int64_t P = n * oh * ow;
+    const int64_t per = (P + gridDim.x - 1) / gridDim.x;
+    const int64_t p_lo = (int64_t)blockIdx.x * per, p_hi = p_lo + per < P ? p_lo + per : P;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int u0 = 0; u0 < nu; u0 += kDeadGroup) {
+        int64_t ch[kDeadGroup];
+        double acc[kDeadGroup];
+#pragma unroll
+        for (int k = 0; k < kDeadGroup; ++k) { ch[k] = u0 + k < nu ? list[u0 + k] : -1; acc[k] = 0.0; }
+        for (int64_t p = p_lo + threadIdx.x; p < p_hi; p += 256) {
+            int64_t pix = p;
+            if (sh != 1 || sw != 1) {
+                const int64_t img = p / (oh * ow);
+                const unsigned rem = (unsigned)(p - img * oh * ow), y = rem / (unsigned)ow, x = rem - y * (unsigned)ow;
+                pix = (img * H + (int64_t)y * sh) * W + (int64_t)x * sw;
+            }
+            const float *src = act + pix * Cin;
+#pragma unroll
+            for (int k = 0; k < kDeadGroup; ++k)
+                if (ch[k] >= 0) { const double v = (double)src[ch[k]]; acc[k] = fma(v, v, acc[k]); }
+        }
+#pragma unroll
+        for (int k = 0; k < kDeadGroup; ++k) {
+            const double s = wave_sum(acc[k]);
+            if (lane == 0) sm[wave][k] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < kDeadGroup && u0 + (int)threadIdx.x < nu)
+            partial2[(int64_t)blockIdx.x * Cin + u0 + threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256)
+gpfq_channel_dead_final_kernel(const double *__restrict__ partial2, int64_t Cin, int nblocks, const DeadCtl *__restrict__ ctl,
+                               const int32_t *__restrict__ list, int32_t *__restrict__ dead)
+{
+    const int nu = ctl->n_undecided;
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < nu; u += gridDim.x * 256) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += partial2[(int64_t)b * Cin + u];
+        dead[list[u]] = ((double)(float)sqrt(s) < 1e-16) ? 1 : 0;
+    }
+}
+
+static size_t dead_al(size_t x) { return (x + 255) & ~(size_t)255; }
+size_t channel_dead_workspace_bytes(int64_t Cin)
+{
+    // [phase-1 partial sums][control][list][phase-3 partial sums]
+    return dead_al(channel_sumsq_workspace_bytes(Cin)) + dead_al(sizeof(DeadCtl)) + dead_al((size_t)Cin * sizeof(int32_t)) +
+           dead_al((size_t)kDeadBlocks * (size_t)Cin * sizeof(double));
+}
+
+hipError_t launch_channel_dead(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int sh, int sw, int32_t *dead,
+                               void *workspace, int64_t prefix_positions, hipStream_t stream)
+{
+    const int64_t oh = (H + sh - 1) / sh, ow = (W + sw - 1) / sw, P = n * oh * ow;
+    char *ws = static_cast<char *>(workspace);
+    double *partial = reinterpret_cast<double *>(ws);   ws += dead_al(channel_sumsq_workspace_bytes(Cin));
+    DeadCtl *ctl = reinterpret_cast<DeadCtl *>(ws);     ws += dead_al(sizeof(DeadCtl));
+    int32_t *list = reinterpret_cast<int32_t *>(ws);    ws += dead_al((size_t)Cin * sizeof(int32_t));
+    double *partial2 = reinterpret_cast<double *>(ws);
+    // prefix: about 8 MiB of the tensor, at least 256 positions (0 = that default; tests pass short prefixes)
+    int64_t P1 = prefix_positions > 0 ? prefix_positions : (int64_t)(1 << 21) / (Cin > 0 ? Cin : 1);
+    if (prefix_positions <= 0 && P1 < 256) P1 = 256;
+    if (P1 > P) P1 = P;
+    const bool vec = (Cin % 4 == 0) && ((uintptr_t)act % 16 == 0);
+    const int64_t G = vec ? Cin / 4 : Cin;
+    int64_t nb = (P1 + 63) / 64;
+    const int64_t chunks = (G + 255) / 256;
+    const int64_t cap = kSumsqBlocks / chunks > 0 ? kSumsqBlocks / chunks : 1;
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    if (vec)
+        hipLaunchKernelGGL(gpfq_channel_sumsq_kernel<4>, dim3((unsigned)nb, (unsigned)chunks), dim3(256), 0, stream, act, n, H, W, Cin, sh, sw,
+                           oh, ow, P1, partial);
+    else
+        hipLaunchKernelGGL(gpfq_channel_sumsq_kernel<1>, dim3((unsigned)nb, (unsigned)chunks), dim3(256), 0, stream, act, n, H, W, Cin, sh, sw,
+                           oh, ow, P1, partial);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gpfq_channel_dead_list_kernel, dim3(1), dim3(256), 0, stream, partial, Cin, (int)nb, P1 == P, dead, ctl, list);
+    if ((e = hipGetLastError()) != hipSuccess || P1 == P) return e;
+    int64_t nb2 = (P + 255) / 256;
+    if (nb2 > kDeadBlocks) nb2 = kDeadBlocks;
+    hipLaunchKernelGGL(gpfq_channel_dead_scan_kernel, dim3((unsigned)nb2), dim3(256), 0, stream, act, n, H, W, Cin, sh, sw, oh, ow, ctl, list,
+                       partial2);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(gpfq_channel_dead_final_kernel, dim3(8), dim3(256), 0, stream, partial2, Cin, (int)nb2, ctl, list, dead);
     return hipGetLastError();
 }
 

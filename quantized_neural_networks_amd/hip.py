@@ -41,6 +41,8 @@ SYMBOLS = {
     "gpfq_quantize_conv3x3_nhwc": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _dp, _int, _int, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpfq_channel_sumsq_workspace_bytes": (_sz, [_i64]),
     "gpfq_channel_sumsq": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _vp, _sz, _vp]),
+    "gpfq_channel_dead_workspace_bytes": (_sz, [_i64]),
+    "gpfq_channel_dead": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _int, _i64, _vp, _vp, _sz, _vp]),
     "gpfq_conv_channels_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _i64, _int]),
     "gpfq_quantize_conv_channels": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int,
                                            _vp, _dp, _int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -75,7 +77,7 @@ def lib_path():
     return _build.LIB
 
 
-ABI_VERSION = 212                  # gpfq_version() of the library this binding was written against
+ABI_VERSION = 300                  # gpfq_version() of the library this binding was written against
 
 
 def load():
@@ -306,6 +308,25 @@ def channel_sumsq(act, strides=(1, 1)):
         rc = lib.gpfq_channel_sumsq(act.data_ptr(), n, H, W, Cin, int(strides[0]), int(strides[1]), out.data_ptr(), ws.data_ptr(), nbytes, _stream())
     _check(rc, "gpfq_channel_sumsq")
     return out
+
+
+def channel_dead(act, strides=(1, 1), prefix_positions=0):
+    """bool [Cin]: channels of NHWC f32 activations whose float32-rounded norm over the positions a (1, 1) kernel with these
+    strides visits is below 1e-16 (gpfq_channel_dead): a prefix of the positions decides every live channel, only channels
+    still undecided are summed in full.  No sync."""
+    _dev(act, torch.float32, "act")
+    if act.dim() != 4 or not act.is_contiguous():
+        raise GpfqError("channel_dead needs a contiguous NHWC tensor")
+    n, H, W, Cin = act.shape
+    lib = load()
+    nbytes = lib.gpfq_channel_dead_workspace_bytes(Cin)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=act.device)
+    out = torch.empty(Cin, dtype=torch.int32, device=act.device)
+    with torch.cuda.device(act.device):
+        rc = lib.gpfq_channel_dead(act.data_ptr(), n, H, W, Cin, int(strides[0]), int(strides[1]), int(prefix_positions),
+                                   out.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    _check(rc, "gpfq_channel_dead")
+    return out != 0
 
 
 def neuron_major(W, lo=0, hi=None):

@@ -63,3 +63,8 @@ def test_bench_two_ranks_over_gloo_split_the_fixed_layer():
     assert 0 < out["roofline"]["frac"] <= 1.0
     weak = out["weak_scaling_companion"]                 # the same launch also steps --neurons per GPU (weak scaling)
     assert weak["scaling"] == "weak" and weak["value"] > 0 and "Dense(256->1024)" in weak["workload"]
+    col = out["collective"]                              # what the collective saw: backend, group size, its own time, every rank's kernel
+    assert col["backend"].startswith("gloo") and col["world_size"] == 2
+    assert len(col["kernel_ms_per_rank"]) == 2 and all(v > 0 for v in col["kernel_ms_per_rank"])
+    assert col["allgather_ms"] > 0 and len(col["allgather_ms_per_rank"]) == 2
+    assert col["gathered_bytes_per_rank"] == 512 * 256 * 2 // 8      # 512 neurons x 256 weights at 2 bits (ternary)

@@ -557,6 +557,8 @@ def test_conv1x1_shortcut_equals_general_path(oracle_mod, stride, bits):
     act_q[..., 3] = 0.0                                                  # dead channel
     if stride == 2:
         act_q[:, ::2, ::2, 1] = 0.0                                      # dead only on the sub-sampled grid
+    act_q[..., 4] = 1e-17                                                # tiny values: alive only through their number ...
+    act_q[..., 2] = 0.0; act_q[0, 0, 0, 2] = 0.9e-16                     # ... or dead although not zero (norm < 1e-16, :83)
     W = (r.standard_normal((1, 1, 5, 7)) / 2).astype(np.float32)
     Wd, aw, aq = (torch.from_numpy(a).cuda() for a in (W, act_w, act_q))
     alphabet, _ = layer.layer_alphabet(Wd, np.linspace(-1, 1, int(round(2 ** bits))), 2)
@@ -565,8 +567,8 @@ def test_conv1x1_shortcut_equals_general_path(oracle_mod, stride, bits):
     assert torch.isnan(fast["resid"]).all() and not torch.isnan(full["resid"]).any()
     assert torch.equal(fast["Q"], full["Q"]) and torch.equal(fast["idx"], full["idx"])
     Q = fast["Q"].cpu().numpy()
-    assert (Q[0, 0, 3] == 0).all() and (stride == 1 or (Q[0, 0, 1] == 0).all())
-    for c in (0, 3):
+    assert (Q[0, 0, 3] == 0).all() and (stride == 1 or (Q[0, 0, 1] == 0).all()) and (Q[0, 0, 2] == 0).all()
+    for c in (0, 2, 3, 4):
         Pw = ref_patches(act_w, c, 1, 1, stride, stride, 1, 1, "VALID")
         Pq = ref_patches(act_q, c, 1, 1, stride, stride, 1, 1, "VALID")
         for f in range(7):
