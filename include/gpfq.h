@@ -62,8 +62,10 @@ extern "C" {
 
 /* gpfq_quantize_neurons `path` selector */
 #define GPFQ_PATH_AUTO      0   /* rows beyond GPFQ_GRAM_MIN_M samples with walks of <= GPFQ_GRAM_MAX_N steps (and no u_out):
-                                   the Gram path + a rerun of what it flags (one stream synchronisation); else on-chip
-                                   residual when m fits the registers, else streaming */
+                                   the Gram path + a rerun of what it flags (ONE stream synchronisation and a small D2H copy inside
+                                   the call: not capturable into a hipGraph -- gpfq_set_option("auto_gram", 0) keeps AUTO on the
+                                   asynchronous kernels, or call gpfq_quantize_neurons_gram and handle its `uncertified` flags
+                                   yourself); else on-chip residual when m fits the registers, else streaming */
 #define GPFQ_PATH_ONCHIP    1   /* residual u lives in VGPRs (of up to 16 wavefronts per neuron), rows staged through LDS (m <= GPFQ_ONCHIP_MAX_M) */
 #define GPFQ_PATH_STREAM    2   /* residual u lives in HBM (any m; conv patch matrices)          */
 
@@ -122,6 +124,8 @@ const char *gpfq_last_dense_kernel(void);
  *   "waves_per_neuron"  2..16: force the wide kernel (one neuron over that many wavefronts), 0 = heuristic
  *                  (rows longer than 2048 samples, and layers too narrow to fill the chip)
  *   "gram_slack_log2"   Gram paths: error bounds multiplied by 2^value (tests force the repair/rerun branches)
+ *   "auto_gram"    1 (default): GPFQ_PATH_AUTO may divert long rows to the Gram path (one stream synchronisation inside the call);
+ *                  0: AUTO only picks between the asynchronous on-chip and streaming kernels
  *   "conv_fused"   1 (default): conv layers read their patch rows from the channel planes; 0: per-channel patch matrices
  *   "conv_nhwc"    1 (default): 3x3 / stride 1 / SAME layers with 64+ channels per shard read the NHWC activations directly
  *                  (gpfq_quantize_conv3x3_nhwc); 0: channel planes first

@@ -8,6 +8,8 @@ library.  Staleness is decided by CONTENT, not by time stamps (a snapshot of the
 `libgpfq_hip.so.sha` holds the hash of all sources, headers and flags the library was built from, and
 hip.load() refuses a library whose hash does not match the tree.
 """
+import contextlib
+import fcntl
 import hashlib
 import os
 import shutil
@@ -81,23 +83,47 @@ def _compile(hipcc, src, verbose):
     return obj
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """One builder at a time across processes (every rank of a torchrun job may find the library stale at once):
+    an advisory lock on csrc/.build.lock; the others wait, then find the library fresh."""
+    fd = os.open(os.path.join(CSRC, ".build.lock"), os.O_CREAT | os.O_RDWR, 0o644)
+    try:
+        fcntl.flock(fd, fcntl.LOCK_EX)
+        yield
+    finally:
+        fcntl.flock(fd, fcntl.LOCK_UN)
+        os.close(fd)
+
+
 def build(force=False, verbose=False):
-    """Compile the HIP library if missing or built from other sources/flags; returns its path."""
+    """Compile the HIP library if missing or built from other sources/flags; returns its path.  Safe to call from
+    several processes at once: the build runs under a file lock, the library and its stamp are put in place by
+    os.replace (a process that already mapped the old file keeps it; nobody ever opens a half-written one)."""
     if not force and not _stale():
         return LIB
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    os.makedirs(OBJDIR, exist_ok=True)
-    if force:
-        for f in os.listdir(OBJDIR):
-            os.remove(os.path.join(OBJDIR, f))
-    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(lambda s: _compile(hipcc, s, verbose), SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
-    with open(STAMP, "w") as f:
-        f.write(tree_hash())
+    with _build_lock():
+        if not force and not _stale():                  # another process built it while this one waited
+            return LIB
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        os.makedirs(OBJDIR, exist_ok=True)
+        if force:
+            for f in os.listdir(OBJDIR):
+                os.remove(os.path.join(OBJDIR, f))
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+            objs = list(ex.map(lambda s: _compile(hipcc, s, verbose), SOURCES))
+        tmp_lib = LIB + ".tmp.%d" % os.getpid()
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+        tmp_stamp = STAMP + ".tmp.%d" % os.getpid()
+        with open(tmp_stamp, "w") as f:
+            f.write(tree_hash())
+        if os.path.exists(STAMP):
+            os.remove(STAMP)                            # never a fresh stamp beside a stale library
+        os.replace(tmp_lib, LIB)
+        os.replace(tmp_stamp, STAMP)
     return LIB
 
 

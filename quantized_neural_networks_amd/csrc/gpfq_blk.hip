@@ -802,7 +802,8 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                     anyinc |= __float_as_uint(wc[j]) | __float_as_uint(qc[j]);
                 }
             }
-            eps += ((anyinc << 1) != 0u) ? rEa : 0.0;
+            // (each of the up to 2B-1 pending increments may lose up to Ea = 2^-149 sum|Xq_t| to subnormal float32 products)
+            eps += ((anyinc << 1) != 0u) ? (double)(2 * B - 1) * rEa : 0.0;
             const double wd = (double)wc[s];
             const double du = D[s] + corr;                                       // predicted <Xq_t, u_{t-1}>
             const bool   du_exact = eps == 0.0;                                  // every pending increment orthogonal to Xq_t element-wise

@@ -177,6 +177,7 @@ static std::atomic<int> g_wpn{0};              // wide kernel: wavefronts per ne
 static std::atomic<int> g_variant{0};          // bit 0: row-group kernel without the float64 copy of Xq in LDS; bit 1: wide kernel with LDS-staged rows
 static std::atomic<int> g_pipe{-1};            // pipelined dense kernels: -1 = heuristic, 0 = never, 1 = one step per slot (gpfq_pipe.hip) whenever it
                                    // applies, 2 = blocks of steps per slot (gpfq_blk.hip) whenever it applies
+static std::atomic<int> g_auto_gram{1};        // GPFQ_PATH_AUTO may take the Gram path (one stream synchronisation inside the call); 0: AUTO stays asynchronous
 static std::atomic<int> g_conv_fused{1};       // conv channel loop: 3x3/stride-1 Gram matrices straight from the planes
 static std::atomic<int> g_conv_nhwc{1};        // 3x3 / stride 1 / SAME layers straight from the NHWC activations (no channel-major copy)
 static std::atomic<int> g_conv_strip{0};
@@ -211,6 +212,7 @@ int gpfq_set_option(const char *key, int value)
         g_wpn = value; return GPFQ_OK;
     }
     if (!std::strcmp(key, "gram_slack_log2")) { g_gram_slack_log2 = value; return GPFQ_OK; }
+    if (!std::strcmp(key, "auto_gram")) { g_auto_gram = value ? 1 : 0; return GPFQ_OK; }
     if (!std::strcmp(key, "conv_fused")) { g_conv_fused = value ? 1 : 0; return GPFQ_OK; }
     if (!std::strcmp(key, "conv_nhwc")) { g_conv_nhwc = value ? 1 : 0; return GPFQ_OK; }
     if (!std::strcmp(key, "conv_shift")) {
@@ -255,7 +257,7 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     // (alphabets beyond 64 members have no wavefront-per-neuron chain for walks beyond 64 steps: those stay on the element-wise paths)
-    if (path == GPFQ_PATH_AUTO && N > 0 && m > 0 && auto_wants_gram(N, m, C, u_out != nullptr) && !(H.is_big && N > 64) && workspace &&
+    if (path == GPFQ_PATH_AUTO && g_auto_gram && N > 0 && m > 0 && auto_wants_gram(N, m, C, u_out != nullptr) && !(H.is_big && N > 64) && workspace &&
         (uintptr_t)workspace % 16 == 0 && workspace_bytes >= auto_gram_workspace_bytes(N, m, C)) {
         // Long rows, short walks: Gram records once per layer, the recurrence on scalars with every decision certified,
         // uncertifiable chains repaired on the device; whatever is still flagged afterwards (practically never) is rerun
@@ -448,7 +450,7 @@ int gpfq_assemble_kernel(const void *qidx, int bits, const double *alphabet, int
         return fail(GPFQ_ERR_INVALID_ARG, "alphabets of %d members have %s indices (gpfq_index_bits)", M, H.is_big ? "int16" : "int8 or packed");
     if (N == 0 || C == 0) return GPFQ_OK;
     if (!qidx) return fail(GPFQ_ERR_INVALID_ARG, "qidx is NULL");
-    if (N > 2147483647LL * 32 || (C + 31) / 32 > 65535) return fail(GPFQ_ERR_UNSUPPORTED, "kernel too large to assemble in one call");
+    if (N > 2147483647LL * 32) return fail(GPFQ_ERR_UNSUPPORTED, "kernel too large to assemble in one call");
     hipError_t e = gpfq::launch_assemble(static_cast<const int8_t *>(qidx), H.A, N, C, bits, Q, static_cast<int8_t *>(qidx_t),
                                          static_cast<hipStream_t>(stream), H.big());
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_assemble_kernel");

@@ -475,10 +475,10 @@ hipError_t launch_channel_planes(const float *act, int64_t npos, int64_t Cin, in
 template <class Alph, class Idx>
 __global__ void __launch_bounds__(256)
 gpfq_assemble_kernel(const Idx *__restrict__ qidx, Alph A, int64_t N, int64_t C, int bits,
-                     float *__restrict__ Q, Idx *__restrict__ idxT)
+                     float *__restrict__ Q, Idx *__restrict__ idxT, int64_t jtile0)
 {
     __shared__ Idx tile[32][33];
-    const int64_t t0 = (int64_t)blockIdx.x * 32, j0 = (int64_t)blockIdx.y * 32;
+    const int64_t t0 = (int64_t)blockIdx.x * 32, j0 = ((int64_t)blockIdx.y + jtile0) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
     const int64_t NB = (N * bits + 7) / 8;
     for (int r = ty; r < 32; r += 8) {
@@ -507,10 +507,11 @@ gpfq_assemble_kernel(const Idx *__restrict__ qidx, Alph A, int64_t N, int64_t C,
 // The common case -- one int8 index per weight, N and C multiples of four -- in 64 x 64 tiles with 4-byte index reads and
 // 16-byte value writes (the 32 x 32 form reads single bytes: 43 -> 27 us for 4096 x 4096).
 __global__ void __launch_bounds__(256)
-gpfq_assemble64_kernel(const int8_t *__restrict__ qidx, AlphabetArg A, int64_t N, int64_t C, float *__restrict__ Q, int8_t *__restrict__ idxT)
+gpfq_assemble64_kernel(const int8_t *__restrict__ qidx, AlphabetArg A, int64_t N, int64_t C, float *__restrict__ Q, int8_t *__restrict__ idxT,
+                       int64_t jtile0)
 {
     __shared__ int8_t tile[64][68];                               // [neuron][step], rows 4-byte aligned
-    const int64_t t0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;
+    const int64_t t0 = (int64_t)blockIdx.x * 64, j0 = ((int64_t)blockIdx.y + jtile0) * 64;
     const int c4 = threadIdx.x & 15, r0 = threadIdx.x >> 4;       // 16 x 16
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
@@ -544,17 +545,28 @@ hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, 
                            hipStream_t stream, const AlphabetBig *big)
 {
     if (N == 0 || C == 0) return hipSuccess;
+    // the neuron tiles ride on grid.y (at most 65535): kernels of more rows -- a multi-GPU 1 x 1 conv layer has Cin * F of them,
+    // 2^21 for ResNet50's conv5_block1_0_conv -- take several launches, each told its first tile
+    constexpr int64_t kMaxY = 65535;
     if (!big && bits == 8 && N % 4 == 0 && C % 4 == 0 && (uintptr_t)qidx % 4 == 0 && (uintptr_t)Q % 16 == 0 && (uintptr_t)idxT % 4 == 0) {
-        hipLaunchKernelGGL(gpfq_assemble64_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, stream,
-                           qidx, A, N, C, Q, idxT);
+        const int64_t tiles = (C + 63) / 64;
+        for (int64_t j = 0; j < tiles; j += kMaxY) {
+            const int64_t ny = tiles - j < kMaxY ? tiles - j : kMaxY;
+            hipLaunchKernelGGL(gpfq_assemble64_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)ny), dim3(256), 0, stream,
+                               qidx, A, N, C, Q, idxT, j);
+        }
         return hipGetLastError();
     }
-    const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((C + 31) / 32));
-    if (big)
-        hipLaunchKernelGGL((gpfq_assemble_kernel<AlphabetBig, int16_t>), grid, dim3(256), 0, stream,
-                           reinterpret_cast<const int16_t *>(qidx), *big, N, C, bits, Q, reinterpret_cast<int16_t *>(idxT));
-    else
-        hipLaunchKernelGGL((gpfq_assemble_kernel<AlphabetArg, int8_t>), grid, dim3(256), 0, stream, qidx, A, N, C, bits, Q, idxT);
+    const int64_t tiles = (C + 31) / 32;
+    for (int64_t j = 0; j < tiles; j += kMaxY) {
+        const int64_t ny = tiles - j < kMaxY ? tiles - j : kMaxY;
+        const dim3 grid((unsigned)((N + 31) / 32), (unsigned)ny);
+        if (big)
+            hipLaunchKernelGGL((gpfq_assemble_kernel<AlphabetBig, int16_t>), grid, dim3(256), 0, stream,
+                               reinterpret_cast<const int16_t *>(qidx), *big, N, C, bits, Q, reinterpret_cast<int16_t *>(idxT), j);
+        else
+            hipLaunchKernelGGL((gpfq_assemble_kernel<AlphabetArg, int8_t>), grid, dim3(256), 0, stream, qidx, A, N, C, bits, Q, idxT, j);
+    }
     return hipGetLastError();
 }
 

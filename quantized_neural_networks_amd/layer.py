@@ -59,11 +59,32 @@ def shard_bounds(n_units, world_size, rank):
     return lo, min(lo + per, n_units)
 
 
+_warned_unsharded = False
+
+
+def _warn_unsharded_once():
+    """group=None inside an initialised multi-rank job: every rank quantizes the whole layer on its own.  That is the
+    documented meaning, but a caller who expected the default group gets N redundant copies of the
+    work and no error -- say so once."""
+    global _warned_unsharded
+    if _warned_unsharded:
+        return
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        _warned_unsharded = True
+        import warnings
+        warnings.warn("quantized_neural_networks_amd.layer: torch.distributed is initialised with "
+                      f"{dist.get_world_size()} ranks but no process group was passed: this rank quantizes the whole layer "
+                      "alone (pass group=dist.group.WORLD / process_group=... to shard the neurons over the ranks)",
+                      RuntimeWarning, stacklevel=3)
+
+
 def _group_info(group):
     """(world, rank) of an EXPLICIT process group; ``None`` means "this process alone" even inside an initialised
     torch.distributed job (a rank-0-only quantization under torchrun must not wait for collectives the other ranks
     never enter).  Pass ``dist.group.WORLD`` to shard over all ranks."""
     if group is None:
+        _warn_unsharded_once()
         return 1, 0
     import torch.distributed as dist
     return dist.get_world_size(group), dist.get_rank(group)
