@@ -353,8 +353,10 @@ class QuantizedNeuralNetwork:
         except Exception as exc:
             self._log(f"\t\tLayer {layer_idx} generated an exception: {exc}")
             raise exc
-        for neuron_idx in range(N_ell_plus_1):
-            self._log(f"\t\tNeuron {neuron_idx} of {N_ell_plus_1} quantized successfully.")
+        # the reference logs one line per neuron as its futures complete (:567); here all neurons complete together, so the
+        # same lines go out as ONE logger call (4096 separate calls cost about as much as the kernel that quantized them)
+        self._log("\n".join(f"\t\tNeuron {neuron_idx} of {N_ell_plus_1} quantized successfully."
+                            for neuron_idx in range(N_ell_plus_1)))
         self._update_weights(layer_idx, Q)
         self._log(f"\tdone. {time()-tic:.2f} seconds.")
         self.last_layer_stats[layer_idx] = dict(rad=rad, alphabet=layer_alphabet,
