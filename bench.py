@@ -176,9 +176,9 @@ def main():
     if world > 1:
         ag_ms = [a.elapsed_time(b) for a, b in ev_ag]
         mine = torch.tensor([float(np.mean(kernel_ms)), float(np.mean(ag_ms)), float(np.min(ag_ms))], dtype=torch.float64, device=dev)
-        every = torch.empty((dist.get_world_size(group), 3), dtype=torch.float64, device=dev)
+        every = torch.empty(dist.get_world_size(group) * 3, dtype=torch.float64, device=dev)   # (concatenated form: gloo takes no other)
         dist.all_gather_into_tensor(every, mine, group=group)
-        every = every.cpu().numpy()
+        every = every.cpu().numpy().reshape(-1, 3)
         collective = {"backend": dist.get_backend(group) + (" (RCCL over xGMI)" if dist.get_backend(group) == "nccl" else ""),
                       "world_size": dist.get_world_size(group), "op": "all_gather_into_tensor of packed alphabet indices, one per layer",
                       "gathered_bytes_per_rank": int(st.get("gather_bytes", 0)),

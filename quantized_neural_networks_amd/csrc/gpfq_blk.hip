@@ -197,7 +197,7 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
 
 // LDS carve-up (byte offsets), shared by host and device.
 struct BlkLds {
-    int tile_bytes, tile_pitch, off_w, off_d, off_wq, off_x2, off_e, off_out, off_ctl, total;
+    int tile_bytes, tile_pitch, off_w, off_d, off_wq, off_x2, off_e, off_out, off_ctl, off_zero, total;
 };
 constexpr int kOutSteps = 32;                                    // steps of outputs staged in LDS between flushes
 
@@ -219,7 +219,8 @@ __host__ __device__ inline BlkLds blk_lds(int mp, int nb, int B, int nsw)
     L.off_x2 = o;   o += nw * nb * 16;                          // [NW][NB] (f64, f64)   exact partials (slow path)
     L.off_e = o;    o += 68 * 8;                                // [2 + 64 + 2] f64      -inf, -inf, alphabet, +inf, +inf
     L.off_out = o;  o += nb * kOutSteps * 8;                    // [NB][32] (idx i32, q f32) until the flush
-    L.off_ctl = o;  o += 16;                                    // [2] (by slot parity) smallest step a neuron of the block is stopped at, -1: none
+    L.off_ctl = o;  o += 16;                                    // [2] (by slot parity) smallest step a neuron of the block is stopped at, -1: none; [2] dummy
+    L.off_zero = o; o += 32;                                    // zeros (band entries a step does not have)
     L.total = o;
     return L;
 }
@@ -243,6 +244,10 @@ struct BlkK {
     float sym_a;
     const float *Xq;                // (symmetric form's slow path)
     int64_t ldx;
+    // The alphabet as an arithmetic progression (blk_uniform): member k = a0 + k step in float64, whose float32 rounding is
+    // float32(alphabet[k]) for every k (checked on the host); inv = 1 / step, c0 = -a0 / step (0, 0 for a single member).  The
+    // chain of decisions finds its candidate index and value by arithmetic; the certification looks the true members up.
+    double uni_a0, uni_step, uni_inv, uni_c0;
 };
 
 #ifdef GPFQ_BLK_STAMPS
@@ -689,55 +694,26 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         float  wc[B], qc[B];                                      // this block: weights, decisions (as float32 values)
         double D[B];
         int stop = B;                                             // first step of the block this neuron could not certify
-        // ---- prologue: D_t of the B rows (the partial sums of the previous slot), the weights of the block, and the contribution
-        // of block b-1's increments, which does not depend on this block's decisions and is spread over the sub-lanes: sub-lane
-        // r (mod B) forms the sums of step r, the chain fetches them by DPP (R is 4 or 8 and B <= 4: quad_perm broadcasts inside each
-        // aligned group of four lanes).  Written as: EVERY LDS read first, then the arithmetic, then the stores -- a store between
-        // two reads orders them (the compiler must assume they alias), and step by step this prologue was eight LDS round trips
-        // (2400-2900 cycles per slot, as long as the chain of decisions itself) right after the barrier, when the LDS is busiest.
-        double cPm = 0.0, ePm = 0.0;
+        // ---- the slot's decisions, in three parts (round 3).  Until round 2 a decision was ~100 instructions issued B times in
+        // sequence by this one wavefront (3300 cycles per slot of four: the floor of every narrow layer).  Only a sliver of that is
+        // the DEPENDENT part -- the next decision needs nothing of this one but q -- so:
+        //  (1) prologue, one step per sub-lane (sub-lane sm = lane mod B owns step sm): D of the own step (the sweeps' partial sums),
+        //      everything the pending increments of block b-1 and the WEIGHTS of this block's earlier steps contribute to the
+        //      predicted dot product and to its error bound -- none of it depends on this block's decisions;
+        //  (2) the chain, identical in all sub-lanes of a neuron: du_s = A_s - sum_{j<s} q_j H2[s][j], the quotient, the nearest member
+        //      by ARITHMETIC on the uniform alphabet (k = rint((t - a_0) / step), clamped; q = a_0 + k step -- the host has checked that
+        //      this reproduces float32(alphabet[k]) for every k: blk_uniform) -- about 16 instructions per step, no table, no LDS;
+        //  (3) certification, one step per sub-lane again: the error bound, the margins against the TRUE table neighbours
+        //      alphabet[k-1], alphabet[k], alphabet[k+1], rule (ii)'s certainty.  The first step of a neuron that fails stops its chain
+        //      for the block exactly as before (slow path below): what the chain guessed from there on is discarded.
+        //  Every LDS read is issued before the arithmetic; the stores come last (a store between two reads orders them).
+        double cPm = 0.0, ePm = 0.0;                                            // own step: block b-1's increments (also the slow path's)
         unsigned anyP = 0u;
-        double2 st01, st23, st45;                                               // record header of the step about to be decided
 #pragma unroll
         for (int j = 0; j < B; ++j) anyP |= __float_as_uint(wprev[j]) | __float_as_uint(qprev[j]);
-        if (b < K.nblk) {
-            double dpart[B][NW / R];
-            double2 hb[B], eb[B];
-            const int sm = lane & (B - 1);                        // this lane's step (B is a power of two <= 4)
-            const int rbm = tbase + sm * RB;
-#pragma unroll
-            for (int s = 0; s < B; ++s) {
-#pragma unroll
-                for (int q = 0; q < NW / R; ++q)
-                    dpart[s][q] = lds_ld<double>(lds, o_d + ((((b & 1) * NW + q * R) * B) + s) * NB * 8);
-                wc[s] = lds_ld<float>(lds, o_w + (b & 1) * NB * B * 4 + 4 * s);
-            }
-#pragma unroll
-            for (int j = 0; j < B; ++j) {
-                const int d = B + sm - j;
-                hb[j] = lds_ld<double2>(lds, rbm + 64 + 32 * (d - 1)); eb[j] = lds_ld<double2>(lds, rbm + 64 + 32 * (d - 1) + 16);
-            }
-            st01 = lds_ld<double2>(lds, tbase); st23 = lds_ld<double2>(lds, tbase + 16); st45 = lds_ld<double2>(lds, tbase + 32);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < B; ++s) {
-                double d = 0.0;
-#pragma unroll
-                for (int q = 0; q < NW / R; ++q) d += dpart[s][q];
-                D[s] = sub_sum<R>(d);
-                qc[s] = 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < B; ++j) {
-                const double wj = (double)wprev[j], qj = (double)qprev[j];
-                cPm = fma(wj, hb[j].x, cPm); cPm = fma(-qj, hb[j].y, cPm);
-                ePm = fma(fabs(wj), eb[j].x, ePm); ePm = fma(fabs(qj), eb[j].y, ePm);
-            }
-            if (r == 0) {
-#pragma unroll
-                for (int s = 0; s < B; ++s) lds_st<float2>(lds, o_wq + cbq + 8 * s, make_float2(wc[s], 0.f));   // w is known now, q follows
-            }
-        }
+        const int nvalid = (int)min((int64_t)B, N - (int64_t)b * B);            // steps beyond N pad the last block: no-ops
+        const int oslot0 = (int)(((int64_t)b * B) % kOutSteps);
+        const int o_dummy = L.off_ctl + 8;
         auto quad_bcast = [&](double x, int s) -> double {       // value of lane (4 * (lane / 4) + s)
             int lo = __double2loint(x), hi = __double2hiint(x);
             if (s == 0) { lo = __builtin_amdgcn_mov_dpp(lo, 0x00, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x00, 0xF, 0xF, true); }
@@ -746,56 +722,179 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             if (s == 3) { lo = __builtin_amdgcn_mov_dpp(lo, 0xFF, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xFF, 0xF, 0xF, true); }
             return __hiloint2double(hi, lo);
         };
+        if (b < K.nblk) {
+            const int sm = lane & (B - 1);                        // this lane's step (B is a power of two <= 4)
+            const int rbm = tbase + sm * RB;
+            // ---- (1) reads
+            double dp[NW];                                        // partial sums of the own step, every sweep wavefront's slot
+#pragma unroll
+            for (int w = 0; w < NW; ++w) dp[w] = lds_ld<double>(lds, L.off_d + ((((b & 1) * NW + w) * B + sm) * NB + n) * 8);
+#pragma unroll
+            for (int s = 0; s < B; ++s) wc[s] = lds_ld<float>(lds, o_w + (b & 1) * NB * B * 4 + 4 * s);
+            double2 s01[B];                                       // (1 / nrm^2, <Xq_t, X_t>) of every step
+#pragma unroll
+            for (int s = 0; s < B; ++s) s01[s] = lds_ld<double2>(lds, tbase + s * RB);
+            double h2[B][B];                                      // <Xq_s, Xq_j>, j < s
+#pragma unroll
+            for (int s = 0; s < B; ++s)
+#pragma unroll
+                for (int j = 0; j < B; ++j)
+                    if (j < s) h2[s][j] = lds_ld<double>(lds, tbase + s * RB + 64 + 32 * (s - j - 1) + 8);
+            const double2 o01 = lds_ld<double2>(lds, rbm), o23 = lds_ld<double2>(lds, rbm + 16), o45 = lds_ld<double2>(lds, rbm + 32);
+            const float w_own_raw = lds_ld<float>(lds, o_w + (b & 1) * NB * B * 4 + 4 * sm);
+            double2 hp[B], ep[B];                                 // band of the own step against block b-1: distance B + sm - j
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                const int d = B + sm - j;
+                hp[j] = lds_ld<double2>(lds, rbm + 64 + 32 * (d - 1)); ep[j] = lds_ld<double2>(lds, rbm + 64 + 32 * (d - 1) + 16);
+            }
+            double2 hi_[B], ei_[B];                               // ... against this block's steps j < sm (zeros for j >= sm)
+#pragma unroll
+            for (int j = 0; j + 1 < B; ++j) {
+                const int o = j < sm ? rbm + 64 + 32 * (sm - j - 1) : L.off_zero;
+                hi_[j] = lds_ld<double2>(lds, o); ei_[j] = lds_ld<double2>(lds, j < sm ? o + 16 : o);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- (1) arithmetic
+            double wd[B], wG[B];
+#pragma unroll
+            for (int s = 0; s < B; ++s) {
+                wc[s] = s < nvalid ? wc[s] : 0.f;
+                qc[s] = 0.f;
+                wd[s] = (double)wc[s];
+                wG[s] = wd[s] * s01[s].y;
+            }
+            double Dm;                                            // D of the own step: fixed-order tree over the wavefronts' slots
+            {
+                double t[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) t[w] = dp[w];
+#pragma unroll
+                for (int span = 1; span < NW; span *= 2)
+#pragma unroll
+                    for (int w = 0; w + span < NW; w += 2 * span) t[w] += t[w + span];
+                Dm = t[0];
+            }
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                const double wj = (double)wprev[j], qj = (double)qprev[j];
+                cPm = fma(wj, hp[j].x, cPm); cPm = fma(-qj, hp[j].y, cPm);
+                ePm = fma(fabs(wj), ep[j].x, ePm); ePm = fma(fabs(qj), ep[j].y, ePm);
+            }
+            double Aw = cPm, Ew = ePm;                            // + this block's weights before the own step
+#pragma unroll
+            for (int j = 0; j + 1 < B; ++j) { Aw = fma(wd[j], hi_[j].x, Aw); Ew = fma(fabs(wd[j]), ei_[j].x, Ew); }
+            const double Am = Dm + Aw;
+            double A[B];
+#pragma unroll
+            for (int s = 0; s < B; ++s) A[s] = quad_bcast(Am, s);
+            STAMP(dta);
+            // ---- (2) the chain
+            const double u_a0 = K.uni_a0, u_step = K.uni_step, u_inv = K.uni_inv, u_c0 = K.uni_c0, u_kmax = (double)(M - 1);
+            auto pick = [&](double tt, double &kd) -> float {     // nearest member of the uniform alphabet, by arithmetic
+                kd = fmin(fmax(rint(fma(tt, u_inv, u_c0)), 0.0), u_kmax);
+                return (float)fma(kd, u_step, u_a0);
+            };
+            float q32s[B];
+            double qd[B];
+            double du_m = 0.0;
+            unsigned any_run = anyP, any_m = anyP;
+#pragma unroll
+            for (int s = 0; s < B; ++s) {
+                double du = A[s];
+#pragma unroll
+                for (int j = 0; j < B; ++j)
+                    if (j < s) du = fma(-qd[j], h2[s][j], du);
+                const double tq = (du + wG[s]) * s01[s].x;
+                const double tt = fabs(du) < 1e-10 ? wd[s] : tq;
+                double kd;
+                float q32 = pick(tt, kd);
+                q32 = s01[s].x == 0.0 ? 0.f : q32;                // rule (i): the pre-pass stores 1 / nrm^2 = 0 for nrm < 1e-16
+                q32s[s] = q32;
+                qd[s] = (double)q32;
+                du_m = sm == s ? du : du_m;
+                any_m = sm == s ? any_run : any_m;
+                any_run |= __float_as_uint(wc[s]) | __float_as_uint(q32);
+            }
+            // ---- (3) certification of the own step
+            const bool valid_m = sm < nvalid;
+            const float w_m = valid_m ? w_own_raw : 0.f;
+            const double wdm = (double)w_m, rden = o01.x, wGm = wdm * o01.y;
+            const double rcb = o23.x, rca = o23.y, rEa = o45.x;
+            const bool rule1 = rden == 0.0;
+            const bool small = fabs(du_m) < 1e-10;
+            const double tq_m = (du_m + wGm) * rden;
+            const double tt_m = small ? wdm : tq_m;
+            double kd_m;
+            const float qk32 = pick(tt_m, kd_m);                  // (the chain's arithmetic on the chain's operands: the same bits)
+            const int ki = (int)kd_m;
+            const int oe = L.off_e + 8 * (1 + ki);                // table with two sentinels on either side: a[k-1], a[k], a[k+1]
+            const double a_lo = lds_ld<double>(lds, oe), a_k = lds_ld<double>(lds, oe + 8), a_hi = lds_ld<double>(lds, oe + 16);
+            double eps = Ew;
+#pragma unroll
+            for (int j = 0; j + 1 < B; ++j) eps = fma(fabs(qd[j]), ei_[j].y, eps);
+            // (each of the up to 2B-1 pending increments may lose up to Ea = 2^-149 sum|Xq_t| to subnormal float32 products)
+            eps += ((any_m << 1) != 0u) ? (double)(2 * B - 1) * rEa : 0.0;
+            const bool du_exact = eps == 0.0;                     // every pending increment orthogonal to Xq_t element-wise
+            const bool msq = du_exact & small;                    // rule (ii), certain
+            const bool sure = du_exact | (fabs(du_m) - eps >= 1e-10);   // ... or certainly not rule (ii)
+            // twice the modelling error of the prediction (quotient units) + float64 slack
+            const double delta2 = 2.0 * (fma(fabs(wdm), rcb, rca) + eps * rden)
+                                  + 0x1p-43 * (fabs(Dm) + fabs(du_m - Dm) + fabs(wGm)) * rden;
+            const double d_k = fabs(a_k - tt_m), d_lo = fabs(a_lo - tt_m), d_hi = fabs(a_hi - tt_m);
+            const bool far = (d_lo - d_k > delta2) & (d_hi - d_k > delta2);      // beyond the bound from both boundaries
+            const bool first = (d_k < d_lo) & (d_k <= d_hi);                     // exact t (rule (ii)): argmin's first minimum (:57)
+            const bool cert = (msq ? first : far) & sure;
+            const bool ok = rule1 | cert | !valid_m;
+            // first step of each neuron that is not certain: the R sub-lanes of a neuron sit side by side, sub-lane sm at bit sm
+            const unsigned long long bad = __ballot(!ok);
+            const unsigned field = (unsigned)(bad >> (lane & ~(R - 1))) & ((1u << B) - 1u);
+            stop = field ? __builtin_ctz(field) : B;
+            STAMP(dtb);
+#pragma unroll
+            for (int s = 0; s < B; ++s) qc[s] = s < stop ? q32s[s] : 0.f;
+            const bool keep = sm < stop;
+            const float q_m = rule1 ? 0.f : qk32;
+            const float q_st = keep ? q_m : 0.f;
+            // what the sweeps multiply the (scaled) Xq row with: q, or minus its sign; (w, 0) for a step still to be decided
+            const float qpub = SYM ? (q_st > 0.f ? -1.f : (q_st < 0.f ? 1.f : 0.f)) : q_st;
+            const bool st = r < B;                                // (sub-lanes B.. repeat sub-lanes 0..B-1)
+            lds_st<float2>(lds, st ? o_wq + cbq + 8 * sm : o_dummy, make_float2(w_m, qpub));
+            lds_st<int2>(lds, (st & keep & valid_m) ? o_out + ((oslot0 + sm) % kOutSteps) * 8 : o_dummy,
+                         make_int2(rule1 ? K.zero_idx : ki, __float_as_int(q_m)));
+            // smallest stop over the workgroup's active neurons: scalar, from the ballot
+            const unsigned long long badA = __ballot(!ok & active);
+            int smin = B;
+#pragma unroll
+            for (int k = B - 1; k >= 0; --k) {
+                unsigned long long pat = 0ull;
+#pragma unroll
+                for (int g = 0; g < 64 / B; ++g) pat |= 1ull << (g * B + k);
+                if (badA & pat) smin = k;
+            }
+            if (lane == 0) lds_st<int>(lds, L.off_ctl + 4 * (b & 1), smin < B ? smin : -1);
+        } else {
+            STAMP(dta);
+            STAMP(dtb);
+            if (lane == 0) lds_st<int>(lds, L.off_ctl + 4 * (b & 1), -1);
+        }
 
-        // The chain of B dependent decisions is the longest path of a workgroup whenever the sweeps are short (rows of up to 768
-        // samples, alphabets beyond 16 members, few neurons per GPU), and one wavefront issues it alone: what counts is its
-        // instruction count and how early its LDS reads are issued.  So the record of a step (row statistics, the Gram-band entries
-        // of the in-block corrections) is requested one step AHEAD, at the top of the decision before -- the reads do not depend on
-        // any decision, but behind a decision's LDS stores the compiler could not move them -- and a decision is straight-line code:
-        // its outputs are selected, its stores go to a dummy slot when they are not wanted.
-        const int nvalid = (int)min((int64_t)B, N - (int64_t)b * B);            // steps beyond N pad the last block: no-ops
-        const int oslot0 = (int)(((int64_t)b * B) % kOutSteps);
-        const int o_dummy = L.off_ctl + 8;
-        double2 bandH[B], bandE[B];                                            // the entries (s, j < s) of that step, at j
-
-        // One decision (:83-89, :57); commit == this lane's chain is still running.  Returns false when not certifiable.
-        // fresh: the record values prefetched above (the hot chain); otherwise read here (the slow path's resumed chains).
-        auto decide = [&](int s, bool commit, auto inregs_tag, auto fresh_tag) -> bool {
-            constexpr bool IN_REGS = decltype(inregs_tag)::value, FRESH = decltype(fresh_tag)::value;
+        // One decision (:83-89, :57) in full, from the record in LDS: the slow path's resumed chains (and what the hot chain above
+        // is checked against by the parity tests).  commit == this lane's chain is still running.  Returns false when not certifiable.
+        auto decide = [&](int s, bool commit, auto inregs_tag) -> bool {
+            constexpr bool IN_REGS = decltype(inregs_tag)::value;
             const int rb = tbase + s * RB;
-            double2 r01, r23, r45;
-            if constexpr (FRESH) { r01 = st01; r23 = st23; r45 = st45; }
-            else { r01 = lds_ld<double2>(lds, rb); r23 = lds_ld<double2>(lds, rb + 16); r45 = lds_ld<double2>(lds, rb + 32); }
+            const double2 r01 = lds_ld<double2>(lds, rb), r23 = lds_ld<double2>(lds, rb + 16), r45 = lds_ld<double2>(lds, rb + 32);
             const double rden = r01.x, rG = r01.y, rcb = r23.x, rca = r23.y, rEa = r45.x, nrm = r45.y;
             const bool rule1 = nrm < 1e-16;                                      // rule (i): literal 0
             // not yet applied increments: block b-1 (formed above by sub-lane s) and this block's steps before s (distance s - j)
             double corr = quad_bcast(cPm, s), eps = quad_bcast(ePm, s);
             unsigned anyinc = anyP;
-            double2 hh[B], ee[B];
 #pragma unroll
             for (int j = 0; j < B; ++j) {
                 if (j < s) {
                     const int d = s - j;
-                    if constexpr (FRESH) { hh[j] = bandH[j]; ee[j] = bandE[j]; }
-                    else { hh[j] = lds_ld<double2>(lds, rb + 64 + 32 * (d - 1)); ee[j] = lds_ld<double2>(lds, rb + 64 + 32 * (d - 1) + 16); }
-                }
-            }
-            if constexpr (FRESH) {                                               // the next step's record, ahead of this step's stores
-                if (s + 1 < B) {
-                    st01 = lds_ld<double2>(lds, rb + RB); st23 = lds_ld<double2>(lds, rb + RB + 16); st45 = lds_ld<double2>(lds, rb + RB + 32);
-                }
-#pragma unroll
-                for (int j = 0; j < B; ++j)
-                    if (j < s + 1 && s + 1 < B) {
-                        const int d = s + 1 - j;
-                        bandH[j] = lds_ld<double2>(lds, rb + RB + 64 + 32 * (d - 1));
-                        bandE[j] = lds_ld<double2>(lds, rb + RB + 64 + 32 * (d - 1) + 16);
-                    }
-            }
-#pragma unroll
-            for (int j = 0; j < B; ++j) {
-                if (j < s) {
-                    const double2 h = hh[j], e = ee[j];
+                    const double2 h = lds_ld<double2>(lds, rb + 64 + 32 * (d - 1)), e = lds_ld<double2>(lds, rb + 64 + 32 * (d - 1) + 16);
                     const double wj = (double)wc[j], qj = (double)qc[j];
                     corr = fma(wj, h.x, corr); corr = fma(-qj, h.y, corr);
                     eps = fma(fabs(wj), e.x, eps); eps = fma(fabs(qj), e.y, eps);
@@ -821,8 +920,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             if constexpr (SYM) {
                 // {-a, 0, a} / {-a, a}, exactly symmetric in float64 (blk_sym_a): the boundaries are -a/2 and a/2 (or 0), exact, and
                 // the nearest member follows from two comparisons -- a tie goes to the lower index as argmin does (:57), though a
-                // decision that close is never certified.  Twice the distance from the nearer boundary is the margin.  No table
-                // look-up, no LDS round trip in the chain.
+                // decision that close is never certified.  Twice the distance from the nearer boundary is the margin.
                 const bool up = tt > sym_hb, mid = tt > -sym_hb;
                 idx_l = up ? M - 1 : (mid ? 1 : 0);
                 q_l = up ? sym_top : (mid ? 0.0 : -sym_top);
@@ -866,32 +964,6 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         };
         using T_ = std::true_type;
         using F_ = std::false_type;
-
-        STAMP(dta);
-        if (b < K.nblk) {
-            if (in_regs) {
-#pragma unroll
-                for (int s = 0; s < B; ++s) {
-                    const bool ok = decide(s, stop == B, T_{}, T_{});
-                    stop = (stop == B && !ok) ? s : stop;
-                    __builtin_amdgcn_sched_barrier(0);            // (the next step's reads are already requested: nothing else should move up)
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < B; ++s) {
-                    const bool ok = decide(s, stop == B, F_{}, T_{});
-                    stop = (stop == B && !ok) ? s : stop;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            STAMP(dtb);
-            // smallest stop over the workgroup's active neurons (B: nobody stopped): one ballot per step, scalar from there (a
-            // butterfly over the lanes goes through ds_bpermute: four LDS round trips at the end of every slot's chain)
-            const int smin = wave_min_stop(active ? stop : B);
-            if (lane == 0) lds_st<int>(lds, L.off_ctl + 4 * (b & 1), smin < B ? smin : -1);
-        } else if (lane == 0) {
-            lds_st<int>(lds, L.off_ctl + 4 * (b & 1), -1);
-        }
         STAMP(dt1);
         slot_barrier();
         STAMP(dt2);
@@ -904,6 +976,14 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             const int S = __builtin_amdgcn_readfirstlane(lds_ld<int>(lds, L.off_ctl + 4 * (b & 1)));
             if (S < 0) break;
             slot_barrier();                                       // exact partials published
+            // (the hot path only forms the own step's D: here every sub-lane needs all of them, sub-lane r adding slots r, r + R, ...)
+#pragma unroll
+            for (int s = 0; s < B; ++s) {
+                double d = 0.0;
+#pragma unroll
+                for (int q = 0; q < NW / R; ++q) d += lds_ld<double>(lds, o_d + ((((b & 1) * NW + q * R) * B) + s) * NB * 8);
+                D[s] = sub_sum<R>(d);
+            }
             double du = 0.0, dw = 0.0;
 #pragma unroll
             for (int q = 0; q < NW / R; ++q) {
@@ -940,7 +1020,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 #pragma unroll
             for (int s = 0; s < B; ++s) {
                 if (s > S) {                                      // (uniform)
-                    const bool ok = in_regs ? decide(s, mine && stop2 == B, T_{}, F_{}) : decide(s, mine && stop2 == B, F_{}, F_{});
+                    const bool ok = in_regs ? decide(s, mine && stop2 == B, T_{}) : decide(s, mine && stop2 == B, F_{});
                     if (mine && stop2 == B && !ok) stop2 = s;
                 }
             }
@@ -1066,11 +1146,36 @@ static BlkShape blk_shape(int64_t m, int64_t C)
     return {0, 0, 0, 0, 0};
 }
 
+// The alphabet as an arithmetic progression, if it is one in the sense the chain of decisions needs: strictly ascending and
+// float32(fma(k, step, a0)) == float32(alphabet[k]) for every k, with step = (a[M-1] - a[0]) / (M - 1) -- the same fused operation
+// the kernel performs.  Everything the reference builds (rad * linspace(-1, 1, M), scripts/quantized_network.py:396, :545) is.
+static bool blk_uniform(const AlphabetArg &A, double *a0, double *step, double *inv, double *c0)
+{
+    const int M = A.M;
+    if (M < 1 || !std::isfinite(A.a[0]) || !std::isfinite(A.a[M - 1])) return false;
+    *a0 = A.a[0];
+    if (M == 1) { *step = 0.0; *inv = 0.0; *c0 = 0.0; return true; }
+    *step = (A.a[M - 1] - A.a[0]) / (double)(M - 1);
+    if (!(*step > 0.0) || !std::isfinite(*step)) return false;
+    *inv = 1.0 / *step;
+    *c0 = -*a0 * *inv;
+    if (!std::isfinite(*inv) || !std::isfinite(*c0)) return false;
+    for (int k = 0; k < M; ++k) {
+        if (k > 0 && !(A.a[k - 1] < A.a[k])) return false;
+        if ((float)std::fma((double)k, *step, *a0) != (float)A.a[k]) return false;
+        // and the index arithmetic finds a member from its own value (monotone rounding does the rest)
+        if (std::rint(std::fma(A.a[k], *inv, *c0)) != (double)k) return false;
+    }
+    return true;
+}
+
 bool blk_supported(const PipeArgs &a)
 {
     const BlkShape sh = blk_shape(a.m, a.C);
     if (sh.G == 0 || a.N < 1 || a.m < 1) return false;
     if (a.A.M > 64 || !a.A.ascending) return false;
+    double a0, step, inv, c0;
+    if (!blk_uniform(a.A, &a0, &step, &inv, &c0)) return false;      // (other alphabets keep the row-group kernels)
     return a.N + 64 < (1LL << 31) / 64;
 }
 
@@ -1109,6 +1214,7 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
     K.qidx = a.qidx; K.Qt = a.Qt; K.resid = a.resid; K.u_out = a.u_out; K.fallback_count = a.fallback_count;
     K.stamps = a.fallback_count ? a.fallback_count + 8 : nullptr;      // (diagnostic build: the unused row-statistics area behind the counter block)
     K.sym_a = SYM ? blk_sym_a(a) : 0.f; K.Xq = a.Xq; K.ldx = a.ld;
+    if (!blk_uniform(a.A, &K.uni_a0, &K.uni_step, &K.uni_inv, &K.uni_c0)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NSW + 1)), (size_t)L.total, stream, K, a.A);
     return hipGetLastError();
 }
