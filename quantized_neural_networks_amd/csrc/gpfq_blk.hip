@@ -65,15 +65,15 @@ static_assert(sizeof(BlkStats) == 64 && sizeof(BandEntry) == 32, "header layout"
 __host__ __device__ constexpr int blk_hdr_bytes(int B) { return (64 + (2 * B - 1) * 32 + 127) & ~127; }
 // The row t + B travels as float64 (the sweep's dot products then need no conversion) -- except in the one-step-per-slot shapes,
 // which are bound by the record stream itself: there it stays float32 (12 instead of 16 bytes per sample) and is converted in the sweep.
-__host__ __device__ constexpr bool blk_row64(int B) { return B > 1; }
-__host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B) { return blk_hdr_bytes(B) + (blk_row64(B) ? 16 : 12) * mp; }
+__host__ __device__ constexpr bool blk_row64(int64_t mp, int B) { (void)mp; return B > 1; }
+__host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B) { return blk_hdr_bytes(B) + (blk_row64(mp, B) ? 16 : 12) * mp; }
 
 // ---- pre-pass ---------------------------------------------------------------------------------
 // One workgroup per slot record t: statistics of row t, its Gram band against rows t-1 .. t-(2B-1), float32 copies
 // of rows t-B, the float64 copy of Xq row t+B; zero-padded to mp samples.  One pass over the samples with all 3 + 4 (2B-1)
 // sums in registers and ONE workgroup reduction.  The launch is bound by its float64 arithmetic (about 60 operations per
 // sample of a row: seven band distances x four sums): 49 us for 4096 rows of 1024 samples.
-template <int B>
+template <int B, bool R64>
 __global__ void __launch_bounds__(256)
 gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t N, int m, int mp,
                      const float *__restrict__ nrm32, char *__restrict__ recs, float sym_a)
@@ -126,7 +126,7 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
             for (int d = 1; d <= ND; ++d) { bx4[d - 1] = row(X, t - d); bq4[d - 1] = row(Xq, t - d); }
             *reinterpret_cast<float4 *>(ox + i) = xp;
             *reinterpret_cast<float4 *>(oq + i) = sym_a != 0.f ? make_float4(__fmul_rn(sym_a, qp.x), __fmul_rn(sym_a, qp.y), __fmul_rn(sym_a, qp.z), __fmul_rn(sym_a, qp.w)) : qp;
-            if constexpr (blk_row64(B)) {
+            if constexpr (R64) {
                 *reinterpret_cast<double2 *>(od + i) = make_double2((double)qn.x, (double)qn.y);
                 *reinterpret_cast<double2 *>(od + i + 2) = make_double2((double)qn.z, (double)qn.w);
             } else {
@@ -151,7 +151,7 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
             const bool in = i < m;
             ox[i] = (has_prev && in) ? px[i] : 0.f;
             oq[i] = (has_prev && in) ? (sym_a != 0.f ? __fmul_rn(sym_a, pq[i]) : pq[i]) : 0.f;   // symmetric form: f32(a Xq), see BlkK::sym_a
-            if constexpr (blk_row64(B)) od[i] = (double)((has_next && in) ? nq[i] : 0.f);
+            if constexpr (R64) od[i] = (double)((has_next && in) ? nq[i] : 0.f);
             else reinterpret_cast<float *>(od)[i] = (has_next && in) ? nq[i] : 0.f;
             if (has_cur && in) {
                 float b1[ND], b2[ND];
@@ -273,9 +273,9 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     const int nslots = K.nblk + 1;
     const int o_x  = HDR + 8 * (pbase + kq);                      // float2 x   [pair]  (row t - B of record t)
     const int o_q  = o_x + 4 * MP;                                // float2 xq  [pair]
-    constexpr int DB = blk_row64(B) ? 16 : 8;                     // bytes of a sample pair of row t + B
+    constexpr int DB = blk_row64(MP, B) ? 16 : 8;                 // bytes of a sample pair of row t + B
     const int o_d  = HDR + 8 * MP + DB * (pbase + kq);           // double2 (float2) xqd[pair]  (row t + B)
-    using DRaw = std::conditional_t<blk_row64(B), double2, float2>;   // as it sits in the record; converted where it is consumed
+    using DRaw = std::conditional_t<blk_row64(MP, B), double2, float2>;   // as it sits in the record; converted where it is consumed
     auto ld_d = [&](int off) -> DRaw { return lds_ld<DRaw>(lds, off); };
     auto to_d2 = [](const DRaw &v) -> double2 { return make_double2((double)v.x, (double)v.y); };
     const int o_wq = L.off_wq + nloc * B * 8;
@@ -319,11 +319,48 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     load_weights(0);
     dma_wait();
     slot_barrier();
-    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, acc_dma = 0, acc_u = 0, acc_d = 0, acc_w = 0, acc_b = 0;
-    (void)st0; (void)st1; (void)st2; (void)st3; (void)st4; (void)st5; (void)acc_dma; (void)acc_u; (void)acc_d; (void)acc_w; (void)acc_b;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, acc_dma = 0, acc_u = 0, acc_d = 0, acc_w = 0, acc_b = 0, acc_t = 0;
+    (void)st0; (void)st1; (void)st2; (void)st3; (void)st4; (void)st5; (void)acc_dma; (void)acc_u; (void)acc_d; (void)acc_w; (void)acc_b; (void)acc_t;
+
+    // Few pairs per slot (kPreloadAll): EVERY operand of a slot -- the rows of the B updates, the block's (w, q), the rows of the B
+    // dot products -- is requested right after the barrier that ends the slot before, together with the control word of the slow
+    // path, and held in registers: one LDS round trip per slot instead of three in sequence (control word, phase U's operands, phase
+    // D's; 400-900 cycles each with the LDS busiest right after the barrier -- profiles/r03/blk_phase_stamps.txt).
+    constexpr bool kPreloadAll = PW * B <= 8 && PW <= 5;
+    // ... where the registers allow it (u and the operands of a slot together): otherwise they are requested at the top of
+    // phase U as in round 2
+    constexpr bool kHoist = kPreloadAll && PW * B <= 4;
+    constexpr int PB = kPreloadAll ? B : 1, PP = kPreloadAll ? PW : 1;
+    // (the rows of the dot products too when they are few registers: otherwise phase D requests them itself, as before)
+    constexpr bool kPreD = kHoist && PW * B * (blk_row64(MP, B) ? 4 : 2) <= 16;
+    constexpr int DBn = kPreD ? B : 1, DPn = kPreD ? PW : 1;
+    float2 xs[PB][PP], qs[PB][PP], wqa[PB][4];
+    DRaw ds[DBn][DPn];
+    auto preload_wq = [&](int b) {                                // (w, q) of block b - 1, for slot b's updates
+        const int pbq = ((b - 1) & 1) * NB * B * 8;
+#pragma unroll
+        for (int s = 0; s < PB; ++s)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) wqa[s][n] = lds_ld<float2>(lds, o_wq + pbq + (n * B + s) * 8);
+    };
+    auto preload_rows = [&](int b) {
+        const int tbase = (b & 1) * L.tile_pitch;
+#pragma unroll
+        for (int s = 0; s < PB; ++s)
+#pragma unroll
+            for (int p = 0; p < PP; ++p) {
+                xs[s][p] = lds_ld<float2>(lds, tbase + s * RB + o_x + 8 * p * KQ);
+                qs[s][p] = lds_ld<float2>(lds, tbase + s * RB + o_q + 8 * p * KQ);
+                if constexpr (kPreD) ds[s][p] = ld_d(tbase + s * RB + o_d + DB * p * KQ);
+            }
+    };
+    if constexpr (kHoist) { preload_wq(0); preload_rows(0); }
 
     for (int b = 0; b < nslots; ++b) {
         STAMP(st0);
+#ifdef GPFQ_BLK_STAMPS
+        if (b) acc_t += st0 - st5;                                // from the barrier to the top of the next slot: control word, next operands
+#endif
         if (b + 1 < nslots) load_weights(b + 1);                  // the block's weights: one piece
         const int bn = b + 1 < nslots ? b + 1 : b;                // (the last slot rewrites its own tile with the same bytes)
         STAMP(st1);
@@ -356,7 +393,6 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 #pragma unroll
             for (int n = 0; n < 4; ++n) { u[n][2 * p] += c0[n]; u[n][2 * p + 1] += c1[n]; }
         };
-        constexpr bool kPreloadAll = PW * B <= 8 && PW <= 5;      // few pairs per slot: see below
         // ---- phase U: the B updates of block b-1, in order: u += f32(w x) - f32(q xq)  (:119) ----
         // Software-pipelined by hand: the operands of the NEXT pair (and the next step's four (w, q)) are requested before
         // the arithmetic of the current one (sched_barrier keeps hipcc from sinking the requests to their first use,
@@ -366,18 +402,8 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             // (32 instructions per pair) is shorter than an LDS round trip with twelve wavefronts on the LDS -- the sweep of a
             // 4-neuron workgroup took 600 cycles per (pair, step) against 316 for the arithmetic.  So every operand of the slot is
             // requested up front (at most 8 pairs + the block's (w, q): 64 registers) and the steps run back to back.
-            float2 xs[B][PW], qs[B][PW], wqa[B][4];
-#pragma unroll
-            for (int s = 0; s < B; ++s) {
-#pragma unroll
-                for (int n = 0; n < 4; ++n) wqa[s][n] = lds_ld<float2>(lds, o_wq + pbq + (n * B + s) * 8);
-#pragma unroll
-                for (int p = 0; p < PW; ++p) {
-                    xs[s][p] = lds_ld<float2>(lds, tbase + s * RB + o_x + 8 * p * KQ);
-                    qs[s][p] = lds_ld<float2>(lds, tbase + s * RB + o_q + 8 * p * KQ);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            // (operands: requested after the last barrier where the registers allow it, see preload_rows)
+            if constexpr (!kHoist) { preload_wq(b); preload_rows(b); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
             for (int s = 0; s < B; ++s) {
                 if (s == 0) __builtin_amdgcn_s_setprio(2);
@@ -446,19 +472,22 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         STAMP(st2);
         // ---- phase D: this wavefront's share of <Xq_t, u> for the B rows of block b+1 ----
         if (b + 1 < nslots && kPreloadAll) {
-            DRaw ds[B][PW];
+            DRaw dsl[B][PW];
 #pragma unroll
             for (int r = 0; r < B; ++r)
 #pragma unroll
-                for (int p = 0; p < PW; ++p) ds[r][p] = ld_d(tbase + r * RB + o_d + DB * p * KQ);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int p = 0; p < PW; ++p) {
+                    if constexpr (kPreD) dsl[r][p] = ds[r][p];
+                    else dsl[r][p] = ld_d(tbase + r * RB + o_d + DB * p * KQ);
+                }
+            if constexpr (!kPreD) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < B; ++r) {
                 if (r == B / 2) __builtin_amdgcn_s_setprio(0);
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int p = 0; p < PW; ++p) {
-                    const double2 d2 = to_d2(ds[r][p]);
+                    const double2 d2 = to_d2(dsl[r][p]);
 #pragma unroll
                     for (int n = 0; n < 4; ++n) {
                         acc[n] = fma(d2.x, u[n][2 * p], acc[n]);
@@ -504,9 +533,15 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 #endif
 
         // ---- slow path: neurons of block b stopped at an uncertifiable step (rare) ----
+        int ctl = lds_ld<int>(lds, L.off_ctl + 4 * (b & 1));      // (requested first: it is waited for alone)
+        if constexpr (kHoist) {
+            if (b + 1 < nslots) { preload_wq(b + 1); preload_rows(b + 1); }
+        }
+        bool any_slow = false;
         for (;;) {
-            const int S = __builtin_amdgcn_readfirstlane(lds_ld<int>(lds, L.off_ctl + 4 * (b & 1)));
+            const int S = __builtin_amdgcn_readfirstlane(ctl);
             if (S < 0) break;
+            any_slow = true;
             // u is the residual BEFORE block b.  Exact <Xq_t, u_{t-1}> and <Xq_t, u_{t-1} + f32(w_t X_t)> (:86, :89) for
             // t = bB + S: the block's first S updates replayed into temporaries; rows of block b are records of tile b+1.
             const int nb_ = ((b + 1) & 1) * L.tile_pitch;
@@ -554,13 +589,17 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             if (writer) lds_st<double2>(lds, o_x2, make_double2(vu, vw));
             slot_barrier();                                       // partials published
             slot_barrier();                                       // chains resumed, control word rewritten
+            ctl = lds_ld<int>(lds, L.off_ctl + 4 * (b & 1));
+        }
+        if constexpr (kHoist) {
+            if (any_slow && b + 1 < nslots) preload_wq(b + 1);    // the slow path has rewritten decisions of block b
         }
     }
 
 #ifdef GPFQ_BLK_STAMPS
     if (K.stamps && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7)) {
         unsigned long long *o = K.stamps + (wave == 0 ? 0 : 8);
-        o[0] = acc_dma; o[1] = acc_u; o[2] = acc_d; o[3] = acc_w; o[4] = acc_b; o[5] = (unsigned long long)nslots;
+        o[0] = acc_dma; o[1] = acc_u; o[2] = acc_d; o[3] = acc_w; o[4] = acc_b; o[5] = (unsigned long long)nslots; o[6] = acc_t;
     }
 #endif
     // ---- epilogue: residual norms through the same partial-sum path, residual vectors straight to memory ----
@@ -619,9 +658,6 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 
     // alphabet members r, r + R, ... of this sub-lane (NaN beyond M: never counted); larger alphabets loop over LDS
     const bool in_regs = M <= 4 * R;
-    double am[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) am[q] = (r + q * R < M) ? lds_ld<double>(lds, L.off_e + 8 * (2 + r + q * R)) : kNaN;
 
     const double sym_top = SYM ? lds_ld<double>(lds, L.off_e + 8 * (2 + M - 1)) : 0.0;      // a;  a / 2 (0 for {-a, a})
     const double sym_hb = (SYM && M == 3) ? 0.5 * sym_top : 0.0;
@@ -678,6 +714,31 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         }
     };
 
+    // The record HEADERS a slot's decisions read (row statistics + Gram band: a few hundred bytes per step, about thirty LDS reads
+    // per lane) were requested from the tile in LDS right after the slot's barrier -- exactly when every sweep wavefront requests
+    // its operands: 2300 of the decision wavefront's 3500 cycles per slot were that queue (profiles/r03/blk_phase_stamps.txt).
+    // They do not depend on anything the slot computes, so they now come from GLOBAL memory (the same bytes the LDS-DMA is
+    // fetching: L2 hits), requested one slot ahead into registers: after the barrier only the sweeps' partial sums and the
+    // block's weights are read from LDS.
+    const int smh = lane & (B - 1);                               // this lane's step of a block
+    constexpr int BI = B > 1 ? B - 1 : 1;
+    // Only what the predicted dot products need: the bounds (E1, E2, cb, ca, Ea) are read from the tile in LDS while the chain
+    // computes -- they are consumed by the certification after it, off the critical path.
+    double2 g01 = make_double2(0.0, 0.0);                         // own step: (1/nrm^2, G)
+    double2 ghp[B];                                               // own step against block b-1: (H1, H2) at distance B + sm - j
+    double2 ghi[BI];                                              // own step against this block's steps j < sm (zeros beyond)
+    // (what every sub-lane needs of the OTHER steps -- 1/nrm^2, G and <Xq_s, Xq_j> -- is fetched from the sub-lane that owns the
+    //  step by DPP instead of being kept in another 28 registers across the slot)
+    const char *zero_hdr = K.recs + (int64_t)(K.nblk + 1) * B * RB;   // a record beyond the walk: its header is all zeros
+    auto prefetch_headers = [&](int b1) {
+        const char *tb = K.recs + (int64_t)b1 * B * RB, *rm = tb + (int64_t)smh * RB;
+        g01 = *reinterpret_cast<const double2 *>(rm);
+#pragma unroll
+        for (int j = 0; j < B; ++j) ghp[j] = *reinterpret_cast<const double2 *>(rm + 64 + 32 * (B + smh - j - 1));
+#pragma unroll
+        for (int j = 0; j + 1 < B; ++j) ghi[j] = *reinterpret_cast<const double2 *>(j < smh ? rm + 64 + 32 * (smh - j - 1) : zero_hdr + 64);
+    };
+    prefetch_headers(0);
     slot_barrier();                                               // (tile 0 landed)
     // The B dependent decisions of a slot are a latency chain on a SIMD that two sweep wavefronts keep busy: at equal priority
     // every instruction of the chain waits its turn behind theirs (9640 cycles per slot, the longest path of the workgroup);
@@ -685,10 +746,13 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     __builtin_amdgcn_s_setprio(3);
 
     int64_t flushed = 0;                                          // steps [0, flushed) are in memory
-    unsigned long long dt0 = 0, dt1 = 0, dt2 = 0, dta = 0, dtb = 0, dacc_work = 0, dacc_bar = 0, dacc_pro = 0, dacc_chain = 0;
-    (void)dt0; (void)dt1; (void)dt2; (void)dta; (void)dtb; (void)dacc_work; (void)dacc_bar; (void)dacc_pro; (void)dacc_chain;
+    unsigned long long dt0 = 0, dt1 = 0, dt2 = 0, dta = 0, dtb = 0, dacc_work = 0, dacc_bar = 0, dacc_pro = 0, dacc_chain = 0, dacc_tail = 0;
+    (void)dt0; (void)dt1; (void)dt2; (void)dta; (void)dtb; (void)dacc_work; (void)dacc_bar; (void)dacc_pro; (void)dacc_chain; (void)dacc_tail;
     for (int b = 0; b < nslots; ++b) {
         STAMP(dt0);
+#ifdef GPFQ_BLK_STAMPS
+        if (b) dacc_tail += dt0 - dt2;                            // after the barrier: header prefetch, output flush
+#endif
         const int tbase = (b & 1) * L.tile_pitch;
         const int cbq = (b & 1) * NB * B * 8;
         float  wc[B], qc[B];                                      // this block: weights, decisions (as float32 values)
@@ -708,6 +772,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         //      for the block exactly as before (slow path below): what the chain guessed from there on is discarded.
         //  Every LDS read is issued before the arithmetic; the stores come last (a store between two reads orders them).
         double cPm = 0.0, ePm = 0.0;                                            // own step: block b-1's increments (also the slow path's)
+        int ctl_now = -1;                                                       // the control word this wavefront publishes (it never reads it back)
         unsigned anyP = 0u;
 #pragma unroll
         for (int j = 0; j < B; ++j) anyP |= __float_as_uint(wprev[j]) | __float_as_uint(qprev[j]);
@@ -723,46 +788,29 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             return __hiloint2double(hi, lo);
         };
         if (b < K.nblk) {
-            const int sm = lane & (B - 1);                        // this lane's step (B is a power of two <= 4)
-            const int rbm = tbase + sm * RB;
+            const int sm = smh;                                   // this lane's step (B is a power of two <= 4)
             // ---- (1) reads
             double dp[NW];                                        // partial sums of the own step, every sweep wavefront's slot
 #pragma unroll
             for (int w = 0; w < NW; ++w) dp[w] = lds_ld<double>(lds, L.off_d + ((((b & 1) * NW + w) * B + sm) * NB + n) * 8);
 #pragma unroll
             for (int s = 0; s < B; ++s) wc[s] = lds_ld<float>(lds, o_w + (b & 1) * NB * B * 4 + 4 * s);
-            double2 s01[B];                                       // (1 / nrm^2, <Xq_t, X_t>) of every step
-#pragma unroll
-            for (int s = 0; s < B; ++s) s01[s] = lds_ld<double2>(lds, tbase + s * RB);
-            double h2[B][B];                                      // <Xq_s, Xq_j>, j < s
-#pragma unroll
-            for (int s = 0; s < B; ++s)
-#pragma unroll
-                for (int j = 0; j < B; ++j)
-                    if (j < s) h2[s][j] = lds_ld<double>(lds, tbase + s * RB + 64 + 32 * (s - j - 1) + 8);
-            const double2 o01 = lds_ld<double2>(lds, rbm), o23 = lds_ld<double2>(lds, rbm + 16), o45 = lds_ld<double2>(lds, rbm + 32);
             const float w_own_raw = lds_ld<float>(lds, o_w + (b & 1) * NB * B * 4 + 4 * sm);
-            double2 hp[B], ep[B];                                 // band of the own step against block b-1: distance B + sm - j
+            // (the record headers: prefetched from global memory one slot ahead, see prefetch_headers)
+            double2 hp[B], hi_[BI];
+            const double2 o01 = g01;
 #pragma unroll
-            for (int j = 0; j < B; ++j) {
-                const int d = B + sm - j;
-                hp[j] = lds_ld<double2>(lds, rbm + 64 + 32 * (d - 1)); ep[j] = lds_ld<double2>(lds, rbm + 64 + 32 * (d - 1) + 16);
-            }
-            double2 hi_[B], ei_[B];                               // ... against this block's steps j < sm (zeros for j >= sm)
+            for (int j = 0; j + 1 < B; ++j) hi_[j] = ghi[j];
 #pragma unroll
-            for (int j = 0; j + 1 < B; ++j) {
-                const int o = j < sm ? rbm + 64 + 32 * (sm - j - 1) : L.off_zero;
-                hi_[j] = lds_ld<double2>(lds, o); ei_[j] = lds_ld<double2>(lds, j < sm ? o + 16 : o);
-            }
+            for (int s = 0; s < B; ++s) hp[s] = ghp[s];
             __builtin_amdgcn_sched_barrier(0);
             // ---- (1) arithmetic
-            double wd[B], wG[B];
+            double wd[B];
 #pragma unroll
             for (int s = 0; s < B; ++s) {
                 wc[s] = s < nvalid ? wc[s] : 0.f;
                 qc[s] = 0.f;
                 wd[s] = (double)wc[s];
-                wG[s] = wd[s] * s01[s].y;
             }
             double Dm;                                            // D of the own step: fixed-order tree over the wavefronts' slots
             {
@@ -779,15 +827,23 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             for (int j = 0; j < B; ++j) {
                 const double wj = (double)wprev[j], qj = (double)qprev[j];
                 cPm = fma(wj, hp[j].x, cPm); cPm = fma(-qj, hp[j].y, cPm);
-                ePm = fma(fabs(wj), ep[j].x, ePm); ePm = fma(fabs(qj), ep[j].y, ePm);
             }
-            double Aw = cPm, Ew = ePm;                            // + this block's weights before the own step
+            double Aw = cPm;                                      // + this block's weights before the own step
 #pragma unroll
-            for (int j = 0; j + 1 < B; ++j) { Aw = fma(wd[j], hi_[j].x, Aw); Ew = fma(fabs(wd[j]), ei_[j].x, Ew); }
+            for (int j = 0; j + 1 < B; ++j) Aw = fma(wd[j], hi_[j].x, Aw);
             const double Am = Dm + Aw;
             double A[B];
 #pragma unroll
             for (int s = 0; s < B; ++s) A[s] = quad_bcast(Am, s);
+            // the bounds of the own step, from the tile in LDS: requested now, consumed after the chain
+            const int rbm = tbase + sm * RB;
+            const double2 o23 = lds_ld<double2>(lds, rbm + 16);
+            const double rEa = lds_ld<double>(lds, rbm + 32);
+            double2 ep[B], ei_[BI];
+#pragma unroll
+            for (int j = 0; j < B; ++j) ep[j] = lds_ld<double2>(lds, rbm + 64 + 32 * (B + sm - j - 1) + 16);
+#pragma unroll
+            for (int j = 0; j + 1 < B; ++j) ei_[j] = lds_ld<double2>(lds, j < sm ? rbm + 64 + 32 * (sm - j - 1) + 16 : L.off_zero);
             STAMP(dta);
             // ---- (2) the chain
             const double u_a0 = K.uni_a0, u_step = K.uni_step, u_inv = K.uni_inv, u_c0 = K.uni_c0, u_kmax = (double)(M - 1);
@@ -801,15 +857,17 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             unsigned any_run = anyP, any_m = anyP;
 #pragma unroll
             for (int s = 0; s < B; ++s) {
+                // (1/nrm^2, G and <Xq_s, Xq_j> of step s from the sub-lane that owns it)
+                const double rden_s = quad_bcast(o01.x, s), wG_s = wd[s] * quad_bcast(o01.y, s);
                 double du = A[s];
 #pragma unroll
-                for (int j = 0; j < B; ++j)
-                    if (j < s) du = fma(-qd[j], h2[s][j], du);
-                const double tq = (du + wG[s]) * s01[s].x;
+                for (int j = 0; j + 1 < B; ++j)
+                    if (j < s) du = fma(-qd[j], quad_bcast(hi_[j].y, s), du);
+                const double tq = (du + wG_s) * rden_s;
                 const double tt = fabs(du) < 1e-10 ? wd[s] : tq;
                 double kd;
                 float q32 = pick(tt, kd);
-                q32 = s01[s].x == 0.0 ? 0.f : q32;                // rule (i): the pre-pass stores 1 / nrm^2 = 0 for nrm < 1e-16
+                q32 = rden_s == 0.0 ? 0.f : q32;                  // rule (i): the pre-pass stores 1 / nrm^2 = 0 for nrm < 1e-16
                 q32s[s] = q32;
                 qd[s] = (double)q32;
                 du_m = sm == s ? du : du_m;
@@ -820,7 +878,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             const bool valid_m = sm < nvalid;
             const float w_m = valid_m ? w_own_raw : 0.f;
             const double wdm = (double)w_m, rden = o01.x, wGm = wdm * o01.y;
-            const double rcb = o23.x, rca = o23.y, rEa = o45.x;
+            const double rcb = o23.x, rca = o23.y;
             const bool rule1 = rden == 0.0;
             const bool small = fabs(du_m) < 1e-10;
             const double tq_m = (du_m + wGm) * rden;
@@ -830,9 +888,13 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             const int ki = (int)kd_m;
             const int oe = L.off_e + 8 * (1 + ki);                // table with two sentinels on either side: a[k-1], a[k], a[k+1]
             const double a_lo = lds_ld<double>(lds, oe), a_k = lds_ld<double>(lds, oe + 8), a_hi = lds_ld<double>(lds, oe + 16);
-            double eps = Ew;
 #pragma unroll
-            for (int j = 0; j + 1 < B; ++j) eps = fma(fabs(qd[j]), ei_[j].y, eps);
+            for (int j = 0; j < B; ++j) {
+                ePm = fma(fabs((double)wprev[j]), ep[j].x, ePm); ePm = fma(fabs((double)qprev[j]), ep[j].y, ePm);
+            }
+            double eps = ePm;
+#pragma unroll
+            for (int j = 0; j + 1 < B; ++j) { eps = fma(fabs(wd[j]), ei_[j].x, eps); eps = fma(fabs(qd[j]), ei_[j].y, eps); }
             // (each of the up to 2B-1 pending increments may lose up to Ea = 2^-149 sum|Xq_t| to subnormal float32 products)
             eps += ((any_m << 1) != 0u) ? (double)(2 * B - 1) * rEa : 0.0;
             const bool du_exact = eps == 0.0;                     // every pending increment orthogonal to Xq_t element-wise
@@ -872,7 +934,8 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                 for (int g = 0; g < 64 / B; ++g) pat |= 1ull << (g * B + k);
                 if (badA & pat) smin = k;
             }
-            if (lane == 0) lds_st<int>(lds, L.off_ctl + 4 * (b & 1), smin < B ? smin : -1);
+            ctl_now = smin < B ? smin : -1;
+            if (lane == 0) lds_st<int>(lds, L.off_ctl + 4 * (b & 1), ctl_now);
         } else {
             STAMP(dta);
             STAMP(dtb);
@@ -883,6 +946,9 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         // is checked against by the parity tests).  commit == this lane's chain is still running.  Returns false when not certifiable.
         auto decide = [&](int s, bool commit, auto inregs_tag) -> bool {
             constexpr bool IN_REGS = decltype(inregs_tag)::value;
+            double am[4];                                                        // (slow path only: not kept across the slots)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) am[q] = (IN_REGS && r + q * R < M) ? lds_ld<double>(lds, L.off_e + 8 * (2 + r + q * R)) : kNaN;
             const int rb = tbase + s * RB;
             const double2 r01 = lds_ld<double2>(lds, rb), r23 = lds_ld<double2>(lds, rb + 16), r45 = lds_ld<double2>(lds, rb + 32);
             const double rden = r01.x, rG = r01.y, rcb = r23.x, rca = r23.y, rEa = r45.x, nrm = r45.y;
@@ -973,7 +1039,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 
         // ---- slow path: exact decision of the stopped step, then the chain resumes ----
         for (;;) {
-            const int S = __builtin_amdgcn_readfirstlane(lds_ld<int>(lds, L.off_ctl + 4 * (b & 1)));
+            const int S = ctl_now;                                // (wave-uniform: formed from ballots)
             if (S < 0) break;
             slot_barrier();                                       // exact partials published
             // (the hot path only forms the own step's D: here every sub-lane needs all of them, sub-lane r adding slots r, r + R, ...)
@@ -1026,10 +1092,12 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             }
             stop = stop2;
             const int smin = wave_min_stop(active ? stop : B);
-            if (lane == 0) lds_st<int>(lds, L.off_ctl + 4 * (b & 1), smin < B ? smin : -1);
+            ctl_now = smin < B ? smin : -1;
+            if (lane == 0) lds_st<int>(lds, L.off_ctl + 4 * (b & 1), ctl_now);
             slot_barrier();                                       // chains resumed, control word rewritten
         }
 
+        if (b + 1 < K.nblk) prefetch_headers(b + 1);              // (used after the next barrier)
         // block b is final: it becomes "the previous block"; flush the output ring when it is full
 #pragma unroll
         for (int j = 0; j < B; ++j) { wprev[j] = (b < K.nblk) ? wc[j] : 0.f; qprev[j] = (b < K.nblk) ? qc[j] : 0.f; }
@@ -1043,7 +1111,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 
     if (K.fallback_count && n_fallback) atomicAdd(K.fallback_count, n_fallback);   // rare
 #ifdef GPFQ_BLK_STAMPS
-    if (K.stamps && blockIdx.x == 0 && lane == 0) { K.stamps[16] = dacc_work; K.stamps[17] = dacc_bar; K.stamps[18] = dacc_pro; K.stamps[19] = dacc_chain; }
+    if (K.stamps && blockIdx.x == 0 && lane == 0) { K.stamps[16] = dacc_work; K.stamps[17] = dacc_bar; K.stamps[18] = dacc_pro; K.stamps[19] = dacc_chain; K.stamps[20] = dacc_tail; }
 #endif
     slot_barrier();                                               // residual-norm partials published
     if (K.resid) {
@@ -1181,10 +1249,16 @@ bool blk_supported(const PipeArgs &a)
 
 size_t blk_workspace_bytes(int64_t N, int64_t m)
 {
-    const BlkShape sh = blk_shape(m, 1 << 30);                     // (the record layout depends on the row length only)
-    if (!sh.G) return 0;
-    const int64_t nblk = (N + sh.B - 1) / sh.B;
-    return (size_t)((nblk + 1) * sh.B + 1) * (size_t)blk_rec_bytes(sh.mp, sh.B);   // slots 0..nblk, + one record of DMA over-read
+    // (the record layout depends on the row length and, through the steps per slot, on the width class of the layer: the largest)
+    size_t need = 0;
+    for (int64_t C : {(int64_t)1 << 30, (int64_t)2048, (int64_t)1024}) {
+        const BlkShape sh = blk_shape(m, C);
+        if (!sh.G) continue;
+        const int64_t nblk = (N + sh.B - 1) / sh.B;
+        const size_t b = (size_t)((nblk + 1) * sh.B + 1) * (size_t)blk_rec_bytes(sh.mp, sh.B);   // slots 0..nblk, + one record of DMA over-read
+        if (b > need) need = b;
+    }
+    return need;
 }
 
 // a32 of a symmetric alphabet {-a, 0, a} or {-a, a} (BlkK::sym_a), else 0.  PipeArgs::variant bit 1 (option "variant" bit 5) keeps the general form (A/B timing).
@@ -1220,7 +1294,7 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
 }
 
 // (the eleven-wavefront variants of the shapes that also exist with eight are kept in the general form only: an experiment switch)
-constexpr bool blk_has_sym(int S, int NSW) { return NSW == 8 || S > 32; }
+constexpr bool blk_has_sym(int S, int NSW) { return NSW != 11 || S > 32; }
 
 template <int G, int S, int B, int NSW = 8>
 static hipError_t launch_blk_inst(const PipeArgs &a, const BlkShape &sh, hipStream_t stream)
@@ -1238,7 +1312,7 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     if (!sh.G) return hipErrorInvalidValue;
     const int64_t nblk = (a.N + sh.B - 1) / sh.B;
     const int64_t nrec = (nblk + 1) * sh.B + 1;
-    auto *prep = sh.B == 4 ? gpfq_blk_prep_kernel<4> : (sh.B == 2 ? gpfq_blk_prep_kernel<2> : gpfq_blk_prep_kernel<1>);
+    auto *prep = sh.B == 4 ? gpfq_blk_prep_kernel<4, true> : (sh.B == 2 ? gpfq_blk_prep_kernel<2, true> : gpfq_blk_prep_kernel<1, false>);
     const float sym_a = blk_has_sym(sh.S, sh.NW) ? blk_sym_a(a) : 0.f;   // (exactly the launches launch_blk_inst gives the symmetric form)
     hipLaunchKernelGGL(prep, dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp,
                        a.nrm32, static_cast<char *>(a.workspace), sym_a);
