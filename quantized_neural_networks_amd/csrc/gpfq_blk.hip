@@ -65,8 +65,11 @@ static_assert(sizeof(BlkStats) == 64 && sizeof(BandEntry) == 32, "header layout"
 __host__ __device__ constexpr int blk_hdr_bytes(int B) { return (64 + (2 * B - 1) * 32 + 127) & ~127; }
 // The row t + B travels as float64 (the sweep's dot products then need no conversion) -- except in the one-step-per-slot shapes,
 // which are bound by the record stream itself: there it stays float32 (12 instead of 16 bytes per sample) and is converted in the sweep.
-__host__ __device__ constexpr bool blk_row64(int64_t mp, int B) { (void)mp; return B > 1; }
-__host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B) { return blk_hdr_bytes(B) + (blk_row64(mp, B) ? 16 : 12) * mp; }
+// -- and in the shapes with one neuron group per sweep wavefront (G = 1: 4 or 2 neurons per workgroup, the narrow layers), which put
+// up to 256 workgroups on the chip that EACH pull the whole record stream out of the L2s: 256 x 66 KiB per slot of four steps was
+// 10 TB/s, the bound of those shapes (profiles/r03/blk_phase_stamps.txt); a lane converts its two samples for two or four neurons.
+__host__ __device__ constexpr bool blk_row64(int G, int B) { return B > 1 && G > 1; }
+__host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B, int G) { return blk_hdr_bytes(B) + (blk_row64(G, B) ? 16 : 12) * mp; }
 
 // ---- pre-pass ---------------------------------------------------------------------------------
 // One workgroup per slot record t: statistics of row t, its Gram band against rows t-1 .. t-(2B-1), float32 copies
@@ -76,13 +79,14 @@ __host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B) { return 
 template <int B, bool R64>
 __global__ void __launch_bounds__(256)
 gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t N, int m, int mp,
-                     const float *__restrict__ nrm32, char *__restrict__ recs, float sym_a)
+                     const float *__restrict__ nrm32, char *__restrict__ recs, char *__restrict__ hdrs, float sym_a)
 {
+    constexpr int GREC = R64 ? 2 : 1;                         // (any G with this row format: the record size depends on nothing else)
     constexpr int ND = 2 * B - 1, NV = 3 + 4 * ND;
     __shared__ double sm[4][((NV + 3) & ~3) + 1];
     const int64_t t = blockIdx.x;
     constexpr int hdr = blk_hdr_bytes(B);
-    char *rb = recs + t * blk_rec_bytes(mp, B);
+    char *rb = recs + t * blk_rec_bytes(mp, B, GREC);
     float  *ox = reinterpret_cast<float *>(rb + hdr);
     float  *oq = ox + mp;
     double *od = reinterpret_cast<double *>(rb + hdr + 8 * (int64_t)mp);
@@ -186,18 +190,20 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
         st.ca = 0x1p-149 * s2 * st.rden * up;
         st.Ea = 0x1p-149 * s2 * up;
         *reinterpret_cast<BlkStats *>(rb) = st;
+        *reinterpret_cast<BlkStats *>(hdrs + t * hdr) = st;
     } else if (threadIdx.x <= ND) {
         const int d = threadIdx.x;
         BandEntry e;
         e.H1 = total(3 + 4 * (d - 1)); e.H2 = total(4 + 4 * (d - 1));
         e.E1 = 0x1p-23 * total(5 + 4 * (d - 1)) * up; e.E2 = 0x1p-23 * total(6 + 4 * (d - 1)) * up;
         *reinterpret_cast<BandEntry *>(rb + 64 + 32 * (d - 1)) = e;
+        *reinterpret_cast<BandEntry *>(hdrs + t * hdr + 64 + 32 * (d - 1)) = e;
     }
 }
 
 // LDS carve-up (byte offsets), shared by host and device.
 struct BlkLds {
-    int tile_bytes, tile_pitch, off_w, off_d, off_wq, off_x2, off_e, off_out, off_ctl, off_zero, total;
+    int tile_bytes, tile_pitch, off_w, off_d, off_wq, off_x2, off_e, off_out, off_ctl, off_zero, off_hr, hr_pitch, total;
 };
 constexpr int kOutSteps = 32;                                    // steps of outputs staged in LDS between flushes
 
@@ -206,11 +212,11 @@ constexpr int kOutSteps = 32;                                    // steps of out
 __host__ __device__ constexpr int blk_sublanes(int nb) { return 64 / nb > 8 ? 8 : 64 / nb; }   // R: lanes of the decision wavefront per neuron
 __host__ __device__ constexpr int blk_slots(int nsw, int nb) { return (nsw + blk_sublanes(nb) - 1) / blk_sublanes(nb) * blk_sublanes(nb); }
 
-__host__ __device__ inline BlkLds blk_lds(int mp, int nb, int B, int nsw)
+__host__ __device__ inline BlkLds blk_lds(int mp, int nb, int B, int nsw, int G)
 {
     BlkLds L;
     const int nw = blk_slots(nsw, nb);
-    L.tile_bytes = B * (int)blk_rec_bytes(mp, B);
+    L.tile_bytes = B * (int)blk_rec_bytes(mp, B, G);
     L.tile_pitch = (L.tile_bytes + 1023) & ~1023;               // the DMA moves whole 1 KiB pieces
     int o = 2 * L.tile_pitch;
     L.off_w = o;    o += 2 * nb * B * 4;    o = (o + 15) & ~15; // [2][NB][B] f32        weights of the block
@@ -221,12 +227,16 @@ __host__ __device__ inline BlkLds blk_lds(int mp, int nb, int B, int nsw)
     L.off_out = o;  o += nb * kOutSteps * 8;                    // [NB][32] (idx i32, q f32) until the flush
     L.off_ctl = o;  o += 16;                                    // [2] (by slot parity) smallest step a neuron of the block is stopped at, -1: none; [2] dummy
     L.off_zero = o; o += 32;                                    // zeros (band entries a step does not have)
+    o = (o + 15) & ~15;
+    L.hr_pitch = (B * blk_hdr_bytes(B) + 1023) & ~1023;         // the headers of a tile, whole 1 KiB DMA pieces
+    L.off_hr = o;   o += 3 * L.hr_pitch;                        // [3] header ring: tile k in buffer k % 3 (lands two slots ahead)
     L.total = o;
     return L;
 }
 
 struct BlkK {
     const char *recs;
+    const char *hdrs;           // the record headers once more, compact: [record][blk_hdr_bytes(B)] (the decision wavefront's copy)
     const float *Wt;
     int64_t ldw;
     int64_t N, C;
@@ -257,34 +267,36 @@ struct BlkK {
 #endif
 
 // ---- sweep wavefront -------------------------------------------------------------------------------
-template <int G, int PW, int MP, int B, int NSW, bool SYM>
+template <int G, int PW, int MP, int B, int NSW, bool SYM, int NL>
 __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic, const BlkLds &L, int wave, int lane, int pbase)
 {
-    constexpr int NB = 4 * G, KQ = 64 / G, NW = blk_slots(NSW, NB);
+    constexpr int NB = NL * G, KQ = 64 / G, NW = blk_slots(NSW, NB);   // NL neurons per lane (4; 2 in the narrow-layer shapes)
+    constexpr int RSH = NL == 4 ? 0 : (NL == 2 ? 1 : 2);          // folded sums: neuron i of the lane ends up in rows i << RSH .. of the wavefront
     constexpr int HDR = blk_hdr_bytes(B);
-    constexpr int RB = (int)blk_rec_bytes(MP, B);
+    constexpr int RB = (int)blk_rec_bytes(MP, B, G);
     lchar *lds = (lchar *)lds_generic;
     const int ng = lane & (G - 1), kq = lane / G, row = lane >> 4;
-    const bool writer = (lane & 15 & ~(G - 1)) == 0;             // one lane per (row, ng) publishes the folded sums
-    const int nloc = 4 * ng;                                      // first of this lane's four neurons
+    const bool writer = (lane & 15 & ~(G - 1)) == 0 && (row & ((1 << RSH) - 1)) == 0;   // one lane per (neuron, ng) publishes the folded sums
+    const int nloc = NL * ng;                                     // first of this lane's NL neurons
+    const int nrow = row >> RSH;                                  // the neuron (of the lane's NL) whose folded sums this row holds
     const int64_t jbase = (int64_t)blockIdx.x * NB;
     const unsigned ldsT_addr = lds_addr(lds_generic), ldsW_addr = lds_addr(lds_generic + L.off_w);
     const int64_t N = K.N;
     const int nslots = K.nblk + 1;
     const int o_x  = HDR + 8 * (pbase + kq);                      // float2 x   [pair]  (row t - B of record t)
     const int o_q  = o_x + 4 * MP;                                // float2 xq  [pair]
-    constexpr int DB = blk_row64(MP, B) ? 16 : 8;                 // bytes of a sample pair of row t + B
+    constexpr int DB = blk_row64(G, B) ? 16 : 8;                  // bytes of a sample pair of row t + B
     const int o_d  = HDR + 8 * MP + DB * (pbase + kq);           // double2 (float2) xqd[pair]  (row t + B)
-    using DRaw = std::conditional_t<blk_row64(MP, B), double2, float2>;   // as it sits in the record; converted where it is consumed
+    using DRaw = std::conditional_t<blk_row64(G, B), double2, float2>;   // as it sits in the record; converted where it is consumed
     auto ld_d = [&](int off) -> DRaw { return lds_ld<DRaw>(lds, off); };
     auto to_d2 = [](const DRaw &v) -> double2 { return make_double2((double)v.x, (double)v.y); };
     const int o_wq = L.off_wq + nloc * B * 8;
-    const int o_dw = L.off_d + (wave * B * NB + nloc + row) * 8;
-    const int o_x2 = L.off_x2 + (wave * NB + nloc + row) * 16;
+    const int o_dw = L.off_d + (wave * B * NB + nloc + nrow) * 8;
+    const int o_x2 = L.off_x2 + (wave * NB + nloc + nrow) * 16;
 
-    double u[4][2 * PW];
+    double u[NL][2 * PW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NL; ++i)
 #pragma unroll
         for (int e = 0; e < 2 * PW; ++e) u[i][e] = 0.0;          // zeros(m), :115
 
@@ -315,10 +327,20 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         }
     };
 
+    // The record headers once more, compact, two slots AHEAD into a ring of three: the decision wavefront reads tile b + 1's
+    // at the end of slot b, when the LDS is quiet (see blk_decision_role).  One 1 KiB piece per wavefront (tile k -> buffer k % 3).
+    constexpr int NHP = (B * HDR + 1023) >> 10;
+    auto load_headers = [&](int b2, int buf) {
+        if (wave < NHP && b2 <= K.nblk)
+            glds16_s(K.hdrs + (int64_t)b2 * B * HDR + ((int64_t)wave << 10), lane16,
+                     lds_addr(lds_generic + L.off_hr) + (unsigned)buf * (unsigned)L.hr_pitch + ((unsigned)wave << 10));
+    };
     for (int k = 0; wave + NSW * k < NPIECES; ++k) issue_piece(0, k);
     load_weights(0);
+    load_headers(0, 0); load_headers(1, 1);
     dma_wait();
     slot_barrier();
+    int hbuf = 2;                                                 // (b + 2) % 3
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, acc_dma = 0, acc_u = 0, acc_d = 0, acc_w = 0, acc_b = 0, acc_t = 0;
     (void)st0; (void)st1; (void)st2; (void)st3; (void)st4; (void)st5; (void)acc_dma; (void)acc_u; (void)acc_d; (void)acc_w; (void)acc_b; (void)acc_t;
 
@@ -332,16 +354,16 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     constexpr bool kHoist = kPreloadAll && PW * B <= 4;
     constexpr int PB = kPreloadAll ? B : 1, PP = kPreloadAll ? PW : 1;
     // (the rows of the dot products too when they are few registers: otherwise phase D requests them itself, as before)
-    constexpr bool kPreD = kHoist && PW * B * (blk_row64(MP, B) ? 4 : 2) <= 16;
+    constexpr bool kPreD = kHoist && PW * B * (blk_row64(G, B) ? 4 : 2) <= 16;
     constexpr int DBn = kPreD ? B : 1, DPn = kPreD ? PW : 1;
-    float2 xs[PB][PP], qs[PB][PP], wqa[PB][4];
+    float2 xs[PB][PP], qs[PB][PP], wqa[PB][NL];
     DRaw ds[DBn][DPn];
     auto preload_wq = [&](int b) {                                // (w, q) of block b - 1, for slot b's updates
         const int pbq = ((b - 1) & 1) * NB * B * 8;
 #pragma unroll
         for (int s = 0; s < PB; ++s)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) wqa[s][n] = lds_ld<float2>(lds, o_wq + pbq + (n * B + s) * 8);
+            for (int n = 0; n < NL; ++n) wqa[s][n] = lds_ld<float2>(lds, o_wq + pbq + (n * B + s) * 8);
     };
     auto preload_rows = [&](int b) {
         const int tbase = (b & 1) * L.tile_pitch;
@@ -362,6 +384,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         if (b) acc_t += st0 - st5;                                // from the barrier to the top of the next slot: control word, next operands
 #endif
         if (b + 1 < nslots) load_weights(b + 1);                  // the block's weights: one piece
+        load_headers(b + 2, hbuf); hbuf = hbuf == 2 ? 0 : hbuf + 1;
         const int bn = b + 1 < nslots ? b + 1 : b;                // (the last slot rewrites its own tile with the same bytes)
         STAMP(st1);
         const int tbase = (b & 1) * L.tile_pitch;
@@ -369,29 +392,29 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 
         // one sample pair of one step: f32 products and subtraction on two samples at once (v_pk_mul_f32 / v_pk_add_f32 or, for
         // symmetric alphabets, v_pk_fma_f32), conversions, float64 additions
-        auto update_pair = [&](int p, const float2 &x2, const float2 &q2, const float (&wv)[4], const float (&qv)[4]) {
+        auto update_pair = [&](int p, const float2 &x2, const float2 &q2, const float (&wv)[NL], const float (&qv)[NL]) {
             const pk2 xv = {x2.x, x2.y}, qx = {q2.x, q2.y};
             // f32 products and subtraction on two samples at once (v_pk_mul_f32 / v_pk_add_f32): each half rounds
             // exactly as the scalar instruction (no contraction: -ffp-contract=off).  Written stage by stage over the
             // four neurons so that no instruction consumes the result of the one right before it (hipcc pads those
             // packed-to-scalar dependences with s_nop, which cost issue slots)
-            pk2 pr[4], rr[4], dd[4];
-            double c0[4], c1[4];
+            pk2 pr[NL], rr[NL], dd[NL];
+            double c0[NL], c1[NL];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) pr[n] = pk2{wv[n], wv[n]} * xv;
+            for (int n = 0; n < NL; ++n) pr[n] = pk2{wv[n], wv[n]} * xv;
             if constexpr (SYM) {                      // qv = -sg, qx = f32(a xq): v_pk_fma_f32, one rounding
 #pragma unroll
-                for (int n = 0; n < 4; ++n) dd[n] = __builtin_elementwise_fma(pk2{qv[n], qv[n]}, qx, pr[n]);
+                for (int n = 0; n < NL; ++n) dd[n] = __builtin_elementwise_fma(pk2{qv[n], qv[n]}, qx, pr[n]);
             } else {
 #pragma unroll
-                for (int n = 0; n < 4; ++n) rr[n] = pk2{qv[n], qv[n]} * qx;
+                for (int n = 0; n < NL; ++n) rr[n] = pk2{qv[n], qv[n]} * qx;
 #pragma unroll
-                for (int n = 0; n < 4; ++n) dd[n] = pr[n] - rr[n];
+                for (int n = 0; n < NL; ++n) dd[n] = pr[n] - rr[n];
             }
 #pragma unroll
-            for (int n = 0; n < 4; ++n) { c0[n] = (double)dd[n].x; c1[n] = (double)dd[n].y; }
+            for (int n = 0; n < NL; ++n) { c0[n] = (double)dd[n].x; c1[n] = (double)dd[n].y; }
 #pragma unroll
-            for (int n = 0; n < 4; ++n) { u[n][2 * p] += c0[n]; u[n][2 * p + 1] += c1[n]; }
+            for (int n = 0; n < NL; ++n) { u[n][2 * p] += c0[n]; u[n][2 * p + 1] += c1[n]; }
         };
         // ---- phase U: the B updates of block b-1, in order: u += f32(w x) - f32(q xq)  (:119) ----
         // Software-pipelined by hand: the operands of the NEXT pair (and the next step's four (w, q)) are requested before
@@ -408,9 +431,9 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             for (int s = 0; s < B; ++s) {
                 if (s == 0) __builtin_amdgcn_s_setprio(2);
                 if (s == B / 2) __builtin_amdgcn_s_setprio(1);
-                float wv[4], qv[4];
+                float wv[NL], qv[NL];
 #pragma unroll
-                for (int n = 0; n < 4; ++n) { wv[n] = wqa[s][n].x; qv[n] = wqa[s][n].y; }
+                for (int n = 0; n < NL; ++n) { wv[n] = wqa[s][n].x; qv[n] = wqa[s][n].y; }
 #pragma unroll
                 for (int p = 0; p < PW; ++p) {
                     if (p < PTS) {
@@ -427,9 +450,9 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         } else
         {
             float2 x2n = lds_ld<float2>(lds, tbase + o_x), q2n = lds_ld<float2>(lds, tbase + o_q);
-            float2 wqn[4];
+            float2 wqn[NL];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) wqn[n] = lds_ld<float2>(lds, o_wq + pbq + (n * B) * 8);
+            for (int n = 0; n < NL; ++n) wqn[n] = lds_ld<float2>(lds, o_wq + pbq + (n * B) * 8);
             // two steps per trip for the B = 4 shapes: the rotation of the prefetched (w, q) of the next step is then a renaming
             // instead of eight v_mov per step (3.76 -> 3.64 ms at 4096 x 4096 x 1024); the B = 2 shapes would unroll completely
             // and run out of registers
@@ -442,13 +465,13 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
                 // cycles by age).  With the laggard preferred the wavefronts of a SIMD reach the barrier together.
                 if (s == 0) __builtin_amdgcn_s_setprio(2);
                 if (s == B / 2) __builtin_amdgcn_s_setprio(1);
-                float wv[4], qv[4];
+                float wv[NL], qv[NL];
 #pragma unroll
-                for (int n = 0; n < 4; ++n) { wv[n] = wqn[n].x; qv[n] = wqn[n].y; }
+                for (int n = 0; n < NL; ++n) { wv[n] = wqn[n].x; qv[n] = wqn[n].y; }
                 const int rb = tbase + s * RB;
                 const int sn = s + 1 < B ? s + 1 : s;             // (the last step re-requests its own: harmless)
 #pragma unroll
-                for (int n = 0; n < 4; ++n) wqn[n] = lds_ld<float2>(lds, o_wq + pbq + (n * B + sn) * 8);
+                for (int n = 0; n < NL; ++n) wqn[n] = lds_ld<float2>(lds, o_wq + pbq + (n * B + sn) * 8);
 #pragma unroll
                 for (int p = 0; p < PW; ++p) {
                     const float2 x2 = x2n, q2 = q2n;
@@ -484,17 +507,19 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 #pragma unroll
             for (int r = 0; r < B; ++r) {
                 if (r == B / 2) __builtin_amdgcn_s_setprio(0);
-                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                double acc[NL];
+#pragma unroll
+                for (int n = 0; n < NL; ++n) acc[n] = 0.0;
 #pragma unroll
                 for (int p = 0; p < PW; ++p) {
                     const double2 d2 = to_d2(dsl[r][p]);
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) {
+                    for (int n = 0; n < NL; ++n) {
                         acc[n] = fma(d2.x, u[n][2 * p], acc[n]);
                         acc[n] = fma(d2.y, u[n][2 * p + 1], acc[n]);
                     }
                 }
-                const double v = fold_klanes<G>(acc);
+                const double v = fold_klanes_n<G, NL>(acc);
                 if (writer) lds_st<double>(lds, o_dw + ((((b + 1) & 1) * NW) * B + r) * NB * 8, v);
             }
         } else
@@ -503,7 +528,9 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 #pragma clang loop unroll_count(B == 4 ? 2 : 1)
             for (int r = 0; r < B; ++r) {
                 if (r == B / 2) __builtin_amdgcn_s_setprio(0);
-                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                double acc[NL];
+#pragma unroll
+                for (int n = 0; n < NL; ++n) acc[n] = 0.0;
                 const int rb = tbase + r * RB;
                 const int rn = r + 1 < B ? r + 1 : r;
 #pragma unroll
@@ -513,13 +540,13 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
                     d2n = ld_d(rbn + o_d + DB * pn * KQ);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) {
+                    for (int n = 0; n < NL; ++n) {
                         acc[n] = fma(d2.x, u[n][2 * p], acc[n]);
                         acc[n] = fma(d2.y, u[n][2 * p + 1], acc[n]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                const double v = fold_klanes<G>(acc);
+                const double v = fold_klanes_n<G, NL>(acc);
                 if (writer) lds_st<double>(lds, o_dw + ((((b + 1) & 1) * NW) * B + r) * NB * 8, v);
             }
         }
@@ -546,10 +573,12 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             // t = bB + S: the block's first S updates replayed into temporaries; rows of block b are records of tile b+1.
             const int nb_ = ((b + 1) & 1) * L.tile_pitch;
             const int cbq = (b & 1) * NB * B * 8;
-            double eu[4] = {0.0, 0.0, 0.0, 0.0}, ew[4] = {0.0, 0.0, 0.0, 0.0};
+            double eu[NL], ew[NL];
+#pragma unroll
+            for (int n = 0; n < NL; ++n) { eu[n] = 0.0; ew[n] = 0.0; }
             // (one neuron and one pair at a time: the slow path must not cost the hot loop registers)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
+            for (int n = 0; n < NL; ++n) {
                 const float w = lds_ld<float2>(lds, o_wq + cbq + (n * B + S) * 8).x;
 #pragma unroll 1
                 for (int p = 0; p < PW; ++p) {
@@ -585,7 +614,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
                     ew[n] = fma((double)q2.y, t1 + (double)__fmul_rn(w, x2.y), ew[n]);
                 }
             }
-            const double vu = fold_klanes<G>(eu), vw = fold_klanes<G>(ew);
+            const double vu = fold_klanes_n<G, NL>(eu), vw = fold_klanes_n<G, NL>(ew);
             if (writer) lds_st<double2>(lds, o_x2, make_double2(vu, vw));
             slot_barrier();                                       // partials published
             slot_barrier();                                       // chains resumed, control word rewritten
@@ -604,21 +633,21 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 #endif
     // ---- epilogue: residual norms through the same partial-sum path, residual vectors straight to memory ----
     if (K.resid) {
-        double ss[4];
+        double ss[NL];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < NL; ++n) {
             double q = 0.0;
 #pragma unroll
             for (int e = 0; e < 2 * PW; ++e) q = fma(u[n][e], u[n][e], q);
             ss[n] = q;
         }
-        const double v = fold_klanes<G>(ss);
+        const double v = fold_klanes_n<G, NL>(ss);
         if (writer) lds_st<double>(lds, o_dw, v);
     }
     slot_barrier();
     if (K.u_out) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < NL; ++n) {
             const int64_t jn = jbase + nloc + n;
             if (jn < K.C) {
 #pragma unroll
@@ -634,11 +663,11 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 }
 
 // ---- decision wavefront ------------------------------------------------------------------------------
-template <int G, int MP, int B, int NSW, bool SYM>
+template <int G, int MP, int B, int NSW, bool SYM, int NL>
 __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_generic, const BlkLds &L, int lane)
 {
-    constexpr int NB = 4 * G, R = blk_sublanes(NB), NW = blk_slots(NSW, NB);
-    constexpr int RB = (int)blk_rec_bytes(MP, B);
+    constexpr int NB = NL * G, R = blk_sublanes(NB), NW = blk_slots(NSW, NB);
+    constexpr int RB = (int)blk_rec_bytes(MP, B, G);
     lchar *lds = (lchar *)lds_generic;
     // neuron of the workgroup, sub-lane.  Four-neuron workgroups use 32 lanes; the other half shadows the last neuron (same reads,
     // same decisions, same stores to the same addresses) and is left out of the counters
@@ -717,11 +746,13 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     // The record HEADERS a slot's decisions read (row statistics + Gram band: a few hundred bytes per step, about thirty LDS reads
     // per lane) were requested from the tile in LDS right after the slot's barrier -- exactly when every sweep wavefront requests
     // its operands: 2300 of the decision wavefront's 3500 cycles per slot were that queue (profiles/r03/blk_phase_stamps.txt).
-    // They do not depend on anything the slot computes, so they now come from GLOBAL memory (the same bytes the LDS-DMA is
-    // fetching: L2 hits), requested one slot ahead into registers: after the barrier only the sweeps' partial sums and the
-    // block's weights are read from LDS.
+    // They do not depend on anything the slot computes.  Tried first: global loads one slot ahead (the same bytes the LDS-DMA
+    // fetches) -- they queue in the CU's vector-memory path behind the DMA pieces of eight sweep wavefronts and came back just as
+    // late.  So the headers travel once more, compact (1.5 KiB per tile), by LDS-DMA into a ring of three buffers TWO slots ahead,
+    // and this wavefront reads tile b + 1's at the END of slot b, when the LDS is quiet: after the barrier only the sweeps'
+    // partial sums and the block's weights are read.
     const int smh = lane & (B - 1);                               // this lane's step of a block
-    constexpr int BI = B > 1 ? B - 1 : 1;
+    constexpr int BI = B > 1 ? B - 1 : 1, HDRB = blk_hdr_bytes(B);
     // Only what the predicted dot products need: the bounds (E1, E2, cb, ca, Ea) are read from the tile in LDS while the chain
     // computes -- they are consumed by the certification after it, off the critical path.
     double2 g01 = make_double2(0.0, 0.0);                         // own step: (1/nrm^2, G)
@@ -729,17 +760,17 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     double2 ghi[BI];                                              // own step against this block's steps j < sm (zeros beyond)
     // (what every sub-lane needs of the OTHER steps -- 1/nrm^2, G and <Xq_s, Xq_j> -- is fetched from the sub-lane that owns the
     //  step by DPP instead of being kept in another 28 registers across the slot)
-    const char *zero_hdr = K.recs + (int64_t)(K.nblk + 1) * B * RB;   // a record beyond the walk: its header is all zeros
-    auto prefetch_headers = [&](int b1) {
-        const char *tb = K.recs + (int64_t)b1 * B * RB, *rm = tb + (int64_t)smh * RB;
-        g01 = *reinterpret_cast<const double2 *>(rm);
+    auto prefetch_headers = [&](int buf) {                        // the tile in buffer `buf` of the header ring
+        const int rm = L.off_hr + buf * L.hr_pitch + smh * HDRB;
+        g01 = lds_ld<double2>(lds, rm);
 #pragma unroll
-        for (int j = 0; j < B; ++j) ghp[j] = *reinterpret_cast<const double2 *>(rm + 64 + 32 * (B + smh - j - 1));
+        for (int j = 0; j < B; ++j) ghp[j] = lds_ld<double2>(lds, rm + 64 + 32 * (B + smh - j - 1));
 #pragma unroll
-        for (int j = 0; j + 1 < B; ++j) ghi[j] = *reinterpret_cast<const double2 *>(j < smh ? rm + 64 + 32 * (smh - j - 1) : zero_hdr + 64);
+        for (int j = 0; j + 1 < B; ++j) ghi[j] = lds_ld<double2>(lds, j < smh ? rm + 64 + 32 * (smh - j - 1) : L.off_zero);
     };
+    slot_barrier();                                               // (tile 0 and the headers of tiles 0, 1 landed)
     prefetch_headers(0);
-    slot_barrier();                                               // (tile 0 landed)
+    int hnext = 1;                                                // (b + 1) % 3
     // The B dependent decisions of a slot are a latency chain on a SIMD that two sweep wavefronts keep busy: at equal priority
     // every instruction of the chain waits its turn behind theirs (9640 cycles per slot, the longest path of the workgroup);
     // ahead of them it takes 6800 and the sweeps, which have the slack, fill the gaps.
@@ -1097,7 +1128,8 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             slot_barrier();                                       // chains resumed, control word rewritten
         }
 
-        if (b + 1 < K.nblk) prefetch_headers(b + 1);              // (used after the next barrier)
+        if (b + 1 < K.nblk) prefetch_headers(hnext);              // the next tile's headers (landed a slot ago), into registers
+        hnext = hnext == 2 ? 0 : hnext + 1;
         // block b is final: it becomes "the previous block"; flush the output ring when it is full
 #pragma unroll
         for (int j = 0; j < B; ++j) { wprev[j] = (b < K.nblk) ? wc[j] : 0.f; qprev[j] = (b < K.nblk) ? qc[j] : 0.f; }
@@ -1128,6 +1160,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 // Sample-pair split over the sweep wavefronts: PairSplit for eight of them (the decision wavefront, wavefront 8, shares
 // SIMD 0 with wavefronts 0 and 4); with eleven the twelve wavefronts of a workgroup are three per SIMD.
 template <int S, int NSW> struct BlkSplit { static constexpr const int *pw = PairSplit<S>::pw; };
+template <> struct BlkSplit<4, 4>   { static constexpr int pw_[4] = {1, 1, 1, 1}; static constexpr const int *pw = pw_; };   // rows of up to 512 samples, four sweep wavefronts
 template <> struct BlkSplit<32, 11> { static constexpr int pw_[11] = {3, 3, 3, 3, 3, 3, 3, 2, 3, 3, 3}; static constexpr const int *pw = pw_; };
 template <> struct BlkSplit<24, 11> { static constexpr int pw_[11] = {2, 2, 2, 2, 2, 2, 2, 1, 3, 3, 3}; static constexpr const int *pw = pw_; };
 template <> struct BlkSplit<64, 11> { static constexpr int pw_[11] = {6, 6, 6, 6, 6, 6, 6, 4, 6, 6, 6}; static constexpr const int *pw = pw_; };
@@ -1136,14 +1169,16 @@ template <> struct BlkSplit<16, 11> { static constexpr int pw_[11] = {2, 2, 1, 1
 
 // G neuron groups per sweep wavefront (4G neurons per workgroup), S sample pairs per k-lane over the NSW sweep
 // wavefronts (rows of MP = (128 / G) * S samples), B steps per slot.
-template <int G, int S, int B, int NSW, bool SYM>
+// NL neurons per lane of a sweep wavefront: NL * G neurons per workgroup (4; 2 for layers of at most 512 neurons, which
+// then fill twice the CUs with half the element-wise work per slot -- a narrow layer is bound by the time of ONE slot).
+template <int G, int S, int B, int NSW, bool SYM, int NL>
 __global__ void __launch_bounds__(64 * (NSW + 1))
 gpfq_blk_kernel(BlkK K, AlphabetArg A)
 {
-    constexpr int NB = 4 * G, KQ = 64 / G, MP = 2 * KQ * S;
+    constexpr int NB = NL * G, KQ = 64 / G, MP = 2 * KQ * S;
     using PS = BlkSplit<S, NSW>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const BlkLds L = blk_lds(MP, NB, B, NSW);
+    const BlkLds L = blk_lds(MP, NB, B, NSW, G);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1163,20 +1198,20 @@ gpfq_blk_kernel(BlkK K, AlphabetArg A)
         int pbase = 0, pw = 1;
 #pragma unroll
         for (int w = 0; w < NSW; ++w) { pbase += (w < wave) ? KQ * PS::pw[w] : 0; pw = (w == wave) ? PS::pw[w] : pw; }
-        constexpr int PMAX = S == 64 ? 6 : (S == 48 ? 5 : (NSW == 11 ? 3 : (S == 32 ? 5 : (S == 24 ? 4 : 3))));
-        if (pw == 1) blk_sweep_role<G, 1, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase);
-        else if (pw == 2) blk_sweep_role<G, 2, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase);
-        else if (pw == 3) blk_sweep_role<G, 3, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase);
-        else if (pw == 4) { if constexpr (PMAX >= 4) blk_sweep_role<G, 4, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase); }
-        else if (pw == 5) { if constexpr (PMAX >= 5) blk_sweep_role<G, 5, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase); }
-        else { if constexpr (PMAX >= 6) blk_sweep_role<G, 6, MP, B, NSW, SYM>(K, lds, L, wave, lane, pbase); }
+        constexpr int PMAX = S == 64 ? 6 : (S == 48 || S == 40 ? 5 : (NSW == 11 ? 3 : (S == 32 ? 5 : (S == 24 ? 4 : 3))));
+        if (pw == 1) blk_sweep_role<G, 1, MP, B, NSW, SYM, NL>(K, lds, L, wave, lane, pbase);
+        else if (pw == 2) blk_sweep_role<G, 2, MP, B, NSW, SYM, NL>(K, lds, L, wave, lane, pbase);
+        else if (pw == 3) blk_sweep_role<G, 3, MP, B, NSW, SYM, NL>(K, lds, L, wave, lane, pbase);
+        else if (pw == 4) { if constexpr (PMAX >= 4) blk_sweep_role<G, 4, MP, B, NSW, SYM, NL>(K, lds, L, wave, lane, pbase); }
+        else if (pw == 5) { if constexpr (PMAX >= 5) blk_sweep_role<G, 5, MP, B, NSW, SYM, NL>(K, lds, L, wave, lane, pbase); }
+        else { if constexpr (PMAX >= 6) blk_sweep_role<G, 6, MP, B, NSW, SYM, NL>(K, lds, L, wave, lane, pbase); }
     } else {
-        blk_decision_role<G, MP, B, NSW, SYM>(K, lds, L, lane);
+        blk_decision_role<G, MP, B, NSW, SYM, NL>(K, lds, L, lane);
     }
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-struct BlkShape { int G, S, B, mp, NW; };
+struct BlkShape { int G, S, B, mp, NW, NL; };      // NL: neurons per lane (4 G or 2 G neurons per workgroup)
 static std::atomic<int> g_blk_nw{8};      // sweep wavefronts of the 16-neuron shapes (experiment switch: blk_set_sweep_waves)
 static std::atomic<int> g_blk_four{1};    // 4-neuron workgroups for layers of at most 1024 neurons on rows of 769..2048 samples
 void blk_set_four_groups(int on) { g_blk_four.store(on ? 1 : 0, std::memory_order_relaxed); }
@@ -1187,31 +1222,46 @@ void blk_set_sweep_waves(int nw) { g_blk_nw.store(nw == 11 ? 11 : 8, std::memory
 // C: neurons of the call.  Rows of 769..1024 samples are the one shape whose slot is bound by the sweeps (nine sample pairs
 // on three of the SIMDs), not by the chain of decisions: up to 2048 neurons -- one round of 256 workgroups with 8 neurons
 // each -- the sweeps are halved by giving a workgroup 8 neurons instead of 16 (4096 x 2048, m = 1024: 4.0 -> 2.9 ms).
+static std::atomic<int> g_blk_pairs{1};   // two-neuron workgroups for layers of at most 512 neurons
+void blk_set_pair_groups(int on) { g_blk_pairs.store(on ? 1 : 0, std::memory_order_relaxed); }
+
 static BlkShape blk_shape(int64_t m, int64_t C)
 {
     const int nw4 = g_blk_nw.load(std::memory_order_relaxed);
-    if (m > 256 && m <= 512) return {4, 16, 4, 512, nw4};
-    if (m > 512 && m <= 768) return {4, 24, 4, 768, nw4};
+    // Layers of at most 512 neurons: TWO neurons per workgroup (two per lane of the sweep wavefronts).  A narrow layer is bound by
+    // the time of one slot, a slot by the instructions its workgroup issues (profiles/r03/blk_phase_stamps.txt): half the neurons
+    // are half the element-wise work per slot on twice the CUs.  Rows of up to 5120 samples (cfg4's Dense(2048 -> 128) on 5008).
+    if (C <= 512 && g_blk_pairs.load(std::memory_order_relaxed) != 0) {
+        if (m > 256 && m <= 512) return {1, 4, 4, 512, 4, 2};
+        if (m > 512 && m <= 1024) return {1, 8, 4, 1024, 8, 2};
+        if (m > 1024 && m <= 1536) return {1, 12, 2, 1536, 8, 2};
+        if (m > 1536 && m <= 2048) return {1, 16, 2, 2048, 8, 2};
+        if (m > 2048 && m <= 3072) return {1, 24, 1, 3072, 8, 2};
+        if (m > 3072 && m <= 4096) return {1, 32, 1, 4096, 8, 2};
+        if (m > 4096 && m <= 5120) return {1, 40, 1, 5120, 8, 2};
+    }
+    if (m > 256 && m <= 512) return {4, 16, 4, 512, nw4, 4};
+    if (m > 512 && m <= 768) return {4, 24, 4, 768, nw4, 4};
     // layers of at most 1024 neurons on rows of 769+ samples: FOUR neurons per workgroup (a quarter of the 16-neuron sweep per slot;
     // 256 workgroups hold 1024 neurons) -- the slot is then the chain of decisions
     const bool four = C <= 1024 && g_blk_four.load(std::memory_order_relaxed) != 0;
-    if (four && m > 768 && m <= 1024) return {1, 8, 4, 1024, 8};
-    if (four && m > 1024 && m <= 1536) return {1, 12, 2, 1536, 8};
-    if (four && m > 1536 && m <= 2048) return {1, 16, 2, 2048, 8};
-    if (m > 768 && m <= 1024) return C <= 2048 ? BlkShape{2, 16, 4, 1024, 8} : BlkShape{4, 32, 4, 1024, nw4};
+    if (four && m > 768 && m <= 1024) return {1, 8, 4, 1024, 8, 4};
+    if (four && m > 1024 && m <= 1536) return {1, 12, 2, 1536, 8, 4};
+    if (four && m > 1536 && m <= 2048) return {1, 16, 2, 2048, 8, 4};
+    if (m > 768 && m <= 1024) return C <= 2048 ? BlkShape{2, 16, 4, 1024, 8, 4} : BlkShape{4, 32, 4, 1024, nw4, 4};
     // rows beyond 1024 samples: 8 neurons per workgroup and eight sweep wavefronts -- or, in layers of more than 2048 neurons (where
     // that takes two rounds of workgroups), 16 neurons over eleven sweep wavefronts: one round, half the decisions and folds per weight
     // (a 16-neuron workgroup takes 1.6 x as long as an 8-neuron one: 6.5 against 4.1 ms for 4096 steps of 2048 samples; rounds of 256)
     const int64_t rounds16 = (C + 4095) / 4096, rounds8 = (C + 2047) / 2048;
     const bool wide = C > 2048 && 8 * rounds16 <= 5 * rounds8 && g_blk_wide.load(std::memory_order_relaxed) != 0;
-    if (m > 1024 && m <= 1536) return wide ? BlkShape{4, 48, 2, 1536, 11} : BlkShape{2, 24, 2, 1536, 8};
-    if (m > 1536 && m <= 2048) return wide ? BlkShape{4, 64, 2, 2048, 11} : BlkShape{2, 32, 2, 2048, 8};
+    if (m > 1024 && m <= 1536) return wide ? BlkShape{4, 48, 2, 1536, 11, 4} : BlkShape{2, 24, 2, 1536, 8, 4};
+    if (m > 1536 && m <= 2048) return wide ? BlkShape{4, 64, 2, 2048, 11, 4} : BlkShape{2, 32, 2, 2048, 8, 4};
     // rows of 2049..4096 samples: a record is 48 / 64 KiB, so a slot is ONE step (B = 1) -- 8 neurons over eleven sweep wavefronts
     // (six 64-sample pairs each), or 4 neurons over eight for layers of at most 1024 neurons.  Still four to five times the
     // several-wavefronts-per-neuron kernel these rows had (4096 x 4096 x 4096: 38 ms)
-    if (m > 2048 && m <= 3072) return four ? BlkShape{1, 24, 1, 3072, 8} : BlkShape{2, 48, 1, 3072, 11};
-    if (m > 3072 && m <= 4096) return four ? BlkShape{1, 32, 1, 4096, 8} : BlkShape{2, 64, 1, 4096, 11};
-    return {0, 0, 0, 0, 0};
+    if (m > 2048 && m <= 3072) return four ? BlkShape{1, 24, 1, 3072, 8, 4} : BlkShape{2, 48, 1, 3072, 11, 4};
+    if (m > 3072 && m <= 4096) return four ? BlkShape{1, 32, 1, 4096, 8, 4} : BlkShape{2, 64, 1, 4096, 11, 4};
+    return {0, 0, 0, 0, 0, 0};
 }
 
 // The alphabet as an arithmetic progression, if it is one in the sense the chain of decisions needs: strictly ascending and
@@ -1237,6 +1287,13 @@ static bool blk_uniform(const AlphabetArg &A, double *a0, double *step, double *
     return true;
 }
 
+// workspace: [records of slots 0..nblk, + one record of DMA over-read][compact headers of the same records, + 2 KiB of over-read]
+static size_t blk_recs_bytes(int64_t nblk, const BlkShape &sh)
+{
+    return ((size_t)((nblk + 1) * sh.B + 1) * (size_t)blk_rec_bytes(sh.mp, sh.B, sh.G) + 255) & ~(size_t)255;
+}
+static size_t blk_hdrs_bytes(int64_t nblk, int B) { return (size_t)((nblk + 1) * B + 1) * (size_t)blk_hdr_bytes(B) + 2048; }
+
 bool blk_supported(const PipeArgs &a)
 {
     const BlkShape sh = blk_shape(a.m, a.C);
@@ -1251,11 +1308,11 @@ size_t blk_workspace_bytes(int64_t N, int64_t m)
 {
     // (the record layout depends on the row length and, through the steps per slot, on the width class of the layer: the largest)
     size_t need = 0;
-    for (int64_t C : {(int64_t)1 << 30, (int64_t)2048, (int64_t)1024}) {
+    for (int64_t C : {(int64_t)1 << 30, (int64_t)2048, (int64_t)1024, (int64_t)512}) {
         const BlkShape sh = blk_shape(m, C);
         if (!sh.G) continue;
         const int64_t nblk = (N + sh.B - 1) / sh.B;
-        const size_t b = (size_t)((nblk + 1) * sh.B + 1) * (size_t)blk_rec_bytes(sh.mp, sh.B);   // slots 0..nblk, + one record of DMA over-read
+        const size_t b = blk_recs_bytes(nblk, sh) + blk_hdrs_bytes(nblk, sh.B);
         if (b > need) need = b;
     }
     return need;
@@ -1273,17 +1330,18 @@ static float blk_sym_a(const PipeArgs &a)
     return hi;
 }
 
-template <int G, int S, int B, int NSW, bool SYM>
+template <int G, int S, int B, int NSW, bool SYM, int NL>
 static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStream_t stream)
 {
-    constexpr int NB = 4 * G;
-    const BlkLds L = blk_lds(sh.mp, NB, B, NSW);
+    constexpr int NB = NL * G;
+    const BlkLds L = blk_lds(sh.mp, NB, B, NSW, G);
     const unsigned grid = (unsigned)((a.C + NB - 1) / NB);
-    auto *kern = gpfq_blk_kernel<G, S, B, NSW, SYM>;
+    auto *kern = gpfq_blk_kernel<G, S, B, NSW, SYM, NL>;
     hipError_t e = ensure_dynamic_lds((const void *)kern, (size_t)L.total);
     if (e != hipSuccess) return e;
     BlkK K;
     K.recs = static_cast<const char *>(a.workspace); K.Wt = a.Wt; K.ldw = a.ldw;
+    K.hdrs = K.recs + blk_recs_bytes((a.N + B - 1) / B, sh);
     K.N = a.N; K.C = a.C; K.m = (int)a.m; K.M = a.A.M; K.zero_idx = a.A.zero_idx; K.nblk = (int)((a.N + B - 1) / B);
     K.qidx = a.qidx; K.Qt = a.Qt; K.resid = a.resid; K.u_out = a.u_out; K.fallback_count = a.fallback_count;
     K.stamps = a.fallback_count ? a.fallback_count + 8 : nullptr;      // (diagnostic build: the unused row-statistics area behind the counter block)
@@ -1296,14 +1354,14 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
 // (the eleven-wavefront variants of the shapes that also exist with eight are kept in the general form only: an experiment switch)
 constexpr bool blk_has_sym(int S, int NSW) { return NSW != 11 || S > 32; }
 
-template <int G, int S, int B, int NSW = 8>
+template <int G, int S, int B, int NSW = 8, int NL = 4>
 static hipError_t launch_blk_inst(const PipeArgs &a, const BlkShape &sh, hipStream_t stream)
 {
     // (sweep-bound shapes gain 3-4 %, the others nothing)
     if constexpr (blk_has_sym(S, NSW)) {
-        if (blk_sym_a(a) != 0.f) return launch_blk_sym<G, S, B, NSW, true>(a, sh, stream);
+        if (blk_sym_a(a) != 0.f) return launch_blk_sym<G, S, B, NSW, true, NL>(a, sh, stream);
     }
-    return launch_blk_sym<G, S, B, NSW, false>(a, sh, stream);
+    return launch_blk_sym<G, S, B, NSW, false, NL>(a, sh, stream);
 }
 
 hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
@@ -1312,12 +1370,20 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     if (!sh.G) return hipErrorInvalidValue;
     const int64_t nblk = (a.N + sh.B - 1) / sh.B;
     const int64_t nrec = (nblk + 1) * sh.B + 1;
-    auto *prep = sh.B == 4 ? gpfq_blk_prep_kernel<4, true> : (sh.B == 2 ? gpfq_blk_prep_kernel<2, true> : gpfq_blk_prep_kernel<1, false>);
+    const bool r64 = blk_row64(sh.G, sh.B);
+    auto *prep = sh.B == 4 ? (r64 ? gpfq_blk_prep_kernel<4, true> : gpfq_blk_prep_kernel<4, false>)
+                           : (sh.B == 2 ? (r64 ? gpfq_blk_prep_kernel<2, true> : gpfq_blk_prep_kernel<2, false>) : gpfq_blk_prep_kernel<1, false>);
     const float sym_a = blk_has_sym(sh.S, sh.NW) ? blk_sym_a(a) : 0.f;   // (exactly the launches launch_blk_inst gives the symmetric form)
     hipLaunchKernelGGL(prep, dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp,
-                       a.nrm32, static_cast<char *>(a.workspace), sym_a);
+                       a.nrm32, static_cast<char *>(a.workspace), static_cast<char *>(a.workspace) + blk_recs_bytes(nblk, sh), sym_a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (sh.NL == 2) {                                              // two-neuron workgroups (layers of at most 512 neurons)
+        if (sh.B == 4) return sh.S == 4 ? launch_blk_inst<1, 4, 4, 4, 2>(a, sh, stream) : launch_blk_inst<1, 8, 4, 8, 2>(a, sh, stream);
+        if (sh.B == 2) return sh.S == 12 ? launch_blk_inst<1, 12, 2, 8, 2>(a, sh, stream) : launch_blk_inst<1, 16, 2, 8, 2>(a, sh, stream);
+        if (sh.S == 24) return launch_blk_inst<1, 24, 1, 8, 2>(a, sh, stream);
+        return sh.S == 32 ? launch_blk_inst<1, 32, 1, 8, 2>(a, sh, stream) : launch_blk_inst<1, 40, 1, 8, 2>(a, sh, stream);
+    }
     if (sh.B == 1) {
         if (sh.G == 2) return sh.S == 64 ? launch_blk_inst<2, 64, 1, 11>(a, sh, stream) : launch_blk_inst<2, 48, 1, 11>(a, sh, stream);
         return sh.S == 32 ? launch_blk_inst<1, 32, 1>(a, sh, stream) : launch_blk_inst<1, 24, 1>(a, sh, stream);

@@ -203,6 +203,7 @@ int gpfq_set_option(const char *key, int value)
     }
     if (!std::strcmp(key, "blk_four_groups")) { gpfq::blk_set_four_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_wide_groups")) { gpfq::blk_set_wide_groups(value); return GPFQ_OK; }
+    if (!std::strcmp(key, "blk_pair_groups")) { gpfq::blk_set_pair_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_sweep_waves")) {
         if (value != 8 && value != 11) return fail(GPFQ_ERR_INVALID_ARG, "blk_sweep_waves must be 8 or 11");
         gpfq::blk_set_sweep_waves(value); return GPFQ_OK;
@@ -324,7 +325,9 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
             // stay with the kernels that split a neuron over several wavefronts (4096 x 128, m = 512: 3.05 vs 3.16 ms; m = 2048:
             // 2.06 vs 2.20) -- except for rows of 769+ samples, where workgroups of 8 and of 4 neurons make it the fastest at any
             // width (4096 x 2048, m = 1024: 2.5 vs 5.4 ms; 4096 x 128, m = 2048: 2.9 vs 4.5; 2048 x 128, m = 4096: 2.3 vs 2.5).
-            const bool fits = m > 256 && m <= 4096 && M <= 64 && (C >= 512 || m > 768);
+            // Round 3: two-neuron workgroups (layers of at most 512 neurons, rows of up to 5120 samples) make it the fastest for narrow
+            // layers as well (784 x 128, m = 512, 16 levels; 2048 x 128, m = 5008: tools/latency_shapes.sh, profiles/r03/).
+            const bool fits = m > 256 && M <= 64 && (m <= 4096 || (m <= 5120 && C <= 512));
             const bool want = g_pipe == 1;
             if ((g_pipe == 2 || (g_pipe < 0 && !forced_old && fits)) && N > 0 && m > 0 && gpfq::blk_supported(pa) && workspace &&
                 (uintptr_t)workspace % 16 == 0 && workspace_bytes >= onchip_workspace_bytes(N, m)) {

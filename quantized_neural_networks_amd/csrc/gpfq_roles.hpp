@@ -91,6 +91,25 @@ __device__ __forceinline__ double fold_klanes(const double (&a)[4])
     return x;
 }
 
+// The same for NL = 4, 2 or 1 values per lane.  Two values: one half-wave swap packs them (lanes 0-31 / 32-63), the row swap
+// of the packed value with itself folds rows 0+1 and 2+3 -- afterwards rows 0, 1 hold value 0 and rows 2, 3 value 1.  One value:
+// both swaps with itself, every row holds it.
+template <int G, int NL>
+__device__ __forceinline__ double fold_klanes_n(const double (&a)[NL])
+{
+    if constexpr (NL == 4) {
+        return fold_klanes<G>(a);
+    } else {
+        double x = NL == 2 ? fold32(a[0], a[NL - 1]) : fold32(a[0], a[0]);
+        x = fold16(x, x);
+        if constexpr (G <= 8) x = ror_add<8>(x);
+        if constexpr (G <= 4) x = ror_add<4>(x);
+        if constexpr (G <= 2) x = ror_add<2>(x);
+        if constexpr (G <= 1) x = ror_add<1>(x);
+        return x;
+    }
+}
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_add(double x)
 {
@@ -132,6 +151,7 @@ template <> struct PairSplit<24> { static constexpr int pw[8] = {1, 3, 3, 3, 2, 
 template <> struct PairSplit<16> { static constexpr int pw[8] = {1, 2, 2, 2, 1, 3, 3, 2}; };
 template <> struct PairSplit<12> { static constexpr int pw[8] = {1, 2, 2, 1, 1, 2, 2, 1}; };
 template <> struct PairSplit<8>  { static constexpr int pw[8] = {1, 1, 1, 1, 1, 1, 1, 1}; };
+template <> struct PairSplit<40> { static constexpr int pw[8] = {5, 5, 5, 5, 5, 5, 5, 5}; };
 
 // LDS through 32-bit address-space-3 pointers: offsets stay 32-bit integer arithmetic (generic pointers into the
 // dynamic LDS array cost 64-bit adds and multiplies per access in the hot loop).
