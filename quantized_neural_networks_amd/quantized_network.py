@@ -259,6 +259,62 @@ class QuantizedNeuralNetwork:
         dist.all_gather_into_tensor(out, pad, group=self.process_group)
         return out[:n]
 
+    # Look-ahead of the ANALOG network.  The analog activations at the input of the next layer to be quantized do not depend on
+    # the layer being quantized now (only the quantized network's do: :461-462), so as soon as a layer's inputs are captured the
+    # analog frontier is advanced to the next quantized layer on a second HIP stream -- under the quantization kernels of this
+    # layer and, with a process group, under its index all-gather.  A latency-bound dense walk leaves most of the chip idle; a
+    # conv layer's Gram kernels do not, and then the two simply share the GPU.  Same values: the same kernels on the same inputs.
+    # Measured on one MI355X (tools/e2e_cnn.py, the CIFAR10 CNN at 5000 images): 48.0 ms without, 51 ms with -- on a single GPU the
+    # conv layers' kernels fill the chip and the second stream only adds launches, so the default (None) switches it on with a
+    # process group of more than one rank (where the all-gather and the shorter per-rank walks leave the GPU waiting) and off
+    # otherwise; True / False force it.
+    lookahead_capture = None
+
+    def _lookahead_enabled(self):
+        if self.lookahead_capture is not None:
+            return bool(self.lookahead_capture)
+        return _layer._group_info(self.process_group)[0] > 1
+
+    def _next_quantized_layer(self, layer_idx):
+        """Index of the next layer quantize_network() will quantize after `layer_idx`, or None."""
+        for k in range(layer_idx + 1, len(self.trained_net.layers)):
+            if self._will_quantize(k):
+                return k
+        return None
+
+    def _will_quantize(self, k):
+        return self.trained_net.layers[k].__class__.__name__ == "Dense" and k not in self.ignore_layers
+
+    def _start_lookahead(self, fr, layer_idx):
+        self._ahead = None
+        nxt = self._next_quantized_layer(layer_idx)
+        if (nxt is None or self.device.type != "cuda" or fr["w"].device.type != "cuda" or not self._lookahead_enabled()):
+            return
+        side = getattr(self, "_side_stream", None)
+        if side is None:
+            side = self._side_stream = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        side.wait_stream(main)                                    # the frontier it starts from is being produced on `main`
+        fr["w"].record_stream(side)                               # (and must outlive the side stream's reads if it is dropped early)
+        tl = self.trained_net.layers
+        with torch.cuda.stream(side):
+            w = fr["w"]
+            for k in range(fr["k"] + 1, nxt):
+                w = self._advance(tl[k], w)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._ahead = dict(base=fr["w"], k0=fr["k"], k=nxt - 1, w=w, event=ev)
+
+    def _take_lookahead(self, fr, layer_idx):
+        """The analog activations at layer_idx - 1 if the side stream has them for THIS frontier, else None."""
+        ahead, self._ahead = getattr(self, "_ahead", None), None
+        if ahead is None or ahead["base"] is not fr["w"] or ahead["k0"] != fr["k"] or ahead["k"] != layer_idx - 1:
+            return None
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(ahead["event"])
+        ahead["w"].record_stream(main)                            # allocated on the side stream, consumed (and later freed) on this one
+        return ahead["w"]
+
     def _capture_incremental(self, layer_idx, transpose):
         raw, sizes = self._raw_inputs()
         n = raw.shape[0]
@@ -268,18 +324,41 @@ class QuantizedNeuralNetwork:
             mine = raw[lo:hi]
             fr = dict(k=-1, w=mine, q=mine)                     # outputs of "layer -1" = the data itself
         tl, ql = self.trained_net.layers, self.quantized_net.layers
-        for k in range(fr["k"] + 1, layer_idx):
-            same = fr["q"] is fr["w"] and all(torch.equal(a, b) for a, b in zip(tl[k]._weights, ql[k]._weights))
-            w = self._advance(tl[k], fr["w"])
-            q = w if same else self._advance(ql[k], fr["q"])
-            fr = dict(k=k, w=w, q=q)
+
+        def same_weights(k):
+            return all(torch.equal(a, b) for a, b in zip(tl[k]._weights, ql[k]._weights))
+
+        steps = range(fr["k"] + 1, layer_idx)
+        w_ahead = self._take_lookahead(fr, layer_idx) if len(steps) else None
+        # the look-ahead holds the END of the analog chain only: it serves when the quantized chain either equals it all the
+        # way (nothing quantized yet) or parts from it at the first step (the layer quantized last) -- front-to-back order
+        # gives nothing else; otherwise the chains are walked together as before
+        if w_ahead is not None and fr["q"] is fr["w"] and not all(same_weights(k) for k in steps) and same_weights(steps[0]):
+            w_ahead = None
+        if w_ahead is not None:
+            if fr["q"] is fr["w"] and all(same_weights(k) for k in steps):
+                q = w_ahead
+            else:
+                q = fr["q"]
+                for k in steps:
+                    q = self._advance(ql[k], q)
+            fr = dict(k=layer_idx - 1, w=w_ahead, q=q)
+        else:
+            for k in steps:
+                same = fr["q"] is fr["w"] and same_weights(k)
+                w = self._advance(tl[k], fr["w"])
+                q = w if same else self._advance(ql[k], fr["q"])
+                fr = dict(k=k, w=w, q=q)
         self._frontier = fr
         full_w = raw if fr["k"] < 0 else self._gather_samples(fr["w"], n, world, per)
         wX = self._assemble_capture(full_w, sizes, transpose)
         # both networks still agree up to here (first quantized layer): one tensor, as for layer 0 (:478-481)
         if fr["q"] is fr["w"]:
-            return wX, wX
-        return wX, self._assemble_capture(self._gather_samples(fr["q"], n, world, per), sizes, transpose)
+            qX = wX
+        else:
+            qX = self._assemble_capture(self._gather_samples(fr["q"], n, world, per), sizes, transpose)
+        self._start_lookahead(fr, layer_idx)                      # the analog network runs on while this layer is quantized
+        return wX, qX
 
     def _assemble_capture(self, act, sizes, transpose):
         """Columns in the reference's layout (:491-495): batch b lands at offset b*(its own size)."""
@@ -391,6 +470,10 @@ class QuantizedCNN(QuantizedNeuralNetwork):
         self.alphabet = np.linspace(-1, 1, num=int(round(2 ** (bits))))
         self.logger = logger
         self._init_device(device, process_group, fix_partial_batch)
+
+    def _will_quantize(self, k):
+        name = self.trained_net.layers[k].__class__.__name__
+        return name == "Dense" or (name in {"Conv2D", "DepthwiseConv2D"} and self.is_quantize_conv2d)
 
     def _quantize_dense_layer(self, layer_idx):
         super()._quantize_layer_parallel(layer_idx)

@@ -257,6 +257,33 @@ def test_incremental_capture_equals_recomputation(qn, ks):
             assert np.mean(wa == wb) > 0.97                          # a few decisions may move with the last bits
 
 
+@pytest.mark.parametrize("conv", [True, False])
+def test_analog_lookahead_on_second_stream_changes_nothing(qn, ks, conv):
+    """The analog network's activations for the NEXT quantized layer are computed on a second HIP stream while the current layer
+    is quantized (scripts/quantized_network.py:456-462: only the quantized network's inputs depend on Q).  Forced on for a
+    single process (default: with a process group only), it must capture the same activations -- same kernels on the same
+    inputs -- and give the same quantized weights, for conv + dense and dense-only quantization."""
+    r = np.random.default_rng(8)
+    x = r.random((40, 16, 16, 3)).astype(np.float32)
+    y = np.zeros((40, 6), dtype=np.float32)
+    nets = [_cnn(ks), _cnn(ks)]
+    nets[1].set_weights(nets[0].get_weights())
+    qs = [qn.QuantizedCNN(network=n, batch_size=8, get_data=qn.CIFAR10Sequence(x, y, 8), logger=ListLogger(), bits=3,
+                          alphabet_scalar=4, is_quantize_conv2d=conv) for n in nets]
+    qs[0].lookahead_capture, qs[1].lookahead_capture = True, False
+    recs = [_record_captures(q) for q in qs]
+    for q in qs:
+        q.quantize_network()
+    assert qs[0]._side_stream is not None and not hasattr(qs[1], "_side_stream")
+    assert recs[0].keys() == recs[1].keys() and len(recs[0]) >= 2
+    for k in recs[0]:
+        for a, b in zip(recs[0][k], recs[1][k]):
+            assert np.array_equal(a, b), k
+    for la, lb in zip(qs[0].quantized_net.layers, qs[1].quantized_net.layers):
+        for wa, wb in zip(la.get_weights(), lb.get_weights()):
+            assert np.array_equal(wa, wb)
+
+
 def test_cnn_dense_only(qn, ks):
     net = _cnn(ks)
     x = np.random.default_rng(1).random((8, 16, 16, 3)).astype(np.float32)

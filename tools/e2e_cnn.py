@@ -41,10 +41,11 @@ def build():
 r = np.random.default_rng(0)
 x = r.random((n, 32, 32, 3)).astype(np.float32)
 y = np.zeros((n, 10), dtype=np.float32)
-for it in range(2):
+for it in range(4):
     net = build()
     log = TimingLogger()
     q = qn.QuantizedCNN(network=net, batch_size=batch, get_data=qn.CIFAR10Sequence(x, y, batch), logger=log, bits=3, alphabet_scalar=4)
+    q.lookahead_capture = it >= 2            # runs 2, 3: with the analog look-ahead on the second stream (default on a single GPU: off)
     torch.cuda.synchronize(); t0 = time.time()
     if it == 1 and "--profile" in sys.argv:
         import cProfile, pstats
@@ -56,7 +57,7 @@ for it in range(2):
     else:
         q.quantize_network()
     torch.cuda.synchronize(); total = time.time() - t0
-    print(f"run {it}: quantize_network() {total*1e3:.1f} ms for {n} images, batch {batch}")
+    print(f"run {it}: quantize_network() {total*1e3:.1f} ms for {n} images, batch {batch}" + ("  (analog look-ahead on)" if q.lookahead_capture else ""))
 # phase split of the last run from the log: "Feeding input data ... done. X seconds."
 feed = 0.0
 lines = [m for _, m in log.lines]
