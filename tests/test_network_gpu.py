@@ -274,8 +274,9 @@ def test_analog_lookahead_on_second_stream_changes_nothing(qn, ks, conv):
     recs = [_record_captures(q) for q in qs]
     for q in qs:
         q.quantize_network()
-    assert qs[0]._side_stream is not None and not hasattr(qs[1], "_side_stream")
-    assert recs[0].keys() == recs[1].keys() and len(recs[0]) >= 2
+    # (dense-only: this network has a single Dense layer, nothing follows to look ahead to)
+    assert (getattr(qs[0], "_side_stream", None) is not None) == conv and not hasattr(qs[1], "_side_stream")
+    assert recs[0].keys() == recs[1].keys() and len(recs[0]) >= (2 if conv else 1)
     for k in recs[0]:
         for a, b in zip(recs[0][k], recs[1][k]):
             assert np.array_equal(a, b), k
