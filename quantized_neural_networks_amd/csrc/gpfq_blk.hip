@@ -776,7 +776,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     // ahead of them it takes 6800 and the sweeps, which have the slack, fill the gaps.
     __builtin_amdgcn_s_setprio(3);
 
-    int64_t flushed = 0;                                          // steps [0, flushed) are in memory
+    int64_t flushed = 0, flush_hi = 0;                            // steps [0, flushed) are in memory; [flushed, flush_hi) are due
     unsigned long long dt0 = 0, dt1 = 0, dt2 = 0, dta = 0, dtb = 0, dacc_work = 0, dacc_bar = 0, dacc_pro = 0, dacc_chain = 0, dacc_tail = 0;
     (void)dt0; (void)dt1; (void)dt2; (void)dta; (void)dtb; (void)dacc_work; (void)dacc_bar; (void)dacc_pro; (void)dacc_chain; (void)dacc_tail;
     for (int b = 0; b < nslots; ++b) {
@@ -827,7 +827,11 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 #pragma unroll
             for (int s = 0; s < B; ++s) wc[s] = lds_ld<float>(lds, o_w + (b & 1) * NB * B * 4 + 4 * s);
             const float w_own_raw = lds_ld<float>(lds, o_w + (b & 1) * NB * B * 4 + 4 * sm);
-            // (the record headers: prefetched from global memory one slot ahead, see prefetch_headers)
+            if (flush_hi > flushed) {                             // (outputs of earlier slots: under the latency of the reads above)
+                flush(flushed, flush_hi);
+                flushed = flush_hi;
+            }
+            // (the record headers: requested before the last barrier, see prefetch_headers)
             double2 hp[B], hi_[BI];
             const double2 o01 = g01;
 #pragma unroll
@@ -967,6 +971,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             }
             ctl_now = smin < B ? smin : -1;
             if (lane == 0) lds_st<int>(lds, L.off_ctl + 4 * (b & 1), ctl_now);
+            if (b + 1 < K.nblk) prefetch_headers(hnext);          // the next tile's headers (landed a slot ago): the LDS is quiet now
         } else {
             STAMP(dta);
             STAMP(dtb);
@@ -1061,6 +1066,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         };
         using T_ = std::true_type;
         using F_ = std::false_type;
+        hnext = hnext == 2 ? 0 : hnext + 1;
         STAMP(dt1);
         slot_barrier();
         STAMP(dt2);
@@ -1128,18 +1134,14 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             slot_barrier();                                       // chains resumed, control word rewritten
         }
 
-        if (b + 1 < K.nblk) prefetch_headers(hnext);              // the next tile's headers (landed a slot ago), into registers
-        hnext = hnext == 2 ? 0 : hnext + 1;
-        // block b is final: it becomes "the previous block"; flush the output ring when it is full
+        // block b is final: it becomes "the previous block"; the output ring is flushed when it is full -- at the top of the next
+        // slot, AFTER that slot's LDS reads have been requested (they are what the slot waits for)
 #pragma unroll
         for (int j = 0; j < B; ++j) { wprev[j] = (b < K.nblk) ? wc[j] : 0.f; qprev[j] = (b < K.nblk) ? qc[j] : 0.f; }
         const int64_t done = min((int64_t)(b + 1) * B, N);
-        if (b < K.nblk && (done - flushed >= kOutSteps - B + 1 || done == N)) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            flush(flushed, done);
-            flushed = done;
-        }
+        if (b < K.nblk && (done - flushed >= kOutSteps - B + 1 || done == N)) { flush_hi = done; }
     }
+    if (flush_hi > flushed) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); flush(flushed, flush_hi); }
 
     if (K.fallback_count && n_fallback) atomicAdd(K.fallback_count, n_fallback);   // rare
 #ifdef GPFQ_BLK_STAMPS
@@ -1261,6 +1263,10 @@ static BlkShape blk_shape(int64_t m, int64_t C)
     // several-wavefronts-per-neuron kernel these rows had (4096 x 4096 x 4096: 38 ms)
     if (m > 2048 && m <= 3072) return four ? BlkShape{1, 24, 1, 3072, 8, 4} : BlkShape{2, 48, 1, 3072, 11, 4};
     if (m > 3072 && m <= 4096) return four ? BlkShape{1, 32, 1, 4096, 8, 4} : BlkShape{2, 64, 1, 4096, 11, 4};
+    // rows of 4097..5120 samples (the reference's CIFAR10 runs calibrate on 5000 images, quantize_pretrained_cnn.py:78): a 60 KiB
+    // record, 4 neurons per workgroup at any width -- a layer of 4096 neurons takes four rounds of workgroups, still several times
+    // the several-wavefronts-per-neuron kernel these rows had
+    if (m > 4096 && m <= 5120) return {1, 40, 1, 5120, 8, 4};
     return {0, 0, 0, 0, 0, 0};
 }
 
@@ -1384,6 +1390,7 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
         if (sh.S == 24) return launch_blk_inst<1, 24, 1, 8, 2>(a, sh, stream);
         return sh.S == 32 ? launch_blk_inst<1, 32, 1, 8, 2>(a, sh, stream) : launch_blk_inst<1, 40, 1, 8, 2>(a, sh, stream);
     }
+    if (sh.B == 1 && sh.S == 40) return launch_blk_inst<1, 40, 1>(a, sh, stream);
     if (sh.B == 1) {
         if (sh.G == 2) return sh.S == 64 ? launch_blk_inst<2, 64, 1, 11>(a, sh, stream) : launch_blk_inst<2, 48, 1, 11>(a, sh, stream);
         return sh.S == 32 ? launch_blk_inst<1, 32, 1>(a, sh, stream) : launch_blk_inst<1, 24, 1>(a, sh, stream);

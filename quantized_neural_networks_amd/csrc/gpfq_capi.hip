@@ -327,7 +327,7 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
             // width (4096 x 2048, m = 1024: 2.5 vs 5.4 ms; 4096 x 128, m = 2048: 2.9 vs 4.5; 2048 x 128, m = 4096: 2.3 vs 2.5).
             // Round 3: two-neuron workgroups (layers of at most 512 neurons, rows of up to 5120 samples) make it the fastest for narrow
             // layers as well (784 x 128, m = 512, 16 levels; 2048 x 128, m = 5008: tools/latency_shapes.sh, profiles/r03/).
-            const bool fits = m > 256 && M <= 64 && (m <= 4096 || (m <= 5120 && C <= 512));
+            const bool fits = m > 256 && M <= 64 && m <= 5120;
             const bool want = g_pipe == 1;
             if ((g_pipe == 2 || (g_pipe < 0 && !forced_old && fits)) && N > 0 && m > 0 && gpfq::blk_supported(pa) && workspace &&
                 (uintptr_t)workspace % 16 == 0 && workspace_bytes >= onchip_workspace_bytes(N, m)) {
