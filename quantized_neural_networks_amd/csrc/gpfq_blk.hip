@@ -44,6 +44,7 @@
 // cycle counts (diagnostic build: GPFQ_DIAG="-DGPFQ_BLK_STAMPS").
 #include <atomic>
 #include <cmath>
+#include <cstring>
 #include <type_traits>
 
 #include "gpfq_device.hpp"
@@ -265,6 +266,11 @@ struct BlkK {
     // float32(alphabet[k]) for every k (checked on the host); inv = 1 / step, c0 = -a0 / step (0, 0 for a single member).  The
     // chain of decisions finds its candidate index and value by arithmetic; the certification looks the true members up.
     double uni_a0, uni_step, uni_inv, uni_c0;
+    // ... up to one float32 ulp: alphabet[k] = rad (2k - M + 1) / (M - 1) is a small rational multiple of a float32 median, and such
+    // values sit EXACTLY on float32 rounding ties a few per cent of the time -- the float64 product rad * linspace[k] and the fused
+    // a0 + k step then round to different neighbours (2 of 16 members of a typical 4-bit alphabet).  Bit k of uni_plus / uni_minus:
+    // float32(alphabet[k]) is the next float32 above / below (in the integer order of the bit patterns) float32(a0 + k step).
+    unsigned long long uni_plus, uni_minus;
 };
 
 #ifdef GPFQ_BLK_STAMPS
@@ -889,9 +895,14 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             STAMP(dta);
             // ---- (2) the chain
             const double u_a0 = K.uni_a0, u_step = K.uni_step, u_inv = K.uni_inv, u_c0 = K.uni_c0, u_kmax = (double)(M - 1);
+            const unsigned long long u_plus = K.uni_plus, u_minus = K.uni_minus;
+            const int u_zero = K.zero_idx;
             auto pick = [&](double tt, double &kd) -> float {     // nearest member of the uniform alphabet, by arithmetic
                 kd = fmin(fmax(rint(fma(tt, u_inv, u_c0)), 0.0), u_kmax);
-                return (float)fma(kd, u_step, u_a0);
+                const int ki = (int)kd;
+                const int adj = (int)((unsigned)(u_plus >> ki) & 1u) - (int)((unsigned)(u_minus >> ki) & 1u);
+                const float v = __int_as_float(__float_as_int((float)fma(kd, u_step, u_a0)) + adj);   // float32(alphabet[k]), see BlkK
+                return ki == u_zero ? 0.f : v;
             };
             float q32s[B];
             double qd[B];
@@ -1280,10 +1291,12 @@ static BlkShape blk_shape(int64_t m, int64_t C)
 // The alphabet as an arithmetic progression, if it is one in the sense the chain of decisions needs: strictly ascending and
 // float32(fma(k, step, a0)) == float32(alphabet[k]) for every k, with step = (a[M-1] - a[0]) / (M - 1) -- the same fused operation
 // the kernel performs.  Everything the reference builds (rad * linspace(-1, 1, M), scripts/quantized_network.py:396, :545) is.
-static bool blk_uniform(const AlphabetArg &A, double *a0, double *step, double *inv, double *c0)
+static bool blk_uniform(const AlphabetArg &A, double *a0, double *step, double *inv, double *c0, unsigned long long *plus,
+                        unsigned long long *minus)
 {
     const int M = A.M;
-    if (M < 1 || !std::isfinite(A.a[0]) || !std::isfinite(A.a[M - 1])) return false;
+    *plus = *minus = 0ull;
+    if (M < 1 || M > 64 || !std::isfinite(A.a[0]) || !std::isfinite(A.a[M - 1])) return false;
     *a0 = A.a[0];
     if (M == 1) { *step = 0.0; *inv = 0.0; *c0 = 0.0; return true; }
     *step = (A.a[M - 1] - A.a[0]) / (double)(M - 1);
@@ -1293,7 +1306,17 @@ static bool blk_uniform(const AlphabetArg &A, double *a0, double *step, double *
     if (!std::isfinite(*inv) || !std::isfinite(*c0)) return false;
     for (int k = 0; k < M; ++k) {
         if (k > 0 && !(A.a[k - 1] < A.a[k])) return false;
-        if ((float)std::fma((double)k, *step, *a0) != (float)A.a[k]) return false;
+        if (A.a[k] == 0.0) {                                   // (the member 0 is returned as such, BlkK::zero_idx, if the progression passes through it)
+            if (!(std::fabs(std::fma((double)k, *step, *a0)) <= 0x1p-40 * std::fmax(std::fabs(A.a[0]), std::fabs(A.a[M - 1])))) return false;
+        } else {
+            const float want = (float)A.a[k], have = (float)std::fma((double)k, *step, *a0);
+            int32_t iw, ih;
+            std::memcpy(&iw, &want, 4); std::memcpy(&ih, &have, 4);
+            const int64_t d = (int64_t)iw - (int64_t)ih;
+            if (d == 1) *plus |= 1ull << k;
+            else if (d == -1) *minus |= 1ull << k;
+            else if (d != 0) return false;
+        }
         // and the index arithmetic finds a member from its own value (monotone rounding does the rest)
         if (std::rint(std::fma(A.a[k], *inv, *c0)) != (double)k) return false;
     }
@@ -1313,7 +1336,8 @@ bool blk_supported(const PipeArgs &a)
     if (sh.G == 0 || a.N < 1 || a.m < 1) return false;
     if (a.A.M > 64 || !a.A.ascending) return false;
     double a0, step, inv, c0;
-    if (!blk_uniform(a.A, &a0, &step, &inv, &c0)) return false;      // (other alphabets keep the row-group kernels)
+    unsigned long long up, dn;
+    if (!blk_uniform(a.A, &a0, &step, &inv, &c0, &up, &dn)) return false;      // (other alphabets keep the row-group kernels)
     return a.N + 64 < (1LL << 31) / 64;
 }
 
@@ -1359,7 +1383,7 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
     K.qidx = a.qidx; K.Qt = a.Qt; K.resid = a.resid; K.u_out = a.u_out; K.fallback_count = a.fallback_count;
     K.stamps = a.fallback_count ? a.fallback_count + 8 : nullptr;      // (diagnostic build: the unused row-statistics area behind the counter block)
     K.sym_a = SYM ? blk_sym_a(a) : 0.f; K.Xq = a.Xq; K.ldx = a.ld;
-    if (!blk_uniform(a.A, &K.uni_a0, &K.uni_step, &K.uni_inv, &K.uni_c0)) return hipErrorInvalidValue;
+    if (!blk_uniform(a.A, &K.uni_a0, &K.uni_step, &K.uni_inv, &K.uni_c0, &K.uni_plus, &K.uni_minus)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NSW + 1)), (size_t)L.total, stream, K, a.A);
     return hipGetLastError();
 }
