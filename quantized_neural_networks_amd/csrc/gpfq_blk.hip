@@ -70,14 +70,10 @@ __host__ __device__ constexpr int blk_hdr_bytes(int B) { return (64 + (2 * B - 1
 // up to 256 workgroups on the chip that EACH pull the whole record stream out of the L2s: 256 x 66 KiB per slot of four steps was
 // 10 TB/s, the bound of those shapes (profiles/r03/blk_phase_stamps.txt); a lane converts its two samples for two or four neurons.
 __host__ __device__ constexpr bool blk_row64(int G, int B) { return B > 1 && G > 1; }
-// kRowSkew bytes between the X row and the Xq row of a record (and again before the third row): without it the two rows of an update
-// sit a multiple of 4 KiB apart -- the same LDS banks -- and every ds_read2st64_b64 that fetches a pair of them takes 7 clocks
-// instead of 4 (tools/ubench/lds_broadcast.hip; SQ_LDS_BANK_CONFLICT was 1300 cycles per slot and CU in round 2).
-constexpr int kRowSkew = 128;
-__host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B, int G)
-{
-    return blk_hdr_bytes(B) + (blk_row64(G, B) ? 16 : 12) * mp + 2 * kRowSkew;
-}
+// (Tried in round 3: 128 bytes of skew between the rows of a record, so that the X and Xq rows of an update do not sit a multiple
+//  of 4 KiB apart.  SQ_LDS_BANK_CONFLICT did not move -- 3.2e8 against 3.4e8 cycles per launch: a 128-byte span of a row covers all
+//  32 banks, two rows per ds_read2st64_b64 are two passes wherever they lie -- and neither did the time.)
+__host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B, int G) { return blk_hdr_bytes(B) + (blk_row64(G, B) ? 16 : 12) * mp; }
 
 // ---- pre-pass ---------------------------------------------------------------------------------
 // One workgroup per slot record t: statistics of row t, its Gram band against rows t-1 .. t-(2B-1), float32 copies
@@ -96,8 +92,8 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
     constexpr int hdr = blk_hdr_bytes(B);
     char *rb = recs + t * blk_rec_bytes(mp, B, GREC);
     float  *ox = reinterpret_cast<float *>(rb + hdr);
-    float  *oq = ox + mp + kRowSkew / 4;
-    double *od = reinterpret_cast<double *>(rb + hdr + 8 * (int64_t)mp + 2 * kRowSkew);
+    float  *oq = ox + mp;
+    double *od = reinterpret_cast<double *>(rb + hdr + 8 * (int64_t)mp);
     const bool has_prev = t >= B && t - B < N, has_cur = t < N, has_next = t + B < N;
     const float *px = X + (t - B) * ld, *pq = Xq + (t - B) * ld;
     const float *cx = X + t * ld, *cq = Xq + t * ld;
@@ -297,9 +293,9 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     const int64_t N = K.N;
     const int nslots = K.nblk + 1;
     const int o_x  = HDR + 8 * (pbase + kq);                      // float2 x   [pair]  (row t - B of record t)
-    const int o_q  = o_x + 4 * MP + kRowSkew;                     // float2 xq  [pair]
+    const int o_q  = o_x + 4 * MP;                                // float2 xq  [pair]
     constexpr int DB = blk_row64(G, B) ? 16 : 8;                  // bytes of a sample pair of row t + B
-    const int o_d  = HDR + 8 * MP + 2 * kRowSkew + DB * (pbase + kq);   // double2 (float2) xqd[pair]  (row t + B)
+    const int o_d  = HDR + 8 * MP + DB * (pbase + kq);           // double2 (float2) xqd[pair]  (row t + B)
     using DRaw = std::conditional_t<blk_row64(G, B), double2, float2>;   // as it sits in the record; converted where it is consumed
     auto ld_d = [&](int off) -> DRaw { return lds_ld<DRaw>(lds, off); };
     auto to_d2 = [](const DRaw &v) -> double2 { return make_double2((double)v.x, (double)v.y); };
