@@ -89,8 +89,9 @@ int gpfq_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, float *nrm
 /* Bytes of scratch gpfq_quantize_neurons needs for this shape on this path.  The on-chip path
  * keeps per-row statistics there (32*N + 64 bytes, rounded up to 256; after the call the first 8 bytes
  * hold, as a uint64, how many decisions were re-derived with the exact dot product -- diagnostics
- * only) and, for rows of up to 2048 samples, the slot records of the pipelined kernel
- * ((N + 17) * (128 + 16 * padded m) bytes: row statistics + zero-padded operand rows laid out per step);
+ * only) and the slot records of the block-pipelined kernel
+ * (about (N + 9) * (384 + 16 * padded m) bytes for rows of up to 5120 samples: per step the row statistics, the Gram band and the
+ * zero-padded operand rows, plus a compact second copy of the headers);
  * with less it still runs -- on the row-group kernels, or without any workspace in the reference's
  * verbatim flow (same results, slower). */
 size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path);
