@@ -125,6 +125,8 @@ const char *gpfq_last_dense_kernel(void);
  *   "waves_per_neuron"  2..16: force the wide kernel (one neuron over that many wavefronts), 0 = heuristic
  *                  (rows longer than 2048 samples, and layers too narrow to fill the chip)
  *   "gram_slack_log2"   Gram paths: error bounds multiplied by 2^value (tests force the repair/rerun branches)
+ *   "conv_s2"      1 (default): 7x7 / stride 2 / VALID conv layers form their Gram records from shift sums of the parity classes of the
+ *                  channel planes (gpfq_gram_s2.hip); 0: the matrix-core kernel
  *   "auto_gram"    1 (default): GPFQ_PATH_AUTO may divert long rows to the Gram path (one stream synchronisation inside the call);
  *                  0: AUTO only picks between the asynchronous on-chip and streaming kernels
  *   "conv_fused"   1 (default): conv layers read their patch rows from the channel planes; 0: per-channel patch matrices

@@ -21,7 +21,7 @@ LIB = os.path.join(CSRC, "libgpfq_hip.so")
 STAMP = LIB + ".sha"
 OBJDIR = os.path.join(CSRC, "build")
 SOURCES = ["gpfq_capi.hip", "gpfq_onchip.hip", "gpfq_rows.hip", "gpfq_pipe.hip", "gpfq_blk.hip", "gpfq_wide.hip", "gpfq_stream.hip",
-           "gpfq_gram.hip", "gpfq_gram_image.hip", "gpfq_gram_conv.hip", "gpfq_gram_mfma.hip", "gpfq_misc.hip"]
+           "gpfq_gram.hip", "gpfq_gram_image.hip", "gpfq_gram_conv.hip", "gpfq_gram_s2.hip", "gpfq_gram_mfma.hip", "gpfq_misc.hip"]
 HEADERS = ["gpfq_device.hpp", "gpfq_launch.hpp", "gpfq_gram_tile.hpp", "gpfq_roles.hpp", os.path.join("..", "..", "include", "gpfq.h")]
 
 # -ffp-contract=off: the float32 products/subtraction of the residual update must round

@@ -216,6 +216,7 @@ int gpfq_set_option(const char *key, int value)
     if (!std::strcmp(key, "auto_gram")) { g_auto_gram = value ? 1 : 0; return GPFQ_OK; }
     if (!std::strcmp(key, "conv_fused")) { g_conv_fused = value ? 1 : 0; return GPFQ_OK; }
     if (!std::strcmp(key, "conv_nhwc")) { g_conv_nhwc = value ? 1 : 0; return GPFQ_OK; }
+    if (!std::strcmp(key, "conv_s2")) { gpfq::conv_set_s2(value); return GPFQ_OK; }
     if (!std::strcmp(key, "conv_shift")) {
         if (value < 0 || value > 2) return fail(GPFQ_ERR_INVALID_ARG, "conv_shift must be 0, 1 or 2");
         g_conv_shift = value; return GPFQ_OK;
@@ -594,8 +595,11 @@ size_t gpfq_conv_channels_workspace_bytes(int64_t n, int64_t H, int64_t W, int64
     if (cols <= 0 || K <= 0 || F < 0 || nch < 0) return 0;
     if (!want_resid && g_conv_fused && gpfq::gram_image_supported(n, H, W, kh, kw, sh, sw, rh, rw, same_padding))
         return gpfq::gram_image_workspace_bytes(nch, F);
-    if (!want_resid && g_conv_fused && gpfq::gram_conv_supported(n, H, W, nch, kh, kw, oh, ow))
-        return gpfq::gram_conv_workspace_bytes(K, nch, F, cols);
+    if (!want_resid && g_conv_fused && gpfq::gram_conv_supported(n, H, W, nch, kh, kw, oh, ow)) {
+        size_t b = al256c(gpfq::gram_conv_workspace_bytes(K, nch, F, cols));
+        if (!same_padding && gpfq::gram_s2_supported(n, H, W, kh, kw, sh, sw, rh, rw, 0, 0)) b += gpfq::gram_s2_workspace_bytes(n, H, W, nch);
+        return b;
+    }
     const int64_t ldp = (cols + 3) & ~(int64_t)3;
     return 2 * al256c((size_t)K * ldp * sizeof(float)) + al256c((size_t)K * sizeof(float)) + gpfq::gram_workspace_bytes(K, cols, F);
 }
@@ -659,6 +663,8 @@ static int conv_channels_impl(int phase, double *records, int32_t *negflags,
         g.slack = std::ldexp(1.0, g_gram_slack_log2);
         g.variant = g_variant;
         g.phase = phase; g.records = records; g.negflags = negflags;
+        if (pad_top == 0 && pad_left == 0 && gpfq::gram_s2_supported(n, H, W, kh, kw, sh, sw, rh, rw, pad_top, pad_left))
+            g.s2_part = reinterpret_cast<double *>(static_cast<char *>(workspace) + al256c(gpfq::gram_conv_workspace_bytes(K, nch, F, cols)));
         hipError_t e = gpfq::launch_gram_conv(g, static_cast<hipStream_t>(stream));
         return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_conv_channels(implicit)");
     }

@@ -6,6 +6,8 @@
 // gathered straight from the channel planes, for all channels of a shard in one launch (grid: column
 // walkers x lower-triangle tiles x channels), so a 7x7/2 layer no longer writes and re-reads 20 GB of patch
 // data per channel.  The 3x3 / stride-1 case has its own kernel (gpfq_gram_image.hip).
+#include <atomic>
+
 #include "gpfq_device.hpp"
 #include "gpfq_gram_tile.hpp"
 #include "gpfq_launch.hpp"
@@ -384,6 +386,9 @@ bool gram_conv_supported(int64_t n, int64_t H, int64_t W, int64_t nch, int kh, i
     return n * H * W < (1LL << 31) - (1LL << 20) && n * oh * ow < (1LL << 30);
 }
 
+static std::atomic<int> g_conv_s2{1};
+void conv_set_s2(int on) { g_conv_s2.store(on ? 1 : 0, std::memory_order_relaxed); }
+
 size_t gram_conv_workspace_bytes(int64_t K, int64_t nch, int64_t F, int64_t m)
 {
     size_t b = 0;
@@ -450,6 +455,16 @@ hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream)
         if (e != hipSuccess) return e;
         e = launch_gram_reduce(a.records, 1, (int)K, gram, nrm, a.nch, stream);
         if (e != hipSuccess) return e;
+    } else if (g_conv_s2.load(std::memory_order_relaxed) && a.s2_part &&
+               gram_s2_supported(a.n, a.H, a.W, a.kh, a.kw, a.sh, a.sw, a.rh, a.rw, a.pt, a.pl)) {
+        // 7x7 / stride 2 / VALID: shift sums of the parity classes of the planes instead of every (t, s) product (gpfq_gram_s2.hip)
+        e = launch_gram_s2(a.act_w, a.act_q, a.n, a.H, a.W, a.nch, a.s2_part, gram, nrm, negflag, stream);
+        if (e != hipSuccess) return e;
+        if (a.phase == 1) {
+            e = hipMemcpyAsync(a.records, gram, (size_t)a.nch * gram_record(K) * sizeof(double), hipMemcpyDeviceToDevice, stream);
+            if (e != hipSuccess) return e;
+            return hipMemcpyAsync(a.negflags, negflag, (size_t)a.nch * sizeof(int), hipMemcpyDeviceToDevice, stream);
+        }
     } else {
         if (mfma) {
             const dim3 grid((unsigned)walkers, 1, (unsigned)a.nch);

@@ -205,10 +205,17 @@ struct ConvGramArgs {
     int phase = 0;          // as ImageGramArgs: 1 = records only, 2 = from records ([nch][K*K*2 + K] f64, [nch] i32)
     double *records = nullptr;
     int32_t *negflags = nullptr;
+    double *s2_part = nullptr;   // gram_s2_workspace_bytes of scratch behind the workspace proper (7x7 / 2 layers; NULL: the matrix-core kernel)
 };
 bool gram_conv_supported(int64_t n, int64_t H, int64_t W, int64_t nch, int kh, int kw, int64_t oh, int64_t ow);
 size_t gram_conv_workspace_bytes(int64_t K, int64_t nch, int64_t F, int64_t m);
 hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream);
+// 7x7 / stride 2 / VALID (ResNet50's conv1): the Gram records from shift sums of the parity classes of the planes (gpfq_gram_s2.hip)
+bool gram_s2_supported(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw, int rh, int rw, int pt, int pl);
+size_t gram_s2_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t nch);
+hipError_t launch_gram_s2(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch, double *part,
+                          double *gram, float *nrm32, int *negflag, hipStream_t stream);
+void conv_set_s2(int on);           // the shift-sum form for 7x7 / 2 layers (speed only; 0: the matrix-core kernel)
 
 bool gram_image_supported(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw, int rh, int rw, int same_padding);
 size_t gram_image_workspace_bytes(int64_t nch, int64_t F);

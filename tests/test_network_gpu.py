@@ -574,6 +574,67 @@ def test_conv_implicit_im2col(oracle_mod, n, H, W, Cin, F, kh, kw, stride, rate,
             assert np.array_equal(Q[:, :, c, f].reshape(-1), qo.astype(np.float32)), (c, f)
 
 
+@pytest.mark.parametrize("n,H,W,Cin,F,kind", [
+    (70, 38, 38, 2, 2, "relu"),          # three strips of interior columns, seven border columns
+    (40, 45, 36, 1, 3, "signed"),        # odd sizes, not square: one decimated class is a column / row shorter; Cauchy-Schwarz bounds
+    (24, 64, 70, 3, 2, "first"),         # a first layer (both networks see the images: G2 = G1), several bands of rows
+    (30, 40, 52, 2, 2, "dead"),          # a patch row that is zero on its window only, and a dead channel
+    (12, 32, 32, 1, 2, "sparse"),        # the smallest image the plan takes
+])
+def test_conv7x7_stride2_shift_sums(oracle_mod, n, H, W, Cin, F, kind):
+    """7x7 / stride 2 / VALID layers (ResNet50's conv1 on the padded input) form their Gram records from shift sums of the four
+    parity classes of the planes (gpfq_gram_s2.hip): every patch row is a stride-1 shift of a decimated plane, the interior of all
+    windows is summed once per (class pair, shift) and the border rows / columns are added per region.  Against the oracle on the
+    reference's patch matrices (scripts/quantized_network.py:185-233) and against the matrix-core kernel (option conv_s2 = 0)."""
+    from quantized_neural_networks_amd import hip, layer
+    oh, ow = (H - 7) // 2 + 1, (W - 7) // 2 + 1
+    assert oh > 7 and 3 + (ow + 3) - (3 + 4 * ((ow - 3) // 4)) <= 8      # the shapes the shift-sum plan takes (s2_plan)
+    r = np.random.default_rng(n + H + W)
+    if kind == "signed":
+        act_w = r.standard_normal((n, H, W, Cin)).astype(np.float32)
+    elif kind == "sparse":
+        act_w = np.maximum(r.standard_normal((n, H, W, Cin)) - 1.2, 0).astype(np.float32)
+    else:
+        act_w = r.random((n, H, W, Cin)).astype(np.float32)
+    if kind == "first":
+        act_q = act_w
+    elif kind == "signed":
+        act_q = (act_w + 0.05 * r.standard_normal(act_w.shape)).astype(np.float32)
+    else:
+        act_q = np.maximum(act_w + 0.05 * r.standard_normal(act_w.shape), 0).astype(np.float32)
+    if kind == "dead":
+        act_q[..., 1] = 0.0                                      # a dead channel: rule (i) for all 49 rows
+        # row t = (6, 6) of channel 0 reads positions (2 oy + 6, 2 ox + 6): zero exactly there, alive everywhere else
+        act_q[:, 6::2, 6::2, 0] = 0.0
+    Wk = (r.standard_normal((7, 7, Cin, F)) / 7).astype(np.float32)
+    Wd = torch.from_numpy(Wk).cuda()
+    alphabet, _ = layer.layer_alphabet(Wd, np.linspace(-1, 1, 8), 4)
+    aw = torch.from_numpy(act_w).cuda()
+    aq = aw if kind == "first" else torch.from_numpy(act_q).cuda()
+    kwargs = dict(strides=(2, 2), padding="VALID", rate=(1, 1), want_resid=False)
+    try:
+        out = layer.quantize_conv2d(Wd, aw, aq, alphabet, **kwargs)
+        hip.set_option("conv_s2", 0)
+        mfma = layer.quantize_conv2d(Wd, aw, aq, alphabet, **kwargs)
+        hip.set_option("conv_s2", 1)
+        hip.set_option("gram_slack_log2", 14)               # some chains repaired on the device from the planes
+        rep = layer.quantize_conv2d(Wd, aw, aq, alphabet, **kwargs)
+    finally:
+        hip.set_option("conv_s2", 1)
+        hip.set_option("gram_slack_log2", 0)
+    assert torch.equal(out["Q"], mfma["Q"]) and torch.equal(out["idx"], mfma["idx"])
+    assert torch.equal(out["Q"], rep["Q"]) and torch.equal(out["idx"], rep["idx"])
+    Q = out["Q"].cpu().numpy()
+    for c in range(Cin):
+        Pw = ref_patches(act_w, c, 7, 7, 2, 2, 1, 1, "VALID")
+        Pq = ref_patches(act_q, c, 7, 7, 2, 2, 1, 1, "VALID")
+        for f in range(F):
+            qo, _, _ = oracle_mod.neuron(Wk[:, :, c, f].reshape(-1), Pw, Pq, alphabet)
+            assert np.array_equal(Q[:, :, c, f].reshape(-1), qo.astype(np.float32)), (c, f)
+    if kind == "dead":
+        assert (Q[:, :, 1] == 0).all() and (Q[6, 6, 0] == 0).all()
+
+
 @pytest.mark.parametrize("stride,bits", [(1, 2), (2, np.log2(3)), (1, 4)])
 def test_conv1x1_shortcut_equals_general_path(oracle_mod, stride, bits):
     """1x1 kernels take the MSQ shortcut; it must give what the general per-channel path gives,
