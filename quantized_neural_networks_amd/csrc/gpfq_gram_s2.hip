@@ -39,7 +39,7 @@ constexpr int kS2K = 7;
 constexpr int kS2Threads = 1024;       // 16 wavefronts = 4 classes of s x 4 row shifts
 constexpr int kS2Acc = 15;             // 7 (G1) + 7 (G2) + sum x^2
 constexpr int kS2Slots = 9;            // regions per launch and class: interior columns + up to 8 border columns
-constexpr int kS2RB = 16;              // position rows per band (32: 141 KiB of LDS, measured 2.6 x slower with distinct tensors)
+constexpr int kS2RB = 16;              // position rows per band (32 needs 141 KiB of LDS for two tensors: one workgroup per CU either way; not faster)
 constexpr int kS2MaxLaunch = 8;
 
 struct S2Params {
@@ -59,6 +59,7 @@ struct S2Params {
     int *negflag;
 };
 
+template <bool SAME>                  // both networks see the same planes (a first layer): G2 = G1, one tensor staged
 __global__ void __launch_bounds__(kS2Threads)
 gpfq_gram_s2_kernel(S2Params p)
 {
@@ -75,7 +76,7 @@ gpfq_gram_s2_kernel(S2Params p)
     const int LP = p.LP;
     const int cls_stride = LR * LP + 32;                            // (+128 bytes: the four classes of a wavefront's lanes start in different banks)
     float *Lx = s2_lds;                                             // [4][LR][LP]
-    float *Lq = p.same_act ? s2_lds : s2_lds + 4 * cls_stride;
+    float *Lq = SAME ? s2_lds : s2_lds + 4 * cls_stride;
     const float *pw = p.act_w + (int64_t)blockIdx.z * p.plane;
     const float *pq = p.act_q + (int64_t)blockIdx.z * p.plane;
 
@@ -86,7 +87,7 @@ gpfq_gram_s2_kernel(S2Params p)
     unsigned signs = 0;
 
     // pads (left 4, right >= 4 floats of every row) are zero for the whole launch: zero everything once
-    for (int i = tid; i < (p.same_act ? 4 : 8) * cls_stride; i += kS2Threads) s2_lds[i] = 0.f;
+    for (int i = tid; i < (SAME ? 4 : 8) * cls_stride; i += kS2Threads) s2_lds[i] = 0.f;
     __syncthreads();
 
     const int items = p.n * nbands;
@@ -96,37 +97,36 @@ gpfq_gram_s2_kernel(S2Params p)
         // ---- stage decimated rows [y0 - 3, y1) of all four classes: full rows 2 (y0 - 3) .. 2 y1 - 1, de-interleaved ----
         const int nfull = 2 * (rows + kS2D);
         const float *iw = pw + (int64_t)img * p.H * p.W, *iq = pq + (int64_t)img * p.H * p.W;
-        // (every wavefront requests ALL its elements of the band -- up to 3 rows x 4 column chunks x 2 tensors -- before it writes
+        // (every wavefront requests ALL its elements of the band -- up to 3 rows x 4 column chunks of one tensor -- before it writes
         //  the first to LDS: one memory latency per band instead of one per element; wider images take further passes)
-        constexpr int kRI = 3;                                      // rows per wavefront and pass (24 registers in flight)
-        for (int fr0 = 0; fr0 < nfull; fr0 += kRI * (kS2Threads / 64))
-        for (int c0 = 0; c0 < p.W; c0 += 256) {
-            float vx[kRI][4], vq[kRI][4];
+        constexpr int kRI = (2 * (kS2RB + kS2D) + kS2Threads / 64 - 1) / (kS2Threads / 64);     // rows per wavefront: 3
+        for (int tz = 0; tz < (SAME ? 1 : 2); ++tz) {              // one tensor at a time: 12 registers in flight
+            const float *src = tz ? iq : iw;
+            float *dst = tz ? Lq : Lx;
+            for (int c0 = 0; c0 < p.W; c0 += 256) {
+                float v[kRI][4];
 #pragma unroll
-            for (int i = 0; i < kRI; ++i) {
-                const int fr = fr0 + wave + (kS2Threads / 64) * i;
-                const int f = 2 * (y0 - kS2D + (fr >> 1)) + (fr & 1);
-                const bool rin = fr < nfull && f >= 0 && f < p.H;
+                for (int i = 0; i < kRI; ++i) {
+                    const int fr = wave + (kS2Threads / 64) * i;
+                    const int f = 2 * (y0 - kS2D + (fr >> 1)) + (fr & 1);
+                    const bool rin = fr < nfull && f >= 0 && f < p.H;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c = c0 + 64 * j + lane;
-                    const bool in = rin && c < p.W;
-                    vx[i][j] = in ? iw[(int64_t)f * p.W + c] : 0.f;
-                    vq[i][j] = (in && !p.same_act) ? iq[(int64_t)f * p.W + c] : 0.f;
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = c0 + 64 * j + lane;
+                        v[i][j] = (rin && c < p.W) ? src[(int64_t)f * p.W + c] : 0.f;
+                    }
                 }
-            }
 #pragma unroll
-            for (int i = 0; i < kRI; ++i) {
-                const int fr = fr0 + wave + (kS2Threads / 64) * i;
-                const int li = fr >> 1, py = fr & 1;
+                for (int i = 0; i < kRI; ++i) {
+                    const int fr = wave + (kS2Threads / 64) * i;
+                    const int li = fr >> 1, py = fr & 1;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c = c0 + 64 * j + lane;
-                    if (fr < nfull && c < p.W) {
-                        const int o = (py * 2 + (c & 1)) * cls_stride + li * LP + 4 + (c >> 1);
-                        Lx[o] = vx[i][j];
-                        neg_track(signs, vx[i][j]);
-                        if (!p.same_act) { Lq[o] = vq[i][j]; neg_track(signs, vq[i][j]); }
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = c0 + 64 * j + lane;
+                        if (fr < nfull && c < p.W) {
+                            dst[(py * 2 + (c & 1)) * cls_stride + li * LP + 4 + (c >> 1)] = v[i][j];
+                            neg_track(signs, v[i][j]);
+                        }
                     }
                 }
             }
@@ -150,7 +150,7 @@ gpfq_gram_s2_kernel(S2Params p)
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int d = 0; d < 7; ++d) a1[d] = fma(qa[e], xw[e + d], a1[d]);
-            if (!p.same_act) {
+            if (!SAME) {
                 const float4 *W4 = reinterpret_cast<const float4 *>(__builtin_assume_aligned(Lq, 16)) + (ow_ >> 2);
                 const float4 w0 = W4[0], w1 = W4[1], w2 = W4[2];
                 const double qw[10] = {(double)w0.x, (double)w0.y, (double)w0.z, (double)w0.w, (double)w1.x, (double)w1.y, (double)w1.z,
@@ -179,7 +179,7 @@ gpfq_gram_s2_kernel(S2Params p)
                 const double qa = (double)Lq[oq];
 #pragma unroll
                 for (int d = 0; d < 7; ++d) b1[d] = fma(qa, (double)Lx[ow_ + d], b1[d]);
-                if (!p.same_act) {
+                if (!SAME) {
 #pragma unroll
                     for (int d = 0; d < 7; ++d) b2[d] = fma(qa, (double)Lq[ow_ + d], b2[d]);
                 }
@@ -195,8 +195,8 @@ gpfq_gram_s2_kernel(S2Params p)
     auto row_sum = [](double v) { v = ror_add<8>(v); v = ror_add<4>(v); v = ror_add<2>(v); v = ror_add<1>(v); return v; };
 #pragma unroll
     for (int d = 0; d < 7; ++d) {
-        const double s1 = row_sum(a1[d]), s2 = row_sum(p.same_act ? a1[d] : a2[d]);
-        const double t1 = ror_add<8>(b1[d]), t2 = ror_add<8>(p.same_act ? b1[d] : b2[d]);
+        const double s1 = row_sum(a1[d]), s2 = row_sum(SAME ? a1[d] : a2[d]);
+        const double t1 = ror_add<8>(b1[d]), t2 = ror_add<8>(SAME ? b1[d] : b2[d]);
         if (slot == 0) { out[(0 * 16 + wave) * kS2Acc + d] = s1; out[(0 * 16 + wave) * kS2Acc + 7 + d] = s2; }
         if (slot < 8) { out[((1 + slot) * 16 + wave) * kS2Acc + d] = t1; out[((1 + slot) * 16 + wave) * kS2Acc + 7 + d] = t2; }
     }
@@ -326,7 +326,8 @@ hipError_t launch_gram_s2(const float *act_w, const float *act_q, int64_t n, int
     const bool same_act = act_w == act_q;
     S2Plan P;
     if (!s2_plan(n, H, W, kS2K, kS2K, 2, 2, 1, 1, 0, 0, same_act, &P)) return hipErrorInvalidValue;
-    hipError_t attr = ensure_dynamic_lds((const void *)gpfq_gram_s2_kernel, P.lds);
+    hipError_t attr = same_act ? ensure_dynamic_lds((const void *)gpfq_gram_s2_kernel<true>, P.lds)
+                               : ensure_dynamic_lds((const void *)gpfq_gram_s2_kernel<false>, P.lds);
     if (attr != hipSuccess) return attr;
     S2Params p{};
     p.act_w = act_w; p.act_q = act_q; p.plane = n * H * W; p.n = (int)n; p.H = (int)H; p.W = (int)W; p.Wd = P.Wd;
@@ -346,7 +347,8 @@ hipError_t launch_gram_s2(const float *act_w, const float *act_q, int64_t n, int
         if (P.nwg[l] > maxwg) maxwg = P.nwg[l];
     }
     // ONE launch: blockIdx.y = row region (the border rows' workgroups run beside the interior's instead of after it)
-    hipLaunchKernelGGL(gpfq_gram_s2_kernel, dim3((unsigned)maxwg, (unsigned)P.nlaunch, (unsigned)nch), dim3(kS2Threads), P.lds, stream, p);
+    if (same_act) hipLaunchKernelGGL(gpfq_gram_s2_kernel<true>, dim3((unsigned)maxwg, (unsigned)P.nlaunch, (unsigned)nch), dim3(kS2Threads), P.lds, stream, p);
+    else hipLaunchKernelGGL(gpfq_gram_s2_kernel<false>, dim3((unsigned)maxwg, (unsigned)P.nlaunch, (unsigned)nch), dim3(kS2Threads), P.lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int64_t rec = gram_record(kS2K * kS2K);
