@@ -31,9 +31,10 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++
 # through extra register moves there.
 EXTRA_FLAGS = {"gpfq_pipe.hip": ["-fno-slp-vectorize"], "gpfq_blk.hip": ["-fno-slp-vectorize"]}
 # diagnostic builds (never the shipped library): GPFQ_DIAG="-DGPFQ_BLK_STAMPS" adds in-kernel phase stamps to gpfq_blk.hip,
-# "-DGPFQ_WIDE_STAMPS" to the several-wavefronts-per-neuron kernel of gpfq_wide.hip (printed from the kernel)
+# "-DGPFQ_WIDE_STAMPS" to the several-wavefronts-per-neuron kernel of gpfq_wide.hip (printed from the kernel),
+# "-DGPFQ_S2_SKIP=n" leaves a phase of gpfq_gram_s2_kernel out (wrong sums: timing experiments only)
 if os.environ.get("GPFQ_DIAG"):
-    for _src in ("gpfq_blk.hip", "gpfq_wide.hip"):
+    for _src in ("gpfq_blk.hip", "gpfq_wide.hip", "gpfq_gram_s2.hip"):
         EXTRA_FLAGS[_src] = EXTRA_FLAGS.get(_src, []) + os.environ["GPFQ_DIAG"].split()
 
 

@@ -36,11 +36,14 @@ namespace {
 
 constexpr int kS2D = 3;                // largest tap shift in a decimated plane: 7 taps -> a in 0..3
 constexpr int kS2K = 7;
+constexpr int kS2L = 4;                // zero floats left of a staged row: column j at index j + 4 puts a strip's operand positions (4 s ..) on a 16-byte boundary
 constexpr int kS2Threads = 1024;       // 16 wavefronts = 4 classes of s x 4 row shifts
 constexpr int kS2Acc = 15;             // 7 (G1) + 7 (G2) + sum x^2
 constexpr int kS2Slots = 9;            // regions per launch and class: interior columns + up to 8 border columns
-constexpr int kS2RB = 16;              // position rows per band (32 needs 141 KiB of LDS for two tensors: one workgroup per CU either way; not faster)
 constexpr int kS2MaxLaunch = 8;
+#ifndef GPFQ_S2_SKIP
+#define GPFQ_S2_SKIP 0                  // diagnostic builds: 1 no border columns, 2 no interior strips, 3 classes scattered once only, 4 no staging at all
+#endif
 
 struct S2Params {
     const float *act_w, *act_q;
@@ -53,11 +56,25 @@ struct S2Params {
     int64_t offs[kS2MaxLaunch];        // its partials inside a channel's block
     int nstrip;                        // interior columns [3, 3 + 4 nstrip)
     int nbc, bc[8];                    // border columns
-    int LP;                            // LDS row pitch in floats (column j at index j + 4)
+    int LP;                            // LDS row pitch in floats (column j at index j + kS2L)
+    int RB;                            // position rows per band
+    int cls;                           // floats per class in LDS: (RB + 3) rows of LP, rounded up to 64
+    int rawcap;                        // floats per tensor in the raw area: 2 (RB + 3) full rows
     double *part;                      // partials of channel 0: per region [nwg][4 classes][kS2Slots][16 roles][kS2Acc]
     int64_t part_cs;                   // doubles from one channel's partials (all regions) to the next channel's
     int *negflag;
 };
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int OFF> __device__ __forceinline__ void lds_rd128(v4f &v, unsigned addr)
+{
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+template <int OFF> __device__ __forceinline__ void lds_rd64(v2f &v, unsigned addr)
+{
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
 
 template <bool SAME>                  // both networks see the same planes (a first layer): G2 = G1, one tensor staged
 __global__ void __launch_bounds__(kS2Threads)
@@ -67,16 +84,21 @@ gpfq_gram_s2_kernel(S2Params p)
     const int reg = blockIdx.y;
     if ((int)blockIdx.x >= p.nwgs[reg]) return;
     const int r0 = p.r0s[reg], r1 = p.r1s[reg];
-    const int nbands = (r1 - r0 + kS2RB - 1) / kS2RB;
+    const int RB = p.RB;                                            // position rows per band
+    const int nbands = (r1 - r0 + RB - 1) / RB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ps = wave & 3, dyi = wave >> 2;                       // role: class of s, row shift -dyi
     const int pt = lane >> 4, slot = lane & 15;                     // class of t, lane slot within the class
-    constexpr int LR = kS2RB + kS2D;                                // staged rows per class
     const int LP = p.LP;
-    const int cls_stride = LR * LP + 32;                            // (+128 bytes: the four classes of a wavefront's lanes start in different banks)
+    // class pitch: a multiple of 256 bytes.  A ds_read_b128 is served in groups of 16 lanes -- 8 of one class with strips {0-3, 12-15}
+    // and 8 of the next with strips {4-11} (MI355X_MICROARCH.md, LDS) -- over 64 banks: with equal class bases (mod 256 B) the 16
+    // strips of a group are the 16 slots of a bank row (a pitch of 128 B more, as in the first version, made every own-row read 2-way).
+    const int cls_stride = p.cls;
     float *Lx = s2_lds;                                             // [4][LR][LP]
     float *Lq = SAME ? s2_lds : s2_lds + 4 * cls_stride;
+    const unsigned lx_base = lds_addr(Lx), lq_base = lds_addr(Lq);
+    float *raw = s2_lds + (SAME ? 4 : 8) * cls_stride;              // [tensors][rawcap]: the band's full rows as they lie in the plane
     const float *pw = p.act_w + (int64_t)blockIdx.z * p.plane;
     const float *pq = p.act_q + (int64_t)blockIdx.z * p.plane;
 
@@ -91,68 +113,100 @@ gpfq_gram_s2_kernel(S2Params p)
     __syncthreads();
 
     const int items = p.n * nbands;
+    // Staging of band `item`: its full rows [2 (y0 - 3), 2 y1) are ONE contiguous piece of the plane -- LDS-DMA (4 bytes per lane,
+    // no registers, no alignment demands) copies it to the raw area while the previous band is being summed; the de-interleave
+    // pass (LDS -> LDS) then scatters it into the four classes.  Rows above / below the plane are not read (zero-filled below).
+    auto band_rows = [&](int item, int &img, int &y0, int &rows, int &fs, int &fe) {
+        img = item / nbands;
+        const int band = item - img * nbands;
+        y0 = r0 + band * RB;
+        rows = min(r1, y0 + RB) - y0;
+        const int f0 = 2 * (y0 - kS2D);
+        fs = max(f0, 0); fe = min(f0 + 2 * (rows + kS2D), p.H);
+    };
+    auto issue = [&](int item) {
+        int img, y0, rows, fs, fe;
+        band_rows(item, img, y0, rows, fs, fe);
+        const int total = (fe - fs) * p.W;
+        const int64_t at = ((int64_t)img * p.H + fs) * p.W;
+#pragma unroll
+        for (int tz = 0; tz < (SAME ? 1 : 2); ++tz) {
+            const float *src = (tz ? pq : pw) + at;
+            const unsigned dst = lds_addr(raw + tz * p.rawcap);
+            for (int c = wave * 64; c < total && GPFQ_S2_SKIP != 4; c += kS2Threads) {
+                if (c + lane < total) glds4(src + c + lane, dst + 4u * (unsigned)c);
+            }
+        }
+    };
+    if ((int)blockIdx.x < items) issue(blockIdx.x);
     for (int it = blockIdx.x; it < items; it += p.nwgs[reg]) {
-        const int img = it / nbands, band = it - img * nbands;
-        const int y0 = r0 + band * kS2RB, y1 = min(r1, y0 + kS2RB), rows = y1 - y0;
-        // ---- stage decimated rows [y0 - 3, y1) of all four classes: full rows 2 (y0 - 3) .. 2 y1 - 1, de-interleaved ----
-        const int nfull = 2 * (rows + kS2D);
-        const float *iw = pw + (int64_t)img * p.H * p.W, *iq = pq + (int64_t)img * p.H * p.W;
-        // (every wavefront requests ALL its elements of the band -- up to 3 rows x 4 column chunks of one tensor -- before it writes
-        //  the first to LDS: one memory latency per band instead of one per element; wider images take further passes)
-        constexpr int kRI = (2 * (kS2RB + kS2D) + kS2Threads / 64 - 1) / (kS2Threads / 64);     // rows per wavefront: 3
-        for (int tz = 0; tz < (SAME ? 1 : 2); ++tz) {              // one tensor at a time: 12 registers in flight
-            const float *src = tz ? iq : iw;
+        int img, y0, rows, fs, fe;
+        band_rows(it, img, y0, rows, fs, fe);
+        const int nfull = 2 * (rows + kS2D), f0 = 2 * (y0 - kS2D);
+        dma_wait();
+        __syncthreads();                                            // the raw rows have landed; the previous band's sums are done
+#pragma unroll
+        for (int tz = 0; tz < (SAME ? 1 : 2) && (GPFQ_S2_SKIP < 3 || it == (int)blockIdx.x); ++tz) {
+            const float *rw_ = raw + tz * p.rawcap;
             float *dst = tz ? Lq : Lx;
-            for (int c0 = 0; c0 < p.W; c0 += 256) {
-                float v[kRI][4];
-#pragma unroll
-                for (int i = 0; i < kRI; ++i) {
-                    const int fr = wave + (kS2Threads / 64) * i;
-                    const int f = 2 * (y0 - kS2D + (fr >> 1)) + (fr & 1);
-                    const bool rin = fr < nfull && f >= 0 && f < p.H;
+            for (int fr = wave; fr < nfull; fr += kS2Threads / 64) {
+                const int f = f0 + fr, li = fr >> 1, py = fr & 1;
+                const bool rin = f >= fs && f < fe;
+                const float *rr = rw_ + (f - fs) * p.W;
+                float *dd = dst + py * 2 * cls_stride + li * LP + kS2L;
+                for (int c0 = 0; c0 < p.W; c0 += 256) {
+                    float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int c = c0 + 64 * j + lane;
-                        v[i][j] = (rin && c < p.W) ? src[(int64_t)f * p.W + c] : 0.f;
+                        v[j] = (rin && c < p.W) ? rr[c] : 0.f;
                     }
-                }
-#pragma unroll
-                for (int i = 0; i < kRI; ++i) {
-                    const int fr = wave + (kS2Threads / 64) * i;
-                    const int li = fr >> 1, py = fr & 1;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int c = c0 + 64 * j + lane;
-                        if (fr < nfull && c < p.W) {
-                            dst[(py * 2 + (c & 1)) * cls_stride + li * LP + 4 + (c >> 1)] = v[i][j];
-                            neg_track(signs, v[i][j]);
-                        }
+                        if (c < p.W) { dd[(c & 1) * cls_stride + (c >> 1)] = v[j]; neg_track(signs, v[j]); }
                     }
                 }
             }
         }
-        __syncthreads();
+        __syncthreads();                                            // the classes are ready, the raw area is free
+        if (it + p.nwgs[reg] < items) issue(it + p.nwgs[reg]);
         // ---- set A: strips of four interior columns, all 16 lanes of a class ----
         // (item k = row * nstrip + strip, k = slot, slot + 16, ...: stepped without a division)
         int row = 0, strip = slot;
         while (strip >= p.nstrip) { strip -= p.nstrip; ++row; }
-        for (; row < rows;) {
-            const int oq = pt * cls_stride + (row + kS2D) * LP + 4 + 4 * strip;            // own row, columns 4 strip .. (positions 3 + 4 strip ..)
-            const int ow_ = ps * cls_stride + (row + kS2D - dyi) * LP + 4 + 4 * strip;    // operand row, columns (3 + 4 strip) - 3 ..
-            const float4 *Q4 = reinterpret_cast<const float4 *>(__builtin_assume_aligned(Lq, 16)) + (oq >> 2);
-            const float4 *X4 = reinterpret_cast<const float4 *>(__builtin_assume_aligned(Lx, 16)) + (ow_ >> 2);
-            const float4 q0 = Q4[0], q1 = Q4[1];
-            const float4 x0 = X4[0], x1 = X4[1], x2 = X4[2];
-            const double qa[4] = {(double)q0.w, (double)q1.x, (double)q1.y, (double)q1.z};
-            const double xw[10] = {(double)x0.x, (double)x0.y, (double)x0.z, (double)x0.w, (double)x1.x, (double)x1.y, (double)x1.z,
-                                   (double)x1.w, (double)x2.x, (double)x2.y};
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int d = 0; d < 7; ++d) a1[d] = fma(qa[e], xw[e + d], a1[d]);
+        int oq = pt * cls_stride + (row + kS2D) * LP + kS2L + 4 * strip;          // own row: positions 3 + 4 strip .. are floats 3 .. 6 from here
+        int ow_ = oq + (ps - pt) * cls_stride - dyi * LP;                         // operand row: positions (3 + 4 strip) - 3 ..
+        const int wrap = LP - 4 * p.nstrip;                                    // from the end of a row's strips to the next row's first
+        const int drow = 16 / p.nstrip, dstrip = 16 - drow * p.nstrip, dstep = drow * LP + 4 * dstrip;
+        for (; row < rows && GPFQ_S2_SKIP != 2;) {
+            // (reads issued by hand: left to itself the compiler narrows the own-row pair to ds_read2_b32 -- 32-bank addressing, 4-way
+            //  conflicts between the lanes of two classes -- and waits for all eight before the first product)
+            const unsigned aq = lq_base + 4u * (unsigned)oq, ax = lx_base + 4u * (unsigned)ow_;
+            v4f q0, q1, x0, x1, w0, w1;
+            v2f x2, w2;
+            lds_rd128<0>(q0, aq); lds_rd128<16>(q1, aq);
+            lds_rd128<0>(x0, ax); lds_rd128<16>(x1, ax); lds_rd64<32>(x2, ax);
             if (!SAME) {
-                const float4 *W4 = reinterpret_cast<const float4 *>(__builtin_assume_aligned(Lq, 16)) + (ow_ >> 2);
-                const float4 w0 = W4[0], w1 = W4[1], w2 = W4[2];
+                const unsigned aw = lq_base + 4u * (unsigned)ow_;
+                lds_rd128<0>(w0, aw); lds_rd128<16>(w1, aw); lds_rd64<32>(w2, aw);
+                asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(q0), "+v"(q1), "+v"(x0), "+v"(x1), "+v"(x2));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(x0), "+v"(x1), "+v"(x2));
+            }
+            const double qa[4] = {(double)q0.w, (double)q1.x, (double)q1.y, (double)q1.z};
+            {
+                const double xw[10] = {(double)x0.x, (double)x0.y, (double)x0.z, (double)x0.w, (double)x1.x, (double)x1.y, (double)x1.z,
+                                       (double)x1.w, (double)x2.x, (double)x2.y};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int d = 0; d < 7; ++d) a1[d] = fma(qa[e], xw[e + d], a1[d]);
+            }
+            if (!SAME) {
+                // (the first Gram's sums are operands of the wait: they stay in front of it, under the second operand's latency)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]),
+                             "+v"(a1[4]), "+v"(a1[5]), "+v"(a1[6]));
                 const double qw[10] = {(double)w0.x, (double)w0.y, (double)w0.z, (double)w0.w, (double)w1.x, (double)w1.y, (double)w1.z,
                                        (double)w1.w, (double)w2.x, (double)w2.y};
 #pragma unroll
@@ -167,15 +221,16 @@ gpfq_gram_s2_kernel(S2Params p)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) a3 = fma(xa[e], xa[e], a3);
             }
-            strip += 16;
-            while (strip >= p.nstrip) { strip -= p.nstrip; ++row; }
+            strip += dstrip; row += drow; oq += dstep; ow_ += dstep;          // 16 items on
+            const bool w = strip >= p.nstrip;
+            strip -= w ? p.nstrip : 0; row += w ? 1 : 0; oq += w ? wrap : 0; ow_ += w ? wrap : 0;
         }
         // ---- set B: border column (slot mod 8), the rows split between lanes slot and slot + 8 ----
-        if ((slot & 7) < p.nbc) {
+        if ((slot & 7) < p.nbc && GPFQ_S2_SKIP != 1) {
             const int cx = p.bc[slot & 7];
             for (int row = slot >> 3; row < rows; row += 2) {
-                const int oq = pt * cls_stride + (row + kS2D) * LP + 4 + cx;
-                const int ow_ = ps * cls_stride + (row + kS2D - dyi) * LP + 4 + cx - kS2D;
+                const int oq = pt * cls_stride + (row + kS2D) * LP + kS2L + cx;
+                const int ow_ = ps * cls_stride + (row + kS2D - dyi) * LP + kS2L + cx - kS2D;
                 const double qa = (double)Lq[oq];
 #pragma unroll
                 for (int d = 0; d < 7; ++d) b1[d] = fma(qa, (double)Lx[ow_ + d], b1[d]);
@@ -263,7 +318,7 @@ gpfq_gram_s2_combine_kernel(const double *__restrict__ part, S2Combine c, double
 }
 
 struct S2Plan {
-    int oh, ow, Wd, nstrip, nbc, bc[8], LP;
+    int oh, ow, Wd, nstrip, nbc, bc[8], LP, RB, cls, rawcap;
     int nlaunch;
     int r0[kS2MaxLaunch], r1[kS2MaxLaunch], nwg[kS2MaxLaunch];
     int64_t off[kS2MaxLaunch];
@@ -283,9 +338,20 @@ bool s2_plan(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw, in
     q.nbc = 0;
     for (int c = 0; c < kS2D; ++c) q.bc[q.nbc++] = c;
     for (int c = kS2D + 4 * q.nstrip; c < ow + kS2D; ++c) { if (q.nbc >= 8) return false; q.bc[q.nbc++] = c; }
-    q.LP = (4 + q.Wd + kS2D + 4 + 3) & ~3;                           // 4 zeros left, the row, >= 7 zeros right
-    q.lds = (size_t)(same_act ? 4 : 8) * ((kS2RB + kS2D) * q.LP + 32) * sizeof(float);
-    if (q.lds > 156 * 1024) return false;
+    q.LP = (kS2L + q.Wd + kS2D + 4 + 3) & ~3;                        // 4 zeros left, the row, >= 7 zeros right
+    // pitch = 4 (mod 32) floats: the border-column walks read one column of two consecutive rows per class (ds_read_b32, 32 banks):
+    // with a pitch of 0 (mod 32) -- 128 floats for ResNet50's conv1 -- the two rows of every read share their banks (2-way)
+    while ((q.LP & 31) != 4) q.LP += 4;
+    // the longest band whose classes (4 per tensor) and raw rows fit the 160 KiB of a CU
+    const int ntz = same_act ? 1 : 2;
+    q.RB = 0;
+    for (int rb = 32; rb >= 4; rb >>= 1) {
+        const int rawcap = (int)((2 * (rb + kS2D) * W + 63) & ~(int64_t)63);
+        const int cls = ((rb + kS2D) * q.LP + 63) & ~63;
+        const size_t lds = ((size_t)ntz * 4 * cls + (size_t)ntz * rawcap) * sizeof(float);
+        if (lds <= 158 * 1024) { q.RB = rb; q.cls = cls; q.rawcap = rawcap; q.lds = lds; break; }
+    }
+    if (!q.RB) return false;
     // launches: the interior rows, then every border row
     int l = 0;
     int64_t off = 0;
@@ -294,7 +360,7 @@ bool s2_plan(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw, in
         off += (int64_t)nwg * 4 * kS2Slots * 16 * kS2Acc;
         ++l;
     };
-    const int64_t items = n * ((oh - kS2D + kS2RB - 1) / kS2RB);
+    const int64_t items = n * ((oh - kS2D + q.RB - 1) / q.RB);
     add(kS2D, oh, (int)(items < 512 ? items : 512));
     for (int r = 0; r < kS2D; ++r) add(r, r + 1, (int)(n < 128 ? n : 128));
     for (int r = oh; r < oh + kS2D; ++r) add(r, r + 1, (int)(n < 128 ? n : 128));
@@ -334,7 +400,7 @@ hipError_t launch_gram_s2(const float *act_w, const float *act_q, int64_t n, int
     p.same_act = same_act ? 1 : 0;
     p.nstrip = P.nstrip; p.nbc = P.nbc;
     for (int i = 0; i < 8; ++i) p.bc[i] = P.bc[i];
-    p.LP = P.LP; p.negflag = negflag; p.part_cs = P.part_per_channel;
+    p.LP = P.LP; p.RB = P.RB; p.cls = P.cls; p.rawcap = P.rawcap; p.negflag = negflag; p.part_cs = P.part_per_channel;
     S2Combine c{};
     c.nlaunch = P.nlaunch; c.oh = P.oh; c.ow = P.ow; c.nstrip = P.nstrip; c.nbc = P.nbc;
     for (int i = 0; i < 8; ++i) c.bc[i] = P.bc[i];
