@@ -34,7 +34,7 @@ EXTRA_FLAGS = {"gpfq_pipe.hip": ["-fno-slp-vectorize"], "gpfq_blk.hip": ["-fno-s
 # "-DGPFQ_WIDE_STAMPS" to the several-wavefronts-per-neuron kernel of gpfq_wide.hip (printed from the kernel),
 # "-DGPFQ_S2_SKIP=n" leaves a phase of gpfq_gram_s2_kernel out (wrong sums: timing experiments only)
 if os.environ.get("GPFQ_DIAG"):
-    for _src in ("gpfq_blk.hip", "gpfq_wide.hip", "gpfq_gram_s2.hip"):
+    for _src in ("gpfq_blk.hip", "gpfq_wide.hip", "gpfq_gram_s2.hip", "gpfq_gram_image.hip"):
         EXTRA_FLAGS[_src] = EXTRA_FLAGS.get(_src, []) + os.environ["GPFQ_DIAG"].split()
 
 

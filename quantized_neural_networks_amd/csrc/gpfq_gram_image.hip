@@ -435,17 +435,18 @@ struct NhwcParams {
 constexpr int kNhwcStrip = 5;             // positions of an image row per item (the window is kNhwcStrip + 4 columns wide)
 constexpr int kNhwcDepth = 4;             // rows of the LDS ring
 
-template <bool SAME_ACT>
-__global__ void __launch_bounds__(64)
-gpfq_gram_shift_nhwc_kernel(NhwcParams p)
+// The walk of one class.  SW = kNhwcStrip for the classes of the middle columns; SW = 1 for the border-column classes, whose one
+// position per row needs five columns, not nine: what bounds this kernel is the rate at which the CU's vector-memory path takes
+// LDS-DMA requests (profiles/r03/nhwc_pair_experiment.txt), so a class requests no column and no row it does not sum over --
+// rows above the image (zeros) are neither requested nor walked.
+template <bool SAME_ACT, int SW>
+__device__ __forceinline__ void nhwc_class_walk(const NhwcParams &p, float *ring_base, int cls)
 {
-    constexpr int SW = kNhwcStrip, NC = SW + 4, D = kNhwcDepth, NT = SAME_ACT ? 1 : 2;
-    __shared__ float ring[D][NT][NC][64];
+    constexpr int NC = SW + 4, D = kNhwcDepth, NT = SAME_ACT ? 1 : 2;
+    float (*ring)[NT][NC][64] = reinterpret_cast<float (*)[NT][NC][64]>(ring_base);
     const int lane = threadIdx.x;
     const int64_t ch = (int64_t)blockIdx.y * 64 + lane;
     const bool live = ch < p.nch;
-    int cls = 0;
-    while ((int)blockIdx.x >= p.slot_off[cls + 1]) ++cls;
     const int k = blockIdx.x - p.slot_off[cls], nk = p.slot_off[cls + 1] - p.slot_off[cls];
     const int cy = cls / 3, cx = cls - 3 * cy;
     const int H = p.H, W = p.W;
@@ -454,7 +455,9 @@ gpfq_gram_shift_nhwc_kernel(NhwcParams p)
     const int ns = (xhi - xlo + SW) / SW;
     const int64_t nitems = (int64_t)p.n * ns;
     const float *bw = p.act_w + (live ? ch : 0), *bq = p.act_q + (live ? ch : 0);
-    const unsigned ring_addr = lds_addr(&ring[0][0][0][0]);
+    const unsigned ring_addr = lds_addr(ring_base);
+    const int nr = yb - ya + 3;                                     // rows ya - 2 .. yb of the walk, j = 0 .. nr - 1
+    const int j0 = ya < 2 ? 2 - ya : 0;                             // rows j < j0 lie above the image
 
     double c1[13], c2[13], c3 = 0.0;
 #pragma unroll
@@ -466,19 +469,16 @@ gpfq_gram_shift_nhwc_kernel(NhwcParams p)
         const int64_t img = item / ns;
         const int xa = xlo + SW * (int)(item - img * ns);          // first position; window columns xa - 2 .. xa + SW + 1
         const int64_t ibase = img * H * (int64_t)W * p.cin;
-        const int nr = yb - ya + 3;                                 // rows ya - 2 .. yb of the walk, j = 0 .. nr - 1
-        // request row j of the walk into ring slot j % D (rows / columns outside the image are requested from a clamped address
-        // and read as zeros by the consumer: every row is then exactly 2 * NC requests, which keeps the wait counts static)
+        // request row j of the walk into ring slot (j - j0) % D (columns outside the image are requested from a clamped address
+        // and read as zeros by the consumer: every row is then exactly NT * NC requests, which keeps the wait counts static)
         auto request = [&](int j) {
-            int y = ya - 2 + j;
-            y = y < 0 ? 0 : y;
-            const int64_t rb = ibase + (int64_t)y * W * p.cin;
+            const int64_t rb = ibase + (int64_t)(ya - 2 + j) * W * p.cin;
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
                 int col = xa - 2 + i;
                 col = col < 0 ? 0 : (col >= W ? W - 1 : col);
-                glds4(bw + rb + (int64_t)col * p.cin, ring_addr + (unsigned)((((j % D) * NT + 0) * NC + i) * 256));
-                if (!SAME_ACT) glds4(bq + rb + (int64_t)col * p.cin, ring_addr + (unsigned)((((j % D) * NT + 1) * NC + i) * 256));
+                glds4(bw + rb + (int64_t)col * p.cin, ring_addr + (unsigned)(((((j - j0) % D) * NT + 0) * NC + i) * 256));
+                if (!SAME_ACT) glds4(bq + rb + (int64_t)col * p.cin, ring_addr + (unsigned)(((((j - j0) % D) * NT + 1) * NC + i) * 256));
             }
         };
         float rx[NC], rq[NC];
@@ -487,28 +487,33 @@ gpfq_gram_shift_nhwc_kernel(NhwcParams p)
             if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NC * NT) : "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 * NC * NT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const bool vy = ya - 2 + j >= 0;
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
                 const int col = xa - 2 + i;
-                const bool ok = vy && col >= 0 && col < W && live;
-                const float a = ring[j % D][0][i][lane];
+                const bool ok = col >= 0 && col < W && live;
+                const float a = ring[(j - j0) % D][0][i][lane];
                 rx[i] = ok ? a : 0.f;
-                if (!SAME_ACT) { const float b = ring[j % D][NT - 1][i][lane]; rq[i] = ok ? b : 0.f; }
+                if (!SAME_ACT) { const float b = ring[(j - j0) % D][NT - 1][i][lane]; rq[i] = ok ? b : 0.f; }
             }
         };
         static_assert(D == 4, "the wait counts above are written for a ring of four rows");
 #pragma unroll
         for (int j = 0; j < D - 1; ++j)
-            if (j < nr) request(j);
+            if (j0 + j < nr) request(j0 + j);
         double Bx[3][NC], Bq[3][NC];
-        // rows ya - 2, ya - 1 (j = 0, 1) fill the two buffers above; each consumed row frees its ring slot for row j + D
-        consume(0); if (3 < nr) request(3);
 #pragma unroll
-        for (int i = 0; i < NC; ++i) { Bx[1][i] = (double)rx[i]; Bq[1][i] = SAME_ACT ? Bx[1][i] : (double)rq[i]; }
-        consume(1); if (4 < nr) request(4);
+        for (int i = 0; i < NC; ++i) { Bx[1][i] = Bq[1][i] = 0.0; Bx[2][i] = Bq[2][i] = 0.0; }
+        // rows ya - 2, ya - 1 (j = 0, 1), where inside the image, fill the two buffers above; each consumed row frees its ring slot for row j + D
+        if (j0 == 0) {
+            consume(0); if (0 + D - 1 < nr) request(0 + D - 1);
 #pragma unroll
-        for (int i = 0; i < NC; ++i) { Bx[2][i] = (double)rx[i]; Bq[2][i] = SAME_ACT ? Bx[2][i] : (double)rq[i]; }
+            for (int i = 0; i < NC; ++i) { Bx[1][i] = (double)rx[i]; Bq[1][i] = SAME_ACT ? Bx[1][i] : (double)rq[i]; }
+        }
+        if (j0 <= 1) {
+            consume(1); if (1 + D - 1 < nr) request(1 + D - 1);
+#pragma unroll
+            for (int i = 0; i < NC; ++i) { Bx[2][i] = (double)rx[i]; Bq[2][i] = SAME_ACT ? Bx[2][i] : (double)rq[i]; }
+        }
         // one row: ROT names the buffers (row y in B[ROT], y - 1 in B[ROT + 2], y - 2 in B[ROT + 1], indices mod 3)
         auto step = [&](int j, auto rot_tag) {
             constexpr int R0 = decltype(rot_tag)::value, R1 = (R0 + 2) % 3, R2 = (R0 + 1) % 3;
@@ -552,6 +557,17 @@ gpfq_gram_shift_nhwc_kernel(NhwcParams p)
         for (int i = 0; i < 13; ++i) { out[i] = c1[i]; out[13 + i] = SAME_ACT ? c1[i] : c2[i]; }
         out[26] = c3;
     }
+}
+
+template <bool SAME_ACT>
+__global__ void __launch_bounds__(64)
+gpfq_gram_shift_nhwc_kernel(NhwcParams p)
+{
+    __shared__ float ring[kNhwcDepth * (SAME_ACT ? 1 : 2) * (kNhwcStrip + 4) * 64];
+    int cls = 0;
+    while ((int)blockIdx.x >= p.slot_off[cls + 1]) ++cls;
+    if (cls % 3 == 1) nhwc_class_walk<SAME_ACT, kNhwcStrip>(p, ring, cls);
+    else nhwc_class_walk<SAME_ACT, 1>(p, ring, cls);
 }
 
 // Class sums of the NHWC form -> the N = 9 Gram record of a channel + the float32 row norms (as gpfq_gram_shift_combine_kernel).
@@ -762,7 +778,9 @@ static void nhwc_slots(int64_t n, int64_t H, int64_t W, int64_t nch, NhwcParams 
         const int cy = c / 3, cx = c % 3;
         const int64_t rows = cy == 1 ? H - 2 : 1, strips = cx == 1 ? ns_mid : 1;
         items[c] = n * strips;
-        work[c] = (double)items[c] * (double)(rows + 2);
+        // row steps of an item (rows above the image are not walked) x the columns a step requests
+        const int64_t steps = cy == 0 ? 1 : (cy == 1 ? rows + 1 : 3);
+        work[c] = (double)items[c] * (double)steps * (cx == 1 ? kNhwcStrip + 4 : 7);   // (a border-column step: five of the nine requests, a fifth of the sums, the same waits)
         wsum += work[c];
     }
     p.slot_off[0] = 0;
