@@ -295,6 +295,19 @@ int gpfq_channel_dead(const float *act, int64_t n, int64_t H, int64_t W, int64_t
                       int32_t *dead, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * A whole conv layer of kernel_size (1, 1) in one call: every (channel, filter) pair is a ONE-step walk -- u = 0, so rule (ii)
+ * (scripts/quantized_network.py:86-87) returns nearest(alphabet, w) unless the channel is dead on the strided grid, where rule
+ * (i) (:83-84) returns the literal 0 (index: the alphabet's zero member, -1 if it has none).  gpfq_channel_dead + the MSQ pass
+ * with its mask, queued back to back: the values _quantize_conv2D_layer_parallel_jit reaches through its general path (:835-842
+ * is dead code there) for such a layer.
+ * act_q [device] f32 [n][H][W][Cin]; Wt [device] f32 [Cin][F] (the Keras kernel [1][1][Cin][F] as it lies); Q f32 / qidx i8 (i16
+ * beyond 64 members) [Cin][F], either may be NULL; workspace gpfq_conv1x1_workspace_bytes(Cin) bytes, 16-byte aligned.
+ */
+size_t gpfq_conv1x1_workspace_bytes(int64_t Cin);
+int gpfq_quantize_conv1x1(const float *act_q, int64_t n, int64_t H, int64_t W, int64_t Cin, int sh, int sw, const float *Wt, int64_t F,
+                          const double *alphabet, int M, float *Q, void *qidx, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * The channel loop of a conv layer in one call: for each of `nch` input channels build the two patch
  * matrices and run gpfq_quantize_neurons_gram for that channel's F filters -- the body of
  * `for channel_idx in range(num_channels)` in _quantize_conv2D_layer_parallel_jit

@@ -95,7 +95,7 @@ hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes)
 
 extern "C" {
 
-int gpfq_version(void) { return 300; }
+int gpfq_version(void) { return 301; }
 
 const char *gpfq_last_dense_kernel(void) { return g_dense_kernel; }
 
@@ -582,6 +582,33 @@ int gpfq_channel_dead(const float *act, int64_t n, int64_t H, int64_t W, int64_t
     if (n > 0 && !act) return fail(GPFQ_ERR_INVALID_ARG, "NULL activations");
     hipError_t e = gpfq::launch_channel_dead(act, n, H, W, Cin, sh, sw, dead, workspace, prefix_positions, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_channel_dead");
+}
+
+size_t gpfq_conv1x1_workspace_bytes(int64_t Cin)
+{
+    return Cin > 0 ? gpfq_channel_dead_workspace_bytes(Cin) + (((size_t)Cin * sizeof(int32_t) + 255) & ~(size_t)255) : 0;
+}
+
+int gpfq_quantize_conv1x1(const float *act_q, int64_t n, int64_t H, int64_t W, int64_t Cin, int sh, int sw, const float *Wt, int64_t F,
+                          const double *alphabet, int M, float *Q, void *qidx, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (n < 0 || H <= 0 || W <= 0 || Cin <= 0 || F < 0 || sh <= 0 || sw <= 0) return fail(GPFQ_ERR_INVALID_ARG, "bad shape or stride");
+    HostAlphabet A;
+    int rc = make_alphabet(alphabet, M, -1, &A);
+    if (rc != GPFQ_OK) return rc;
+    if (F == 0) return GPFQ_OK;
+    if (!Wt || (!Q && !qidx)) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    if (n > 0 && !act_q) return fail(GPFQ_ERR_INVALID_ARG, "NULL activations");
+    if (workspace_bytes < gpfq_conv1x1_workspace_bytes(Cin) || !workspace || (uintptr_t)workspace % 16 != 0)
+        return fail(GPFQ_ERR_WORKSPACE, "workspace too small or misaligned");
+    int zero_idx = -1;
+    for (int k = 0; k < M; ++k)
+        if (alphabet[k] == 0.0) zero_idx = k;
+    int32_t *dead = reinterpret_cast<int32_t *>(static_cast<char *>(workspace) + gpfq_channel_dead_workspace_bytes(Cin));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = gpfq::launch_channel_dead(act_q, n, H, W, Cin, sh, sw, dead, workspace, 0, st);
+    if (e == hipSuccess) e = gpfq::launch_msq(Wt, Cin * F, A.A, Q, static_cast<int8_t *>(qidx), st, A.big(), dead, F, zero_idx);
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_conv1x1");
 }
 
 static size_t al256c(size_t x) { return (x + 255) & ~(size_t)255; }

@@ -229,8 +229,9 @@ hipError_t launch_row_stats(const float *X, const float *Xq, int64_t N, int64_t 
                             RowStats *stats, hipStream_t stream);
 hipError_t launch_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, float *nrm32, hipStream_t stream);
 // big != NULL (65..256 members): A is unused, index arrays hold int16 elements (assemble: bits = 16)
+// dead / row_len / zero_idx: weights [rows][row_len]; rows with dead[row] != 0 take Q = 0, index zero_idx (a 1 x 1 conv layer's dead channels)
 hipError_t launch_msq(const float *W, int64_t n, const AlphabetArg &A, float *Q, int8_t *qidx, hipStream_t stream,
-                      const AlphabetBig *big = nullptr);
+                      const AlphabetBig *big = nullptr, const int32_t *dead = nullptr, int64_t row_len = 1, int zero_idx = -1);
 hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, int64_t C, int bits, float *Q, int8_t *idxT,
                            hipStream_t stream, const AlphabetBig *big = nullptr);
 hipError_t launch_pack(const int8_t *qidx, int64_t N, int64_t C, int bits, uint8_t *packed, hipStream_t stream);

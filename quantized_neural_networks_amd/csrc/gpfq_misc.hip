@@ -330,10 +330,17 @@ hipError_t launch_row_stats(const float *X, const float *Xq, int64_t N, int64_t 
 // (_bit_round_parallel applied per weight, scripts/quantize_pretrained_mlp.py:109).
 template <class Alph, class Idx>
 __global__ void __launch_bounds__(256)
-gpfq_msq_kernel(const float *__restrict__ W, int64_t n, Alph A, float *__restrict__ Q, Idx *__restrict__ qidx)
+gpfq_msq_kernel(const float *__restrict__ W, int64_t n, Alph A, float *__restrict__ Q, Idx *__restrict__ qidx,
+                const int32_t *__restrict__ dead, int64_t row_len, int zero_idx)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        // (the one-step walks of a 1 x 1 conv layer: weights [channel][filter], a dead channel takes the literal 0 of rule (i))
+        if (dead && dead[i / row_len]) {
+            if (Q) Q[i] = 0.f;
+            if (qidx) qidx[i] = (Idx)zero_idx;
+            continue;
+        }
         const double t = (double)W[i];
         int best = 0;
         double dbest = fabs(A.a[0] - t);
@@ -347,16 +354,18 @@ gpfq_msq_kernel(const float *__restrict__ W, int64_t n, Alph A, float *__restric
 }
 
 hipError_t launch_msq(const float *W, int64_t n, const AlphabetArg &A, float *Q, int8_t *qidx, hipStream_t stream,
-                      const AlphabetBig *big)
+                      const AlphabetBig *big, const int32_t *dead, int64_t row_len, int zero_idx)
 {
     if (n == 0) return hipSuccess;
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
+    if (row_len < 1) row_len = 1;
     if (big)
         hipLaunchKernelGGL((gpfq_msq_kernel<AlphabetBig, int16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, W, n, *big, Q,
-                           reinterpret_cast<int16_t *>(qidx));
+                           reinterpret_cast<int16_t *>(qidx), dead, row_len, zero_idx);
     else
-        hipLaunchKernelGGL((gpfq_msq_kernel<AlphabetArg, int8_t>), dim3((unsigned)blocks), dim3(256), 0, stream, W, n, A, Q, qidx);
+        hipLaunchKernelGGL((gpfq_msq_kernel<AlphabetArg, int8_t>), dim3((unsigned)blocks), dim3(256), 0, stream, W, n, A, Q, qidx,
+                           dead, row_len, zero_idx);
     return hipGetLastError();
 }
 

@@ -43,6 +43,8 @@ SYMBOLS = {
     "gpfq_channel_sumsq": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _vp, _sz, _vp]),
     "gpfq_channel_dead_workspace_bytes": (_sz, [_i64]),
     "gpfq_channel_dead": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _int, _i64, _vp, _vp, _sz, _vp]),
+    "gpfq_conv1x1_workspace_bytes": (_sz, [_i64]),
+    "gpfq_quantize_conv1x1": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _i64, _vp, _int, _vp, _vp, _vp, _sz, _vp]),
     "gpfq_conv_channels_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _i64, _int]),
     "gpfq_quantize_conv_channels": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int,
                                            _vp, _dp, _int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -77,7 +79,7 @@ def lib_path():
     return _build.LIB
 
 
-ABI_VERSION = 300                  # gpfq_version() of the library this binding was written against
+ABI_VERSION = 301                  # gpfq_version() of the library this binding was written against
 
 
 def load():
@@ -327,6 +329,28 @@ def channel_dead(act, strides=(1, 1), prefix_positions=0):
                                    out.data_ptr(), ws.data_ptr(), nbytes, _stream())
     _check(rc, "gpfq_channel_dead")
     return out != 0
+
+
+def quantize_conv1x1(act_q, W2, alphabet, strides=(1, 1)):
+    """A conv layer of kernel_size (1, 1) in one call (gpfq_quantize_conv1x1): act_q NHWC f32, W2 f32 [Cin][F] ->
+    (Q f32 [Cin][F], idx i8 / i16 [Cin][F]); dead channels take 0 / the alphabet's zero index.  No sync."""
+    _dev(act_q, torch.float32, "act_q")
+    _dev(W2, torch.float32, "W2")
+    if act_q.dim() != 4 or not act_q.is_contiguous() or W2.dim() != 2 or not W2.is_contiguous() or W2.shape[0] != act_q.shape[3]:
+        raise GpfqError("quantize_conv1x1 needs a contiguous NHWC tensor and a contiguous [Cin][F] kernel")
+    n, H, W, Cin = act_q.shape
+    F = W2.shape[1]
+    arr, M, _ = _alphabet(alphabet)
+    lib = load()
+    nbytes = lib.gpfq_conv1x1_workspace_bytes(Cin)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=act_q.device)
+    Q = torch.empty((Cin, F), dtype=torch.float32, device=act_q.device)
+    idx = torch.empty((Cin, F), dtype=index_dtype(M), device=act_q.device)
+    with torch.cuda.device(act_q.device):
+        rc = lib.gpfq_quantize_conv1x1(act_q.data_ptr(), n, H, W, Cin, int(strides[0]), int(strides[1]), W2.data_ptr(), F, arr, M,
+                                       Q.data_ptr(), idx.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    _check(rc, "gpfq_quantize_conv1x1")
+    return Q, idx
 
 
 def neuron_major(W, lo=0, hi=None):

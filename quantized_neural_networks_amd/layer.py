@@ -160,14 +160,7 @@ def _quantize_conv1x1(W, act_q, alphabet, strides):
     # all the layer needs of its activations is whether each channel's float32-rounded row norm is below 1e-16: partial sums
     # of squares only grow, so a prefix of the positions settles every live channel and only what is left undecided is
     # summed in full (hip.channel_dead; SAME == VALID for k = 1) -- no pass over the whole NHWC tensor
-    dead = hip.channel_dead(act_q.contiguous(), (sh, sw))
-    Q, idx = hip.msq_round(W.reshape(Cin, F), alphabet)
-    zero_idx = -1
-    for k, a in enumerate(alphabet):
-        if float(a) == 0.0:
-            zero_idx = k
-    Q.masked_fill_(dead[:, None], 0.0)                    # (masked_fill: no host round trip, unlike mask indexing)
-    idx.masked_fill_(dead[:, None], zero_idx)
+    Q, idx = hip.quantize_conv1x1(act_q.contiguous(), W.reshape(Cin, F), alphabet, (sh, sw))     # one library call, no host round trip
     resid = torch.full((Cin, F), float("nan"), dtype=torch.float64, device=W.device)
     return dict(Q=Q.reshape(1, 1, Cin, F), idx=idx.reshape(1, 1, Cin, F), resid=resid)
 
