@@ -1233,6 +1233,8 @@ gpfq_blk_kernel(BlkK K, AlphabetArg A)
 
 // ---- host side ------------------------------------------------------------------------------------
 struct BlkShape { int G, S, B, mp, NW, NL; };      // NL: neurons per lane (4 G or 2 G neurons per workgroup)
+static std::atomic<int> g_blk_single{1};  // one neuron per workgroup for layers of at most 128 neurons (blk_set_single_groups)
+void blk_set_single_groups(int on) { g_blk_single.store(on ? 1 : 0, std::memory_order_relaxed); }
 static std::atomic<int> g_blk_nw{8};      // sweep wavefronts of the 16-neuron shapes (experiment switch: blk_set_sweep_waves)
 static std::atomic<int> g_blk_four{1};    // 4-neuron workgroups for layers of at most 1024 neurons on rows of 769..2048 samples
 void blk_set_four_groups(int on) { g_blk_four.store(on ? 1 : 0, std::memory_order_relaxed); }
@@ -1252,6 +1254,17 @@ static BlkShape blk_shape(int64_t m, int64_t C)
     // Layers of at most 512 neurons: TWO neurons per workgroup (two per lane of the sweep wavefronts).  A narrow layer is bound by
     // the time of one slot, a slot by the instructions its workgroup issues (profiles/r03/blk_phase_stamps.txt): half the neurons
     // are half the element-wise work per slot on twice the CUs.  Rows of up to 5120 samples (cfg4's Dense(2048 -> 128) on 5008).
+    // Layers of at most 128 neurons: ONE neuron per workgroup -- the 64 workgroups of the two-neuron form leave three CUs in four idle,
+    // and a slot's sweeps are half as long again (cfg1's Dense(784 -> 128), cfg4's Dense(2048 -> 128) on 5008 samples)
+    if (C <= 128 && g_blk_pairs.load(std::memory_order_relaxed) != 0 && g_blk_single.load(std::memory_order_relaxed) != 0) {
+        if (m > 256 && m <= 512) return {1, 4, 4, 512, 4, 1};
+        if (m > 512 && m <= 1024) return {1, 8, 4, 1024, 8, 1};
+        if (m > 1024 && m <= 1536) return {1, 12, 2, 1536, 8, 1};
+        if (m > 1536 && m <= 2048) return {1, 16, 2, 2048, 8, 1};
+        if (m > 2048 && m <= 3072) return {1, 24, 1, 3072, 8, 1};
+        if (m > 3072 && m <= 4096) return {1, 32, 1, 4096, 8, 1};
+        if (m > 4096 && m <= 5120) return {1, 40, 1, 5120, 8, 1};
+    }
     if (C <= 512 && g_blk_pairs.load(std::memory_order_relaxed) != 0) {
         if (m > 256 && m <= 512) return {1, 4, 4, 512, 4, 2};
         if (m > 512 && m <= 1024) return {1, 8, 4, 1024, 8, 2};
@@ -1416,6 +1429,12 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
                        a.nrm32, static_cast<char *>(a.workspace), static_cast<char *>(a.workspace) + blk_recs_bytes(nblk, sh), sym_a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (sh.NL == 1) {                                              // one-neuron workgroups (layers of at most 128 neurons)
+        if (sh.B == 4) return sh.S == 4 ? launch_blk_inst<1, 4, 4, 4, 1>(a, sh, stream) : launch_blk_inst<1, 8, 4, 8, 1>(a, sh, stream);
+        if (sh.B == 2) return sh.S == 12 ? launch_blk_inst<1, 12, 2, 8, 1>(a, sh, stream) : launch_blk_inst<1, 16, 2, 8, 1>(a, sh, stream);
+        if (sh.S == 24) return launch_blk_inst<1, 24, 1, 8, 1>(a, sh, stream);
+        return sh.S == 32 ? launch_blk_inst<1, 32, 1, 8, 1>(a, sh, stream) : launch_blk_inst<1, 40, 1, 8, 1>(a, sh, stream);
+    }
     if (sh.NL == 2) {                                              // two-neuron workgroups (layers of at most 512 neurons)
         if (sh.B == 4) return sh.S == 4 ? launch_blk_inst<1, 4, 4, 4, 2>(a, sh, stream) : launch_blk_inst<1, 8, 4, 8, 2>(a, sh, stream);
         if (sh.B == 2) return sh.S == 12 ? launch_blk_inst<1, 12, 2, 8, 2>(a, sh, stream) : launch_blk_inst<1, 16, 2, 8, 2>(a, sh, stream);

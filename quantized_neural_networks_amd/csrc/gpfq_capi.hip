@@ -204,6 +204,7 @@ int gpfq_set_option(const char *key, int value)
     if (!std::strcmp(key, "blk_four_groups")) { gpfq::blk_set_four_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_wide_groups")) { gpfq::blk_set_wide_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_pair_groups")) { gpfq::blk_set_pair_groups(value); return GPFQ_OK; }
+    if (!std::strcmp(key, "blk_single_groups")) { gpfq::blk_set_single_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_sweep_waves")) {
         if (value != 8 && value != 11) return fail(GPFQ_ERR_INVALID_ARG, "blk_sweep_waves must be 8 or 11");
         gpfq::blk_set_sweep_waves(value); return GPFQ_OK;

@@ -81,6 +81,7 @@ bool blk_supported(const PipeArgs &a);
 size_t blk_workspace_bytes(int64_t N, int64_t m);
 hipError_t launch_blk(const PipeArgs &a, hipStream_t stream);
 void blk_set_four_groups(int on);   // 4-neuron workgroups for layers of at most 1024 neurons (speed only)
+void blk_set_single_groups(int on); // 1-neuron workgroups for layers of at most 128 neurons (speed only)
 void blk_set_pair_groups(int on);   // 2-neuron workgroups for layers of at most 512 neurons (speed only)
 void blk_set_wide_groups(int on);   // 16-neuron workgroups for rows beyond 1024 samples (speed only)
 void blk_set_sweep_waves(int nw);   // 8 or 11 sweep wavefronts for the 16-neuron shapes (speed only)
