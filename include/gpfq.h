@@ -351,6 +351,21 @@ int gpfq_quantize_conv3x3_nhwc(const float *act_w, const float *act_q, int64_t n
                                void *qidx, float *Qt, int32_t *uncertified, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * gpfq_quantize_conv_channels for layers whose kernel reads the NHWC activations ITSELF -- no channel-major copy (gpfq_channel_planes)
+ * beforehand.  gpfq_conv_channels_nhwc_supported says which: today the 7 x 7 / stride 2 / VALID shapes of the shift-sum form
+ * (ResNet50's conv1 on its padded input), whose bands are gathered out of the interleaved rows by the LDS-DMA requests.
+ * act_w / act_q [device] f32 [n][H][W][Cin], the shard is channels [c_lo, c_lo + nch); everything else as
+ * gpfq_quantize_conv_channels (workspace: gpfq_conv_channels_workspace_bytes of the same shape, want_resid = 0; residual norms
+ * are not formed).  Replaces the same loop of _quantize_conv2D_layer_parallel_jit (scripts/quantized_network.py:729-809).
+ */
+int gpfq_conv_channels_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t nch, int kh, int kw, int sh, int sw, int rh, int rw,
+                                      int same_padding);
+int gpfq_quantize_conv_channels_nhwc(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t c_lo,
+                                     int64_t nch, int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
+                                     const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
+                                     void *qidx, float *Qt, int32_t *uncertified, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * The same call in two halves, for layers with fewer input channels than GPUs (an image input has 3): the Gram
  * records are SUMS over the patch columns, so every GPU forms them over its share of the images
  * (gpfq_conv_channel_records on the planes of those images), the records are summed over the GPUs (an all-reduce of

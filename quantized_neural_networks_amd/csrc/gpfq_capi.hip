@@ -95,7 +95,7 @@ hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes)
 
 extern "C" {
 
-int gpfq_version(void) { return 301; }
+int gpfq_version(void) { return 302; }
 
 const char *gpfq_last_dense_kernel(void) { return g_dense_kernel; }
 
@@ -179,6 +179,7 @@ static std::atomic<int> g_pipe{-1};            // pipelined dense kernels: -1 = 
                                    // applies, 2 = blocks of steps per slot (gpfq_blk.hip) whenever it applies
 static std::atomic<int> g_auto_gram{1};        // GPFQ_PATH_AUTO may take the Gram path (one stream synchronisation inside the call); 0: AUTO stays asynchronous
 static std::atomic<int> g_conv_fused{1};       // conv channel loop: 3x3/stride-1 Gram matrices straight from the planes
+static std::atomic<int> g_conv_planes_free{1}; // 7x7 / 2 layers read the NHWC activations themselves (gpfq_quantize_conv_channels_nhwc; 0: channel planes first)
 static std::atomic<int> g_conv_nhwc{1};        // 3x3 / stride 1 / SAME layers straight from the NHWC activations (no channel-major copy)
 static std::atomic<int> g_conv_strip{0};
 static std::atomic<int> g_conv_shift{1};    // fused 3x3 conv kernel with SAME padding: the shift form (0 = the per-output-position form)       // fused conv kernel: forced strip length (0 = heuristic)
@@ -217,6 +218,7 @@ int gpfq_set_option(const char *key, int value)
     if (!std::strcmp(key, "auto_gram")) { g_auto_gram = value ? 1 : 0; return GPFQ_OK; }
     if (!std::strcmp(key, "conv_fused")) { g_conv_fused = value ? 1 : 0; return GPFQ_OK; }
     if (!std::strcmp(key, "conv_nhwc")) { g_conv_nhwc = value ? 1 : 0; return GPFQ_OK; }
+    if (!std::strcmp(key, "conv_planes_free")) { g_conv_planes_free = value ? 1 : 0; return GPFQ_OK; }
     if (!std::strcmp(key, "conv_s2")) { gpfq::conv_set_s2(value); return GPFQ_OK; }
     if (!std::strcmp(key, "conv_shift")) {
         if (value < 0 || value > 2) return fail(GPFQ_ERR_INVALID_ARG, "conv_shift must be 0, 1 or 2");
@@ -638,7 +640,7 @@ static int conv_channels_impl(int phase, double *records, int32_t *negflags,
                               int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
                               const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
                               void *qidx_v, float *Qt, double *resid, int32_t *uncertified,
-                              void *workspace, size_t workspace_bytes, void *stream)
+                              void *workspace, size_t workspace_bytes, void *stream, int64_t pix = 1)
 {
     if (n < 0 || H <= 0 || W <= 0 || nch < 0 || F < 0) return fail(GPFQ_ERR_INVALID_ARG, "bad shape");
     if (kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || rh <= 0 || rw <= 0) return fail(GPFQ_ERR_INVALID_ARG, "bad kernel/stride/rate");
@@ -660,7 +662,10 @@ static int conv_channels_impl(int phase, double *records, int32_t *negflags,
     const size_t need = gpfq_conv_channels_workspace_bytes(n, H, W, nch, kh, kw, sh, sw, rh, rw, same_padding, F, resid != nullptr);
     if (!workspace || workspace_bytes < need || (uintptr_t)workspace % 16 != 0)
         return fail(GPFQ_ERR_WORKSPACE, "conv channel loop needs %zu aligned workspace bytes", need);
-    if (!resid && g_conv_fused && gpfq::gram_image_supported(n, H, W, kh, kw, sh, sw, rh, rw, same_padding)) {
+    if (pix > 1 && !(same_padding == 0 && !resid && !phase && g_conv_fused && gpfq::gram_conv_supported(n, H, W, nch, kh, kw, oh, ow) &&
+                     gpfq::gram_s2_supported(n, H, W, kh, kw, sh, sw, rh, rw, 0, 0)))
+        return fail(GPFQ_ERR_UNSUPPORTED, "NHWC activations: only the 7x7 / stride 2 / VALID shift-sum form reads them (gpfq_conv_channels_nhwc_supported)");
+    if (pix == 1 && !resid && g_conv_fused && gpfq::gram_image_supported(n, H, W, kh, kw, sh, sw, rh, rw, same_padding)) {
         // 3x3 / stride 1: Gram matrices of every channel straight from the planes, one batched decide launch
         gpfq::ImageGramArgs g;
         g.act_w = act_w; g.act_q = act_q; g.n = n; g.H = H; g.W = W; g.nch = nch; g.pad = same_padding ? 1 : 0;
@@ -690,7 +695,7 @@ static int conv_channels_impl(int phase, double *records, int32_t *negflags,
         g.workspace = workspace;
         g.slack = std::ldexp(1.0, g_gram_slack_log2);
         g.variant = g_variant;
-        g.phase = phase; g.records = records; g.negflags = negflags;
+        g.phase = phase; g.records = records; g.negflags = negflags; g.pix = pix;
         if (pad_top == 0 && pad_left == 0 && gpfq::gram_s2_supported(n, H, W, kh, kw, sh, sw, rh, rw, pad_top, pad_left))
             g.s2_part = reinterpret_cast<double *>(static_cast<char *>(workspace) + al256c(gpfq::gram_conv_workspace_bytes(K, nch, F, cols)));
         hipError_t e = gpfq::launch_gram_conv(g, static_cast<hipStream_t>(stream));
@@ -780,6 +785,28 @@ int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t 
 {
     return conv_channels_impl(0, nullptr, nullptr, act_w, act_q, n, H, W, nch, kh, kw, sh, sw, rh, rw, same_padding, Wt, alphabet, M,
                               zero_idx, F, qidx, Qt, resid, uncertified, workspace, workspace_bytes, stream);
+}
+
+int gpfq_conv_channels_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t nch, int kh, int kw, int sh, int sw, int rh, int rw, int same_padding)
+{
+    if (n <= 0 || H <= 0 || W <= 0 || nch <= 0 || same_padding || !g_conv_fused || !g_conv_planes_free) return 0;
+    const int64_t oh = gpfq_patch_out_dim(H, kh, sh, rh, 0), ow = gpfq_patch_out_dim(W, kw, sw, rw, 0);
+    if ((int64_t)kh * kw > GPFQ_GRAM_MAX_N || n * oh * ow >= (1LL << 30)) return 0;
+    return gpfq::gram_conv_supported(n, H, W, nch, kh, kw, oh, ow) && gpfq::gram_s2_supported(n, H, W, kh, kw, sh, sw, rh, rw, 0, 0) ? 1 : 0;
+}
+
+int gpfq_quantize_conv_channels_nhwc(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t c_lo,
+                                     int64_t nch, int kh, int kw, int sh, int sw, int rh, int rw, int same_padding,
+                                     const float *Wt, const double *alphabet, int M, int zero_idx, int64_t F,
+                                     void *qidx, float *Qt, int32_t *uncertified, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (Cin <= 0 || c_lo < 0 || nch < 0 || c_lo + nch > Cin) return fail(GPFQ_ERR_INVALID_ARG, "bad channel range");
+    if (!act_w || !act_q) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    if (Cin == 1)                                                   // one channel: the tensor IS its plane
+        return conv_channels_impl(0, nullptr, nullptr, act_w, act_q, n, H, W, nch, kh, kw, sh, sw, rh, rw, same_padding, Wt, alphabet, M,
+                                  zero_idx, F, qidx, Qt, nullptr, uncertified, workspace, workspace_bytes, stream);
+    return conv_channels_impl(0, nullptr, nullptr, act_w + c_lo, act_q + c_lo, n, H, W, nch, kh, kw, sh, sw, rh, rw, same_padding, Wt, alphabet,
+                              M, zero_idx, F, qidx, Qt, nullptr, uncertified, workspace, workspace_bytes, stream, Cin);
 }
 
 int gpfq_conv_channel_records(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch,

@@ -455,10 +455,10 @@ hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream)
         if (e != hipSuccess) return e;
         e = launch_gram_reduce(a.records, 1, (int)K, gram, nrm, a.nch, stream);
         if (e != hipSuccess) return e;
-    } else if (g_conv_s2.load(std::memory_order_relaxed) && a.s2_part &&
+    } else if ((g_conv_s2.load(std::memory_order_relaxed) || a.pix > 1) && a.s2_part &&
                gram_s2_supported(a.n, a.H, a.W, a.kh, a.kw, a.sh, a.sw, a.rh, a.rw, a.pt, a.pl)) {
         // 7x7 / stride 2 / VALID: shift sums of the parity classes of the planes instead of every (t, s) product (gpfq_gram_s2.hip)
-        e = launch_gram_s2(a.act_w, a.act_q, a.n, a.H, a.W, a.nch, a.s2_part, gram, nrm, negflag, stream);
+        e = launch_gram_s2(a.act_w, a.act_q, a.n, a.H, a.W, a.nch, a.s2_part, gram, nrm, negflag, stream, a.pix);
         if (e != hipSuccess) return e;
         if (a.phase == 1) {
             e = hipMemcpyAsync(a.records, gram, (size_t)a.nch * gram_record(K) * sizeof(double), hipMemcpyDeviceToDevice, stream);
@@ -466,6 +466,7 @@ hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream)
             return hipMemcpyAsync(a.negflags, negflag, (size_t)a.nch * sizeof(int), hipMemcpyDeviceToDevice, stream);
         }
     } else {
+        if (a.pix > 1) return hipErrorInvalidValue;        // the tile kernels read channel planes
         if (mfma) {
             const dim3 grid((unsigned)walkers, 1, (unsigned)a.nch);
 #define GPFQ_CM(NB_, REM_)                                                                                                          \
@@ -499,7 +500,7 @@ hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream)
     bs.nch = a.nch; bs.gram_cs = gram_record(K); bs.nrm_cs = K; bs.w_cs = a.F * K; bs.out_cs = a.F * K; bs.unc_cs = a.F;
     bs.hist_cs = a.F * K;
     FixSrc src{};
-    src.X = a.act_w; src.Xq = a.act_q; src.ld = 0; src.m = m; src.planes = 1; src.plane = p.plane; src.pix = 1;
+    src.X = a.act_w; src.Xq = a.act_q; src.ld = 0; src.m = m; src.planes = 1; src.plane = a.pix > 1 ? 1 : p.plane; src.pix = a.pix > 1 ? a.pix : 1;
     src.n = (int)a.n; src.H = p.H; src.W = p.W; src.oh = p.oh; src.ow = p.ow;
     src.kw = a.kw; src.sh = a.sh; src.sw = a.sw; src.rh = a.rh; src.rw = a.rw; src.pt = a.pt; src.pl = a.pl;
     return launch_gram_decide(gram, nrm, a.Wt, K, a.A, (int)K, a.F, a.slack, a.qidx, a.Qt, a.uncertified, q32h, bs, &src, fixws, negflag,

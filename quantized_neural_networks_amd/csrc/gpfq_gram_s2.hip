@@ -47,7 +47,8 @@ constexpr int kS2MaxLaunch = 8;
 
 struct S2Params {
     const float *act_w, *act_q;
-    int64_t plane;                     // n * H * W floats per channel
+    int64_t plane;                     // floats from one channel to the next: n * H * W for channel planes, 1 for NHWC tensors
+    int64_t pix;                       // floats from one pixel to the next: 1 for channel planes, Cin for NHWC tensors
     int n, H, W, Wd;                   // Wd = (W + 1) / 2 decimated columns
     int same_act;
     int nreg;                          // row regions of the launch (blockIdx.y): the interior rows, then one border row each
@@ -128,13 +129,14 @@ gpfq_gram_s2_kernel(S2Params p)
         int img, y0, rows, fs, fe;
         band_rows(item, img, y0, rows, fs, fe);
         const int total = (fe - fs) * p.W;
-        const int64_t at = ((int64_t)img * p.H + fs) * p.W;
+        const int64_t at = ((int64_t)img * p.H + fs) * p.W * p.pix;
 #pragma unroll
         for (int tz = 0; tz < (SAME ? 1 : 2); ++tz) {
             const float *src = (tz ? pq : pw) + at;
             const unsigned dst = lds_addr(raw + tz * p.rawcap);
+            // (NHWC tensors: the piece is every pix-th float -- a gathering request, the LDS image is the same)
             for (int c = wave * 64; c < total && GPFQ_S2_SKIP != 4; c += kS2Threads) {
-                if (c + lane < total) glds4(src + c + lane, dst + 4u * (unsigned)c);
+                if (c + lane < total) glds4(src + (int64_t)(c + lane) * p.pix, dst + 4u * (unsigned)c);
             }
         }
     };
@@ -386,8 +388,9 @@ size_t gram_s2_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t nch)
 }
 
 // Gram records [nch][gram_record(49)] + float32 row norms of all channels; `part` = gram_s2_workspace_bytes bytes.
+// pix = 1: act_* are channel planes [nch][n][H][W]; pix = Cin > 1: NHWC tensors offset to the shard's first channel.
 hipError_t launch_gram_s2(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch, double *part,
-                          double *gram, float *nrm32, int *negflag, hipStream_t stream)
+                          double *gram, float *nrm32, int *negflag, hipStream_t stream, int64_t pix)
 {
     const bool same_act = act_w == act_q;
     S2Plan P;
@@ -396,7 +399,7 @@ hipError_t launch_gram_s2(const float *act_w, const float *act_q, int64_t n, int
                                : ensure_dynamic_lds((const void *)gpfq_gram_s2_kernel<false>, P.lds);
     if (attr != hipSuccess) return attr;
     S2Params p{};
-    p.act_w = act_w; p.act_q = act_q; p.plane = n * H * W; p.n = (int)n; p.H = (int)H; p.W = (int)W; p.Wd = P.Wd;
+    p.act_w = act_w; p.act_q = act_q; p.plane = pix > 1 ? 1 : n * H * W; p.pix = pix > 1 ? pix : 1; p.n = (int)n; p.H = (int)H; p.W = (int)W; p.Wd = P.Wd;
     p.same_act = same_act ? 1 : 0;
     p.nstrip = P.nstrip; p.nbc = P.nbc;
     for (int i = 0; i < 8; ++i) p.bc[i] = P.bc[i];

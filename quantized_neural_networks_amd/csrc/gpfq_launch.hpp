@@ -207,6 +207,7 @@ struct ConvGramArgs {
     double *records = nullptr;
     int32_t *negflags = nullptr;
     double *s2_part = nullptr;   // gram_s2_workspace_bytes of scratch behind the workspace proper (7x7 / 2 layers; NULL: the matrix-core kernel)
+    int64_t pix = 1;             // > 1: act_w / act_q are NHWC tensors of this many channels, offset to the shard's first channel (7x7 / 2 shift-sum form only)
 };
 bool gram_conv_supported(int64_t n, int64_t H, int64_t W, int64_t nch, int kh, int kw, int64_t oh, int64_t ow);
 size_t gram_conv_workspace_bytes(int64_t K, int64_t nch, int64_t F, int64_t m);
@@ -215,7 +216,7 @@ hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream);
 bool gram_s2_supported(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw, int rh, int rw, int pt, int pl);
 size_t gram_s2_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t nch);
 hipError_t launch_gram_s2(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch, double *part,
-                          double *gram, float *nrm32, int *negflag, hipStream_t stream);
+                          double *gram, float *nrm32, int *negflag, hipStream_t stream, int64_t pix = 1);
 void conv_set_s2(int on);           // the shift-sum form for 7x7 / 2 layers (speed only; 0: the matrix-core kernel)
 
 bool gram_image_supported(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw, int rh, int rw, int same_padding);

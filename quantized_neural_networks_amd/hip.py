@@ -43,6 +43,9 @@ SYMBOLS = {
     "gpfq_channel_sumsq": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _vp, _sz, _vp]),
     "gpfq_channel_dead_workspace_bytes": (_sz, [_i64]),
     "gpfq_channel_dead": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _int, _i64, _vp, _vp, _sz, _vp]),
+    "gpfq_conv_channels_nhwc_supported": (_int, [_i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int]),
+    "gpfq_quantize_conv_channels_nhwc": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int,
+                                                 _vp, _vp, _int, _int, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpfq_conv1x1_workspace_bytes": (_sz, [_i64]),
     "gpfq_quantize_conv1x1": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _i64, _vp, _int, _vp, _vp, _vp, _sz, _vp]),
     "gpfq_conv_channels_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _i64, _int]),
@@ -79,7 +82,7 @@ def lib_path():
     return _build.LIB
 
 
-ABI_VERSION = 301                  # gpfq_version() of the library this binding was written against
+ABI_VERSION = 302                  # gpfq_version() of the library this binding was written against
 
 
 def load():
@@ -402,6 +405,44 @@ def quantize_conv_channels(act_w_cm, act_q_cm, Wt_all, alphabet, kernel_size, st
                                              resid.data_ptr() if resid is not None else None, unc.data_ptr(),
                                              ws.data_ptr(), nbytes, _stream())
     _check(rc, "gpfq_quantize_conv_channels")
+
+
+def conv_channels_nhwc_supported(n, H, W, nch, kernel_size, strides, rate, padding):
+    """Whether quantize_conv_channels_nhwc has a kernel for this layer shape (today: 7 x 7 / stride 2 / VALID, the shift-sum form)."""
+    rh, rw = rate if rate else (1, 1)
+    return bool(load().gpfq_conv_channels_nhwc_supported(int(n), int(H), int(W), int(nch), int(kernel_size[0]), int(kernel_size[1]),
+                                                        int(strides[0]), int(strides[1]), int(rh), int(rw),
+                                                        1 if str(padding).upper() == "SAME" else 0))
+
+
+def quantize_conv_channels_nhwc(act_w, act_q, c_lo, c_hi, Wt_all, alphabet, kernel_size, strides, rate, padding, idx, Q, unc):
+    """Channels [c_lo, c_hi) of a conv layer whose kernel reads the NHWC activations itself (gpfq_quantize_conv_channels_nhwc): no
+    channel-major copy.  act_* f32 [n][H][W][Cin]; Wt_all f32 [nch][F][K]; outputs are caller tensors idx / Q [nch][F][K],
+    unc i32 [nch][F].  No sync; returns nothing."""
+    for t, dt in ((act_w, torch.float32), (act_q, torch.float32), (Wt_all, torch.float32), (idx, index_dtype(len(alphabet))),
+                  (Q, torch.float32), (unc, torch.int32)):
+        _dev(t, dt, "tensor")
+        if not t.is_contiguous():
+            raise GpfqError("quantize_conv_channels_nhwc needs contiguous tensors")
+    n, H, W, Cin = act_w.shape
+    nch = c_hi - c_lo
+    kh, kw = kernel_size
+    sh, sw = strides
+    rh, rw = rate if rate else (1, 1)
+    same = 1 if str(padding).upper() == "SAME" else 0
+    F, K = Wt_all.shape[1], Wt_all.shape[2]
+    if (tuple(act_q.shape) != (n, H, W, Cin) or not 0 <= c_lo <= c_hi <= Cin or Wt_all.shape[0] != nch or K != kh * kw
+            or tuple(idx.shape) != (nch, F, K) or tuple(Q.shape) != (nch, F, K) or tuple(unc.shape) != (nch, F)):
+        raise GpfqError("quantize_conv_channels_nhwc: shape mismatch")
+    arr, M, zero_idx = _alphabet(alphabet)
+    lib = load()
+    nbytes = lib.gpfq_conv_channels_workspace_bytes(n, H, W, nch, kh, kw, sh, sw, rh, rw, same, F, 0)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=act_w.device)
+    with torch.cuda.device(act_w.device):
+        rc = lib.gpfq_quantize_conv_channels_nhwc(act_w.data_ptr(), act_q.data_ptr(), n, H, W, Cin, c_lo, nch, kh, kw, sh, sw, rh, rw,
+                                                  same, Wt_all.data_ptr(), arr, M, zero_idx, F, idx.data_ptr(), Q.data_ptr(),
+                                                  unc.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    _check(rc, "gpfq_quantize_conv_channels_nhwc")
 
 
 def conv3x3_nhwc_supported(n, H, W, nch):

@@ -202,6 +202,11 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
     nhwc = (not want_resid and by_channel and (kh, kw) == (3, 3) and tuple(strides) == (1, 1) and tuple(rate or (1, 1)) == (1, 1)
             and str(padding).upper() == "SAME" and len(alphabet) <= hip.GPFQ_MAX_ALPHABET
             and hip.conv3x3_nhwc_supported(act_w.shape[0], act_w.shape[1], act_w.shape[2], c_hi - c_lo))
+    # ... and so do the layers of the 7 x 7 / stride 2 / VALID shift-sum form (ResNet50's conv1): its requests gather the bands out of the
+    # interleaved rows
+    nhwc_any = (not nhwc and not want_resid and by_channel and len(alphabet) <= hip.GPFQ_MAX_ALPHABET
+                and hip.conv_channels_nhwc_supported(act_w.shape[0], act_w.shape[1], act_w.shape[2], c_hi - c_lo, (kh, kw), strides,
+                                                     rate, padding))
     cm = {}
 
     def planes():
@@ -212,7 +217,7 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
 
     def patches(c):
         nonlocal Pw, Pq
-        if nhwc:                                                       # (rare reruns: that channel's slice alone)
+        if nhwc or nhwc_any:                                           # (rare reruns: that channel's slice alone)
             Pw = hip.extract_patches(act_w[..., c:c + 1].contiguous(), 0, (kh, kw), strides, rate, padding, out=Pw)
             Pq = Pw if same else hip.extract_patches(act_q[..., c:c + 1].contiguous(), 0, (kh, kw), strides, rate, padding, out=Pq)
             return
@@ -271,6 +276,9 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
         Unc = torch.zeros((Cin, F), dtype=torch.int32, device=dev)
         if (f_lo, f_hi) == (0, F) and nhwc:
             hip.quantize_conv3x3_nhwc(act_w, act_q, c_lo, c_hi, Wt_all[c_lo:c_hi], alphabet, Ic[c_lo:c_hi], Qc[c_lo:c_hi], Unc[c_lo:c_hi])
+        elif (f_lo, f_hi) == (0, F) and nhwc_any:
+            hip.quantize_conv_channels_nhwc(act_w, act_q, c_lo, c_hi, Wt_all[c_lo:c_hi], alphabet, (kh, kw), strides, rate, padding,
+                                            Ic[c_lo:c_hi], Qc[c_lo:c_hi], Unc[c_lo:c_hi])
         elif (f_lo, f_hi) == (0, F):
             hip.quantize_conv_channels(*planes(), Wt_all[c_lo:c_hi], alphabet, (kh, kw), strides, rate, padding,
                                        Ic[c_lo:c_hi], Qc[c_lo:c_hi], Rc[c_lo:c_hi] if want_resid else None, Unc[c_lo:c_hi])

@@ -618,13 +618,22 @@ def test_conv7x7_stride2_shift_sums(oracle_mod, n, H, W, Cin, F, kind):
         hip.set_option("conv_s2", 0)
         mfma = layer.quantize_conv2d(Wd, aw, aq, alphabet, **kwargs)
         hip.set_option("conv_s2", 1)
-        hip.set_option("gram_slack_log2", 14)               # some chains repaired on the device from the planes
+        hip.set_option("gram_slack_log2", 14)               # some chains repaired on the device, from the NHWC tensors
         rep = layer.quantize_conv2d(Wd, aw, aq, alphabet, **kwargs)
+        hip.set_option("conv_planes_free", 0)               # ... and from channel planes, the kernel fed from planes as well
+        assert not hip.conv_channels_nhwc_supported(n, H, W, Cin, (7, 7), (2, 2), (1, 1), "VALID")
+        rep_planes = layer.quantize_conv2d(Wd, aw, aq, alphabet, **kwargs)
+        hip.set_option("gram_slack_log2", 0)
+        planes = layer.quantize_conv2d(Wd, aw, aq, alphabet, **kwargs)
     finally:
         hip.set_option("conv_s2", 1)
+        hip.set_option("conv_planes_free", 1)
         hip.set_option("gram_slack_log2", 0)
+    assert hip.conv_channels_nhwc_supported(n, H, W, Cin, (7, 7), (2, 2), (1, 1), "VALID")
     assert torch.equal(out["Q"], mfma["Q"]) and torch.equal(out["idx"], mfma["idx"])
     assert torch.equal(out["Q"], rep["Q"]) and torch.equal(out["idx"], rep["idx"])
+    assert torch.equal(out["Q"], planes["Q"]) and torch.equal(out["idx"], planes["idx"])
+    assert torch.equal(out["Q"], rep_planes["Q"]) and torch.equal(out["idx"], rep_planes["idx"])
     Q = out["Q"].cpu().numpy()
     for c in range(Cin):
         Pw = ref_patches(act_w, c, 7, 7, 2, 2, 1, 1, "VALID")
