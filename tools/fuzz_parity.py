@@ -85,6 +85,11 @@ while time.time() < t_end:
         lo_h, lo_w = max(kh + (kh - 1) * (rate - 1), 4), max(kw + (kw - 1) * (rate - 1), 4)
         H = int(rng.integers(lo_h, max(30, lo_h + 4))); Wd = int(rng.integers(lo_w, max(30, lo_w + 4)))
         cin = int(rng.integers(1, 6)); F = int(rng.integers(1, 7))
+        s2_case = rng.random() < 0.08                # 7x7 / 2 / VALID on images of 32+: the shift sums of the parity classes (gpfq_gram_s2.hip)
+        if s2_case:
+            kh = kw = 7; stride = 2; rate = 1; padding = "VALID"
+            H = int(rng.integers(32, 72)); Wd = int(rng.integers(32, 72)); cin = int(rng.integers(1, 5)); F = int(rng.integers(1, 4))
+        hip.set_option("conv_planes_free", int(rng.choice([1, 1, 0])))   # 0: that form fed from channel planes
         nhwc_case = (kh, kw, stride, rate, padding) == (3, 3, 1, 1, "SAME") and rng.random() < 0.5
         if nhwc_case:                               # 64+ channels: the shift form straight from the NHWC activations (LDS-DMA ring)
             cin = int(rng.integers(64, 150)); F = int(rng.integers(1, 4))
@@ -94,6 +99,8 @@ while time.time() < t_end:
         n = int(rng.choice([rng.integers(1, 20), -(-hip.GPFQ_GRAM_MIN_M // (oh * ow)) + int(rng.integers(1, 40))]))
         if nhwc_case:
             n = min(n, 12)                          # (the oracle walks every channel on the host)
+        if s2_case:
+            n = int(rng.integers(1, 24))
         kind = rng.choice(["relu", "sparse", "signed", "uniform"])
         act_w = activations((n, H, Wd, cin), kind)
         first = rng.random() < 0.15
