@@ -443,6 +443,7 @@ template <bool SAME_ACT, int SW>
 __device__ __forceinline__ void nhwc_class_walk(const NhwcParams &p, float *ring_base, int cls)
 {
     constexpr int NC = SW + 4, D = kNhwcDepth, NT = SAME_ACT ? 1 : 2;
+    static_assert(NC == 9 || NC == 5, "the request helpers take rows of nine or five columns");
     float (*ring)[NT][NC][64] = reinterpret_cast<float (*)[NT][NC][64]>(ring_base);
     const int lane = threadIdx.x;
     const int64_t ch = (int64_t)blockIdx.y * 64 + lane;
@@ -454,46 +455,69 @@ __device__ __forceinline__ void nhwc_class_walk(const NhwcParams &p, float *ring
     const int xlo = cx == 1 ? 1 : (cx == 0 ? 0 : W - 1), xhi = cx == 1 ? W - 2 : xlo;
     const int ns = (xhi - xlo + SW) / SW;
     const int64_t nitems = (int64_t)p.n * ns;
-    const float *bw = p.act_w + (live ? ch : 0), *bq = p.act_q + (live ? ch : 0);
+    // requests: the address of a column is SCALAR (row base + column offset, glds4_row9); the lane adds its channel
+    const unsigned voff = (unsigned)(live ? ch : 0) * 4u;
     const unsigned ring_addr = lds_addr(ring_base);
     const int nr = yb - ya + 3;                                     // rows ya - 2 .. yb of the walk, j = 0 .. nr - 1
     const int j0 = ya < 2 ? 2 - ya : 0;                             // rows j < j0 lie above the image
+    const int64_t row_bytes = (int64_t)W * p.cin * 4;
 
     double c1[13], c2[13], c3 = 0.0;
 #pragma unroll
     for (int i = 0; i < 13; ++i) { c1[i] = 0.0; c2[i] = 0.0; }
-    bool neg = false;
+    unsigned sg = 0;                                                // OR of the bit patterns read: the sign bit says "a negative value"
 
     // items k, k + nk, ...: the slots that run side by side hold neighbouring strips of the same images
     for (int64_t item = k; item < nitems; item += nk) {
         const int64_t img = item / ns;
         const int xa = xlo + SW * (int)(item - img * ns);          // first position; window columns xa - 2 .. xa + SW + 1
-        const int64_t ibase = img * H * (int64_t)W * p.cin;
-        // request row j of the walk into ring slot (j - j0) % D (columns outside the image are requested from a clamped address
-        // and read as zeros by the consumer: every row is then exactly NT * NC requests, which keeps the wait counts static)
-        auto request = [&](int j) {
-            const int64_t rb = ibase + (int64_t)(ya - 2 + j) * W * p.cin;
+        // row base of walk row 0, less the 2048 that keeps the column offsets below unsigned
+        const unsigned long long iw = (unsigned long long)(uintptr_t)(p.act_w + (img * H + (ya - 2)) * (int64_t)W * p.cin) - 2048;
+        const unsigned long long iq = (unsigned long long)(uintptr_t)(p.act_q + (img * H + (ya - 2)) * (int64_t)W * p.cin) - 2048;
+        // per item: byte offset of window column i (clamped into the image: a column outside is requested from a valid address and
+        // read as zero by the consumer) from the row base, less the 256 i the request's immediate adds back, plus the 2048
+        unsigned coff[NC];
+        unsigned cvalid = 0;
 #pragma unroll
-            for (int i = 0; i < NC; ++i) {
-                int col = xa - 2 + i;
-                col = col < 0 ? 0 : (col >= W ? W - 1 : col);
-                glds4(bw + rb + (int64_t)col * p.cin, ring_addr + (unsigned)(((((j - j0) % D) * NT + 0) * NC + i) * 256));
-                if (!SAME_ACT) glds4(bq + rb + (int64_t)col * p.cin, ring_addr + (unsigned)(((((j - j0) % D) * NT + 1) * NC + i) * 256));
+        for (int i = 0; i < NC; ++i) {
+            const int col = xa - 2 + i;
+            cvalid |= (col >= 0 && col < W) ? 1u << i : 0u;
+            const int cc = col < 0 ? 0 : (col >= W ? W - 1 : col);
+            coff[i] = (unsigned)((long long)cc * p.cin * 4 - 256 * i + 2048);
+        }
+        // request row j of the walk into ring slot (j - j0) % D: exactly NT * NC requests per row (static wait counts)
+        auto request = [&](int j) {
+            const unsigned long long rw = iw + (unsigned long long)((long long)j * row_bytes);
+            const unsigned long long rq_ = iq + (unsigned long long)((long long)j * row_bytes);
+            const unsigned dst = ring_addr + (unsigned)((((j - j0) % D) * NT) * NC * 256);
+            if constexpr (NC == 9) {
+                glds4_row9((unsigned)rw, (unsigned)(rw >> 32), coff, voff, dst);
+                if (!SAME_ACT) glds4_row9((unsigned)rq_, (unsigned)(rq_ >> 32), coff, voff, dst + NC * 256);
+            } else {
+                glds4_row5((unsigned)rw, (unsigned)(rw >> 32), coff, voff, dst);
+                if (!SAME_ACT) glds4_row5((unsigned)rq_, (unsigned)(rq_ >> 32), coff, voff, dst + NC * 256);
             }
         };
         float rx[NC], rq[NC];
-        auto consume = [&](int j) {                                 // wait for row j, read it (zeros outside the image)
+        auto consume = [&](int j) {                                 // wait for row j, read it
             const int ahead = nr - 1 - j < D - 2 ? nr - 1 - j : D - 2;              // rows requested after it so far (row j + D - 1 follows this read)
             if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NC * NT) : "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 * NC * NT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (cvalid == (1u << NC) - 1) {                         // (uniform) every column inside the image: nothing to mask
 #pragma unroll
-            for (int i = 0; i < NC; ++i) {
-                const int col = xa - 2 + i;
-                const bool ok = col >= 0 && col < W && live;
-                const float a = ring[(j - j0) % D][0][i][lane];
-                rx[i] = ok ? a : 0.f;
-                if (!SAME_ACT) { const float b = ring[(j - j0) % D][NT - 1][i][lane]; rq[i] = ok ? b : 0.f; }
+                for (int i = 0; i < NC; ++i) {
+                    rx[i] = ring[(j - j0) % D][0][i][lane];
+                    if (!SAME_ACT) rq[i] = ring[(j - j0) % D][NT - 1][i][lane];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const bool ok = (cvalid >> i) & 1u;
+                    const float a = ring[(j - j0) % D][0][i][lane];
+                    rx[i] = ok ? a : 0.f;
+                    if (!SAME_ACT) { const float b = ring[(j - j0) % D][NT - 1][i][lane]; rq[i] = ok ? b : 0.f; }
+                }
             }
         };
         static_assert(D == 4, "the wait counts above are written for a ring of four rows");
@@ -505,12 +529,16 @@ __device__ __forceinline__ void nhwc_class_walk(const NhwcParams &p, float *ring
         for (int i = 0; i < NC; ++i) { Bx[1][i] = Bq[1][i] = 0.0; Bx[2][i] = Bq[2][i] = 0.0; }
         // rows ya - 2, ya - 1 (j = 0, 1), where inside the image, fill the two buffers above; each consumed row frees its ring slot for row j + D
         if (j0 == 0) {
-            consume(0); if (0 + D - 1 < nr) request(0 + D - 1);
+            consume(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (0 + D - 1 < nr) request(0 + D - 1);
 #pragma unroll
             for (int i = 0; i < NC; ++i) { Bx[1][i] = (double)rx[i]; Bq[1][i] = SAME_ACT ? Bx[1][i] : (double)rq[i]; }
         }
         if (j0 <= 1) {
-            consume(1); if (1 + D - 1 < nr) request(1 + D - 1);
+            consume(1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (1 + D - 1 < nr) request(1 + D - 1);
 #pragma unroll
             for (int i = 0; i < NC; ++i) { Bx[2][i] = (double)rx[i]; Bq[2][i] = SAME_ACT ? Bx[2][i] : (double)rq[i]; }
         }
@@ -524,23 +552,24 @@ __device__ __forceinline__ void nhwc_class_walk(const NhwcParams &p, float *ring
             for (int i = 0; i < NC; ++i) {
                 Bx[R0][i] = (double)rx[i];
                 Bq[R0][i] = SAME_ACT ? Bx[R0][i] : (double)rq[i];
-                neg |= (rx[i] < 0.f) | (!SAME_ACT && rq[i] < 0.f);
+                sg |= __float_as_uint(rx[i]) | (SAME_ACT ? 0u : __float_as_uint(rq[i]));
             }
 #pragma unroll
             for (int e = 0; e < SW; ++e) {
-                const bool in = xa + e <= xhi;
-                const double qa = in ? Bq[R0][e + 2] : 0.0, xm = in ? Bx[R0][e + 2] : 0.0;
-                c3 = fma(xm, xm, c3);
+                if (xa + e <= xhi) {                                // (uniform: the last strip of a row may be short)
+                    const double qa = Bq[R0][e + 2], xm = Bx[R0][e + 2];
+                    c3 = fma(xm, xm, c3);
 #pragma unroll
-                for (int jj = 0; jj < 3; ++jj) {                     // dy = 0, dx = jj - 2
-                    c1[10 + jj] = fma(qa, Bx[R0][e + jj], c1[10 + jj]);
-                    if (!SAME_ACT) c2[10 + jj] = fma(qa, Bq[R0][e + jj], c2[10 + jj]);
-                }
+                    for (int jj = 0; jj < 3; ++jj) {                 // dy = 0, dx = jj - 2
+                        c1[10 + jj] = fma(qa, Bx[R0][e + jj], c1[10 + jj]);
+                        if (!SAME_ACT) c2[10 + jj] = fma(qa, Bq[R0][e + jj], c2[10 + jj]);
+                    }
 #pragma unroll
-                for (int jj = 0; jj < 5; ++jj) {                     // dy = -2, -1, dx = jj - 2
-                    c1[jj] = fma(qa, Bx[R2][e + jj], c1[jj]);
-                    c1[5 + jj] = fma(qa, Bx[R1][e + jj], c1[5 + jj]);
-                    if (!SAME_ACT) { c2[jj] = fma(qa, Bq[R2][e + jj], c2[jj]); c2[5 + jj] = fma(qa, Bq[R1][e + jj], c2[5 + jj]); }
+                    for (int jj = 0; jj < 5; ++jj) {                 // dy = -2, -1, dx = jj - 2
+                        c1[jj] = fma(qa, Bx[R2][e + jj], c1[jj]);
+                        c1[5 + jj] = fma(qa, Bx[R1][e + jj], c1[5 + jj]);
+                        if (!SAME_ACT) { c2[jj] = fma(qa, Bq[R2][e + jj], c2[jj]); c2[5 + jj] = fma(qa, Bq[R1][e + jj], c2[5 + jj]); }
+                    }
                 }
             }
         };
@@ -551,7 +580,7 @@ __device__ __forceinline__ void nhwc_class_walk(const NhwcParams &p, float *ring
         }
     }
     if (live) {
-        if (neg) atomicOr(p.negflag + ch, 1);
+        if (sg >> 31) atomicOr(p.negflag + ch, 1);
         double *out = p.part + (ch * p.nslots + blockIdx.x) * kShiftN;
 #pragma unroll
         for (int i = 0; i < 13; ++i) { out[i] = c1[i]; out[13 + i] = SAME_ACT ? c1[i] : c2[i]; }

@@ -68,6 +68,47 @@ __device__ __forceinline__ void glds16_s(const void *base_uniform, unsigned lane
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(lane_off), "s"(sa), "s"(lds_dst) : "memory");
 }
+// NC LDS-DMA requests of 4 bytes per lane with ONE write of M0 and SCALAR addresses: request i reads row + off[i] + lane_off and lands at
+// lds_dst + 256 i + 4 lane.  The instruction's immediate offset (256 i) moves both addresses, so off[i] is (byte offset of element i
+// from the row base) - 256 i + 2048 and `row` the row base - 2048: every off[i] is then an unsigned 32-bit number and the 64-bit
+// address of a request is two scalar additions (into s[96:99], named in the clobber list: the load wants an aligned register pair) --
+// no vector instruction per request (a per-lane 64-bit address costs two to three).
+__device__ __forceinline__ void glds4_row9(unsigned row_lo, unsigned row_hi, const unsigned (&off)[9], unsigned lane_off, unsigned lds_dst_uniform)
+{
+    const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst_uniform);
+    unsigned keep;
+    asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[dst]\n\t"
+                 "s_add_u32 s96, %[rlo], %[o0]\n\ts_addc_u32 s97, %[rhi], 0\n\tglobal_load_lds_dword %[vo], s[96:97]\n\t"
+                 "s_add_u32 s98, %[rlo], %[o1]\n\ts_addc_u32 s99, %[rhi], 0\n\tglobal_load_lds_dword %[vo], s[98:99] offset:256\n\t"
+                 "s_add_u32 s96, %[rlo], %[o2]\n\ts_addc_u32 s97, %[rhi], 0\n\tglobal_load_lds_dword %[vo], s[96:97] offset:512\n\t"
+                 "s_add_u32 s98, %[rlo], %[o3]\n\ts_addc_u32 s99, %[rhi], 0\n\tglobal_load_lds_dword %[vo], s[98:99] offset:768\n\t"
+                 "s_add_u32 s96, %[rlo], %[o4]\n\ts_addc_u32 s97, %[rhi], 0\n\tglobal_load_lds_dword %[vo], s[96:97] offset:1024\n\t"
+                 "s_add_u32 s98, %[rlo], %[o5]\n\ts_addc_u32 s99, %[rhi], 0\n\tglobal_load_lds_dword %[vo], s[98:99] offset:1280\n\t"
+                 "s_add_u32 s96, %[rlo], %[o6]\n\ts_addc_u32 s97, %[rhi], 0\n\tglobal_load_lds_dword %[vo], s[96:97] offset:1536\n\t"
+                 "s_add_u32 s98, %[rlo], %[o7]\n\ts_addc_u32 s99, %[rhi], 0\n\tglobal_load_lds_dword %[vo], s[98:99] offset:1792\n\t"
+                 "s_add_u32 s96, %[rlo], %[o8]\n\ts_addc_u32 s97, %[rhi], 0\n\tglobal_load_lds_dword %[vo], s[96:97] offset:2048\n\t"
+                 "s_mov_b32 m0, %[keep]"
+                 : [keep] "=&s"(keep)
+                 : [vo] "v"(lane_off), [dst] "s"(lds_dst), [rlo] "s"(row_lo), [rhi] "s"(row_hi), [o0] "s"(off[0]), [o1] "s"(off[1]), [o2] "s"(off[2]),
+                   [o3] "s"(off[3]), [o4] "s"(off[4]), [o5] "s"(off[5]), [o6] "s"(off[6]), [o7] "s"(off[7]), [o8] "s"(off[8])
+                 : "memory", "scc", "s96", "s97", "s98", "s99");
+}
+__device__ __forceinline__ void glds4_row5(unsigned row_lo, unsigned row_hi, const unsigned (&off)[5], unsigned lane_off, unsigned lds_dst_uniform)
+{
+    const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst_uniform);
+    unsigned keep;
+    asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[dst]\n\t"
+                 "s_add_u32 s96, %[rlo], %[o0]\n\ts_addc_u32 s97, %[rhi], 0\n\tglobal_load_lds_dword %[vo], s[96:97]\n\t"
+                 "s_add_u32 s98, %[rlo], %[o1]\n\ts_addc_u32 s99, %[rhi], 0\n\tglobal_load_lds_dword %[vo], s[98:99] offset:256\n\t"
+                 "s_add_u32 s96, %[rlo], %[o2]\n\ts_addc_u32 s97, %[rhi], 0\n\tglobal_load_lds_dword %[vo], s[96:97] offset:512\n\t"
+                 "s_add_u32 s98, %[rlo], %[o3]\n\ts_addc_u32 s99, %[rhi], 0\n\tglobal_load_lds_dword %[vo], s[98:99] offset:768\n\t"
+                 "s_add_u32 s96, %[rlo], %[o4]\n\ts_addc_u32 s97, %[rhi], 0\n\tglobal_load_lds_dword %[vo], s[96:97] offset:1024\n\t"
+                 "s_mov_b32 m0, %[keep]"
+                 : [keep] "=&s"(keep)
+                 : [vo] "v"(lane_off), [dst] "s"(lds_dst), [rlo] "s"(row_lo), [rhi] "s"(row_hi), [o0] "s"(off[0]), [o1] "s"(off[1]), [o2] "s"(off[2]),
+                   [o3] "s"(off[3]), [o4] "s"(off[4])
+                 : "memory", "scc", "s96", "s97", "s98", "s99");
+}
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr(const void *p)
 {
