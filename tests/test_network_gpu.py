@@ -396,7 +396,7 @@ def test_conv_layer_gram_fast_path(oracle_mod, slack, members):
 
 
 @pytest.mark.parametrize("n,H,W,Cin,F,first", [(6, 9, 11, 70, 3, False), (3, 4, 4, 64, 2, False), (5, 13, 6, 130, 2, True), (2, 20, 23, 64, 2, False),
-                                                (40, 7, 7, 64, 2, False), (1, 5, 31, 128, 2, False), (3, 6, 10, 68, 2, False), (9, 14, 14, 64, 2, False)])
+                                                (40, 7, 7, 64, 2, False), (1, 5, 31, 128, 2, False), (3, 6, 10, 68, 2, False), (9, 14, 14, 64, 2, False), (2, 9, 30, 128, 2, False), (2, 5, 17, 64, 2, True)])
 def test_conv_3x3_from_nhwc(oracle_mod, n, H, W, Cin, F, first):
     """3 x 3 / stride 1 / SAME shards of 64+ channels take the shift form straight from the NHWC activations (lanes along the
     channels, rows through an LDS ring; no channel-major copy): the same bits as the planes form (conv_nhwc = 0), a shard that
