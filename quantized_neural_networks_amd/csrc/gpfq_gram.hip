@@ -14,7 +14,7 @@
 // (2^-24 for each product and 2^-24 of their sum for the subtraction: 2^-23 B_t; the float64 accumulation
 // of u and of the dot products with m < 2^30 is orders below that; a factor 2 of slack; products that
 // round in the subnormal range add at most 2^-128 ||Xq_t||; launch_gram_decide spends the factor 2 only where
-// rows can be that long and uses c = 2^-23 (1 + 2^-8) for m <= 2^18).  The absolute inner products are bounded by
+// rows can be that long and uses c = 2^-23 (1 + 2^-8) for m <= 2^18, 2^-23 (1 + 2^-5) for m <= 2^24 on walks of at most 64 steps).  The absolute inner products are bounded by
 // Cauchy-Schwarz, <|a|,|b|> <= ||a|| ||b||, so B_t <= ||Xq_t|| * sum_{s<t} ( |w_s| ||X_s|| + |q_s| ||Xq_s|| )
 // needs nothing beyond the diagonal of G2 and nx2.  A decision is accepted only if the predicted
 // quotient is farther from every decision boundary of the alphabet than that bound allows
@@ -736,6 +736,11 @@ hipError_t launch_gram_decide(const double *gram, const float *nrm32, const floa
     // most 2^-53 of the same bound per term -- below 2^-34 in all, against the 2^-31 that c = 2^-23 (1 + 2^-8) keeps.
     // Half as many uncertified steps: the repair rounds were 70 % of a 16-level 784-step layer.
     if (src && src->m > 0 && src->m <= (1 << 18) && N <= 1024) slack *= 0.5 * (1.0 + 0x1p-8);
+    // Rows of up to 2^24 samples (every conv layer of ResNet50 but conv1 at 4096 images): the Gram entries' own accumulation is the one
+    // long float64 chain, at most m 2^-53 <= 2^-29 of the bound in any summation order; with the 2^-34 of the rest that stays below the
+    // 2^-28 that c = 2^-23 (1 + 2^-5) keeps.  (Each flagged chain of such a layer costs a strided pass over its channel: 0.4 ms at
+    // 128 channels @28x28.)
+    else if (src && src->m > 0 && src->m <= (1 << 24) && N <= 64) slack *= 0.5 * (1.0 + 0x1p-5);
     FixState *fix = (src && fix_ws && src->m > 0 && bs.nch * C < (1LL << 31)) ? static_cast<FixState *>(fix_ws) : nullptr;
     if (fix) {
         hipError_t e = hipMemsetAsync(fix, 0, sizeof(int32_t) * (kFixRoundsLong + 1), stream);
