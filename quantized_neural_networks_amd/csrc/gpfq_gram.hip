@@ -14,7 +14,7 @@
 // (2^-24 for each product and 2^-24 of their sum for the subtraction: 2^-23 B_t; the float64 accumulation
 // of u and of the dot products with m < 2^30 is orders below that; a factor 2 of slack; products that
 // round in the subnormal range add at most 2^-128 ||Xq_t||; launch_gram_decide spends the factor 2 only where
-// rows can be that long and uses c = 2^-23 (1 + 2^-8) for m <= 2^18, 2^-23 (1 + 2^-5) for m <= 2^24 on walks of at most 64 steps).  The absolute inner products are bounded by
+// rows can be that long and uses c = 2^-23 (1 + 2^-8) for m <= 2^18, 2^-23 (1 + 2^-5) for m <= 2^24 and 2^-23 (1 + 2^-3) for m <= 2^26 on walks of at most 64 steps).  The absolute inner products are bounded by
 // Cauchy-Schwarz, <|a|,|b|> <= ||a|| ||b||, so B_t <= ||Xq_t|| * sum_{s<t} ( |w_s| ||X_s|| + |q_s| ||Xq_s|| )
 // needs nothing beyond the diagonal of G2 and nx2.  A decision is accepted only if the predicted
 // quotient is farther from every decision boundary of the alphabet than that bound allows
@@ -741,6 +741,8 @@ hipError_t launch_gram_decide(const double *gram, const float *nrm32, const floa
     // 2^-28 that c = 2^-23 (1 + 2^-5) keeps.  (Each flagged chain of such a layer costs a strided pass over its channel: 0.4 ms at
     // 128 channels @28x28.)
     else if (src && src->m > 0 && src->m <= (1 << 24) && N <= 64) slack *= 0.5 * (1.0 + 0x1p-5);
+    // ... and up to 2^26 (ResNet50's conv1 at 4096 images: 51 M columns): m 2^-53 <= 2^-27 against the 2^-26 of c = 2^-23 (1 + 2^-3)
+    else if (src && src->m > 0 && src->m <= (1 << 26) && N <= 64) slack *= 0.5 * (1.0 + 0x1p-3);
     FixState *fix = (src && fix_ws && src->m > 0 && bs.nch * C < (1LL << 31)) ? static_cast<FixState *>(fix_ws) : nullptr;
     if (fix) {
         hipError_t e = hipMemsetAsync(fix, 0, sizeof(int32_t) * (kFixRoundsLong + 1), stream);
