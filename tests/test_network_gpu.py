@@ -643,6 +643,16 @@ def test_conv7x7_stride2_shift_sums(oracle_mod, n, H, W, Cin, F, kind):
             assert np.array_equal(Q[:, :, c, f].reshape(-1), qo.astype(np.float32)), (c, f)
     if kind == "dead":
         assert (Q[:, :, 1] == 0).all() and (Q[6, 6, 0] == 0).all()
+    if Cin >= 2:
+        # a shard of channels that starts inside the tensor (what a rank of a multi-GPU run holds): the C entry directly
+        c_lo, c_hi = 1, Cin
+        Wt = Wd.permute(2, 3, 0, 1).reshape(Cin, F, 49).contiguous()[c_lo:c_hi].contiguous()
+        idx = torch.empty((c_hi - c_lo, F, 49), dtype=hip.index_dtype(len(alphabet)), device="cuda")
+        Qs = torch.empty((c_hi - c_lo, F, 49), dtype=torch.float32, device="cuda")
+        unc = torch.zeros((c_hi - c_lo, F), dtype=torch.int32, device="cuda")
+        hip.quantize_conv_channels_nhwc(aw, aq, c_lo, c_hi, Wt, alphabet, (7, 7), (2, 2), (1, 1), "VALID", idx, Qs, unc)
+        assert int(unc.sum()) == 0
+        assert torch.equal(Qs, out["Q"].permute(2, 3, 0, 1).reshape(Cin, F, 49)[c_lo:c_hi])
 
 
 @pytest.mark.parametrize("stride,bits", [(1, 2), (2, np.log2(3)), (1, 4)])
