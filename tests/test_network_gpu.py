@@ -643,6 +643,22 @@ def test_conv7x7_stride2_shift_sums(oracle_mod, n, H, W, Cin, F, kind):
             assert np.array_equal(Q[:, :, c, f].reshape(-1), qo.astype(np.float32)), (c, f)
     if kind == "dead":
         assert (Q[:, :, 1] == 0).all() and (Q[6, 6, 0] == 0).all()
+    if n >= 24 and kind != "first":
+        # fewer channels than ranks: every rank forms the records over its share of the IMAGES, they are summed, every rank decides
+        # from the sums (layer.quantize_conv2d with Cin < world) -- here two "ranks" in one process
+        recs, negs = [], []
+        for lo, hi in ((0, n // 2), (n // 2, n)):
+            pw_, pq_ = hip.channel_planes(aw[lo:hi].contiguous(), 0, Cin), hip.channel_planes(aq[lo:hi].contiguous(), 0, Cin)
+            rec_, neg_ = hip.conv_channel_records(pw_, pq_, (7, 7), (2, 2), (1, 1), "VALID")
+            recs.append(rec_); negs.append(neg_)
+        Wt_all = Wd.permute(2, 3, 0, 1).reshape(Cin, F, 49).contiguous()
+        idx = torch.empty((Cin, F, 49), dtype=hip.index_dtype(len(alphabet)), device="cuda")
+        Qs = torch.empty((Cin, F, 49), dtype=torch.float32, device="cuda")
+        unc = torch.zeros((Cin, F), dtype=torch.int32, device="cuda")
+        hip.conv_channels_from_records(recs[0] + recs[1], torch.maximum(negs[0], negs[1]), hip.channel_planes(aw, 0, Cin),
+                                       hip.channel_planes(aq, 0, Cin), Wt_all, alphabet, (7, 7), (2, 2), (1, 1), "VALID", idx, Qs, unc)
+        assert int(unc.sum()) == 0
+        assert torch.equal(Qs, out["Q"].permute(2, 3, 0, 1).reshape(Cin, F, 49))
     if Cin >= 2:
         # a shard of channels that starts inside the tensor (what a rank of a multi-GPU run holds): the C entry directly
         c_lo, c_hi = 1, Cin
