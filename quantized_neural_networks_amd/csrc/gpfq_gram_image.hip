@@ -17,6 +17,7 @@
 // consecutive output positions of one row from a 3 x (S+2) register window, and the two wavefronts of a
 // pair own the columns s in {0,3,5,7,8} and {1,2,4,6} of the record (49 + 50 sums), which keeps a wavefront
 // under 128 accumulator registers and two of them resident per SIMD.
+#include <atomic>
 #include <type_traits>
 
 #include "gpfq_device.hpp"
@@ -599,19 +600,59 @@ gpfq_gram_shift_nhwc_kernel(NhwcParams p)
     else nhwc_class_walk<SAME_ACT, 1>(p, ring, cls);
 }
 
-// Class sums of the NHWC form -> the N = 9 Gram record of a channel + the float32 row norms (as gpfq_gram_shift_combine_kernel).
-__global__ void __launch_bounds__(1024)
-gpfq_gram_shift_combine_nhwc_kernel(NhwcParams p, double *__restrict__ gram, float *__restrict__ nrm32)
+// Class sums of the NHWC form, first stage: a launch has thousands of slots (nhwc_slots), 27 doubles each per channel -- a channel's
+// partials are megabytes.  Workgroup (channel, part) adds the slots of its sixteenth of the slot range, class by class, into
+// tpart[channel][part][9][27].
+constexpr int kNhwcParts = 16;
+__global__ void __launch_bounds__(256)
+gpfq_gram_shift_partsum_nhwc_kernel(NhwcParams p, double *__restrict__ tpart)
+{
+    // 64 slots at a time: their 64 x 27 doubles are one contiguous piece of memory, copied to LDS with whole-line requests (a lane per
+    // (slot, sum) straight from memory would fetch every 64-byte sector 27 times over); wavefront w then adds the sums i = w, w + 4, ...
+    // over the 64 slots of the piece -- lane = slot -- and the pieces in order: a fixed order.  Pieces do not straddle classes.
+    __shared__ double tile[64 * kShiftN];
+    const int64_t ch = blockIdx.x;
+    const int part = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = (p.nslots + kNhwcParts - 1) / kNhwcParts;
+    const int k0 = part * per, k1 = k0 + per < p.nslots ? k0 + per : p.nslots;
+    double *out = tpart + (ch * kNhwcParts + part) * 9 * kShiftN;
+    const double *src = p.part + ch * p.nslots * kShiftN;
+    for (int c = 0; c < 9; ++c) {
+        const int lo = p.slot_off[c] > k0 ? p.slot_off[c] : k0, hi = p.slot_off[c + 1] < k1 ? p.slot_off[c + 1] : k1;
+        double acc[(kShiftN + 3) / 4];
+#pragma unroll
+        for (int q = 0; q < (kShiftN + 3) / 4; ++q) acc[q] = 0.0;
+        for (int kb = lo; kb < hi; kb += 64) {
+            const int cnt = hi - kb < 64 ? hi - kb : 64;
+            __syncthreads();
+            for (int e = threadIdx.x; e < cnt * kShiftN; e += 256) tile[e] = src[(int64_t)kb * kShiftN + e];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < (kShiftN + 3) / 4; ++q) {
+                const int i = wave + 4 * q;
+                const double x = (i < kShiftN && lane < cnt) ? tile[lane * kShiftN + i] : 0.0;
+                acc[q] += wave_sum(x);
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < (kShiftN + 3) / 4; ++q)
+                if (wave + 4 * q < kShiftN) out[c * kShiftN + wave + 4 * q] = acc[q];
+        }
+    }
+}
+
+// Second stage: the parts in order -> the N = 9 Gram record of a channel + the float32 row norms (as gpfq_gram_shift_combine_kernel).
+__global__ void __launch_bounds__(256)
+gpfq_gram_shift_combine_nhwc_kernel(NhwcParams p, const double *__restrict__ tpart, double *__restrict__ gram, float *__restrict__ nrm32)
 {
     __shared__ double T[9][kShiftN];
     const int64_t ch = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int idx = wave; idx < 9 * kShiftN; idx += (int)(blockDim.x >> 6)) {      // sixteen wavefronts: few channels are few workgroups
-        const int c = idx / kShiftN, i = idx - c * kShiftN;
+    for (int idx = threadIdx.x; idx < 9 * kShiftN; idx += (int)blockDim.x) {
         double v = 0.0;
-        for (int k = p.slot_off[c] + lane; k < p.slot_off[c + 1]; k += 64) v += p.part[(ch * p.nslots + k) * kShiftN + i];
-        v = wave_sum(v);
-        if (lane == 0) T[c][i] = v;
+        for (int q = 0; q < kNhwcParts; ++q) v += tpart[(ch * kNhwcParts + q) * 9 * kShiftN + idx];
+        T[idx / kShiftN][idx % kShiftN] = v;
     }
     __syncthreads();
     auto qualifies = [](int c, int t) {
@@ -793,11 +834,18 @@ hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream)
 }
 
 // ---- NHWC entry: 3 x 3, stride 1, SAME, all channels of the shard in one launch chain ----
+static std::atomic<int> g_nhwc_slots{8192};            // workgroups of a launch (option conv_nhwc_slots: experiment switch)
+void image_set_nhwc_slots(int n) { g_nhwc_slots.store(n < 256 ? 256 : (n > 65536 ? 65536 : n), std::memory_order_relaxed); }
 static void nhwc_slots(int64_t n, int64_t H, int64_t W, int64_t nch, NhwcParams &p)
 {
-    // slots per class in proportion to its work (items x rows per item), about 4096 wavefronts per 64 channels in all
+    // Slots per class in proportion to its work (items x row steps per item x requests per step), about 8192 one-wavefront
+    // workgroups in the launch -- four times what the chip holds at once: a workgroup belongs to one class and the classes' costs
+    // per step are only estimated below, so many short workgroups, picked up by the CUs as they come free, balance what two long
+    // rounds do not (kernel at 64 ch @56x56 / 128 @28x28 / 256 @14x14 / 512 @7x7, 4096 images: 3.45 / 2.22 / 1.36 / 0.93 ms with 2048
+    // slots, 2.36 / 1.27 / 0.84 / 0.65 with 4096, 1.93 / 1.08 / 0.69 / 0.49 with 8192, 2.14 / 1.06 / 0.65 / 0.43 with 16384); the
+    // partial sums -- 27 doubles per slot and channel, 113 MB per launch -- are what more slots cost (two-stage combine below)
     const int64_t groups = (nch + 63) / 64;
-    int64_t total = 4096 / groups;
+    int64_t total = g_nhwc_slots.load(std::memory_order_relaxed) / groups;
     if (total < 256) total = 256;
     const int64_t ns_mid = (W - 2 + kNhwcStrip - 1) / kNhwcStrip;
     double work[9];
@@ -839,6 +887,7 @@ size_t gram_image_nhwc_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t 
     b += al256i((size_t)nch * F * 9 * sizeof(float));
     b += gram_fix_bytes();
     b += al256i((size_t)nch * sizeof(int));
+    b += al256i((size_t)nch * kNhwcParts * 9 * kShiftN * sizeof(double));     // the first stage's part sums
     return b;
 }
 
@@ -856,14 +905,16 @@ hipError_t launch_gram_image_nhwc(const ImageGramArgs &a, hipStream_t stream)
     float *nrm = reinterpret_cast<float *>(ws);     ws += al256i((size_t)a.nch * 9 * sizeof(float));
     float *q32h = reinterpret_cast<float *>(ws);    ws += al256i((size_t)a.nch * a.F * 9 * sizeof(float));
     void *fixws = ws;                               ws += gram_fix_bytes();
-    int *negflag = reinterpret_cast<int *>(ws);
+    int *negflag = reinterpret_cast<int *>(ws);     ws += al256i((size_t)a.nch * sizeof(int));
+    double *tpart = reinterpret_cast<double *>(ws);
     p.negflag = negflag;
     hipError_t e = hipMemsetAsync(negflag, 0, (size_t)a.nch * sizeof(int), stream);
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)p.nslots, (unsigned)((a.nch + 63) / 64));
     if (a.act_w == a.act_q) hipLaunchKernelGGL((gpfq_gram_shift_nhwc_kernel<true>), grid, dim3(64), 0, stream, p);
     else hipLaunchKernelGGL((gpfq_gram_shift_nhwc_kernel<false>), grid, dim3(64), 0, stream, p);
-    hipLaunchKernelGGL(gpfq_gram_shift_combine_nhwc_kernel, dim3((unsigned)a.nch), dim3(1024), 0, stream, p, gram, nrm);
+    hipLaunchKernelGGL(gpfq_gram_shift_partsum_nhwc_kernel, dim3((unsigned)a.nch, kNhwcParts), dim3(256), 0, stream, p, tpart);
+    hipLaunchKernelGGL(gpfq_gram_shift_combine_nhwc_kernel, dim3((unsigned)a.nch), dim3(256), 0, stream, p, tpart, gram, nrm);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     DecideBatch bs;
