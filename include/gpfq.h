@@ -130,7 +130,7 @@ const char *gpfq_last_dense_kernel(void);
  *   "auto_gram"    1 (default): GPFQ_PATH_AUTO may divert long rows to the Gram path (one stream synchronisation inside the call);
  *                  0: AUTO only picks between the asynchronous on-chip and streaming kernels
  *   "conv_fused"   1 (default): conv layers read their patch rows from the channel planes; 0: per-channel patch matrices
- *   "conv_nhwc"    1 (default): 3x3 / stride 1 / SAME layers with 64+ channels per shard read the NHWC activations directly
+ *   "conv_nhwc"    1 (default): 3x3 / stride 1 / SAME layers with 32+ channels per shard read the NHWC activations directly
  *                  (gpfq_quantize_conv3x3_nhwc); 0: channel planes first
  *   "conv_strip"   plane-correlation kernel: output positions per lane (0 = heuristic, 1, 2 or 4)
  *   "conv_shift"   1 (default): 3x3 / stride 1 / SAME layers on images of 20 x 20 or more (shards of 8+ channels) accumulate shift sums (27 FMAs per
@@ -341,7 +341,7 @@ int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t 
  * records with the lanes along the channels, then the batched decide of gpfq_quantize_conv_channels.  Same results.
  *   act_w, act_q [device] f32 NHWC [n][H][W][Cin]; the call takes channels [c_lo, c_lo + nch) (a rank's shard);
  *   Wt [nch][F][9], outputs qidx / Qt [nch][F][9], uncertified [nch][F] as gpfq_quantize_conv_channels (no residual norms).
- *   gpfq_conv3x3_nhwc_supported: 1 if this form takes the shape (images of 4 x 4 or more, 64+ channels in the shard,
+ *   gpfq_conv3x3_nhwc_supported: 1 if this form takes the shape (images of 4 x 4 or more, 32+ channels in the shard,
  *   options "conv_fused" and "conv_nhwc" on), else 0: use gpfq_channel_planes + gpfq_quantize_conv_channels.
  */
 int gpfq_conv3x3_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t nch);

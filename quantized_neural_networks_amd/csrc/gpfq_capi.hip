@@ -752,7 +752,7 @@ int gpfq_quantize_conv3x3_nhwc(const float *act_w, const float *act_q, int64_t n
     int rc = make_alphabet(alphabet, M, zero_idx, &HA);
     if (rc != GPFQ_OK) return rc;
     if (nch == 0 || F == 0) return GPFQ_OK;
-    if (!gpfq::gram_image_nhwc_supported(n, H, W, nch)) return fail(GPFQ_ERR_UNSUPPORTED, "NHWC form needs images of 4 x 4 or more and 64+ channels");
+    if (!gpfq::gram_image_nhwc_supported(n, H, W, nch)) return fail(GPFQ_ERR_UNSUPPORTED, "NHWC form needs images of 4 x 4 or more and 32+ channels");
     if (!act_w || !act_q || !Wt || !qidx || !Qt || !uncertified) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
     const size_t need = gpfq_conv3x3_nhwc_workspace_bytes(n, H, W, nch, F);
     if (!workspace || workspace_bytes < need || (uintptr_t)workspace % 16 != 0)

@@ -872,8 +872,9 @@ static void nhwc_slots(int64_t n, int64_t H, int64_t W, int64_t nch, NhwcParams 
 
 bool gram_image_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t nch)
 {
-    // (64 channels fill the lanes of a wavefront; with 32 the planes form is as fast or faster: CIFAR10 CNN layers, tools/bench_configs.py)
-    return n > 0 && H >= 4 && W >= 4 && nch >= 64 && n * H * W < (1LL << 30) && H < 32768 && W < 32768;
+    // (64 channels fill the lanes of a wavefront; with 32 -- half of them idle -- this form still beats planes + the LDS-staged kernel since
+    //  round 3: the CIFAR10 CNN's 32 -> 32 @32x32 layer on 5008 images 1.55 -> 0.95 ms, 32 -> 64 @16x16 0.66 -> 0.46)
+    return n > 0 && H >= 4 && W >= 4 && nch >= 32 && n * H * W < (1LL << 30) && H < 32768 && W < 32768;
 }
 
 size_t gram_image_nhwc_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t nch, int64_t F)

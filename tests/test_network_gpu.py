@@ -396,9 +396,9 @@ def test_conv_layer_gram_fast_path(oracle_mod, slack, members):
 
 
 @pytest.mark.parametrize("n,H,W,Cin,F,first", [(6, 9, 11, 70, 3, False), (3, 4, 4, 64, 2, False), (5, 13, 6, 130, 2, True), (2, 20, 23, 64, 2, False),
-                                                (40, 7, 7, 64, 2, False), (1, 5, 31, 128, 2, False), (3, 6, 10, 68, 2, False), (9, 14, 14, 64, 2, False), (2, 9, 30, 128, 2, False), (2, 5, 17, 64, 2, True)])
+                                                (40, 7, 7, 64, 2, False), (1, 5, 31, 128, 2, False), (3, 6, 10, 68, 2, False), (9, 14, 14, 64, 2, False), (2, 9, 30, 128, 2, False), (2, 5, 17, 64, 2, True), (7, 12, 9, 32, 3, False), (4, 8, 8, 40, 2, False)])
 def test_conv_3x3_from_nhwc(oracle_mod, n, H, W, Cin, F, first):
-    """3 x 3 / stride 1 / SAME shards of 64+ channels take the shift form straight from the NHWC activations (lanes along the
+    """3 x 3 / stride 1 / SAME shards of 32+ channels take the shift form straight from the NHWC activations (lanes along the
     channels, rows through an LDS ring; no channel-major copy): the same bits as the planes form (conv_nhwc = 0), a shard that
     starts in the middle of the channels, a dead channel, signed first-layer input, and the oracle on some (channel, filter) pairs."""
     from quantized_neural_networks_amd import hip, layer

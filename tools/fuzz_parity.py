@@ -91,8 +91,8 @@ while time.time() < t_end:
             H = int(rng.integers(32, 72)); Wd = int(rng.integers(32, 72)); cin = int(rng.integers(1, 5)); F = int(rng.integers(1, 4))
         hip.set_option("conv_planes_free", int(rng.choice([1, 1, 0])))   # 0: that form fed from channel planes
         nhwc_case = (kh, kw, stride, rate, padding) == (3, 3, 1, 1, "SAME") and rng.random() < 0.5
-        if nhwc_case:                               # 64+ channels: the shift form straight from the NHWC activations (LDS-DMA ring)
-            cin = int(rng.integers(64, 150)); F = int(rng.integers(1, 4))
+        if nhwc_case:                               # 32+ channels: the shift form straight from the NHWC activations (LDS-DMA ring)
+            cin = int(rng.integers(32, 150)); F = int(rng.integers(1, 4))
         oh, ow = hip.patch_out_dim(H, kh, stride, rate, padding == "SAME"), hip.patch_out_dim(Wd, kw, stride, rate, padding == "SAME")
         if oh * ow == 0:
             continue
