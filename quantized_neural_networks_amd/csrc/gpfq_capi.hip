@@ -221,6 +221,7 @@ int gpfq_set_option(const char *key, int value)
     if (!std::strcmp(key, "conv_planes_free")) { g_conv_planes_free = value ? 1 : 0; return GPFQ_OK; }
     if (!std::strcmp(key, "conv_s2")) { gpfq::conv_set_s2(value); return GPFQ_OK; }
     if (!std::strcmp(key, "conv_nhwc_slots")) { gpfq::image_set_nhwc_slots(value); return GPFQ_OK; }
+    if (!std::strcmp(key, "conv_nhwc_halves")) { gpfq::image_set_nhwc_halves(value); return GPFQ_OK; }
     if (!std::strcmp(key, "conv_shift")) {
         if (value < 0 || value > 2) return fail(GPFQ_ERR_INVALID_ARG, "conv_shift must be 0, 1 or 2");
         g_conv_shift = value; return GPFQ_OK;

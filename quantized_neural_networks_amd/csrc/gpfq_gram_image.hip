@@ -430,6 +430,9 @@ struct NhwcParams {
     int64_t cin;                          // channels of the tensor (the pixel stride)
     int n, H, W, nch;
     int nslots, slot_off[10];             // slots of class c: [slot_off[c], slot_off[c + 1])
+    int halves;                           // 2: shards of at most 32 channels -- lanes 32-63 walk the SECOND half of the images (n even)
+    int n_walk;                           // images a lane walks: n / halves
+    unsigned half_off;                    // bytes from an image of the first half to its partner in the second
     double *part;
     int *negflag;
 };
@@ -447,7 +450,10 @@ __device__ __forceinline__ void nhwc_class_walk(const NhwcParams &p, float *ring
     static_assert(NC == 9 || NC == 5, "the request helpers take rows of nine or five columns");
     float (*ring)[NT][NC][64] = reinterpret_cast<float (*)[NT][NC][64]>(ring_base);
     const int lane = threadIdx.x;
-    const int64_t ch = (int64_t)blockIdx.y * 64 + lane;
+    // (halves == 2: at most 32 channels, lanes 32-63 hold the same channels of the image n / 2 further on -- the walk is per lane, only
+    //  the address of its pixel differs: a constant in the lane's request offset)
+    const int hsel = p.halves == 2 ? lane >> 5 : 0;
+    const int64_t ch = p.halves == 2 ? (lane & 31) : (int64_t)blockIdx.y * 64 + lane;
     const bool live = ch < p.nch;
     const int k = blockIdx.x - p.slot_off[cls], nk = p.slot_off[cls + 1] - p.slot_off[cls];
     const int cy = cls / 3, cx = cls - 3 * cy;
@@ -455,9 +461,9 @@ __device__ __forceinline__ void nhwc_class_walk(const NhwcParams &p, float *ring
     const int ya = cy == 1 ? 1 : (cy == 0 ? 0 : H - 1), yb = cy == 1 ? H - 2 : ya;
     const int xlo = cx == 1 ? 1 : (cx == 0 ? 0 : W - 1), xhi = cx == 1 ? W - 2 : xlo;
     const int ns = (xhi - xlo + SW) / SW;
-    const int64_t nitems = (int64_t)p.n * ns;
+    const int64_t nitems = (int64_t)p.n_walk * ns;
     // requests: the address of a column is SCALAR (row base + column offset, glds4_row9); the lane adds its channel
-    const unsigned voff = (unsigned)(live ? ch : 0) * 4u;
+    const unsigned voff = (unsigned)(live ? ch : 0) * 4u + (unsigned)hsel * p.half_off;
     const unsigned ring_addr = lds_addr(ring_base);
     const int nr = yb - ya + 3;                                     // rows ya - 2 .. yb of the walk, j = 0 .. nr - 1
     const int j0 = ya < 2 ? 2 - ya : 0;                             // rows j < j0 lie above the image
@@ -582,7 +588,7 @@ __device__ __forceinline__ void nhwc_class_walk(const NhwcParams &p, float *ring
     }
     if (live) {
         if (sg >> 31) atomicOr(p.negflag + ch, 1);
-        double *out = p.part + (ch * p.nslots + blockIdx.x) * kShiftN;
+        double *out = p.part + ((ch * p.halves + hsel) * p.nslots + blockIdx.x) * kShiftN;        // [channel][half][slot][27]
 #pragma unroll
         for (int i = 0; i < 13; ++i) { out[i] = c1[i]; out[13 + i] = SAME_ACT ? c1[i] : c2[i]; }
         out[26] = c3;
@@ -617,16 +623,17 @@ gpfq_gram_shift_partsum_nhwc_kernel(NhwcParams p, double *__restrict__ tpart)
     const int per = (p.nslots + kNhwcParts - 1) / kNhwcParts;
     const int k0 = part * per, k1 = k0 + per < p.nslots ? k0 + per : p.nslots;
     double *out = tpart + (ch * kNhwcParts + part) * 9 * kShiftN;
-    const double *src = p.part + ch * p.nslots * kShiftN;
+    const double *src = p.part + ch * p.halves * p.nslots * kShiftN;
     for (int c = 0; c < 9; ++c) {
         const int lo = p.slot_off[c] > k0 ? p.slot_off[c] : k0, hi = p.slot_off[c + 1] < k1 ? p.slot_off[c + 1] : k1;
         double acc[(kShiftN + 3) / 4];
 #pragma unroll
         for (int q = 0; q < (kShiftN + 3) / 4; ++q) acc[q] = 0.0;
+        for (int h = 0; h < p.halves; ++h)                           // (both halves of the images, one after the other)
         for (int kb = lo; kb < hi; kb += 64) {
             const int cnt = hi - kb < 64 ? hi - kb : 64;
             __syncthreads();
-            for (int e = threadIdx.x; e < cnt * kShiftN; e += 256) tile[e] = src[(int64_t)kb * kShiftN + e];
+            for (int e = threadIdx.x; e < cnt * kShiftN; e += 256) tile[e] = src[((int64_t)h * p.nslots + kb) * kShiftN + e];
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < (kShiftN + 3) / 4; ++q) {
@@ -834,6 +841,8 @@ hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream)
 }
 
 // ---- NHWC entry: 3 x 3, stride 1, SAME, all channels of the shard in one launch chain ----
+static std::atomic<int> g_nhwc_halves{1};              // shards of <= 32 channels: lanes 32-63 walk the second half of the images (option conv_nhwc_halves)
+void image_set_nhwc_halves(int on) { g_nhwc_halves.store(on ? 1 : 0, std::memory_order_relaxed); }
 static std::atomic<int> g_nhwc_slots{8192};            // workgroups of a launch (option conv_nhwc_slots: experiment switch)
 void image_set_nhwc_slots(int n) { g_nhwc_slots.store(n < 256 ? 256 : (n > 65536 ? 65536 : n), std::memory_order_relaxed); }
 static void nhwc_slots(int64_t n, int64_t H, int64_t W, int64_t nch, NhwcParams &p)
@@ -882,7 +891,7 @@ size_t gram_image_nhwc_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t 
     NhwcParams p{};
     nhwc_slots(n, H, W, nch, p);
     size_t b = 0;
-    b += al256i((size_t)nch * p.nslots * kShiftN * sizeof(double));
+    b += al256i((size_t)nch * p.nslots * (nch <= 32 ? 2 : 1) * kShiftN * sizeof(double));
     b += al256i((size_t)nch * kRec9 * sizeof(double));
     b += al256i((size_t)nch * 9 * sizeof(float));
     b += al256i((size_t)nch * F * 9 * sizeof(float));
@@ -899,9 +908,14 @@ hipError_t launch_gram_image_nhwc(const ImageGramArgs &a, hipStream_t stream)
     NhwcParams p{};
     p.act_w = a.act_w; p.act_q = a.act_q; p.cin = a.nhwc_cin;
     p.n = (int)a.n; p.H = (int)a.H; p.W = (int)a.W; p.nch = (int)a.nch;
-    nhwc_slots(a.n, a.H, a.W, a.nch, p);
+    // shards of at most 32 channels: the idle half of every wavefront walks the second half of the images
+    const uint64_t half_bytes = (uint64_t)(a.n / 2) * a.H * a.W * a.nhwc_cin * sizeof(float);
+    p.halves = (a.nch <= 32 && a.n % 2 == 0 && a.n >= 2 && half_bytes + 4 * (uint64_t)a.nch < (1ull << 32) && g_nhwc_halves.load(std::memory_order_relaxed)) ? 2 : 1;
+    p.n_walk = (int)(a.n / p.halves);
+    p.half_off = p.halves == 2 ? (unsigned)half_bytes : 0u;
+    nhwc_slots(p.n_walk, a.H, a.W, a.nch, p);
     char *ws = static_cast<char *>(a.workspace);
-    p.part = reinterpret_cast<double *>(ws);        ws += al256i((size_t)a.nch * p.nslots * kShiftN * sizeof(double));
+    p.part = reinterpret_cast<double *>(ws);        ws += al256i((size_t)a.nch * p.nslots * (a.nch <= 32 ? 2 : 1) * kShiftN * sizeof(double));
     double *gram = reinterpret_cast<double *>(ws);  ws += al256i((size_t)a.nch * kRec9 * sizeof(double));
     float *nrm = reinterpret_cast<float *>(ws);     ws += al256i((size_t)a.nch * 9 * sizeof(float));
     float *q32h = reinterpret_cast<float *>(ws);    ws += al256i((size_t)a.nch * a.F * 9 * sizeof(float));

@@ -217,6 +217,7 @@ bool gram_s2_supported(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, 
 size_t gram_s2_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t nch);
 hipError_t launch_gram_s2(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch, double *part,
                           double *gram, float *nrm32, int *negflag, hipStream_t stream, int64_t pix = 1);
+void image_set_nhwc_halves(int on);  // NHWC 3x3 form, <= 32 channels: the idle half of a wavefront walks the second half of the images (speed only)
 void image_set_nhwc_slots(int n);    // NHWC 3x3 form: workgroups per launch (speed only)
 void conv_set_s2(int on);           // the shift-sum form for 7x7 / 2 layers (speed only; 0: the matrix-core kernel)
 

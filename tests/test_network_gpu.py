@@ -396,7 +396,7 @@ def test_conv_layer_gram_fast_path(oracle_mod, slack, members):
 
 
 @pytest.mark.parametrize("n,H,W,Cin,F,first", [(6, 9, 11, 70, 3, False), (3, 4, 4, 64, 2, False), (5, 13, 6, 130, 2, True), (2, 20, 23, 64, 2, False),
-                                                (40, 7, 7, 64, 2, False), (1, 5, 31, 128, 2, False), (3, 6, 10, 68, 2, False), (9, 14, 14, 64, 2, False), (2, 9, 30, 128, 2, False), (2, 5, 17, 64, 2, True), (7, 12, 9, 32, 3, False), (4, 8, 8, 40, 2, False)])
+                                                (40, 7, 7, 64, 2, False), (1, 5, 31, 128, 2, False), (3, 6, 10, 68, 2, False), (9, 14, 14, 64, 2, False), (2, 9, 30, 128, 2, False), (2, 5, 17, 64, 2, True), (7, 12, 9, 32, 3, False), (4, 8, 8, 40, 2, False), (8, 12, 9, 32, 3, False), (6, 7, 21, 32, 2, True), (2, 30, 30, 32, 2, False)])
 def test_conv_3x3_from_nhwc(oracle_mod, n, H, W, Cin, F, first):
     """3 x 3 / stride 1 / SAME shards of 32+ channels take the shift form straight from the NHWC activations (lanes along the
     channels, rows through an LDS ring; no channel-major copy): the same bits as the planes form (conv_nhwc = 0), a shard that
@@ -418,9 +418,14 @@ def test_conv_3x3_from_nhwc(oracle_mod, n, H, W, Cin, F, first):
         hip.set_option("conv_nhwc", 0)
         assert not hip.conv3x3_nhwc_supported(n, H, W, Cin)
         planes = layer.quantize_conv2d(Wd, aw, aq, alphabet, strides=(1, 1), padding="SAME", rate=(1, 1), want_resid=False)
+        hip.set_option("conv_nhwc", 1)
+        hip.set_option("conv_nhwc_halves", 0)                            # (<= 32 channels, an even number of images: one image per wavefront)
+        whole = layer.quantize_conv2d(Wd, aw, aq, alphabet, strides=(1, 1), padding="SAME", rate=(1, 1), want_resid=False)
     finally:
         hip.set_option("conv_nhwc", 1)
+        hip.set_option("conv_nhwc_halves", 1)
     assert torch.equal(out["Q"], planes["Q"]) and torch.equal(out["idx"], planes["idx"])
+    assert torch.equal(out["Q"], whole["Q"]) and torch.equal(out["idx"], whole["idx"])
     Q = out["Q"].cpu().numpy()
     for c in (0, 5, Cin // 2, Cin - 1):
         Pw = ref_patches(act_w, c, 3, 3, 1, 1, 1, 1, "SAME")

@@ -90,6 +90,7 @@ while time.time() < t_end:
             kh = kw = 7; stride = 2; rate = 1; padding = "VALID"
             H = int(rng.integers(32, 72)); Wd = int(rng.integers(32, 72)); cin = int(rng.integers(1, 5)); F = int(rng.integers(1, 4))
         hip.set_option("conv_planes_free", int(rng.choice([1, 1, 0])))   # 0: that form fed from channel planes
+        hip.set_option("conv_nhwc_halves", int(rng.choice([1, 1, 0])))   # 0: shards of <= 32 channels one image per wavefront
         nhwc_case = (kh, kw, stride, rate, padding) == (3, 3, 1, 1, "SAME") and rng.random() < 0.5
         if nhwc_case:                               # 32+ channels: the shift form straight from the NHWC activations (LDS-DMA ring)
             cin = int(rng.integers(32, 150)); F = int(rng.integers(1, 4))
