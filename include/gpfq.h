@@ -132,6 +132,13 @@ const char *gpfq_last_dense_kernel(void);
  *   "conv_fused"   1 (default): conv layers read their patch rows from the channel planes; 0: per-channel patch matrices
  *   "conv_nhwc"    1 (default): 3x3 / stride 1 / SAME layers with 32+ channels per shard read the NHWC activations directly
  *                  (gpfq_quantize_conv3x3_nhwc); 0: channel planes first
+ *   "conv_nhwc_slots"   that form's workgroups per launch (default 8192: many short one-wavefront workgroups balance themselves)
+ *   "conv_nhwc_halves"  1 (default): in shards of at most 32 channels on an even number of images lanes 32-63 of a wavefront walk
+ *                  the second half of the images; 0: they idle
+ *   "conv_planes_free"  1 (default): 7x7 / stride 2 / VALID layers read the NHWC activations themselves
+ *                  (gpfq_quantize_conv_channels_nhwc); 0: channel planes first
+ *   "blk_pair_groups", "blk_single_groups"  1 (default): the block form takes two neurons per workgroup in layers of at most 512
+ *                  neurons, one in layers of at most 128; 0: four / two
  *   "conv_strip"   plane-correlation kernel: output positions per lane (0 = heuristic, 1, 2 or 4)
  *   "conv_shift"   1 (default): 3x3 / stride 1 / SAME layers on images of 20 x 20 or more (shards of 8+ channels) accumulate shift sums (27 FMAs per
  *                  position, border classes apart); 0: the per-output-position records (99 FMAs) that VALID layers and small
