@@ -430,9 +430,10 @@ struct NhwcParams {
     int64_t cin;                          // channels of the tensor (the pixel stride)
     int n, H, W, nch;
     int nslots, slot_off[10];             // slots of class c: [slot_off[c], slot_off[c + 1])
-    int halves;                           // 2: shards of at most 32 channels -- lanes 32-63 walk the SECOND half of the images (n even)
-    int n_walk;                           // images a lane walks: n / halves
-    unsigned half_off;                    // bytes from an image of the first half to its partner in the second
+    int halves;                           // image groups G = 1, 2, 4, 8 or 16: shards of at most 64 / G channels -- lanes [g 64/G, (g + 1) 64/G) of a wavefront walk
+                                          // the g-th G-th of the images (G divides n): no lane idles because the shard is narrow
+    int n_walk;                           // images a lane walks: n / G
+    unsigned half_off;                    // bytes from an image of one group to its partner in the next
     double *part;
     int *negflag;
 };
@@ -450,10 +451,11 @@ __device__ __forceinline__ void nhwc_class_walk(const NhwcParams &p, float *ring
     static_assert(NC == 9 || NC == 5, "the request helpers take rows of nine or five columns");
     float (*ring)[NT][NC][64] = reinterpret_cast<float (*)[NT][NC][64]>(ring_base);
     const int lane = threadIdx.x;
-    // (halves == 2: at most 32 channels, lanes 32-63 hold the same channels of the image n / 2 further on -- the walk is per lane, only
-    //  the address of its pixel differs: a constant in the lane's request offset)
-    const int hsel = p.halves == 2 ? lane >> 5 : 0;
-    const int64_t ch = p.halves == 2 ? (lane & 31) : (int64_t)blockIdx.y * 64 + lane;
+    // (G image groups: at most 64 / G channels, lane group g holds the same channels of the image g n / G further on -- the walk is per
+    //  lane, only the address of its pixel differs: a constant in the lane's request offset)
+    const int lg = 64 / p.halves;                                  // lanes per image group
+    const int hsel = p.halves > 1 ? lane / lg : 0;
+    const int64_t ch = p.halves > 1 ? lane - hsel * lg : (int64_t)blockIdx.y * 64 + lane;
     const bool live = ch < p.nch;
     const int k = blockIdx.x - p.slot_off[cls], nk = p.slot_off[cls + 1] - p.slot_off[cls];
     const int cy = cls / 3, cx = cls - 3 * cy;
@@ -588,7 +590,7 @@ __device__ __forceinline__ void nhwc_class_walk(const NhwcParams &p, float *ring
     }
     if (live) {
         if (sg >> 31) atomicOr(p.negflag + ch, 1);
-        double *out = p.part + ((ch * p.halves + hsel) * p.nslots + blockIdx.x) * kShiftN;        // [channel][half][slot][27]
+        double *out = p.part + ((ch * p.halves + hsel) * p.nslots + blockIdx.x) * kShiftN;        // [channel][image group][slot][27]
 #pragma unroll
         for (int i = 0; i < 13; ++i) { out[i] = c1[i]; out[13 + i] = SAME_ACT ? c1[i] : c2[i]; }
         out[26] = c3;
@@ -629,7 +631,7 @@ gpfq_gram_shift_partsum_nhwc_kernel(NhwcParams p, double *__restrict__ tpart)
         double acc[(kShiftN + 3) / 4];
 #pragma unroll
         for (int q = 0; q < (kShiftN + 3) / 4; ++q) acc[q] = 0.0;
-        for (int h = 0; h < p.halves; ++h)                           // (both halves of the images, one after the other)
+        for (int h = 0; h < p.halves; ++h)                           // (the image groups, one after the other)
         for (int kb = lo; kb < hi; kb += 64) {
             const int cnt = hi - kb < 64 ? hi - kb : 64;
             __syncthreads();
@@ -845,6 +847,15 @@ static std::atomic<int> g_nhwc_halves{1};              // shards of <= 32 channe
 void image_set_nhwc_halves(int on) { g_nhwc_halves.store(on ? 1 : 0, std::memory_order_relaxed); }
 static std::atomic<int> g_nhwc_slots{8192};            // workgroups of a launch (option conv_nhwc_slots: experiment switch)
 void image_set_nhwc_slots(int n) { g_nhwc_slots.store(n < 256 ? 256 : (n > 65536 ? 65536 : n), std::memory_order_relaxed); }
+// Image groups of a shard of nch channels over n images: the largest G in {16, 8, 4, 2} with nch <= 64 / G that divides n (1: none)
+static int nhwc_image_groups(int64_t n, int64_t nch)
+{
+    if (!g_nhwc_halves.load(std::memory_order_relaxed)) return 1;
+    for (int g = 16; g >= 2; g >>= 1)
+        if (nch * g <= 64 && n % g == 0 && n >= g) return g;
+    return 1;
+}
+
 static void nhwc_slots(int64_t n, int64_t H, int64_t W, int64_t nch, NhwcParams &p)
 {
     // Slots per class in proportion to its work (items x row steps per item x requests per step), about 8192 one-wavefront
@@ -883,7 +894,9 @@ bool gram_image_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t nch)
 {
     // (64 channels fill the lanes of a wavefront; with 32 -- half of them idle -- this form still beats planes + the LDS-staged kernel since
     //  round 3: the CIFAR10 CNN's 32 -> 32 @32x32 layer on 5008 images 1.55 -> 0.95 ms, 32 -> 64 @16x16 0.66 -> 0.46)
-    return n > 0 && H >= 4 && W >= 4 && nch >= 32 && n * H * W < (1LL << 30) && H < 32768 && W < 32768;
+    // narrower shards: only where the image groups put their lanes to work (an image count the group count divides)
+    if (nch < 32 && nhwc_image_groups(n, nch) * nch < 32) return false;
+    return n > 0 && H >= 4 && W >= 4 && nch >= 1 && n * H * W < (1LL << 30) && H < 32768 && W < 32768;
 }
 
 size_t gram_image_nhwc_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t nch, int64_t F)
@@ -891,7 +904,7 @@ size_t gram_image_nhwc_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t 
     NhwcParams p{};
     nhwc_slots(n, H, W, nch, p);
     size_t b = 0;
-    b += al256i((size_t)nch * p.nslots * (nch <= 32 ? 2 : 1) * kShiftN * sizeof(double));
+    b += al256i((size_t)nch * p.nslots * (nch <= 4 ? 16 : nch <= 8 ? 8 : nch <= 16 ? 4 : nch <= 32 ? 2 : 1) * kShiftN * sizeof(double));
     b += al256i((size_t)nch * kRec9 * sizeof(double));
     b += al256i((size_t)nch * 9 * sizeof(float));
     b += al256i((size_t)nch * F * 9 * sizeof(float));
@@ -908,14 +921,14 @@ hipError_t launch_gram_image_nhwc(const ImageGramArgs &a, hipStream_t stream)
     NhwcParams p{};
     p.act_w = a.act_w; p.act_q = a.act_q; p.cin = a.nhwc_cin;
     p.n = (int)a.n; p.H = (int)a.H; p.W = (int)a.W; p.nch = (int)a.nch;
-    // shards of at most 32 channels: the idle half of every wavefront walks the second half of the images
-    const uint64_t half_bytes = (uint64_t)(a.n / 2) * a.H * a.W * a.nhwc_cin * sizeof(float);
-    p.halves = (a.nch <= 32 && a.n % 2 == 0 && a.n >= 2 && half_bytes + 4 * (uint64_t)a.nch < (1ull << 32) && g_nhwc_halves.load(std::memory_order_relaxed)) ? 2 : 1;
+    // narrow shards: the lanes a shard of at most 32 / 16 / 8 / 4 channels leaves idle walk further G-ths of the images
+    p.halves = nhwc_image_groups(a.n, a.nch);
+    if ((uint64_t)a.n * a.H * a.W * a.nhwc_cin * sizeof(float) >= (1ull << 32)) p.halves = 1;      // (the group offset is a 32-bit lane offset)
     p.n_walk = (int)(a.n / p.halves);
-    p.half_off = p.halves == 2 ? (unsigned)half_bytes : 0u;
+    p.half_off = p.halves > 1 ? (unsigned)((uint64_t)p.n_walk * a.H * a.W * a.nhwc_cin * sizeof(float)) : 0u;
     nhwc_slots(p.n_walk, a.H, a.W, a.nch, p);
     char *ws = static_cast<char *>(a.workspace);
-    p.part = reinterpret_cast<double *>(ws);        ws += al256i((size_t)a.nch * p.nslots * (a.nch <= 32 ? 2 : 1) * kShiftN * sizeof(double));
+    p.part = reinterpret_cast<double *>(ws);        ws += al256i((size_t)a.nch * p.nslots * (a.nch <= 4 ? 16 : a.nch <= 8 ? 8 : a.nch <= 16 ? 4 : a.nch <= 32 ? 2 : 1) * kShiftN * sizeof(double));
     double *gram = reinterpret_cast<double *>(ws);  ws += al256i((size_t)a.nch * kRec9 * sizeof(double));
     float *nrm = reinterpret_cast<float *>(ws);     ws += al256i((size_t)a.nch * 9 * sizeof(float));
     float *q32h = reinterpret_cast<float *>(ws);    ws += al256i((size_t)a.nch * a.F * 9 * sizeof(float));

@@ -198,7 +198,7 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
     same = act_q is act_w
     act_w = act_w.contiguous()
     act_q = act_w if same else act_q.contiguous()
-    # 3 x 3 / stride 1 / SAME shards of 32+ channels read the NHWC tensors directly; everything else goes through the planes
+    # 3 x 3 / stride 1 / SAME shards of 32+ channels (narrower ones where image groups fill the lanes) read the NHWC tensors directly; everything else goes through the planes
     nhwc = (not want_resid and by_channel and (kh, kw) == (3, 3) and tuple(strides) == (1, 1) and tuple(rate or (1, 1)) == (1, 1)
             and str(padding).upper() == "SAME" and len(alphabet) <= hip.GPFQ_MAX_ALPHABET
             and hip.conv3x3_nhwc_supported(act_w.shape[0], act_w.shape[1], act_w.shape[2], c_hi - c_lo))

@@ -396,7 +396,8 @@ def test_conv_layer_gram_fast_path(oracle_mod, slack, members):
 
 
 @pytest.mark.parametrize("n,H,W,Cin,F,first", [(6, 9, 11, 70, 3, False), (3, 4, 4, 64, 2, False), (5, 13, 6, 130, 2, True), (2, 20, 23, 64, 2, False),
-                                                (40, 7, 7, 64, 2, False), (1, 5, 31, 128, 2, False), (3, 6, 10, 68, 2, False), (9, 14, 14, 64, 2, False), (2, 9, 30, 128, 2, False), (2, 5, 17, 64, 2, True), (7, 12, 9, 32, 3, False), (4, 8, 8, 40, 2, False), (8, 12, 9, 32, 3, False), (6, 7, 21, 32, 2, True), (2, 30, 30, 32, 2, False)])
+                                                (40, 7, 7, 64, 2, False), (1, 5, 31, 128, 2, False), (3, 6, 10, 68, 2, False), (9, 14, 14, 64, 2, False), (2, 9, 30, 128, 2, False), (2, 5, 17, 64, 2, True), (7, 12, 9, 32, 3, False), (4, 8, 8, 40, 2, False), (8, 12, 9, 32, 3, False), (6, 7, 21, 32, 2, True), (2, 30, 30, 32, 2, False),
+                                                (32, 9, 11, 3, 2, True), (16, 10, 7, 3, 3, False), (8, 12, 9, 16, 3, False), (24, 6, 9, 7, 2, False), (4, 8, 8, 20, 2, False)])
 def test_conv_3x3_from_nhwc(oracle_mod, n, H, W, Cin, F, first):
     """3 x 3 / stride 1 / SAME shards of 32+ channels take the shift form straight from the NHWC activations (lanes along the
     channels, rows through an LDS ring; no channel-major copy): the same bits as the planes form (conv_nhwc = 0), a shard that
@@ -405,8 +406,9 @@ def test_conv_3x3_from_nhwc(oracle_mod, n, H, W, Cin, F, first):
     r = np.random.default_rng(n + W + Cin)
     act_w = (r.random((n, H, W, Cin)) - (0.3 if first else 0.0)).astype(np.float32)
     act_q = act_w if first else np.maximum(act_w + 0.05 * r.standard_normal(act_w.shape), 0).astype(np.float32)
+    dead = 5 if Cin > 5 else Cin - 1
     if not first:
-        act_q[..., 5] = 0.0                                              # dead channel: rule (i) everywhere
+        act_q[..., dead] = 0.0                                           # dead channel: rule (i) everywhere
     Wk = (r.standard_normal((3, 3, Cin, F)) / 3).astype(np.float32)
     Wd = torch.from_numpy(Wk).cuda()
     alphabet, _ = layer.layer_alphabet(Wd, np.linspace(-1, 1, 3), 3)
@@ -427,14 +429,14 @@ def test_conv_3x3_from_nhwc(oracle_mod, n, H, W, Cin, F, first):
     assert torch.equal(out["Q"], planes["Q"]) and torch.equal(out["idx"], planes["idx"])
     assert torch.equal(out["Q"], whole["Q"]) and torch.equal(out["idx"], whole["idx"])
     Q = out["Q"].cpu().numpy()
-    for c in (0, 5, Cin // 2, Cin - 1):
+    for c in sorted({0, dead, Cin // 2, Cin - 1}):
         Pw = ref_patches(act_w, c, 3, 3, 1, 1, 1, 1, "SAME")
         Pq = ref_patches(act_q, c, 3, 3, 1, 1, 1, 1, "SAME")
         for f in range(F):
             qo, _, _ = oracle_mod.neuron(Wk[:, :, c, f].reshape(-1), Pw, Pq, alphabet)
             assert np.array_equal(Q[:, :, c, f].reshape(-1), qo.astype(np.float32)), (c, f)
     if not first:
-        assert (Q[:, :, 5] == 0).all()
+        assert (Q[:, :, dead] == 0).all()
     # a shard of channels that starts inside the tensor (what a rank of a multi-GPU run holds): the C entry directly
     c_lo, c_hi = 3, 3 + 64
     Wt = Wd.permute(2, 3, 0, 1).reshape(Cin, F, 9).contiguous()[c_lo:c_hi].contiguous()

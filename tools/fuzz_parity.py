@@ -93,13 +93,15 @@ while time.time() < t_end:
         hip.set_option("conv_nhwc_halves", int(rng.choice([1, 1, 0])))   # 0: shards of <= 32 channels one image per wavefront
         nhwc_case = (kh, kw, stride, rate, padding) == (3, 3, 1, 1, "SAME") and rng.random() < 0.5
         if nhwc_case:                               # 32+ channels: the shift form straight from the NHWC activations (LDS-DMA ring)
-            cin = int(rng.integers(32, 150)); F = int(rng.integers(1, 4))
+            cin = int(rng.choice([rng.integers(32, 150), rng.integers(1, 32)])); F = int(rng.integers(1, 4))
         oh, ow = hip.patch_out_dim(H, kh, stride, rate, padding == "SAME"), hip.patch_out_dim(Wd, kw, stride, rate, padding == "SAME")
         if oh * ow == 0:
             continue
         n = int(rng.choice([rng.integers(1, 20), -(-hip.GPFQ_GRAM_MIN_M // (oh * ow)) + int(rng.integers(1, 40))]))
         if nhwc_case:
             n = min(n, 12)                          # (the oracle walks every channel on the host)
+            if cin < 32:
+                n = 16                              # narrow shards take the NHWC form by image groups (2 .. 16 divide n)
         if s2_case:
             n = int(rng.integers(1, 24))
         kind = rng.choice(["relu", "sparse", "signed", "uniform"])
