@@ -130,11 +130,11 @@ const char *gpfq_last_dense_kernel(void);
  *   "auto_gram"    1 (default): GPFQ_PATH_AUTO may divert long rows to the Gram path (one stream synchronisation inside the call);
  *                  0: AUTO only picks between the asynchronous on-chip and streaming kernels
  *   "conv_fused"   1 (default): conv layers read their patch rows from the channel planes; 0: per-channel patch matrices
- *   "conv_nhwc"    1 (default): 3x3 / stride 1 / SAME layers read the NHWC activations directly (shards of 32+ channels, and narrower ones whose image count a power of two up to 16 divides: see "conv_nhwc_halves")
+ *   "conv_nhwc"    1 (default): 3x3 / stride 1 / SAME layers read the NHWC activations directly (shards of 32+ channels, and of 8 to 31 where 2, 4 or 8 divides the image count: see "conv_nhwc_halves")
  *                  (gpfq_quantize_conv3x3_nhwc); 0: channel planes first
  *   "conv_nhwc_slots"   that form's workgroups per launch (default 8192: many short one-wavefront workgroups balance themselves)
- *   "conv_nhwc_halves"  1 (default): in shards of at most 32 / 16 / 8 / 4 channels the lanes the shard leaves idle walk further
- *                  halves / quarters / eighths / sixteenths of the images (where that count divides the number of images); 0: they idle
+ *   "conv_nhwc_halves"  1 (default): in shards of at most 32 / 16 / 8 channels the lanes the shard leaves idle walk further
+ *                  halves / quarters / eighths of the images (where that count divides the number of images); 0: they idle
  *   "conv_planes_free"  1 (default): 7x7 / stride 2 / VALID layers read the NHWC activations themselves
  *                  (gpfq_quantize_conv_channels_nhwc); 0: channel planes first
  *   "blk_pair_groups", "blk_single_groups"  1 (default): the block form takes two neurons per workgroup in layers of at most 512
@@ -348,7 +348,7 @@ int gpfq_quantize_conv_channels(const float *act_w, const float *act_q, int64_t 
  * records with the lanes along the channels, then the batched decide of gpfq_quantize_conv_channels.  Same results.
  *   act_w, act_q [device] f32 NHWC [n][H][W][Cin]; the call takes channels [c_lo, c_lo + nch) (a rank's shard);
  *   Wt [nch][F][9], outputs qidx / Qt [nch][F][9], uncertified [nch][F] as gpfq_quantize_conv_channels (no residual norms).
- *   gpfq_conv3x3_nhwc_supported: 1 if this form takes the shape (images of 4 x 4 or more, 32+ channels in the shard -- or fewer on an image count that 2, 4, 8 or 16 divides so that image groups fill at least half of a wavefront's lanes,
+ *   gpfq_conv3x3_nhwc_supported: 1 if this form takes the shape (images of 4 x 4 or more, 32+ channels in the shard -- or 8 to 31 on an image count that 2, 4 or 8 divides so that image groups fill at least half of a wavefront's lanes,
  *   options "conv_fused" and "conv_nhwc" on), else 0: use gpfq_channel_planes + gpfq_quantize_conv_channels.
  */
 int gpfq_conv3x3_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t nch);

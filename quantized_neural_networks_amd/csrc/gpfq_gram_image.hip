@@ -895,7 +895,9 @@ bool gram_image_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t nch)
     // (64 channels fill the lanes of a wavefront; with 32 -- half of them idle -- this form still beats planes + the LDS-staged kernel since
     //  round 3: the CIFAR10 CNN's 32 -> 32 @32x32 layer on 5008 images 1.55 -> 0.95 ms, 32 -> 64 @16x16 0.66 -> 0.46)
     // narrower shards: only where the image groups put their lanes to work (an image count the group count divides)
-    if (nch < 32 && nhwc_image_groups(n, nch) * nch < 32) return false;
+    // (and from 8 channels up: 3 -> 32 @32x32 on 5008 images takes 0.45 ms here against 0.34 through planes -- sixteen groups' partials and
+    //  4-byte requests 12 bytes apart --, 8 -> 8 @56x56 0.74 against 0.96, 16 -> 32 @32x32 0.56 against 0.89)
+    if (nch < 32 && (nch < 8 || nhwc_image_groups(n, nch) * nch < 32)) return false;
     return n > 0 && H >= 4 && W >= 4 && nch >= 1 && n * H * W < (1LL << 30) && H < 32768 && W < 32768;
 }
 

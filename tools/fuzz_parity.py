@@ -93,7 +93,7 @@ while time.time() < t_end:
         hip.set_option("conv_nhwc_halves", int(rng.choice([1, 1, 0])))   # 0: shards of <= 32 channels one image per wavefront
         nhwc_case = (kh, kw, stride, rate, padding) == (3, 3, 1, 1, "SAME") and rng.random() < 0.5
         if nhwc_case:                               # 32+ channels: the shift form straight from the NHWC activations (LDS-DMA ring)
-            cin = int(rng.choice([rng.integers(32, 150), rng.integers(1, 32)])); F = int(rng.integers(1, 4))
+            cin = int(rng.choice([rng.integers(32, 150), rng.integers(8, 32)])); F = int(rng.integers(1, 4))
         oh, ow = hip.patch_out_dim(H, kh, stride, rate, padding == "SAME"), hip.patch_out_dim(Wd, kw, stride, rate, padding == "SAME")
         if oh * ow == 0:
             continue
