@@ -1,5 +1,5 @@
 // Gram records of a 7x7 / stride 2 / VALID conv layer (ResNet50's conv1 on the zero-padded input) from SHIFT SUMS of the
-// parity classes of the channel planes -- the stride-2 analogue of gpfq_gram_shift_kernel (gpfq_gram_image.hip).
+// parity classes of each channel's image -- the stride-2 analogue of gpfq_gram_shift_kernel (gpfq_gram_image.hip).
 //
 // Replaces, for that kernel shape, the patch-matrix inner products behind _quantize_filter2D_parallel_jit
 // (scripts/quantized_network.py:185-233; patch rows: :123-183, :729-809): same records, same decide step.
@@ -24,7 +24,10 @@
 //    to one region, and gpfq_gram_s2_combine_kernel ADDS the regions in which a row t qualifies -- never a full sum minus a border,
 //    so exactly zero norms (rule (i), :83-84) stay exactly zero.
 //  * A band of decimated rows (+ 3 above) of all four classes of both tensors is staged in LDS de-interleaved, 4 zero columns left
-//    and >= 4 right of every row, zero rows above the plane: no bounds checks in the sweeps.
+//    and >= 4 right of every row, zero rows above the plane: no bounds checks in the sweeps.  The band's full rows are one run of the
+//    channel's pixels -- contiguous floats of a channel plane, or every Cin-th float of the NHWC tensor itself (S2Params::pix: the
+//    layer then needs no channel planes at all) -- copied by LDS-DMA into a raw area under the previous band's sums and scattered
+//    LDS -> LDS into the classes.
 #include "gpfq_device.hpp"
 #include "gpfq_gram_tile.hpp"
 #include "gpfq_launch.hpp"
