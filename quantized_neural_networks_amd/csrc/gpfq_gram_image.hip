@@ -433,6 +433,7 @@ struct NhwcParams {
     int halves;                           // image groups G = 1, 2, 4, 8 or 16: shards of at most 64 / G channels -- lanes [g 64/G, (g + 1) 64/G) of a wavefront walk
                                           // the g-th G-th of the images (G divides n): no lane idles because the shard is narrow
     int n_walk;                           // images a lane walks: n / G
+    int parts;                            // workgroups per channel of the first combine stage (<= kNhwcParts): ~256 slots each
     unsigned half_off;                    // bytes from an image of one group to its partner in the next
     double *part;
     int *negflag;
@@ -611,7 +612,7 @@ gpfq_gram_shift_nhwc_kernel(NhwcParams p)
 // Class sums of the NHWC form, first stage: a launch has thousands of slots (nhwc_slots), 27 doubles each per channel -- a channel's
 // partials are megabytes.  Workgroup (channel, part) adds the slots of its sixteenth of the slot range, class by class, into
 // tpart[channel][part][9][27].
-constexpr int kNhwcParts = 16;
+constexpr int kNhwcParts = 16;            // at most: nhwc_parts()
 __global__ void __launch_bounds__(256)
 gpfq_gram_shift_partsum_nhwc_kernel(NhwcParams p, double *__restrict__ tpart)
 {
@@ -622,7 +623,7 @@ gpfq_gram_shift_partsum_nhwc_kernel(NhwcParams p, double *__restrict__ tpart)
     const int64_t ch = blockIdx.x;
     const int part = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per = (p.nslots + kNhwcParts - 1) / kNhwcParts;
+    const int per = (p.nslots + p.parts - 1) / p.parts;
     const int k0 = part * per, k1 = k0 + per < p.nslots ? k0 + per : p.nslots;
     double *out = tpart + (ch * kNhwcParts + part) * 9 * kShiftN;
     const double *src = p.part + ch * p.halves * p.nslots * kShiftN;
@@ -660,7 +661,7 @@ gpfq_gram_shift_combine_nhwc_kernel(NhwcParams p, const double *__restrict__ tpa
     const int64_t ch = blockIdx.x;
     for (int idx = threadIdx.x; idx < 9 * kShiftN; idx += (int)blockDim.x) {
         double v = 0.0;
-        for (int q = 0; q < kNhwcParts; ++q) v += tpart[(ch * kNhwcParts + q) * 9 * kShiftN + idx];
+        for (int q = 0; q < p.parts; ++q) v += tpart[(ch * kNhwcParts + q) * 9 * kShiftN + idx];
         T[idx / kShiftN][idx % kShiftN] = v;
     }
     __syncthreads();
@@ -943,7 +944,8 @@ hipError_t launch_gram_image_nhwc(const ImageGramArgs &a, hipStream_t stream)
     const dim3 grid((unsigned)p.nslots, (unsigned)((a.nch + 63) / 64));
     if (a.act_w == a.act_q) hipLaunchKernelGGL((gpfq_gram_shift_nhwc_kernel<true>), grid, dim3(64), 0, stream, p);
     else hipLaunchKernelGGL((gpfq_gram_shift_nhwc_kernel<false>), grid, dim3(64), 0, stream, p);
-    hipLaunchKernelGGL(gpfq_gram_shift_partsum_nhwc_kernel, dim3((unsigned)a.nch, kNhwcParts), dim3(256), 0, stream, p, tpart);
+    p.parts = p.nslots / 256 < 1 ? 1 : (p.nslots / 256 > kNhwcParts ? kNhwcParts : p.nslots / 256);
+    hipLaunchKernelGGL(gpfq_gram_shift_partsum_nhwc_kernel, dim3((unsigned)a.nch, (unsigned)p.parts), dim3(256), 0, stream, p, tpart);
     hipLaunchKernelGGL(gpfq_gram_shift_combine_nhwc_kernel, dim3((unsigned)a.nch), dim3(256), 0, stream, p, tpart, gram, nrm);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
