@@ -269,6 +269,12 @@ struct BlkK {
     unsigned long long uni_plus, uni_minus;
 };
 
+#ifdef GPFQ_BLK_NO_MFMA            // diagnostic build: phase D on the vector unit everywhere (A/B timing of round 4's matrix form)
+constexpr bool kNoMfmaD = true;
+#else
+constexpr bool kNoMfmaD = false;
+#endif
+
 #ifdef GPFQ_BLK_STAMPS
 #define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -367,8 +373,10 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     // phase U as in round 2
     constexpr bool kHoist = kPreloadAll && PW * B <= 4;
     constexpr int PB = kPreloadAll ? B : 1, PP = kPreloadAll ? PW : 1;
+    // Phase D on the matrix unit (round 4; G = 4 neuron groups x B = 4 steps x NL = 4 neurons per lane, row t + B as float64): see phase D.
+    constexpr bool kMfmaD = G == 4 && B == 4 && NL == 4 && blk_row64(G, B) && !kNoMfmaD;
     // (the rows of the dot products too when they are few registers: otherwise phase D requests them itself, as before)
-    constexpr bool kPreD = kHoist && PW * B * (blk_row64(G, B) ? 4 : 2) <= 16;
+    constexpr bool kPreD = kHoist && PW * B * (blk_row64(G, B) ? 4 : 2) <= 16 && !kMfmaD;
     constexpr int DBn = kPreD ? B : 1, DPn = kPreD ? PW : 1;
     float2 xs[PB][PP], qs[PB][PP], wqa[PB][NL];
     DRaw ds[DBn][DPn];
@@ -508,6 +516,47 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         for (int k = PTS * B * PPP < PER_MIN ? PTS * B * PPP : PER_MIN; wave + NSW * k < NPIECES; ++k) issue_piece(bn, k);   // the rest
         STAMP(st2);
         // ---- phase D: this wavefront's share of <Xq_t, u> for the B rows of block b+1 ----
+        if constexpr (kMfmaD) {
+            // Round 4: the B x 16 dot products of a slot are a (steps x samples) . (samples x neurons) product, and
+            // v_mfma_f64_4x4x4_4b_f64 forms four independent 4 x 4 x 4 blocks of it per issue: D_b[i][j] += sum_k A_b[i][k] B_b[k][j], lane
+            // maps (tools/ubench/mfma_f64_4x4x4.hip, profiles/r04/ubench_mfma_f64_4x4x4.txt) A: i + 4 b + 16 k, B: j + 4 b + 16 k,
+            // D: j + 4 b + 16 i.  With the sweep's lane = ng + 4 kq that is
+            //   A = u[n][e] AS IT STANDS: i = ng (the lane's neuron group: neuron 4 i + n), block b = kq & 3, k = kq >> 2
+            //       (the four k-lanes b, b + 4, b + 8, b + 12: the contraction runs over their samples),
+            //   B = Xq_{step j}[the lane's own sample]: lane (ng, kq) reads the row of STEP ng instead of every step's
+            //       (one ds_read_b128 per pair instead of four),
+            //   D = one value per lane: step j = lane & 3, neuron 4 (lane >> 4) + n, partial over the k-lanes = b mod 4.
+            // One issue does the 256 multiply-adds of four v_fma_f64 (16 cycles: the vector unit's own float64 rate -- the MFMA
+            // occupies it, the ubench's costs add -- but ONE issue slot instead of four at the 5.6 cycles two wavefronts per SIMD
+            // sustain), the sum over samples happens inside the instruction, and what is left of the k-lane fold (16 values over 16
+            // lanes: 84 instructions per slot) is the sum over the four blocks: two row rotations per accumulator.
+            // The order of the float64 additions differs from the vector form's (as that one's differs from BLAS ddot's): the
+            // certification's 2^-43 term is the slack for exactly that, and the residual never sees these sums.
+            if (b + 1 < nslots) {
+                __builtin_amdgcn_s_setprio(0);
+                double acc[NL];
+#pragma unroll
+                for (int n = 0; n < NL; ++n) acc[n] = 0.0;
+                const int rbm = tbase + ng * RB + o_d;
+                double2 d2n = lds_ld<double2>(lds, rbm);
+#pragma unroll
+                for (int p = 0; p < PW; ++p) {
+                    const double2 d2 = d2n;
+                    if (p + 1 < PW) d2n = lds_ld<double2>(lds, rbm + DB * (p + 1) * KQ);
+#pragma unroll
+                    for (int n = 0; n < NL; ++n) acc[n] = __builtin_amdgcn_mfma_f64_4x4x4f64(u[n][2 * p], d2.x, acc[n], 0, 0, 0);
+#pragma unroll
+                    for (int n = 0; n < NL; ++n) acc[n] = __builtin_amdgcn_mfma_f64_4x4x4f64(u[n][2 * p + 1], d2.y, acc[n], 0, 0, 0);
+                }
+#pragma unroll
+                for (int n = 0; n < NL; ++n) { acc[n] = ror_add<8>(acc[n]); acc[n] = ror_add<4>(acc[n]); }   // blocks: lane bits 2, 3
+                if ((lane & 12) == 0) {                           // one lane per (step, neuron group)
+                    const int od = L.off_d + ((((((b + 1) & 1) * NW + wave) * B) + (lane & 3)) * NB + 4 * (lane >> 4)) * 8;
+                    lds_st<double2>(lds, od, make_double2(acc[0], acc[1]));
+                    lds_st<double2>(lds, od + 16, make_double2(acc[2], acc[3]));
+                }
+            }
+        } else
         if (b + 1 < nslots && kPreloadAll) {
             DRaw dsl[B][PW];
 #pragma unroll
@@ -1403,7 +1452,7 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
 }
 
 // (the eleven-wavefront variants of the shapes that also exist with eight are kept in the general form only: an experiment switch)
-constexpr bool blk_has_sym(int S, int NSW) { return NSW != 11 || S > 32; }
+constexpr bool blk_has_sym(int S, int NSW) { (void)S; (void)NSW; return true; }
 
 template <int G, int S, int B, int NSW = 8, int NL = 4>
 static hipError_t launch_blk_inst(const PipeArgs &a, const BlkShape &sh, hipStream_t stream)

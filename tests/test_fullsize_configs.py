@@ -146,6 +146,21 @@ def _conv_sample(hip, oracle_mod, act_w, act_q, W, alphabet, out, k, stride, pad
         del Pwh, Pqh
 
 
+def _conv_slack_ab(hip, layer, W, act_w, act_q, alphabet, base, kw):
+    """The WHOLE index tensor (every (channel, filter) pair: 1 K - 262 K walks) with the Gram path's certification bound
+    doubled (`gram_slack_log2` = 1: wider than any bound the path ever shipped with) and multiplied by 8: a decision the
+    production bound certified wrongly would have to survive bounds 2x and 8x as wide too, or show up here as a
+    difference -- a chain flagged under the wider bound is decided from its exact dot products."""
+    try:
+        for s in (1, 3):
+            hip.set_option("gram_slack_log2", s)
+            wide = layer.quantize_conv2d(W, act_w, act_q, alphabet, **kw)
+            assert torch.equal(wide["idx"], base["idx"]), f"gram_slack_log2 = {s}: the index tensor moved"
+            assert torch.equal(wide["Q"], base["Q"])
+    finally:
+        hip.set_option("gram_slack_log2", 0)
+
+
 def _conv_properties(layer, W, act_w, act_q, alphabet, base, M, kw):
     dev = W.device
     assert torch.equal(base["idx"], layer.quantize_conv2d(W, act_w, act_q, alphabet, **kw)["idx"])        # determinism
@@ -176,6 +191,7 @@ def test_cfg5_resnet50_conv1_full_size(hip, oracle_mod):
     assert tuple(out["idx"].shape) == (7, 7, 3, 64)
     assert hip.patch_out_dim(230, 7, 2, 1, False) == 112
     _conv_properties(layer, W, act_w, act_q, alphabet, out, 3, kw)
+    _conv_slack_ab(hip, layer, W, act_w, act_q, alphabet, out, kw)
     # 49 x 51.4 M x 4 B = 10 GB per patch matrix: two on the device, two copies on the host for the oracle
     _conv_sample(hip, oracle_mod, act_w, act_q, W, alphabet, out, 7, 2, "VALID", [(1, [0, 21, 42, 63])], host_gib_needed=48)
 
@@ -190,5 +206,6 @@ def test_cfg5_resnet50_conv3x3_56_full_size(hip, oracle_mod):
     out = layer.quantize_conv2d(W, act_w, act_q, alphabet, **kw)
     assert int(out["reruns"]) <= 4
     _conv_properties(layer, W, act_w, act_q, alphabet, out, 3, kw)
+    _conv_slack_ab(hip, layer, W, act_w, act_q, alphabet, out, kw)
     _conv_sample(hip, oracle_mod, act_w, act_q, W, alphabet, out, 3, 1, "SAME", [(0, [0, 1, 62, 63]), (63, [5, 17, 33, 60])],
                  host_gib_needed=8)
