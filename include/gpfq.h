@@ -117,8 +117,9 @@ const char *gpfq_last_dense_kernel(void);
  *                  samples) where measured faster -- layers of 512+ neurons, and any width for rows of 769+ samples --,
  *                  0 never, 1 one step per slot (gpfq_pipe.hip, rows up to 2048) whenever it applies, 2 the block form
  *                  whenever it applies
- *   "blk_sweep_waves"   8 (default) or 11: sweep wavefronts per workgroup of the block form's 16-neuron shapes (with the
- *                  decision wavefront two or three wavefronts per SIMD; measured equal within 2 %: DESIGN.md)
+ *   "blk_sweep_waves"   0 (default: by shape -- eleven for rows of 769..1024 samples, eight for shorter rows), 8 or 11: sweep
+ *                  wavefronts per workgroup of the block form's 16-neuron four-step shapes (with the decision wavefront two or
+ *                  three wavefronts per SIMD; same bits: DESIGN.md)
  *   "blk_four_groups"   1 (default): layers of at most 1024 neurons on rows of 769..2048 samples take 4 neurons per workgroup; 0: 8
  *   "blk_wide_groups"   1 (default): rows of 1025..2048 samples in layers of more than 2048 neurons take 16 neurons per workgroup
  *                  (eleven sweep wavefronts, one round of workgroups); 0: 8 neurons per workgroup as narrower layers do

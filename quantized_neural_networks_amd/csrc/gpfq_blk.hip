@@ -267,12 +267,19 @@ struct BlkK {
     // a0 + k step then round to different neighbours (2 of 16 members of a typical 4-bit alphabet).  Bit k of uni_plus / uni_minus:
     // float32(alphabet[k]) is the next float32 above / below (in the integer order of the bit patterns) float32(a0 + k step).
     unsigned long long uni_plus, uni_minus;
+    unsigned char pw[12];       // sample pairs per k-lane of sweep wavefront w (BlkSplit: a launch parameter)
 };
 
 #ifdef GPFQ_BLK_NO_MFMA            // diagnostic build: phase D on the vector unit everywhere (A/B timing of round 4's matrix form)
 constexpr bool kNoMfmaD = true;
 #else
 constexpr bool kNoMfmaD = false;
+#endif
+
+#ifdef GPFQ_BLK_NO_FUSED           // diagnostic build: matrix-unit phase D as a phase of its own, after the updates (round 4's first form)
+constexpr bool kNoFused = true;
+#else
+constexpr bool kNoFused = false;
 #endif
 
 #ifdef GPFQ_BLK_STAMPS
@@ -334,6 +341,10 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     const unsigned lane16 = (unsigned)lane * 16u;
     auto issue_piece = [&](int b1, int k) {
         const int pc = wave + NSW * k;
+#ifdef GPFQ_BLK_X_DMA2                 // timing experiment (same results): every piece of the record stream twice
+        glds16_s(K.recs + (int64_t)b1 * L.tile_bytes + ((int64_t)pc << 10), lane16,
+                 ldsT_addr + (unsigned)(b1 & 1) * (unsigned)L.tile_pitch + ((unsigned)pc << 10));
+#endif
         glds16_s(K.recs + (int64_t)b1 * L.tile_bytes + ((int64_t)pc << 10), lane16,
                  ldsT_addr + (unsigned)(b1 & 1) * (unsigned)L.tile_pitch + ((unsigned)pc << 10));
     };
@@ -368,13 +379,15 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     // dot products -- is requested right after the barrier that ends the slot before, together with the control word of the slow
     // path, and held in registers: one LDS round trip per slot instead of three in sequence (control word, phase U's operands, phase
     // D's; 400-900 cycles each with the LDS busiest right after the barrier -- profiles/r03/blk_phase_stamps.txt).
-    constexpr bool kPreloadAll = PW * B <= 8 && PW <= 5;
+    // Phase D on the matrix unit (round 4; G = 4 neuron groups x B = 4 steps x NL = 4 neurons per lane, row t + B as float64), and with it
+    // the two phases FUSED pair by pair (kFused): see the slot loop.
+    constexpr bool kMfmaD = G == 4 && B == 4 && NL == 4 && blk_row64(G, B) && !kNoMfmaD;
+    constexpr bool kFused = kMfmaD && !kNoFused;
+    constexpr bool kPreloadAll = PW * B <= 8 && PW <= 5 && !kFused;
     // ... where the registers allow it (u and the operands of a slot together): otherwise they are requested at the top of
     // phase U as in round 2
     constexpr bool kHoist = kPreloadAll && PW * B <= 4;
     constexpr int PB = kPreloadAll ? B : 1, PP = kPreloadAll ? PW : 1;
-    // Phase D on the matrix unit (round 4; G = 4 neuron groups x B = 4 steps x NL = 4 neurons per lane, row t + B as float64): see phase D.
-    constexpr bool kMfmaD = G == 4 && B == 4 && NL == 4 && blk_row64(G, B) && !kNoMfmaD;
     // (the rows of the dot products too when they are few registers: otherwise phase D requests them itself, as before)
     constexpr bool kPreD = kHoist && PW * B * (blk_row64(G, B) ? 4 : 2) <= 16 && !kMfmaD;
     constexpr int DBn = kPreD ? B : 1, DPn = kPreD ? PW : 1;
@@ -400,6 +413,64 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     };
     if constexpr (kHoist) { preload_wq(0); preload_rows(0); }
 
+    // The slow path of block bb (rare; after the barrier that ends slot bb): while any neuron of the block is stopped at step S, the exact dot
+    // products of step bb B + S on the residual as it stands BEFORE block bb.
+    auto slow_path = [&](int b, int ctl) {
+        for (;;) {
+            const int S = __builtin_amdgcn_readfirstlane(ctl);
+            if (S < 0) break;
+            // u is the residual BEFORE block b.  Exact <Xq_t, u_{t-1}> and <Xq_t, u_{t-1} + f32(w_t X_t)> (:86, :89) for
+            // t = bB + S: the block's first S updates replayed into temporaries; rows of block b are records of tile b+1.
+            const int nb_ = ((b + 1) & 1) * L.tile_pitch;
+            const int cbq = (b & 1) * NB * B * 8;
+            double eu[NL], ew[NL];
+#pragma unroll
+            for (int n = 0; n < NL; ++n) { eu[n] = 0.0; ew[n] = 0.0; }
+            // (one neuron and one pair at a time: the slow path must not cost the hot loop registers)
+#pragma unroll
+            for (int n = 0; n < NL; ++n) {
+                const float w = lds_ld<float2>(lds, o_wq + cbq + (n * B + S) * 8).x;
+#pragma unroll 1
+                for (int p = 0; p < PW; ++p) {
+                    double t0 = u[n][0], t1 = u[n][1];
+#pragma unroll
+                    for (int pp = 1; pp < PW; ++pp) { t0 = (p == pp) ? u[n][2 * pp] : t0; t1 = (p == pp) ? u[n][2 * pp + 1] : t1; }
+                    for (int j = 0; j < S; ++j) {
+                        const int rb = nb_ + j * RB;
+                        const float2 x2 = lds_ld<float2>(lds, rb + o_x + 8 * p * KQ), q2 = lds_ld<float2>(lds, rb + o_q + 8 * p * KQ);
+                        const float2 wq = lds_ld<float2>(lds, o_wq + cbq + (n * B + j) * 8);
+                        if constexpr (SYM) {
+                            t0 += (double)__fmaf_rn(wq.y, q2.x, __fmul_rn(wq.x, x2.x));
+                            t1 += (double)__fmaf_rn(wq.y, q2.y, __fmul_rn(wq.x, x2.y));
+                        } else {
+                            t0 += (double)__fsub_rn(__fmul_rn(wq.x, x2.x), __fmul_rn(wq.y, q2.x));
+                            t1 += (double)__fsub_rn(__fmul_rn(wq.x, x2.y), __fmul_rn(wq.y, q2.y));
+                        }
+                    }
+                    const int rb = nb_ + S * RB;
+                    const float2 x2 = lds_ld<float2>(lds, rb + o_x + 8 * p * KQ);
+                    float2 q2;
+                    if constexpr (SYM) {                              // the record holds a32 * Xq_t: the row itself from memory (rare path)
+                        const int i0 = 2 * (pbase + p * KQ + kq);
+                        const float *xr = K.Xq + ((int64_t)b * B + S) * K.ldx;
+                        q2.x = i0 < K.m ? xr[i0] : 0.f;
+                        q2.y = i0 + 1 < K.m ? xr[i0 + 1] : 0.f;
+                    } else {
+                        q2 = lds_ld<float2>(lds, rb + o_q + 8 * p * KQ);
+                    }
+                    eu[n] = fma((double)q2.x, t0, eu[n]);
+                    eu[n] = fma((double)q2.y, t1, eu[n]);
+                    ew[n] = fma((double)q2.x, t0 + (double)__fmul_rn(w, x2.x), ew[n]);
+                    ew[n] = fma((double)q2.y, t1 + (double)__fmul_rn(w, x2.y), ew[n]);
+                }
+            }
+            const double vu = fold_klanes_n<G, NL>(eu), vw = fold_klanes_n<G, NL>(ew);
+            if (writer) lds_st<double2>(lds, o_x2, make_double2(vu, vw));
+            slot_barrier();                                       // partials published
+            slot_barrier();                                       // chains resumed, control word rewritten
+            ctl = lds_ld<int>(lds, L.off_ctl + 4 * (b & 1));
+        }
+    };
     for (int b = 0; b < nslots; ++b) {
         STAMP(st0);
 #ifdef GPFQ_BLK_STAMPS
@@ -442,6 +513,128 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         // Software-pipelined by hand: the operands of the NEXT pair (and the next step's four (w, q)) are requested before
         // the arithmetic of the current one (sched_barrier keeps hipcc from sinking the requests to their first use,
         // where every pair would wait out a full LDS round trip).
+        if constexpr (kFused) {
+            // ---- round 4: updates and dot products fused, PAIR by pair ----
+            // For each sample pair p: the B updates of block b-1 on u[.][2p], u[.][2p+1] (element-wise flow, in step order), then that
+            // pair's share of the B x 16 dot products of block b+1 on the matrix unit (see the kMfmaD branch of phase D below for
+            // the lane maps) -- issued two per step UNDER the next pair's updates, so phase D no longer exists as a phase: as one
+            // it cost a slot an LDS round trip nothing hid, a row of matrix instructions issued at the lowest priority while the
+            // other wavefronts of the SIMD were still updating, and the fold behind it (profiles/r04/blk_phase_stamps.txt: 980 -
+            // 2300 cycles per slot for 640 - 1150 cycles of matrix work).  The block's sixteen (w, q) are read once per slot.
+            // (Tried: the slot's first requests hoisted above the wait for the slow path's control word -- one LDS round trip instead of two
+            //  behind every barrier.  hipcc then held address registers across the slow path's code and spilled; a spill's reload puts an
+            //  s_waitcnt vmcnt(0) into the loop, which waits for the LDS-DMA pieces in flight: 2.98 -> 3.26 ms, and 5.0 ms with the
+            //  requests hoisted across the barrier.  profiles/r04/README.md)
+            const int rbm = tbase + ng * RB + o_d;
+            float2 fwq[B][NL], x2n, q2n;
+            double2 dcur;
+            auto first_requests = [&]() {
+#pragma unroll
+                for (int s = 0; s < B; ++s)
+#pragma unroll
+                    for (int n = 0; n < NL; ++n) fwq[s][n] = lds_ld<float2>(lds, o_wq + pbq + (n * B + s) * 8);
+                x2n = lds_ld<float2>(lds, tbase + o_x); q2n = lds_ld<float2>(lds, tbase + o_q);
+                dcur = lds_ld<double2>(lds, rbm);
+            };
+            first_requests();
+            double2 dprev = make_double2(0.0, 0.0);
+            double acc[NL];
+#pragma unroll
+            for (int n = 0; n < NL; ++n) acc[n] = 0.0;
+#ifdef GPFQ_BLK_X_MFMA2
+            double xdummy[NL] = {0.0, 0.0, 0.0, 0.0};
+#endif
+#ifdef GPFQ_BLK_X_VALU2
+            double xu[NL][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+#endif
+#ifdef GPFQ_BLK_X_LDS2
+            float2 xl[2];
+#endif
+            auto mfma_pair = [&](int pp, int i, const double2 &dd) {      // matrix instruction i = 0 .. 7 of pair pp
+                const int n = i & 3, e = i >> 2;
+#ifdef GPFQ_BLK_X_MFMA2                // timing experiment (same results): every matrix instruction twice, the copy into a dummy accumulator
+                xdummy[n] = __builtin_amdgcn_mfma_f64_4x4x4f64(u[n][2 * pp + e], e ? dd.x : dd.y, xdummy[n], 0, 0, 0);
+#endif
+                acc[n] = __builtin_amdgcn_mfma_f64_4x4x4f64(u[n][2 * pp + e], e ? dd.y : dd.x, acc[n], 0, 0, 0);
+            };
+#pragma unroll
+            for (int p = 0; p < PW; ++p) {
+                // issue priority falls with progress through the slot (the laggard of a SIMD is served first, see below)
+                {
+                    // (tried: one level higher for the younger wavefronts of a SIMD, which it serves last at equal priority -- 3.22 - 3.27
+                    //  against 3.26 ms in the build that had it, and the wave-uniform branches it needs made hipcc spill)
+                    const int pr = 2 - (3 * p) / PW;
+                    if (p == 0 || pr != 2 - (3 * (p - 1)) / PW) {
+                        const int v = pr;
+                        if (v >= 2) __builtin_amdgcn_s_setprio(2);
+                        else if (v == 1) __builtin_amdgcn_s_setprio(1);
+                        else __builtin_amdgcn_s_setprio(0);
+                    }
+                }
+                if (p > 0) dcur = lds_ld<double2>(lds, rbm + DB * p * KQ);       // (consumed under the NEXT pair's updates, or at the end)
+#pragma unroll
+                for (int st = 0; st < B; ++st) {
+                    const float2 x2 = x2n, q2 = q2n;
+                    const int sn = st + 1 < B ? st + 1 : 0, pn = st + 1 < B ? p : p + 1;
+                    if (pn < PW) {
+                        x2n = lds_ld<float2>(lds, tbase + sn * RB + o_x + 8 * pn * KQ);
+                        q2n = lds_ld<float2>(lds, tbase + sn * RB + o_q + 8 * pn * KQ);
+                    }
+                    if (p < PTS) {
+#pragma unroll
+                        for (int i = 0; i < PPP; ++i) {
+                            const int k = (PTS * st + p) * PPP + i;
+                            if (PTS * B * PPP <= PER_MIN || k < PER_MIN) issue_piece(bn, k);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    float wv[NL], qv[NL];
+#pragma unroll
+                    for (int n = 0; n < NL; ++n) { wv[n] = fwq[st][n].x; qv[n] = fwq[st][n].y; }
+                    update_pair(p, x2, q2, wv, qv);
+#ifdef GPFQ_BLK_X_VALU2                // timing experiment (same results): the pair's arithmetic twice, the copy into dummy registers
+                    {
+                        const pk2 xv = {x2.x, x2.y}, qx = {q2.x, q2.y};
+#pragma unroll
+                        for (int n = 0; n < NL; ++n) {
+                            pk2 pr = pk2{wv[n], wv[n]} * xv;
+                            asm volatile("" : "+v"(pr));
+                            pk2 dd = SYM ? __builtin_elementwise_fma(pk2{qv[n], qv[n]}, qx, pr) : pr - pk2{qv[n], qv[n]} * qx;
+                            asm volatile("" : "+v"(dd));
+                            xu[n][0] += (double)dd.x; xu[n][1] += (double)dd.y;
+                        }
+                    }
+#endif
+#ifdef GPFQ_BLK_X_LDS2                 // timing experiment (same results): the pair's operand reads twice
+                    if (pn < PW) {
+                        xl[0] = lds_ld<float2>(lds, tbase + sn * RB + o_x + 8 * pn * KQ);
+                        xl[1] = lds_ld<float2>(lds, tbase + sn * RB + o_q + 8 * pn * KQ);
+                        asm volatile("" :: "v"(xl[0]), "v"(xl[1]));
+                    }
+#endif
+                    if (p > 0) { mfma_pair(p - 1, 2 * st, dprev); mfma_pair(p - 1, 2 * st + 1, dprev); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                dprev = dcur;
+            }
+            for (int k = PTS * B * PPP < PER_MIN ? PTS * B * PPP : PER_MIN; wave + NSW * k < NPIECES; ++k) issue_piece(bn, k);   // the rest
+            STAMP(st2);
+#pragma unroll
+            for (int i = 0; i < 2 * NL; ++i) mfma_pair(PW - 1, i, dprev);
+#pragma unroll
+            for (int n = 0; n < NL; ++n) { acc[n] = ror_add<8>(acc[n]); acc[n] = ror_add<4>(acc[n]); }   // blocks: lane bits 2, 3
+#ifdef GPFQ_BLK_X_MFMA2
+            asm volatile("" :: "v"(xdummy[0]), "v"(xdummy[1]), "v"(xdummy[2]), "v"(xdummy[3]));
+#endif
+#ifdef GPFQ_BLK_X_VALU2
+            asm volatile("" :: "v"(xu[0][0]), "v"(xu[0][1]), "v"(xu[1][0]), "v"(xu[1][1]), "v"(xu[2][0]), "v"(xu[2][1]), "v"(xu[3][0]), "v"(xu[3][1]));
+#endif
+            if (b + 1 < nslots && (lane & 12) == 0) {             // one lane per (step, neuron group)
+                const int od = L.off_d + ((((((b + 1) & 1) * NW + wave) * B) + (lane & 3)) * NB + 4 * (lane >> 4)) * 8;
+                lds_st<double2>(lds, od, make_double2(acc[0], acc[1]));
+                lds_st<double2>(lds, od + 16, make_double2(acc[2], acc[3]));
+            }
+        } else {
         if constexpr (kPreloadAll) {
             // One or two pairs per step: the pipelined loop below keeps ONE pair of operands in flight, and a step's arithmetic
             // (32 instructions per pair) is shorter than an LDS round trip with twelve wavefronts on the LDS -- the sweep of a
@@ -613,6 +806,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
                 if (writer) lds_st<double>(lds, o_dw + ((((b + 1) & 1) * NW) * B + r) * NB * 8, v);
             }
         }
+        }   // (!kFused)
         STAMP(st3);
         dma_wait();                                               // this wavefront's share of the next tile has landed
         STAMP(st4);
@@ -623,68 +817,17 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 #endif
 
         // ---- slow path: neurons of block b stopped at an uncertifiable step (rare) ----
+        {
         int ctl = lds_ld<int>(lds, L.off_ctl + 4 * (b & 1));      // (requested first: it is waited for alone)
         if constexpr (kHoist) {
             if (b + 1 < nslots) { preload_wq(b + 1); preload_rows(b + 1); }
         }
-        bool any_slow = false;
-        for (;;) {
-            const int S = __builtin_amdgcn_readfirstlane(ctl);
-            if (S < 0) break;
-            any_slow = true;
-            // u is the residual BEFORE block b.  Exact <Xq_t, u_{t-1}> and <Xq_t, u_{t-1} + f32(w_t X_t)> (:86, :89) for
-            // t = bB + S: the block's first S updates replayed into temporaries; rows of block b are records of tile b+1.
-            const int nb_ = ((b + 1) & 1) * L.tile_pitch;
-            const int cbq = (b & 1) * NB * B * 8;
-            double eu[NL], ew[NL];
-#pragma unroll
-            for (int n = 0; n < NL; ++n) { eu[n] = 0.0; ew[n] = 0.0; }
-            // (one neuron and one pair at a time: the slow path must not cost the hot loop registers)
-#pragma unroll
-            for (int n = 0; n < NL; ++n) {
-                const float w = lds_ld<float2>(lds, o_wq + cbq + (n * B + S) * 8).x;
-#pragma unroll 1
-                for (int p = 0; p < PW; ++p) {
-                    double t0 = u[n][0], t1 = u[n][1];
-#pragma unroll
-                    for (int pp = 1; pp < PW; ++pp) { t0 = (p == pp) ? u[n][2 * pp] : t0; t1 = (p == pp) ? u[n][2 * pp + 1] : t1; }
-                    for (int j = 0; j < S; ++j) {
-                        const int rb = nb_ + j * RB;
-                        const float2 x2 = lds_ld<float2>(lds, rb + o_x + 8 * p * KQ), q2 = lds_ld<float2>(lds, rb + o_q + 8 * p * KQ);
-                        const float2 wq = lds_ld<float2>(lds, o_wq + cbq + (n * B + j) * 8);
-                        if constexpr (SYM) {
-                            t0 += (double)__fmaf_rn(wq.y, q2.x, __fmul_rn(wq.x, x2.x));
-                            t1 += (double)__fmaf_rn(wq.y, q2.y, __fmul_rn(wq.x, x2.y));
-                        } else {
-                            t0 += (double)__fsub_rn(__fmul_rn(wq.x, x2.x), __fmul_rn(wq.y, q2.x));
-                            t1 += (double)__fsub_rn(__fmul_rn(wq.x, x2.y), __fmul_rn(wq.y, q2.y));
-                        }
-                    }
-                    const int rb = nb_ + S * RB;
-                    const float2 x2 = lds_ld<float2>(lds, rb + o_x + 8 * p * KQ);
-                    float2 q2;
-                    if constexpr (SYM) {                              // the record holds a32 * Xq_t: the row itself from memory (rare path)
-                        const int i0 = 2 * (pbase + p * KQ + kq);
-                        const float *xr = K.Xq + ((int64_t)b * B + S) * K.ldx;
-                        q2.x = i0 < K.m ? xr[i0] : 0.f;
-                        q2.y = i0 + 1 < K.m ? xr[i0 + 1] : 0.f;
-                    } else {
-                        q2 = lds_ld<float2>(lds, rb + o_q + 8 * p * KQ);
-                    }
-                    eu[n] = fma((double)q2.x, t0, eu[n]);
-                    eu[n] = fma((double)q2.y, t1, eu[n]);
-                    ew[n] = fma((double)q2.x, t0 + (double)__fmul_rn(w, x2.x), ew[n]);
-                    ew[n] = fma((double)q2.y, t1 + (double)__fmul_rn(w, x2.y), ew[n]);
-                }
+        if (__builtin_amdgcn_readfirstlane(ctl) >= 0) {
+            slow_path(b, ctl);
+            if constexpr (kHoist) {
+                if (b + 1 < nslots) { preload_wq(b + 1); preload_rows(b + 1); }    // (the slow path has rewritten decisions of block b)
             }
-            const double vu = fold_klanes_n<G, NL>(eu), vw = fold_klanes_n<G, NL>(ew);
-            if (writer) lds_st<double2>(lds, o_x2, make_double2(vu, vw));
-            slot_barrier();                                       // partials published
-            slot_barrier();                                       // chains resumed, control word rewritten
-            ctl = lds_ld<int>(lds, L.off_ctl + 4 * (b & 1));
         }
-        if constexpr (kHoist) {
-            if (any_slow && b + 1 < nslots) preload_wq(b + 1);    // the slow path has rewritten decisions of block b
         }
     }
 
@@ -693,6 +836,8 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         unsigned long long *o = K.stamps + (wave == 0 ? 0 : 8);
         o[0] = acc_dma; o[1] = acc_u; o[2] = acc_d; o[3] = acc_w; o[4] = acc_b; o[5] = (unsigned long long)nslots; o[6] = acc_t;
     }
+    if (K.stamps && blockIdx.x == 0 && lane == 0) K.stamps[32 + wave] = acc_dma + acc_u + acc_d + acc_w;   // slot top -> arrival at the barrier, every sweep wavefront
+
 #endif
     // ---- epilogue: residual norms through the same partial-sum path, residual vectors straight to memory ----
     if (K.resid) {
@@ -1231,8 +1376,13 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 // SIMD 0 with wavefronts 0 and 4); with eleven the twelve wavefronts of a workgroup are three per SIMD.
 template <int S, int NSW> struct BlkSplit { static constexpr const int *pw = PairSplit<S>::pw; };
 template <> struct BlkSplit<4, 4>   { static constexpr int pw_[4] = {1, 1, 1, 1}; static constexpr const int *pw = pw_; };   // rows of up to 512 samples, four sweep wavefronts
+// (the 16-neuron B = 4 shapes: more pairs for the OLDER wavefronts of a SIMD -- wavefronts w, w + 4, w + 8 share SIMD w, the decision
+//  wavefront is the third of SIMD 3.  A SIMD serves its oldest ready wavefront first, so with equal shares the wavefronts reach the
+//  barrier in the order of their age -- 4300 / 5500 / 6000 cycles after the top of the slot, profiles/r04/blk_phase_stamps.txt -- and the
+//  youngest runs the tail of the slot alone at a third of the issue rate; priorities by progress only narrow that.)
 template <> struct BlkSplit<32, 11> { static constexpr int pw_[11] = {3, 3, 3, 3, 3, 3, 3, 2, 3, 3, 3}; static constexpr const int *pw = pw_; };
 template <> struct BlkSplit<24, 11> { static constexpr int pw_[11] = {2, 2, 2, 2, 2, 2, 2, 1, 3, 3, 3}; static constexpr const int *pw = pw_; };
+
 template <> struct BlkSplit<64, 11> { static constexpr int pw_[11] = {6, 6, 6, 6, 6, 6, 6, 4, 6, 6, 6}; static constexpr const int *pw = pw_; };
 template <> struct BlkSplit<48, 11> { static constexpr int pw_[11] = {5, 4, 4, 4, 5, 4, 4, 4, 5, 5, 4}; static constexpr const int *pw = pw_; };
 template <> struct BlkSplit<16, 11> { static constexpr int pw_[11] = {2, 2, 1, 1, 2, 2, 1, 1, 1, 1, 2}; static constexpr const int *pw = pw_; };
@@ -1246,7 +1396,6 @@ __global__ void __launch_bounds__(64 * (NSW + 1))
 gpfq_blk_kernel(BlkK K, AlphabetArg A)
 {
     constexpr int NB = NL * G, KQ = 64 / G, MP = 2 * KQ * S;
-    using PS = BlkSplit<S, NSW>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const BlkLds L = blk_lds(MP, NB, B, NSW, G);
     const int tid = threadIdx.x;
@@ -1267,7 +1416,7 @@ gpfq_blk_kernel(BlkK K, AlphabetArg A)
     if (wave < NSW) {
         int pbase = 0, pw = 1;
 #pragma unroll
-        for (int w = 0; w < NSW; ++w) { pbase += (w < wave) ? KQ * PS::pw[w] : 0; pw = (w == wave) ? PS::pw[w] : pw; }
+        for (int w = 0; w < NSW; ++w) { pbase += (w < wave) ? KQ * (int)K.pw[w] : 0; pw = (w == wave) ? (int)K.pw[w] : pw; }
         constexpr int PMAX = S == 64 ? 6 : (S == 48 || S == 40 ? 5 : (NSW == 11 ? 3 : (S == 32 ? 5 : (S == 24 ? 4 : 3))));
         if (pw == 1) blk_sweep_role<G, 1, MP, B, NSW, SYM, NL>(K, lds, L, wave, lane, pbase);
         else if (pw == 2) blk_sweep_role<G, 2, MP, B, NSW, SYM, NL>(K, lds, L, wave, lane, pbase);
@@ -1284,12 +1433,12 @@ gpfq_blk_kernel(BlkK K, AlphabetArg A)
 struct BlkShape { int G, S, B, mp, NW, NL; };      // NL: neurons per lane (4 G or 2 G neurons per workgroup)
 static std::atomic<int> g_blk_single{1};  // one neuron per workgroup for layers of at most 128 neurons (blk_set_single_groups)
 void blk_set_single_groups(int on) { g_blk_single.store(on ? 1 : 0, std::memory_order_relaxed); }
-static std::atomic<int> g_blk_nw{8};      // sweep wavefronts of the 16-neuron shapes (experiment switch: blk_set_sweep_waves)
+static std::atomic<int> g_blk_nw{0};      // sweep wavefronts of the 16-neuron B = 4 shapes: 8, 11, or 0 = by shape (blk_set_sweep_waves)
 static std::atomic<int> g_blk_four{1};    // 4-neuron workgroups for layers of at most 1024 neurons on rows of 769..2048 samples
 void blk_set_four_groups(int on) { g_blk_four.store(on ? 1 : 0, std::memory_order_relaxed); }
 static std::atomic<int> g_blk_wide{1};    // 16-neuron workgroups for rows beyond 1024 samples in layers wider than 2048 neurons
 void blk_set_wide_groups(int on) { g_blk_wide.store(on ? 1 : 0, std::memory_order_relaxed); }
-void blk_set_sweep_waves(int nw) { g_blk_nw.store(nw == 11 ? 11 : 8, std::memory_order_relaxed); }
+void blk_set_sweep_waves(int nw) { g_blk_nw.store(nw == 11 ? 11 : (nw == 8 ? 8 : 0), std::memory_order_relaxed); }
 
 // C: neurons of the call.  Rows of 769..1024 samples are the one shape whose slot is bound by the sweeps (nine sample pairs
 // on three of the SIMDs), not by the chain of decisions: up to 2048 neurons -- one round of 256 workgroups with 8 neurons
@@ -1299,7 +1448,11 @@ void blk_set_pair_groups(int on) { g_blk_pairs.store(on ? 1 : 0, std::memory_ord
 
 static BlkShape blk_shape(int64_t m, int64_t C)
 {
-    const int nw4 = g_blk_nw.load(std::memory_order_relaxed);
+    // Round 4 (dot products on the matrix unit, fused with the updates pair by pair): rows of 769..1024 samples take ELEVEN sweep wavefronts
+    // (three per SIMD: 2.97 against 3.13 ms at 4096 x 4096 x 1024 -- the per-wavefront fold that made eleven lose until round 3 is gone);
+    // shorter rows keep eight (768 samples: 2.53 against 2.63 ms; 512: 1.96 against 1.98)
+    const int nw_opt = g_blk_nw.load(std::memory_order_relaxed);
+    const int nw4 = nw_opt ? nw_opt : 8, nw4_long = nw_opt ? nw_opt : 11;
     // Layers of at most 512 neurons: TWO neurons per workgroup (two per lane of the sweep wavefronts).  A narrow layer is bound by
     // the time of one slot, a slot by the instructions its workgroup issues (profiles/r03/blk_phase_stamps.txt): half the neurons
     // are half the element-wise work per slot on twice the CUs.  Rows of up to 5120 samples (cfg4's Dense(2048 -> 128) on 5008).
@@ -1331,7 +1484,7 @@ static BlkShape blk_shape(int64_t m, int64_t C)
     if (four && m > 768 && m <= 1024) return {1, 8, 4, 1024, 8, 4};
     if (four && m > 1024 && m <= 1536) return {1, 12, 2, 1536, 8, 4};
     if (four && m > 1536 && m <= 2048) return {1, 16, 2, 2048, 8, 4};
-    if (m > 768 && m <= 1024) return C <= 2048 ? BlkShape{2, 16, 4, 1024, 8, 4} : BlkShape{4, 32, 4, 1024, nw4, 4};
+    if (m > 768 && m <= 1024) return C <= 2048 ? BlkShape{2, 16, 4, 1024, 8, 4} : BlkShape{4, 32, 4, 1024, nw4_long, 4};
     // rows beyond 1024 samples: 8 neurons per workgroup and eight sweep wavefronts -- or, in layers of more than 2048 neurons (where
     // that takes two rounds of workgroups), 16 neurons over eleven sweep wavefronts: one round, half the decisions and folds per weight
     // (a 16-neuron workgroup takes 1.6 x as long as an 8-neuron one: 6.5 against 4.1 ms for 4096 steps of 2048 samples; rounds of 256)
@@ -1447,6 +1600,10 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
     K.stamps = a.fallback_count ? a.fallback_count + 8 : nullptr;      // (diagnostic build: the unused row-statistics area behind the counter block)
     K.sym_a = SYM ? blk_sym_a(a) : 0.f; K.Xq = a.Xq; K.ldx = a.ld;
     if (!blk_uniform(a.A, &K.uni_a0, &K.uni_step, &K.uni_inv, &K.uni_c0, &K.uni_plus, &K.uni_minus)) return hipErrorInvalidValue;
+    {
+        const int *pw = BlkSplit<S, NSW>::pw;
+        for (int w = 0; w < 12; ++w) K.pw[w] = (unsigned char)(w < NSW ? pw[w] : 0);
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NSW + 1)), (size_t)L.total, stream, K, a.A);
     return hipGetLastError();
 }

@@ -87,17 +87,18 @@ def main():
         bad_u = int((r["u"] != base["u"]).sum()) if want_u else -1
         fb = hip.exact_fallbacks(r)
         if os.environ.get("GPFQ_DIAG") and mode == 2:
-            st = r["workspace"][64:64 + 24 * 8].view(torch.int64).cpu().numpy()
+            st = r["workspace"][64:64 + 48 * 8].view(torch.int64).cpu().numpy()
             ns = max(int(st[5]), 1)
             for name, o in (("sweep wave 0 (few pairs)", 0), ("sweep wave 7 (most pairs)", 8)):
                 print(f"    {name}: cycles per slot: dma issue {st[o]/ns:.0f}, phase U {st[o+1]/ns:.0f}, phase D+fold {st[o+2]/ns:.0f}, "
                       f"dma wait {st[o+3]/ns:.0f}, barrier {st[o+4]/ns:.0f}, barrier -> next slot {st[o+6]/ns:.0f}  ({ns} slots)")
+            print("    slot top -> barrier arrival, sweep wavefronts 0..: " + " ".join(f"{st[32 + w]/ns:.0f}" for w in range(sw)))
             print(f"    decision wave: work {st[16]/ns:.0f} (prologue {st[18]/ns:.0f}, chain + certification {st[19]/ns:.0f}), barrier {st[17]/ns:.0f}, barrier -> next slot {st[20]/ns:.0f} cycles per slot")
         tmin, tavg = timed(lambda: hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm, want_values=False,
                                                         path=hip.GPFQ_PATH_ONCHIP))
         print(f"  pipe mode={mode} variant={variant} ts={ts or 'auto'} sweeps={sw} [{hip.last_dense_kernel()[:16]}]: min {tmin:.3f} ms avg {tavg:.3f} ms  "
               f"mismatch idx={bad_i} Q={bad_q} u={bad_u} max resid rel diff={rel_r:.2e}  exact fallbacks={fb}")
-    hip.set_option("pipe", -1); hip.set_option("tile_steps", 0); hip.set_option("variant", 0); hip.set_option("blk_sweep_waves", 11)
+    hip.set_option("pipe", -1); hip.set_option("tile_steps", 0); hip.set_option("variant", 0); hip.set_option("blk_sweep_waves", 0)
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ rad = 3 * float(np.median(np.abs(W)))
 alphabet = rad * np.linspace(-1, 1, M)
 Xd, Xqd, Wt = torch.from_numpy(X).cuda(), torch.from_numpy(Xq).cuda(), torch.from_numpy(W.T.copy()).cuda()
 hip.set_option("onchip_mode", arg(2, 1)); hip.set_option("lanes_per_neuron", arg(3, 0))
-hip.set_option("variant", arg(4, 0)); hip.set_option("tile_steps", arg(5, 0)); hip.set_option("blk_sweep_waves", arg(6, 8))
+hip.set_option("variant", arg(4, 0)); hip.set_option("tile_steps", arg(5, 0)); hip.set_option("blk_sweep_waves", arg(6, 0))
 nrm = hip.row_norms(Xqd)
 for _ in range(3):
     r = hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm)
