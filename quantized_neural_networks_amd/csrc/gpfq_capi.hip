@@ -339,7 +339,7 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
                 (uintptr_t)workspace % 16 == 0 && workspace_bytes >= onchip_workspace_bytes(N, m)) {
                 pa.workspace = static_cast<char *>(workspace) + onchip_stats_bytes(N);
                 pa.fallback_count = static_cast<unsigned long long *>(workspace);
-                gpfq::note_dense_kernel("gpfq_blk_kernel (8 sweep wavefronts + 1 decision wavefront per workgroup, blocks of steps per slot)");
+                gpfq::note_dense_kernel("gpfq_blk_kernel (4 to 11 sweep wavefronts + 1 decision wavefront per workgroup, blocks of steps per slot)");
                 hipError_t e = gpfq::launch_blk(pa, s);
                 return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_neurons(block-pipelined)");
             }
@@ -629,7 +629,7 @@ size_t gpfq_conv_channels_workspace_bytes(int64_t n, int64_t H, int64_t W, int64
         return gpfq::gram_image_workspace_bytes(nch, F);
     if (!want_resid && g_conv_fused && gpfq::gram_conv_supported(n, H, W, nch, kh, kw, oh, ow)) {
         size_t b = al256c(gpfq::gram_conv_workspace_bytes(K, nch, F, cols));
-        if (!same_padding && gpfq::gram_s2_supported(n, H, W, kh, kw, sh, sw, rh, rw, 0, 0)) b += gpfq::gram_s2_workspace_bytes(n, H, W, nch);
+        if (!same_padding && gpfq::gram_s2_supported(n, H, W, kh, kw, sh, sw, rh, rw, 0, 0, nch)) b += gpfq::gram_s2_workspace_bytes(n, H, W, nch);
         return b;
     }
     const int64_t ldp = (cols + 3) & ~(int64_t)3;
@@ -665,7 +665,7 @@ static int conv_channels_impl(int phase, double *records, int32_t *negflags,
     if (!workspace || workspace_bytes < need || (uintptr_t)workspace % 16 != 0)
         return fail(GPFQ_ERR_WORKSPACE, "conv channel loop needs %zu aligned workspace bytes", need);
     if (pix > 1 && !(same_padding == 0 && !resid && !phase && g_conv_fused && gpfq::gram_conv_supported(n, H, W, nch, kh, kw, oh, ow) &&
-                     gpfq::gram_s2_supported(n, H, W, kh, kw, sh, sw, rh, rw, 0, 0)))
+                     gpfq::gram_s2_supported(n, H, W, kh, kw, sh, sw, rh, rw, 0, 0, nch)))
         return fail(GPFQ_ERR_UNSUPPORTED, "NHWC activations: only the 7x7 / stride 2 / VALID shift-sum form reads them (gpfq_conv_channels_nhwc_supported)");
     if (pix == 1 && !resid && g_conv_fused && gpfq::gram_image_supported(n, H, W, kh, kw, sh, sw, rh, rw, same_padding)) {
         // 3x3 / stride 1: Gram matrices of every channel straight from the planes, one batched decide launch
@@ -698,7 +698,7 @@ static int conv_channels_impl(int phase, double *records, int32_t *negflags,
         g.slack = std::ldexp(1.0, g_gram_slack_log2);
         g.variant = g_variant;
         g.phase = phase; g.records = records; g.negflags = negflags; g.pix = pix;
-        if (pad_top == 0 && pad_left == 0 && gpfq::gram_s2_supported(n, H, W, kh, kw, sh, sw, rh, rw, pad_top, pad_left))
+        if (pad_top == 0 && pad_left == 0 && gpfq::gram_s2_supported(n, H, W, kh, kw, sh, sw, rh, rw, pad_top, pad_left, nch))
             g.s2_part = reinterpret_cast<double *>(static_cast<char *>(workspace) + al256c(gpfq::gram_conv_workspace_bytes(K, nch, F, cols)));
         hipError_t e = gpfq::launch_gram_conv(g, static_cast<hipStream_t>(stream));
         return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_conv_channels(implicit)");
@@ -794,7 +794,7 @@ int gpfq_conv_channels_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t n
     if (n <= 0 || H <= 0 || W <= 0 || nch <= 0 || same_padding || !g_conv_fused || !g_conv_planes_free) return 0;
     const int64_t oh = gpfq_patch_out_dim(H, kh, sh, rh, 0), ow = gpfq_patch_out_dim(W, kw, sw, rw, 0);
     if ((int64_t)kh * kw > GPFQ_GRAM_MAX_N || n * oh * ow >= (1LL << 30)) return 0;
-    return gpfq::gram_conv_supported(n, H, W, nch, kh, kw, oh, ow) && gpfq::gram_s2_supported(n, H, W, kh, kw, sh, sw, rh, rw, 0, 0) ? 1 : 0;
+    return gpfq::gram_conv_supported(n, H, W, nch, kh, kw, oh, ow) && gpfq::gram_s2_supported(n, H, W, kh, kw, sh, sw, rh, rw, 0, 0, nch) ? 1 : 0;
 }
 
 int gpfq_quantize_conv_channels_nhwc(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t c_lo,

@@ -456,7 +456,7 @@ hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream)
         e = launch_gram_reduce(a.records, 1, (int)K, gram, nrm, a.nch, stream);
         if (e != hipSuccess) return e;
     } else if ((g_conv_s2.load(std::memory_order_relaxed) || a.pix > 1) && a.s2_part &&
-               gram_s2_supported(a.n, a.H, a.W, a.kh, a.kw, a.sh, a.sw, a.rh, a.rw, a.pt, a.pl)) {
+               gram_s2_supported(a.n, a.H, a.W, a.kh, a.kw, a.sh, a.sw, a.rh, a.rw, a.pt, a.pl, a.nch)) {
         // 7x7 / stride 2 / VALID: shift sums of the parity classes of the planes instead of every (t, s) product (gpfq_gram_s2.hip)
         e = launch_gram_s2(a.act_w, a.act_q, a.n, a.H, a.W, a.nch, a.s2_part, gram, nrm, negflag, stream, a.pix);
         if (e != hipSuccess) return e;

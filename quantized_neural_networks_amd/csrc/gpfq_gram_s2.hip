@@ -377,8 +377,13 @@ bool s2_plan(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw, in
 
 }  // namespace
 
-bool gram_s2_supported(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw, int rh, int rw, int pt, int pl)
+// nch: channels of the call.  The plan launches a fixed 512 + 6 * 128 workgroups PER CHANNEL, each writing 4 * 9 * 16 * 15 doubles of
+// partial sums (88 MB per channel): right for an image input (ResNet50's conv1: 3 channels, 265 MB), 5.6 GB and 82 K workgroups for a
+// 64-channel layer -- those stay on the matrix-core kernel.
+constexpr int64_t kS2MaxChannels = 8;
+bool gram_s2_supported(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw, int rh, int rw, int pt, int pl, int64_t nch)
 {
+    if (nch > kS2MaxChannels) return false;
     S2Plan P;
     return s2_plan(n, H, W, kh, kw, sh, sw, rh, rw, pt, pl, false, &P);
 }

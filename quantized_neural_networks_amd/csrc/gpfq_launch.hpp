@@ -213,7 +213,7 @@ bool gram_conv_supported(int64_t n, int64_t H, int64_t W, int64_t nch, int kh, i
 size_t gram_conv_workspace_bytes(int64_t K, int64_t nch, int64_t F, int64_t m);
 hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream);
 // 7x7 / stride 2 / VALID (ResNet50's conv1): the Gram records from shift sums of the parity classes of the planes (gpfq_gram_s2.hip)
-bool gram_s2_supported(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw, int rh, int rw, int pt, int pl);
+bool gram_s2_supported(int64_t n, int64_t H, int64_t W, int kh, int kw, int sh, int sw, int rh, int rw, int pt, int pl, int64_t nch);
 size_t gram_s2_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t nch);
 hipError_t launch_gram_s2(const float *act_w, const float *act_q, int64_t n, int64_t H, int64_t W, int64_t nch, double *part,
                           double *gram, float *nrm32, int *negflag, hipStream_t stream, int64_t pix = 1);

@@ -168,7 +168,7 @@ def auto_path(N, m, C, want_u=False, M=0):
 
     Rows beyond GPFQ_GRAM_MIN_M samples: the Gram path (N x N records + scalar recurrences) beats walking such rows
     step by step whenever the records are affordable (N <= GPFQ_GRAM_MAX_N); the reference's MNIST run is this case.
-    Measured (tools/dense_path_probe.py): with many neurons the crossover already comes at about 8192 samples --
+    Measured in round 2 (a probe since pruned; the numbers are in DESIGN.md, section 4, long walks): with many neurons the crossover already comes at about 8192 samples --
     N = 128, C = 1000, m = 8192: 0.94 ms on chip, 0.41 ms there; N = 784, C = 500, m = 12288: 5.5 vs 4.0 ms.
     Otherwise the residual stays on chip up to GPFQ_ONCHIP_MAX_M samples and streams through HBM beyond
     (the library chooses between those two itself)."""
@@ -635,8 +635,10 @@ def _read_scalar(out, meanwhile=None):
     return np.float32(host[0].item())
 
 
-def median_abs(W, meanwhile=None):
-    """np.median(np.abs(W.flatten())) of a float32 GPU tensor as a numpy float32 (exact select)."""
+def median_abs(W, meanwhile=None, on_device=False):
+    """np.median(np.abs(W.flatten())) of a float32 GPU tensor as a numpy float32 (exact select).
+    on_device=True: the float32 device scalar [1] instead, no host wait (the class surface queues the medians of ALL its layers
+    up front -- they depend on the analog kernels alone -- and reads them back with one copy: medians_to_host)."""
     _dev(W, torch.float32, "W")
     Wc = W.contiguous()
     lib = load()
@@ -646,7 +648,18 @@ def median_abs(W, meanwhile=None):
     with torch.cuda.device(W.device):
         _check(lib.gpfq_median_abs(Wc.data_ptr(), Wc.numel(), out.data_ptr(), ws.data_ptr(), nbytes, _stream()),
                "gpfq_median_abs")
+        if on_device:
+            return out
         return _read_scalar(out, meanwhile)
+
+
+def medians_to_host(scalars):
+    """float32 device scalars (median_abs(..., on_device=True)) -> list of numpy float32, one copy and one host wait for all."""
+    import numpy as np
+    if not scalars:
+        return []
+    host = torch.cat([t.reshape(1) for t in scalars]).cpu().numpy()
+    return [np.float32(v) for v in host]
 
 
 GPFQ_MEDIAN_HIST_OFFSET, GPFQ_MEDIAN_HIST_WORDS = 64, 4096

@@ -308,7 +308,9 @@ class Flatten(Layer):
         return (s[0], int(np.prod(s[1:])))
 
     def call(self, x):
-        return x.reshape(x.shape[0], -1)
+        # (the feature count spelled out: a rank's block of samples may be EMPTY -- six capture chunks over eight ranks -- and
+        #  reshape(0, -1) is ambiguous)
+        return x.reshape(x.shape[0], int(np.prod(x.shape[1:])))
 
 
 class _Pool2D(Layer):
@@ -382,8 +384,12 @@ class BatchNormalization(Layer):
                          torch.zeros(c, device=device), torch.ones(c, device=device)]   # gamma, beta, mean, var
 
     def call(self, x):
+        # TensorFlow's own inference form (tf.nn.batch_normalization: inv = rsqrt(variance + epsilon) * scale;
+        # x * inv + (offset - mean * inv)): per-channel scale and shift, ONE pass over the activations (torch.addcmul) instead of
+        # the three of (x - mean) * inv + offset -- 5 ms of the CIFAR10 CNN's 45 ms capture-and-quantize run went there
         g, b, mu, var = self._weights
-        return (x - mu) * (g / torch.sqrt(var + self.epsilon)) + b
+        inv = g / torch.sqrt(var + self.epsilon)
+        return torch.addcmul(b - mu * inv, x, inv)
 
 
 class Activation(Layer):

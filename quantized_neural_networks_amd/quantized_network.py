@@ -17,6 +17,7 @@ process' GPU) and ``process_group`` (a ``torch.distributed`` group over which th
 layer -- and the samples of the activation capture in between -- are sharded), and ``fix_partial_batch`` to opt out of the reference's
 partial-last-batch layout quirk (:491-495).
 """
+import logging
 from collections import namedtuple
 from math import ceil
 from time import time
@@ -74,6 +75,12 @@ class _SliceSequence(_SequenceBase):
         bx, by = self._slice(idx)
         return np.asarray(bx), np.asarray(by)       # views: the reference copies here (np.array), nothing mutates them
 
+    def _all_inputs(self):
+        """(all inputs as ONE array, batch sizes): what iterating __getitem__ over the batches and concatenating gives, without the
+        copies -- the activation capture takes the calibration set to the GPU in one piece (quantized_network._raw_inputs)."""
+        n, bs = len(self.x), self.batch_size
+        return np.asarray(self.x), [min(bs, n - lo) for lo in range(0, n, bs)]
+
 
 class MNISTSequence(_SliceSequence):
     pass
@@ -94,8 +101,32 @@ class ImageNetSequence(_SliceSequence):
         bx, by = self._slice(idx)
         return np.array([self.preprocess_func(np.load(f)) for f in bx]), np.array(by)
 
+    _all_inputs = None                              # (files are loaded and preprocessed batch by batch)
+
 
 # ------------------------------------------------------------------------------------------
+class _LazyStats(dict):
+    """last_layer_stats[layer]: rad, alphabet, resid, idx (, reruns).  The index tensor and the residual norms stay on the GPU until
+    someone reads them (they are diagnostics: 103 MB of indices for VGG16's fc1 crossed PCIe after every layer until round 3);
+    the first read copies to the host and keeps the NumPy array."""
+
+    def __getitem__(self, key):
+        v = dict.__getitem__(self, key)
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+            dict.__setitem__(self, key, v)
+        return v
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+
 class QuantizedNeuralNetwork:
     """Wrapper around a Keras-style model that quantizes its Dense layers (reference :331-590)."""
 
@@ -216,8 +247,23 @@ class QuantizedNeuralNetwork:
     # depend on the number of ranks, so each chunk has the same shape as in a single-process run; the captured
     # activations are the same bits whenever the forward kernels are deterministic across processes (GEMMs are; MIOpen's
     # timed solver search per process can change the last bits of a convolution).
-    _capture_chunk = 512
+    _capture_chunk = None       # None: by the size of a sample (_chunk_samples); an int fixes it
     shard_capture = True
+
+    def _chunk_samples(self):
+        """Samples per forward chunk of the incremental capture: 2^25 input elements' worth, at least 512 and at most 16384 -- 16384 for
+        the MNIST MLP (784 features), 8192 for CIFAR10 images (the reference's 5000 calibration images are one piece: no
+        concatenation after every layer), 512 for ImageNet ones.  (Fixed at 512 until round 3: the MNIST run's
+        25000 samples went through every layer in 49 pieces, 294 launches of ~10 us of host time each for 7 ms of kernels.)  It does
+        not depend on the number of ranks, so a sample's chunk has the same shape in a sharded run."""
+        if self._capture_chunk is not None:
+            return int(self._capture_chunk)
+        raw, _ = self._raw_inputs()
+        feat = max(int(np.prod(raw.shape[1:])), 1)
+        c = 512
+        while c < 16384 and 2 * c * feat <= (1 << 25):
+            c *= 2
+        return c
 
     def _incremental_capture_possible(self):
         return (getattr(self, "incremental_capture", True) and hasattr(self.trained_net, "forward_upto")
@@ -225,14 +271,20 @@ class QuantizedNeuralNetwork:
 
     def _raw_inputs(self):
         if getattr(self, "_raw", None) is None:
-            batches = [np.asarray(self.get_data.__getitem__(b)[0]) for b in range(self.get_data.__len__())]
-            sizes = [int(a.shape[0]) for a in batches]
-            self._raw = (self._to_device(batches[0] if len(batches) == 1 else np.concatenate(batches, axis=0)), sizes)
+            whole = getattr(self.get_data, "_all_inputs", None)
+            if whole is not None:
+                # this module's own Sequences slice one array: the batches back to back ARE that array (no 313-way concatenate)
+                arr, sizes = whole()
+                self._raw = (self._to_device(arr), sizes)
+            else:
+                batches = [np.asarray(self.get_data.__getitem__(b)[0]) for b in range(self.get_data.__len__())]
+                sizes = [int(a.shape[0]) for a in batches]
+                self._raw = (self._to_device(batches[0] if len(batches) == 1 else np.concatenate(batches, axis=0)), sizes)
         return self._raw
 
     @torch.no_grad()
     def _advance(self, layer, x):
-        step = self._capture_chunk
+        step = self._chunk_samples()
         if x.shape[0] <= step:
             return layer.call(x)
         return torch.cat([layer.call(x[i:i + step]) for i in range(0, x.shape[0], step)])
@@ -243,7 +295,7 @@ class QuantizedNeuralNetwork:
         world, rank = _layer._group_info(self.process_group)
         if world == 1 or not self.shard_capture:
             return 1, 0, n, n
-        chunk = self._capture_chunk
+        chunk = self._chunk_samples()
         n_chunks = -(-n // chunk)
         c_lo, c_hi = _layer.shard_bounds(n_chunks, world, rank)
         return world, min(c_lo * chunk, n), min(c_hi * chunk, n), -(-n_chunks // world) * chunk
@@ -325,10 +377,13 @@ class QuantizedNeuralNetwork:
             fr = dict(k=-1, w=mine, q=mine)                     # outputs of "layer -1" = the data itself
         tl, ql = self.trained_net.layers, self.quantized_net.layers
 
-        def same_weights(k):
-            return all(torch.equal(a, b) for a, b in zip(tl[k]._weights, ql[k]._weights))
-
         steps = range(fr["k"] + 1, layer_idx)
+        # (once per step: torch.equal on device tensors is a device sync)
+        _same = {k: all(torch.equal(a, b) for a, b in zip(tl[k]._weights, ql[k]._weights)) for k in steps} if fr["q"] is fr["w"] else {}
+
+        def same_weights(k):
+            return _same.get(k, False)
+
         w_ahead = self._take_lookahead(fr, layer_idx) if len(steps) else None
         # the look-ahead holds the END of the analog chain only: it serves when the quantized chain either equals it all the
         # way (nothing quantized yet) or parts from it at the first step (the layer quantized last) -- front-to-back order
@@ -409,8 +464,27 @@ class QuantizedNeuralNetwork:
             return ws[0]
         return self._to_device(layer.get_weights()[0])
 
-    def _layer_alphabet(self, Wd):
-        return _layer.layer_alphabet(Wd, self.alphabet, self.alphabet_scalar, self.process_group)   # (:544-545)
+    def _layer_alphabet(self, Wd, layer_idx=None):
+        # (:544-545) -- the median of |W| depends on the ANALOG kernel alone: quantize_network() queues the medians of all its layers
+        # up front and reads them back with ONE host wait (_prefetch_medians) instead of one per layer
+        med = getattr(self, "_medians", {}).pop(layer_idx, None) if layer_idx is not None else None
+        if med is not None:
+            rad = np.float64(self.alphabet_scalar) * np.float64(med)          # legacy-NumPy typing, as layer.layer_alphabet
+            return rad * np.asarray(self.alphabet, dtype=np.float64), rad
+        return _layer.layer_alphabet(Wd, self.alphabet, self.alphabet_scalar, self.process_group)
+
+    def _prefetch_medians(self, layer_indices):
+        """median(|W|) of the given layers' analog kernels, all queued before the first host wait (layers whose kernel is on the
+        GPU and small enough for the one-GPU select; the others compute theirs when their turn comes)."""
+        self._medians = {}
+        todo = []
+        for k in layer_indices:
+            Wd = self._kernel_on_device(self.trained_net.layers[k])
+            world, _ = _layer._group_info(self.process_group)
+            if Wd.is_cuda and Wd.numel() > 0 and (world == 1 or Wd.numel() < _layer._SHARDED_MEDIAN_MIN):
+                todo.append((k, hip.median_abs(Wd.detach().reshape(-1), on_device=True)))
+        for (k, _), v in zip(todo, hip.medians_to_host([t for _, t in todo])):
+            self._medians[k] = v
 
     # -- Dense layer (reference :523-574) ---------------------------------------------------
     def _quantize_layer_parallel(self, layer_idx):
@@ -421,7 +495,7 @@ class QuantizedNeuralNetwork:
         wX, qX = self._get_layer_data_generator(layer_idx, transpose=True)
         self._log(f"\tdone. {time()-tic:2f} seconds.")
 
-        layer_alphabet, rad = self._layer_alphabet(Wd)
+        layer_alphabet, rad = self._layer_alphabet(Wd, layer_idx)
 
         self._log("\tQuantizing neurons (in parallel)...")
         tic = time()
@@ -432,18 +506,32 @@ class QuantizedNeuralNetwork:
         except Exception as exc:
             self._log(f"\t\tLayer {layer_idx} generated an exception: {exc}")
             raise exc
-        # the reference logs one line per neuron as its futures complete (:567); here all neurons complete together, so the
-        # same lines go out as ONE logger call (4096 separate calls cost about as much as the kernel that quantized them)
-        self._log("\n".join(f"\t\tNeuron {neuron_idx} of {N_ell_plus_1} quantized successfully."
-                            for neuron_idx in range(N_ell_plus_1)))
+        self._log_units("\t\tNeuron {} of " + f"{N_ell_plus_1} quantized successfully.", N_ell_plus_1)
         self._update_weights(layer_idx, Q)
         self._log(f"\tdone. {time()-tic:.2f} seconds.")
-        self.last_layer_stats[layer_idx] = dict(rad=rad, alphabet=layer_alphabet,
-                                                resid=out["resid"].cpu().numpy(), idx=out["idx"].cpu().numpy())
+        self.last_layer_stats[layer_idx] = _LazyStats(rad=rad, alphabet=layer_alphabet, resid=out["resid"], idx=out["idx"])
+
+    # The reference logs one record per neuron / filter as its futures complete (:567, :716).  Here all of a layer's units complete
+    # together; the records still go out ONE PER UNIT (handlers and formatters that count or prefix records see what they saw), unless
+    # the logger has INFO disabled (then nothing is formatted at all: 4096 logger calls cost about as much as the kernel that
+    # quantized the neurons) or `batch_unit_log = True` asks for one multi-line record per layer.
+    batch_unit_log = False
+
+    def _log_units(self, fmt, n):
+        lg = self.logger
+        if lg is not None and hasattr(lg, "isEnabledFor") and not lg.isEnabledFor(logging.INFO):
+            return
+        if self.batch_unit_log:
+            self._log("\n".join(fmt.format(i) for i in range(n)))
+        else:
+            for i in range(n):
+                self._log(fmt.format(i))
 
     def quantize_network(self):
         """Quantizes all Dense layers that are not in ``ignore_layers``, in order (:576-590)."""
         num_layers = len(self.trained_net.layers)
+        self._prefetch_medians([k for k, layer in enumerate(self.trained_net.layers)
+                                if layer.__class__.__name__ == "Dense" and k not in self.ignore_layers])
         for layer_idx, layer in enumerate(self.trained_net.layers):
             if layer.__class__.__name__ == "Dense" and layer_idx not in self.ignore_layers:
                 tic = time()
@@ -493,7 +581,7 @@ class QuantizedCNN(QuantizedNeuralNetwork):
         except Exception:
             rate = None
         Wd = self._kernel_on_device(layer)
-        alphabet, rad = self._layer_alphabet(Wd)                                   # (:831-832)
+        alphabet, rad = self._layer_alphabet(Wd, layer_idx)                        # (:831-832)
         num_channels = Wd.shape[-2]
         tic = time()
         self._log(f"\t\tBuilding patch arrays and quantizing channel filters for {num_channels} channels...")
@@ -508,11 +596,14 @@ class QuantizedCNN(QuantizedNeuralNetwork):
             raise Exception
         self._log(f"\t\tdone. {time()-tic:.2f} seconds.")
         self._update_weights(layer_idx, Q)
-        self.last_layer_stats[layer_idx] = dict(rad=rad, alphabet=alphabet, resid=out["resid"].cpu().numpy(),
-                                                idx=out["idx"].cpu().numpy(), reruns=int(out.get("reruns", 0)))
+        self.last_layer_stats[layer_idx] = _LazyStats(rad=rad, alphabet=alphabet, resid=out["resid"], idx=out["idx"],
+                                                      reruns=int(out.get("reruns", 0)))
 
     def quantize_network(self):
         num_layers = len(self.trained_net.layers)
+        self._prefetch_medians([k for k, layer in enumerate(self.trained_net.layers)
+                                if layer.__class__.__name__ == "Dense"
+                                or (layer.__class__.__name__ in {"Conv2D", "DepthwiseConv2D"} and self.is_quantize_conv2d)])
         for layer_idx, layer in enumerate(self.trained_net.layers):
             if layer.__class__.__name__ == "Dense":
                 self._log(f"Quantizing (Dense) layer {layer_idx} of {num_layers}...")

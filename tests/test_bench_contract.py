@@ -68,3 +68,33 @@ def test_bench_two_ranks_over_gloo_split_the_fixed_layer():
     assert len(col["kernel_ms_per_rank"]) == 2 and all(v > 0 for v in col["kernel_ms_per_rank"])
     assert col["allgather_ms"] > 0 and len(col["allgather_ms_per_rank"]) == 2
     assert col["gathered_bytes_per_rank"] == 512 * 256 * 2 // 8      # 512 neurons x 256 weights at 2 bits (ternary)
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_over_gloo_strong_and_weak():
+    """World size 8 (the north-star's), functionally: eight ranks share this box's one GPU, the collectives go over gloo.  The fixed
+    layer (520 neurons: 65 per rank, not a multiple of the 16-neuron workgroups) is split over the ranks, the per-rank arrays
+    of the `collective` object have eight entries, and the same launch steps the weak-scaling companion."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, GPFQ_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--fan-in", "256", "--neurons", "520", "--samples", "512"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=1500, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["C"] == 520 and out["config"]["neurons_per_gpu"] == 65 and "split over 8 GPUs" in out["config"]["workload"]
+    assert "cpu_baseline" not in out and 0 < out["roofline"]["frac"] <= 1.0
+    weak = out["weak_scaling_companion"]
+    assert weak["scaling"] == "weak" and weak["value"] > 0 and "Dense(256->4160)" in weak["workload"]
+    col = out["collective"]
+    assert col["backend"].startswith("gloo") and col["world_size"] == 8
+    assert len(col["kernel_ms_per_rank"]) == 8 and all(v > 0 for v in col["kernel_ms_per_rank"])
+    assert col["allgather_ms"] > 0 and len(col["allgather_ms_per_rank"]) == 8
+    assert col["gathered_bytes_per_rank"] == 8 * 65 * 256 * 2 // 8     # eight 65-neuron shards x 256 weights at 2 bits

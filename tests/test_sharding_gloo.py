@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the neuron/channel sharding and the single all-gather per layer
+"""CPU, world_size 2 and 8, gloo: the neuron/channel sharding and the single all-gather per layer
 reassemble exactly the unsharded result.  The collective plumbing is what is under test (the HIP kernels are covered
 by the -m gpu tests): THIS TEST replaces the entry points of the HIP binding (`hip.quantize_neurons`, ...) by
 oracle-backed stand-ins on CPU tensors in its own worker processes; the product has no hook for that -- layer.py calls
@@ -102,14 +102,17 @@ def _dense_members(case):
     return 200 if case == "dense_int16" else 4              # 200 members: int16 indices, gathered as bytes
 
 
-@pytest.mark.parametrize("case", ["dense", "dense_int16", "conv_channels", "conv_filters"])
-def test_sharded_equals_unsharded(case, tmp_path, oracle_mod):
+@pytest.mark.parametrize("case,world", [("dense", 2), ("dense_int16", 2), ("conv_channels", 2), ("conv_filters", 2),
+                                        # the north-star's world size: 7 neurons / 3 channels / 5 filters over EIGHT ranks -- empty
+                                        # shards, `per`-padded gathers, fewer channels than ranks (filters are sharded instead)
+                                        ("dense", 8), ("dense_int16", 8), ("conv_channels", 8), ("conv_filters", 8)])
+def test_sharded_equals_unsharded(case, world, tmp_path, oracle_mod):
     import torch.multiprocessing as mp
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
     res = [np.load(tmp_path / f"{case}_{r}.npz") for r in range(world)]
     for k in res[0].files:
-        assert np.array_equal(res[0][k], res[1][k]), f"ranks disagree on {k}"
+        for r in range(1, world):
+            assert np.array_equal(res[0][k], res[r][k]), f"ranks 0 and {r} disagree on {k}"
     # unsharded reference: same stand-ins, no process group
     sys.path.insert(0, ROOT)
     from quantized_neural_networks_amd import layer

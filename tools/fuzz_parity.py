@@ -1,7 +1,7 @@
 """Randomised parity sweep on the GPU: random dense layers (all on-chip kernels, streaming, Gram path) and random conv
 layers (kernel size, stride, rate, padding, image size, channel / filter counts, alphabets, sparse or signed
 activations) against the CPU oracle, bit for bit.  Not part of the test suite (minutes of GPU time).
-usage: fuzz_parity.py [seconds] [seed]"""
+usage: fuzz_parity.py [seconds] [seed]      (FUZZ_LONG_P=0.5: more of the long-row conv cases)"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -14,7 +14,8 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device("cuda")
 t_end = time.time() + budget
-n_dense = n_conv = 0
+n_dense = n_conv = n_long = 0
+LONG_P = float(os.environ.get("FUZZ_LONG_P", "0.05"))   # share of conv cases with 2^18 .. 2^22 patch columns
 bad = []
 
 
@@ -94,15 +95,27 @@ while time.time() < t_end:
         nhwc_case = (kh, kw, stride, rate, padding) == (3, 3, 1, 1, "SAME") and rng.random() < 0.5
         if nhwc_case:                               # 32+ channels: the shift form straight from the NHWC activations (LDS-DMA ring)
             cin = int(rng.choice([rng.integers(32, 150), rng.integers(8, 32)])); F = int(rng.integers(1, 4))
+        # long rows (round 4): 2^18 < columns <= 2^22 -- the range where the Gram path's certification bound grows with the row length
+        # (gpfq_gram.hip, launch_gram_decide); the oracle walks GPU-built patch matrices of a few (channel, filter) pairs
+        long_case = rng.random() < LONG_P
+        if long_case:
+            kh, kw, stride, rate, padding = [(3, 3, 1, 1, "SAME"), (3, 3, 1, 1, "SAME"), (7, 7, 2, 1, "VALID"), (5, 5, 1, 1, "SAME"), (3, 3, 2, 1, "SAME"),
+                                             (3, 3, 1, 1, "VALID")][int(rng.integers(0, 6))]
+            H = int(rng.integers(40, 120)); Wd = int(rng.integers(40, 120))
+            cin = int(rng.choice([1, 2, 3, 3, 40])); F = int(rng.integers(1, 4))
+            s2_case = nhwc_case = False
         oh, ow = hip.patch_out_dim(H, kh, stride, rate, padding == "SAME"), hip.patch_out_dim(Wd, kw, stride, rate, padding == "SAME")
         if oh * ow == 0:
             continue
         n = int(rng.choice([rng.integers(1, 20), -(-hip.GPFQ_GRAM_MIN_M // (oh * ow)) + int(rng.integers(1, 40))]))
-        if nhwc_case:
+        if long_case:
+            cols = int(2 ** rng.uniform(18.0, 22.0 if cin <= 3 else 20.5)) + 1
+            n = -(-cols // (oh * ow))
+        if nhwc_case and not long_case:
             n = min(n, 12)                          # (the oracle walks every channel on the host)
             if cin < 32:
                 n = 16                              # narrow shards take the NHWC form by image groups (2 .. 16 divide n)
-        if s2_case:
+        if s2_case and not long_case:
             n = int(rng.integers(1, 24))
         kind = rng.choice(["relu", "sparse", "signed", "uniform"])
         act_w = activations((n, H, Wd, cin), kind)
@@ -119,20 +132,25 @@ while time.time() < t_end:
         out = layer.quantize_conv2d(Wt, aw, aq, alphabet, strides=(stride, stride), padding=padding, rate=(rate, rate), want_resid=want_resid)
         Q = out["Q"].cpu().numpy()
         ok = True
-        for c in (range(cin) if cin <= 8 else sorted(set(int(v) for v in rng.integers(0, cin, 6)) | {0, cin - 1})):
-            Pw = ref_patches(act_w, c, kh, kw, stride, stride, rate, rate, padding)
-            Pq = ref_patches(act_q, c, kh, kw, stride, stride, rate, rate, padding)
+        for c in (range(cin) if cin <= 8 else sorted(set(int(v) for v in rng.integers(0, cin, 2 if long_case else 6)) | {0, cin - 1})):
+            if long_case:                            # patch matrices built on the GPU (gpfq_extract_patches: pinned by tests/test_extract_patches_doc.py)
+                Pw = hip.extract_patches(aw, c, (kh, kw), (stride, stride), (rate, rate), padding).cpu().numpy()
+                Pq = Pw if first else hip.extract_patches(aq, c, (kh, kw), (stride, stride), (rate, rate), padding).cpu().numpy()
+            else:
+                Pw = ref_patches(act_w, c, kh, kw, stride, stride, rate, rate, padding)
+                Pq = ref_patches(act_q, c, kh, kw, stride, stride, rate, rate, padding)
             for f in range(F):
                 qo, _, uo = oracle.neuron(Wk[:, :, c, f].reshape(-1), Pw, Pq, alphabet)
                 ok &= np.array_equal(Q[:, :, c, f].reshape(-1), qo.astype(np.float32))
                 if want_resid:
                     ok &= bool(np.isclose(out["resid"][c, f].item(), np.linalg.norm(uo), rtol=1e-5, atol=0))
         n_conv += 1
+        n_long += int(long_case)
         if not ok:
             bad.append(("conv", n, H, Wd, cin, F, kh, kw, stride, rate, padding, kind, first, M, scalar, want_resid))
     if bad:
         break
-print(f"dense cases {n_dense}, conv cases {n_conv}, mismatches {len(bad)}")
+print(f"dense cases {n_dense}, conv cases {n_conv} (of which {n_long} with 2^18 .. 2^22 columns), mismatches {len(bad)}")
 for b in bad:
     print("MISMATCH", b)
 sys.exit(1 if bad else 0)
