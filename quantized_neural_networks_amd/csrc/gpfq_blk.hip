@@ -561,8 +561,9 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             for (int p = 0; p < PW; ++p) {
                 // issue priority falls with progress through the slot (the laggard of a SIMD is served first, see below)
                 {
-                    // (tried: one level higher for the younger wavefronts of a SIMD, which it serves last at equal priority -- 3.22 - 3.27
-                    //  against 3.26 ms in the build that had it, and the wave-uniform branches it needs made hipcc spill)
+                    // (tried, both measured slower: one level higher for the younger wavefronts of a SIMD, which it serves last at equal
+                    //  priority -- per pair 3.22 - 3.27 against 3.26 ms in the build that had it, the wave-uniform branches made hipcc
+                    //  spill; ONE constant level per wavefront by age instead of levels by progress 3.14 against 3.07 ms)
                     const int pr = 2 - (3 * p) / PW;
                     if (p == 0 || pr != 2 - (3 * (p - 1)) / PW) {
                         const int v = pr;

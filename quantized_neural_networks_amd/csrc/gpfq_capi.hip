@@ -324,7 +324,7 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
             pa.N = N; pa.m = m; pa.C = C; pa.qidx = qidx; pa.Qt = Qt; pa.resid = resid; pa.u_out = u_out;
             pa.ts_override = g_tile_steps; pa.variant = g_variant >> 4;
             const bool forced_old = g_lpn != 0 || g_wpn != 0 || g_onchip_mode != 1 || g_pipe == 0;
-            // measured (tools/blk_shapes.sh): the block-pipelined kernel is ahead of the row-group and wavefront-per-neuron kernels
+            // measured (tools/blk_ab.sh shapes): the block-pipelined kernel is ahead of the row-group and wavefront-per-neuron kernels
             // for rows of 257..4096 samples (2049+: one step per slot; 4096 x 4096 x 4096: 16.6 vs 38 ms) whenever the layer has 512 neurons or more (4096 x 4096, m = 1024: 4.1 vs 5.4 ms;
             // m = 2048, 16 levels: 8.7 vs 10.0; m = 512: 3.2 vs 3.9; 4096 x 1024, m = 1536: 3.7 vs 6.8; 784 x 4096, m = 512: 0.68
             // vs 0.85).  Its time per step does not depend on the number of neurons up to one workgroup per CU; narrower layers
@@ -332,7 +332,7 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
             // 2.06 vs 2.20) -- except for rows of 769+ samples, where workgroups of 8 and of 4 neurons make it the fastest at any
             // width (4096 x 2048, m = 1024: 2.5 vs 5.4 ms; 4096 x 128, m = 2048: 2.9 vs 4.5; 2048 x 128, m = 4096: 2.3 vs 2.5).
             // Round 3: two-neuron workgroups (layers of at most 512 neurons, rows of up to 5120 samples) make it the fastest for narrow
-            // layers as well (784 x 128, m = 512, 16 levels; 2048 x 128, m = 5008: tools/latency_shapes.sh, profiles/r03/).
+            // layers as well (784 x 128, m = 512, 16 levels; 2048 x 128, m = 5008: tools/blk_ab.sh latency, profiles/r03/).
             const bool fits = m > 256 && M <= 64 && m <= 5120;
             const bool want = g_pipe == 1;
             if ((g_pipe == 2 || (g_pipe < 0 && !forced_old && fits)) && N > 0 && m > 0 && gpfq::blk_supported(pa) && workspace &&
