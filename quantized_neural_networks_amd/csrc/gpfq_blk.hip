@@ -381,7 +381,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     // D's; 400-900 cycles each with the LDS busiest right after the barrier -- profiles/r03/blk_phase_stamps.txt).
     // Phase D on the matrix unit (round 4; G = 4 neuron groups x B = 4 steps x NL = 4 neurons per lane, row t + B as float64), and with it
     // the two phases FUSED pair by pair (kFused): see the slot loop.
-    constexpr bool kMfmaD = G == 4 && B == 4 && NL == 4 && blk_row64(G, B) && !kNoMfmaD;
+    constexpr bool kMfmaD = G == 4 && B == 4 && blk_row64(G, B) && !kNoMfmaD;             // (NL = 4, 2 or 1 neurons per lane: 16, 8 or 4 per workgroup)
     constexpr bool kFused = kMfmaD && !kNoFused;
     constexpr bool kPreloadAll = PW * B <= 8 && PW <= 5 && !kFused;
     // ... where the registers allow it (u and the operands of a slot together): otherwise they are requested at the top of
@@ -550,8 +550,8 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 #ifdef GPFQ_BLK_X_LDS2
             float2 xl[2];
 #endif
-            auto mfma_pair = [&](int pp, int i, const double2 &dd) {      // matrix instruction i = 0 .. 7 of pair pp
-                const int n = i & 3, e = i >> 2;
+            auto mfma_pair = [&](int pp, int i, const double2 &dd) {      // matrix instruction i = 0 .. 2 NL - 1 of pair pp
+                const int n = i % NL, e = i / NL;
 #ifdef GPFQ_BLK_X_MFMA2                // timing experiment (same results): every matrix instruction twice, the copy into a dummy accumulator
                 xdummy[n] = __builtin_amdgcn_mfma_f64_4x4x4f64(u[n][2 * pp + e], e ? dd.x : dd.y, xdummy[n], 0, 0, 0);
 #endif
@@ -613,7 +613,11 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
                         asm volatile("" :: "v"(xl[0]), "v"(xl[1]));
                     }
 #endif
-                    if (p > 0) { mfma_pair(p - 1, 2 * st, dprev); mfma_pair(p - 1, 2 * st + 1, dprev); }
+                    if (p > 0) {                                   // the previous pair's 2 NL matrix instructions, spread over this pair's B steps
+#pragma unroll
+                        for (int i = 0; i < 2 * NL; ++i)
+                            if (i * B / (2 * NL) == st) mfma_pair(p - 1, i, dprev);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 dprev = dcur;
@@ -631,9 +635,15 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             asm volatile("" :: "v"(xu[0][0]), "v"(xu[0][1]), "v"(xu[1][0]), "v"(xu[1][1]), "v"(xu[2][0]), "v"(xu[2][1]), "v"(xu[3][0]), "v"(xu[3][1]));
 #endif
             if (b + 1 < nslots && (lane & 12) == 0) {             // one lane per (step, neuron group)
-                const int od = L.off_d + ((((((b + 1) & 1) * NW + wave) * B) + (lane & 3)) * NB + 4 * (lane >> 4)) * 8;
-                lds_st<double2>(lds, od, make_double2(acc[0], acc[1]));
-                lds_st<double2>(lds, od + 16, make_double2(acc[2], acc[3]));
+                const int od = L.off_d + ((((((b + 1) & 1) * NW + wave) * B) + (lane & 3)) * NB + NL * (lane >> 4)) * 8;
+                if constexpr (NL == 4) {
+                    lds_st<double2>(lds, od, make_double2(acc[0], acc[1]));
+                    lds_st<double2>(lds, od + 16, make_double2(acc[2], acc[3]));
+                } else if constexpr (NL == 2) {
+                    lds_st<double2>(lds, od, make_double2(acc[0], acc[NL - 1]));
+                } else {
+                    lds_st<double>(lds, od, acc[0]);
+                }
             }
         } else {
         if constexpr (kPreloadAll) {
@@ -745,9 +755,9 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 #pragma unroll
                 for (int n = 0; n < NL; ++n) { acc[n] = ror_add<8>(acc[n]); acc[n] = ror_add<4>(acc[n]); }   // blocks: lane bits 2, 3
                 if ((lane & 12) == 0) {                           // one lane per (step, neuron group)
-                    const int od = L.off_d + ((((((b + 1) & 1) * NW + wave) * B) + (lane & 3)) * NB + 4 * (lane >> 4)) * 8;
-                    lds_st<double2>(lds, od, make_double2(acc[0], acc[1]));
-                    lds_st<double2>(lds, od + 16, make_double2(acc[2], acc[3]));
+                    const int od = L.off_d + ((((((b + 1) & 1) * NW + wave) * B) + (lane & 3)) * NB + NL * (lane >> 4)) * 8;
+#pragma unroll
+                    for (int n = 0; n < NL; ++n) lds_st<double>(lds, od + 8 * n, acc[n]);
                 }
             }
         } else
@@ -1444,6 +1454,8 @@ void blk_set_sweep_waves(int nw) { g_blk_nw.store(nw == 11 ? 11 : (nw == 8 ? 8 :
 // C: neurons of the call.  Rows of 769..1024 samples are the one shape whose slot is bound by the sweeps (nine sample pairs
 // on three of the SIMDs), not by the chain of decisions: up to 2048 neurons -- one round of 256 workgroups with 8 neurons
 // each -- the sweeps are halved by giving a workgroup 8 neurons instead of 16 (4096 x 2048, m = 1024: 4.0 -> 2.9 ms).
+static std::atomic<int> g_blk_quad{1};    // four neuron groups x 1 / 2 neurons per lane for layers of 129..2048 neurons on rows of 257..1024 samples
+void blk_set_quad_groups(int on) { g_blk_quad.store(on < 0 ? 0 : (on > 2 ? 2 : on), std::memory_order_relaxed); }
 static std::atomic<int> g_blk_pairs{1};   // two-neuron workgroups for layers of at most 512 neurons
 void blk_set_pair_groups(int on) { g_blk_pairs.store(on ? 1 : 0, std::memory_order_relaxed); }
 
@@ -1459,6 +1471,19 @@ static BlkShape blk_shape(int64_t m, int64_t C)
     // are half the element-wise work per slot on twice the CUs.  Rows of up to 5120 samples (cfg4's Dense(2048 -> 128) on 5008).
     // Layers of at most 128 neurons: ONE neuron per workgroup -- the 64 workgroups of the two-neuron form leave three CUs in four idle,
     // and a slot's sweeps are half as long again (cfg1's Dense(784 -> 128), cfg4's Dense(2048 -> 128) on 5008 samples)
+    // Round 4: layers of 129..2048 neurons on rows of 257..1024 samples take FOUR neuron groups per sweep wavefront with one or two
+    // neurons per lane (4 or 8 per workgroup): the fused matrix form of the 16-neuron shape.  The one-group shapes below fold every
+    // step's partial dot products over all 64 lanes (six dependent stages per row); here the matrix instruction leaves two row
+    // rotations per slot, and the short rows no longer put 16 neurons on a workgroup (a layer of 1024 neurons filled 64 CUs):
+    // 4096 x 512 on 1024 samples 1.74 -> 1.56 ms, x 1024 2.10 -> 1.65, x 2048 2.44 -> 1.97; 4096 x 1024 on 768 samples 2.69 -> 1.48,
+    // on 512 samples 1.96 -> 1.38 (profiles/r04/latency_shapes.txt).  At most 128 neurons: the one-neuron shapes stay (1.57 both ways).
+    const int quad = g_blk_quad.load(std::memory_order_relaxed);         // 1 (default): 129..2048 neurons; 2: every layer of at most 2048; 0: off
+    if (quad && C <= 2048 && (quad >= 2 || C > 128) && m > 256 && m <= 1024) {
+        const int nl = C > 1024 ? 2 : 1;
+        if (m <= 512) return {4, 16, 4, 512, 8, nl};
+        if (m <= 768) return {4, 24, 4, 768, 8, nl};
+        return {4, 32, 4, 1024, 8, nl};
+    }
     if (C <= 128 && g_blk_pairs.load(std::memory_order_relaxed) != 0 && g_blk_single.load(std::memory_order_relaxed) != 0) {
         if (m > 256 && m <= 512) return {1, 4, 4, 512, 4, 1};
         if (m > 512 && m <= 1024) return {1, 8, 4, 1024, 8, 1};
@@ -1636,6 +1661,12 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
                        a.nrm32, static_cast<char *>(a.workspace), static_cast<char *>(a.workspace) + blk_recs_bytes(nblk, sh), sym_a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    // (four neuron groups with one or two neurons per lane: the narrow forms of the fused matrix shape)
+    if (sh.G == 4 && sh.NL < 4) {
+        if (sh.S == 16) return sh.NL == 1 ? launch_blk_inst<4, 16, 4, 8, 1>(a, sh, stream) : launch_blk_inst<4, 16, 4, 8, 2>(a, sh, stream);
+        if (sh.S == 24) return sh.NL == 1 ? launch_blk_inst<4, 24, 4, 8, 1>(a, sh, stream) : launch_blk_inst<4, 24, 4, 8, 2>(a, sh, stream);
+        return sh.NL == 1 ? launch_blk_inst<4, 32, 4, 8, 1>(a, sh, stream) : launch_blk_inst<4, 32, 4, 8, 2>(a, sh, stream);
+    }
     if (sh.NL == 1) {                                              // one-neuron workgroups (layers of at most 128 neurons)
         if (sh.B == 4) return sh.S == 4 ? launch_blk_inst<1, 4, 4, 4, 1>(a, sh, stream) : launch_blk_inst<1, 8, 4, 8, 1>(a, sh, stream);
         if (sh.B == 2) return sh.S == 12 ? launch_blk_inst<1, 12, 2, 8, 1>(a, sh, stream) : launch_blk_inst<1, 16, 2, 8, 1>(a, sh, stream);
