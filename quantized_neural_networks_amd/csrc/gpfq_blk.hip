@@ -288,6 +288,28 @@ constexpr bool kNoFused = false;
 #define STAMP(var) do { } while (0)
 #endif
 
+// Sample-pair split over the sweep wavefronts: PairSplit for eight of them (the decision wavefront, wavefront 8, shares
+// SIMD 0 with wavefronts 0 and 4); with eleven the twelve wavefronts of a workgroup are three per SIMD.
+template <int S, int NSW> struct BlkSplit { static constexpr const int *pw = PairSplit<S>::pw; };
+template <> struct BlkSplit<4, 4>   { static constexpr int pw_[4] = {1, 1, 1, 1}; static constexpr const int *pw = pw_; };   // rows of up to 512 samples, four sweep wavefronts
+// (eleven sweep wavefronts: wavefronts w, w + 4, w + 8 share SIMD w, the decision wavefront is the third of SIMD 3, whose sweep
+//  wavefronts 3 and 7 therefore hold five pairs where the other SIMDs hold nine)
+template <> struct BlkSplit<32, 11> { static constexpr int pw_[11] = {3, 3, 3, 3, 3, 3, 3, 2, 3, 3, 3}; static constexpr const int *pw = pw_; };
+template <> struct BlkSplit<24, 11> { static constexpr int pw_[11] = {2, 2, 2, 2, 2, 2, 2, 1, 3, 3, 3}; static constexpr const int *pw = pw_; };
+
+template <> struct BlkSplit<64, 11> { static constexpr int pw_[11] = {6, 6, 6, 6, 6, 6, 6, 4, 6, 6, 6}; static constexpr const int *pw = pw_; };
+template <> struct BlkSplit<48, 11> { static constexpr int pw_[11] = {5, 4, 4, 4, 5, 4, 4, 4, 5, 5, 4}; static constexpr const int *pw = pw_; };
+template <> struct BlkSplit<16, 11> { static constexpr int pw_[11] = {2, 2, 1, 1, 2, 2, 1, 1, 1, 1, 2}; static constexpr const int *pw = pw_; };
+
+// (the four-group narrow shapes with FOUR sweep wavefronts of eight pairs were measured slower than with eight: 4096 x 512 on 1024 samples
+//  1.90 against 1.63 ms, 4096 x 1024 1.94 against 1.70 -- the sweeps are not negligible even there)
+template <int S, int NSW> constexpr bool blk_split_has(int k)
+{
+    for (int w = 0; w < NSW; ++w)
+        if (BlkSplit<S, NSW>::pw[w] == k) return true;
+    return false;
+}
+
 // ---- sweep wavefront -------------------------------------------------------------------------------
 template <int G, int PW, int MP, int B, int NSW, bool SYM, int NL>
 __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic, const BlkLds &L, int wave, int lane, int pbase)
@@ -381,7 +403,10 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     // D's; 400-900 cycles each with the LDS busiest right after the barrier -- profiles/r03/blk_phase_stamps.txt).
     // Phase D on the matrix unit (round 4; G = 4 neuron groups x B = 4 steps x NL = 4 neurons per lane, row t + B as float64), and with it
     // the two phases FUSED pair by pair (kFused): see the slot loop.
-    constexpr bool kMfmaD = G == 4 && B == 4 && blk_row64(G, B) && !kNoMfmaD;             // (NL = 4, 2 or 1 neurons per lane: 16, 8 or 4 per workgroup)
+    // (NL = 4, 2 or 1 neurons per lane: 16, 8 or 4 per workgroup.  Tried with TWO steps per slot -- rows of 1025..2048 samples, half of every
+    //  4 x 4 x 4 block idle -- for layers of at most 2048 neurons: bit-identical and slower than the one- / two-group shapes, 4096 x 1000 on
+    //  2048 samples 3.23 against 2.86 ms, 4096 x 512 3.04 against 2.19: profiles/r04/README.md)
+    constexpr bool kMfmaD = G == 4 && B == 4 && blk_row64(G, B) && !kNoMfmaD;
     constexpr bool kFused = kMfmaD && !kNoFused;
     constexpr bool kPreloadAll = PW * B <= 8 && PW <= 5 && !kFused;
     // ... where the registers allow it (u and the operands of a slot together): otherwise they are requested at the top of
@@ -1383,21 +1408,6 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 
 }  // namespace
 
-// Sample-pair split over the sweep wavefronts: PairSplit for eight of them (the decision wavefront, wavefront 8, shares
-// SIMD 0 with wavefronts 0 and 4); with eleven the twelve wavefronts of a workgroup are three per SIMD.
-template <int S, int NSW> struct BlkSplit { static constexpr const int *pw = PairSplit<S>::pw; };
-template <> struct BlkSplit<4, 4>   { static constexpr int pw_[4] = {1, 1, 1, 1}; static constexpr const int *pw = pw_; };   // rows of up to 512 samples, four sweep wavefronts
-// (the 16-neuron B = 4 shapes: more pairs for the OLDER wavefronts of a SIMD -- wavefronts w, w + 4, w + 8 share SIMD w, the decision
-//  wavefront is the third of SIMD 3.  A SIMD serves its oldest ready wavefront first, so with equal shares the wavefronts reach the
-//  barrier in the order of their age -- 4300 / 5500 / 6000 cycles after the top of the slot, profiles/r04/blk_phase_stamps.txt -- and the
-//  youngest runs the tail of the slot alone at a third of the issue rate; priorities by progress only narrow that.)
-template <> struct BlkSplit<32, 11> { static constexpr int pw_[11] = {3, 3, 3, 3, 3, 3, 3, 2, 3, 3, 3}; static constexpr const int *pw = pw_; };
-template <> struct BlkSplit<24, 11> { static constexpr int pw_[11] = {2, 2, 2, 2, 2, 2, 2, 1, 3, 3, 3}; static constexpr const int *pw = pw_; };
-
-template <> struct BlkSplit<64, 11> { static constexpr int pw_[11] = {6, 6, 6, 6, 6, 6, 6, 4, 6, 6, 6}; static constexpr const int *pw = pw_; };
-template <> struct BlkSplit<48, 11> { static constexpr int pw_[11] = {5, 4, 4, 4, 5, 4, 4, 4, 5, 5, 4}; static constexpr const int *pw = pw_; };
-template <> struct BlkSplit<16, 11> { static constexpr int pw_[11] = {2, 2, 1, 1, 2, 2, 1, 1, 1, 1, 2}; static constexpr const int *pw = pw_; };
-
 // G neuron groups per sweep wavefront (4G neurons per workgroup), S sample pairs per k-lane over the NSW sweep
 // wavefronts (rows of MP = (128 / G) * S samples), B steps per slot.
 // NL neurons per lane of a sweep wavefront: NL * G neurons per workgroup (4; 2 for layers of at most 512 neurons, which
@@ -1428,13 +1438,13 @@ gpfq_blk_kernel(BlkK K, AlphabetArg A)
         int pbase = 0, pw = 1;
 #pragma unroll
         for (int w = 0; w < NSW; ++w) { pbase += (w < wave) ? KQ * (int)K.pw[w] : 0; pw = (w == wave) ? (int)K.pw[w] : pw; }
-        constexpr int PMAX = S == 64 ? 6 : (S == 48 || S == 40 ? 5 : (NSW == 11 ? 3 : (S == 32 ? 5 : (S == 24 ? 4 : 3))));
-        if (pw == 1) blk_sweep_role<G, 1, MP, B, NSW, SYM, NL>(K, lds, L, wave, lane, pbase);
-        else if (pw == 2) blk_sweep_role<G, 2, MP, B, NSW, SYM, NL>(K, lds, L, wave, lane, pbase);
-        else if (pw == 3) blk_sweep_role<G, 3, MP, B, NSW, SYM, NL>(K, lds, L, wave, lane, pbase);
-        else if (pw == 4) { if constexpr (PMAX >= 4) blk_sweep_role<G, 4, MP, B, NSW, SYM, NL>(K, lds, L, wave, lane, pbase); }
-        else if (pw == 5) { if constexpr (PMAX >= 5) blk_sweep_role<G, 5, MP, B, NSW, SYM, NL>(K, lds, L, wave, lane, pbase); }
-        else { if constexpr (PMAX >= 6) blk_sweep_role<G, 6, MP, B, NSW, SYM, NL>(K, lds, L, wave, lane, pbase); }
+        // (one instantiation of the role per pair count that the shape's split holds)
+#define GPFQ_BLK_ROLE(PW_)                                                                                             \
+        if constexpr (blk_split_has<S, NSW>(PW_)) {                                                                    \
+            if (pw == PW_) blk_sweep_role<G, PW_, MP, B, NSW, SYM, NL>(K, lds, L, wave, lane, pbase);                   \
+        }
+        GPFQ_BLK_ROLE(1) GPFQ_BLK_ROLE(2) GPFQ_BLK_ROLE(3) GPFQ_BLK_ROLE(4) GPFQ_BLK_ROLE(5) GPFQ_BLK_ROLE(6)
+#undef GPFQ_BLK_ROLE
     } else {
         blk_decision_role<G, MP, B, NSW, SYM, NL>(K, lds, L, lane);
     }
@@ -1665,6 +1675,7 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     if (sh.G == 4 && sh.NL < 4) {
         if (sh.S == 16) return sh.NL == 1 ? launch_blk_inst<4, 16, 4, 8, 1>(a, sh, stream) : launch_blk_inst<4, 16, 4, 8, 2>(a, sh, stream);
         if (sh.S == 24) return sh.NL == 1 ? launch_blk_inst<4, 24, 4, 8, 1>(a, sh, stream) : launch_blk_inst<4, 24, 4, 8, 2>(a, sh, stream);
+        // (eleven sweep wavefronts buy these shapes nothing: 4096 x 512 on 1024 samples 1.77 against 1.62 ms, 4096 x 2048 1.94 / 1.95)
         return sh.NL == 1 ? launch_blk_inst<4, 32, 4, 8, 1>(a, sh, stream) : launch_blk_inst<4, 32, 4, 8, 2>(a, sh, stream);
     }
     if (sh.NL == 1) {                                              // one-neuron workgroups (layers of at most 128 neurons)
