@@ -847,6 +847,8 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         dma_wait();                                               // this wavefront's share of the next tile has landed
         STAMP(st4);
         slot_barrier();
+        // (tried: the sweeps of the narrow shapes sleeping 128 .. 512 cycles here, a head start for the decision wavefront's reads:
+        //  1.62 / 1.68 / 1.68 against 1.64 ms at 4096 x 512 -- nothing)
         STAMP(st5);
 #ifdef GPFQ_BLK_STAMPS
         acc_dma += st1 - st0; acc_u += st2 - st1; acc_d += st3 - st2; acc_w += st4 - st3; acc_b += st5 - st4;
@@ -1012,6 +1014,11 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 #pragma unroll
         for (int j = 0; j + 1 < B; ++j) ghi[j] = lds_ld<double2>(lds, j < smh ? rm + 64 + 32 * (smh - j - 1) : L.off_zero);
     };
+    // (Round 4, tried and dropped: the next slot's first reads -- the sweeps' partial sums, the block's weights -- requested BEFORE the
+    //  barrier whenever an LDS counter says that every sweep wavefront has finished its slot (in a narrow layer they wait ~2000 cycles
+    //  for this wavefront).  Bit-identical; the prologue stamp fell from 2046 to 1424 cycles, the kernel from 2.08 to 1.99 ms in the
+    //  stamped build and by nothing measurable in the shipped one (1.65 against 1.56-1.64 ms at 4096 x 512 on 1024 samples): what this
+    //  wavefront waits for is not the LDS but its own ~700 instructions per slot at one issue per 5-6 cycles.)
     slot_barrier();                                               // (tile 0 and the headers of tiles 0, 1 landed)
     prefetch_headers(0);
     int hnext = 1;                                                // (b + 1) % 3
