@@ -382,9 +382,13 @@ int gpfq_quantize_conv_channels_nhwc(const float *act_w, const float *act_q, int
  * (gpfq_conv_channel_records on the planes of those images), the records are summed over the GPUs (an all-reduce of
  * nch * (K*K*2 + K) doubles, K = kh*kw; the flags by maximum) and every GPU finishes from the summed records
  * (gpfq_quantize_conv_channels_from_records on the planes of ALL images, which the repair of uncertified chains
- * reads).  Certified decisions do not depend on the order in which the records were summed, so the results are
- * those of the one-call form -- up to the float32 rounding of a row norm whose float64 square sits within one part in
- * 10^16 of a rounding boundary (the norm is the rounded square root of a summed record entry).
+ * reads).  Certified decisions do not depend on the order in which the records were summed, and the one number whose
+ * last bit would -- the float32 row norm, a rounded square root of a sum of squares -- is not taken from the records
+ * for nch <= 15 (images of up to 2^19 pixels): both forms recompute it from act_q of ALL images in a summation order
+ * fixed by n, H, W and the kernel geometry, so the results are those of the one-call form bit for bit, whatever the
+ * number of GPUs up to 16 and however the images were split.  (Beyond 15 channels a layer shards by channel; if it is
+ * run in two halves nevertheless the norm is the rounded square root of the summed record entry, and a sum within one
+ * part in 10^16 of a float32 rounding boundary can round the other way than in the one-call form.)
  *   gpfq_conv_records_supported: 1 when BOTH halves have a plane kernel for this shape (the halves see different
  *   image counts: ask for each before committing all GPUs to this form), else 0.
  *   records [device] f64 [nch][K*K*2 + K], negflags [device] i32 [nch]; workspace as for

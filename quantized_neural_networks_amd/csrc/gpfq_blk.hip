@@ -72,7 +72,10 @@ __host__ __device__ constexpr int blk_hdr_bytes(int B) { return (64 + (2 * B - 1
 __host__ __device__ constexpr bool blk_row64(int G, int B) { return B > 1 && G > 1; }
 // (Tried in round 3: 128 bytes of skew between the rows of a record, so that the X and Xq rows of an update do not sit a multiple
 //  of 4 KiB apart.  SQ_LDS_BANK_CONFLICT did not move -- 3.2e8 against 3.4e8 cycles per launch: a 128-byte span of a row covers all
-//  32 banks, two rows per ds_read2st64_b64 are two passes wherever they lie -- and neither did the time.)
+//  32 banks, two rows per ds_read2st64_b64 are two passes wherever they lie -- and neither did the time.
+//  Round 4: the matrix form reads the float64 rows of FOUR records in one ds_read_b128 (lane = neuron group + 4 k): with records a
+//  multiple of 128 bytes apart (mod 256) groups 0 / 2 and 1 / 3 meet on the same banks.  Headers 64 bytes longer make those reads
+//  conflict-free -- measured: 3.08 against 3.01-3.02 ms on the same box, no gain; the LDS pipeline is not what a slot waits for.)
 __host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B, int G) { return blk_hdr_bytes(B) + (blk_row64(G, B) ? 16 : 12) * mp; }
 
 // ---- pre-pass ---------------------------------------------------------------------------------

@@ -723,6 +723,149 @@ hipError_t launch_gram_reduce(const double *part, int64_t nparts, int N, double 
 
 size_t gram_fix_bytes() { return al256(sizeof(FixState)); }
 
+// Row norms of the patch rows of a few channel images, summed in an order that depends on the layer's dimensions alone.
+// The norm of a patch row is the float32 rounding of sqrt(sum of squares) (:80), and the float64 sum of squares is the one number
+// of a Gram record whose LAST BIT matters to a decision: a record summed in another order (other kernel, other image shards --
+// gpfq_conv_channel_records on each rank's images + an all-reduce) can land the square root on the other side of a float32 rounding
+// boundary (~1e-9 of the rows).  Layers of at most kCanonNormMaxChannels channels -- the ones that are sharded by IMAGES when there are
+// fewer channels than ranks -- therefore take their norms from here, in the one-call form and in the from-records form alike:
+//   pass 1: per pixel and channel the squares of all images, sequentially in image order, in `segs` fixed image ranges;
+//   pass 2: per patch row the pixel sums of its tap lattice, 256 strided walkers + a fixed tree.
+// Every rank holds all the activations (the repair pass reads them), so there is nothing to exchange.  Scratch: FixState::part
+// (idle until the decide pass has listed its chains).
+constexpr int64_t kCanonScratch = (int64_t)kFixMax * kFixBlocks * 2;      // doubles
+
+__global__ void __launch_bounds__(256)
+gpfq_canon_squares_kernel(FixSrc src, int64_t ch0, int cb, int segs, int per, double *__restrict__ part)
+{
+    const int64_t HW = (int64_t)src.H * src.W;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= HW * cb) return;
+    // channel planes: consecutive lanes walk x; NHWC: consecutive lanes walk the channels of a pixel
+    const int64_t c = src.pix > 1 ? e % cb : e / HW;
+    const int64_t r = src.pix > 1 ? e / cb : e - c * HW;
+    const int seg = blockIdx.y;
+    const int b0 = seg * per, b1 = b0 + per < src.n ? b0 + per : src.n;
+    const float *x = src.Xq + (ch0 + c) * src.plane + r * src.pix;
+    const int64_t img = HW * src.pix;
+    double acc = 0.0;
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(x + (int64_t)(b + k) * img);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += (double)v[k] * (double)v[k];
+    }
+    for (; b < b1; ++b) {
+        const float v = __builtin_nontemporal_load(x + (int64_t)b * img);
+        acc += (double)v * (double)v;
+    }
+    part[((int64_t)seg * cb + c) * HW + r] = acc;
+}
+
+typedef float cv4f __attribute__((ext_vector_type(4)));
+// The same sums (same order per element: image after image) where an image's elements of the pass are one contiguous, 16-byte aligned
+// run -- a channel plane, or all the channels of an NHWC tensor: a workgroup walks 4 KiB of the run, a lane four consecutive elements
+// (the element-per-lane form above reads 1 KiB per workgroup and image, every one on another page: 1.9 TB/s on conv1's 2.6 GB).
+__global__ void __launch_bounds__(256)
+gpfq_canon_squares_v4_kernel(FixSrc src, int64_t ch0, int cb, int per, int64_t runlen, double *__restrict__ part)
+{
+    const int64_t HW = (int64_t)src.H * src.W;
+    const int64_t e4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e4 >= runlen) return;
+    const int run = blockIdx.z, seg = blockIdx.y;
+    const int b0 = seg * per, b1 = b0 + per < src.n ? b0 + per : src.n;
+    const float *x = src.Xq + (src.pix > 1 ? 0 : (ch0 + run) * src.plane) + e4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+        cv4f v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const cv4f *>(x + (int64_t)(b + k) * runlen));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            acc[0] += (double)v[k].x * (double)v[k].x; acc[1] += (double)v[k].y * (double)v[k].y;
+            acc[2] += (double)v[k].z * (double)v[k].z; acc[3] += (double)v[k].w * (double)v[k].w;
+        }
+    }
+    for (; b < b1; ++b) {
+        const cv4f v = __builtin_nontemporal_load(reinterpret_cast<const cv4f *>(x + (int64_t)b * runlen));
+        acc[0] += (double)v.x * (double)v.x; acc[1] += (double)v.y * (double)v.y;
+        acc[2] += (double)v.z * (double)v.z; acc[3] += (double)v.w * (double)v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t e = e4 + k;
+        const int64_t c = src.pix > 1 ? e % cb : run, r = src.pix > 1 ? e / cb : e;
+        part[((int64_t)seg * cb + c) * HW + r] = acc[k];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+gpfq_canon_rows_kernel(FixSrc src, int N, int64_t ch0, int cb, int segs, const double *__restrict__ part, float *__restrict__ nrm32,
+                       int64_t nrm_cs)
+{
+    __shared__ double sm[4];
+    const int t = blockIdx.x, c = blockIdx.y;
+    const int ky = t / src.kw, kx = t - ky * src.kw;
+    const int64_t HW = (int64_t)src.H * src.W;
+    const int npos = src.oh * src.ow;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < npos; i += 256) {
+        const int oy = i / src.ow, ox = i - oy * src.ow;
+        const int iy = oy * src.sh + ky * src.rh - src.pt, ix = ox * src.sw + kx * src.rw - src.pl;
+        if (iy < 0 || iy >= src.H || ix < 0 || ix >= src.W) continue;
+        const double *p = part + (int64_t)c * HW + (int64_t)iy * src.W + ix;
+        double v = p[0];
+        for (int s = 1; s < segs; ++s) v += p[(int64_t)s * cb * HW];
+        acc += v;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) nrm32[(ch0 + c) * nrm_cs + t] = (float)sqrt((sm[0] + sm[1]) + (sm[2] + sm[3]));
+}
+
+bool canonical_norms_apply(const FixSrc &src, int64_t nch)
+{
+    return src.planes && src.m > 0 && nch >= 1 && nch <= kCanonNormMaxChannels && (int64_t)src.H * src.W <= kCanonScratch;
+}
+
+hipError_t launch_canonical_norms(const FixSrc &src, int N, int64_t nch, float *nrm32, int64_t nrm_cs, void *fix_ws, hipStream_t stream)
+{
+    if (!fix_ws || !canonical_norms_apply(src, nch) || N < 1) return hipSuccess;
+    double *part = &static_cast<FixState *>(fix_ws)->part[0][0][0];
+    const int64_t HW = (int64_t)src.H * src.W;
+    int64_t cb = kCanonScratch / HW;                       // channels per pass
+    if (cb > nch) cb = nch;
+    int64_t segs = kCanonScratch / (cb * HW);              // image ranges: enough walkers for small images, >= 16 images each
+    if (segs > 64) segs = 64;
+    if (segs > src.n / 16) segs = src.n / 16;
+    if (segs < 1) segs = 1;
+    const int per = (int)((src.n + segs - 1) / segs);
+    segs = (src.n + per - 1) / per;
+    for (int64_t ch0 = 0; ch0 < nch; ch0 += cb) {
+        const int c = (int)(nch - ch0 < cb ? nch - ch0 : cb);
+        // one contiguous run of elements per image: a channel plane, or the whole NHWC tensor when the pass takes all its channels
+        const int64_t runlen = src.pix > 1 ? HW * src.pix : HW;
+        const bool nhwc_all = src.pix > 1 && src.plane == 1 && ch0 == 0 && c == src.pix;
+        bool v4 = (src.pix == 1 || nhwc_all) && runlen % 4 == 0 && ((uintptr_t)src.Xq & 15) == 0 && (src.pix > 1 || src.plane % 4 == 0);
+#ifdef GPFQ_CANON_GENERIC
+        v4 = false;
+#endif
+        if (v4)
+            hipLaunchKernelGGL(gpfq_canon_squares_v4_kernel, dim3((unsigned)((runlen / 4 + 255) / 256), (unsigned)segs, src.pix > 1 ? 1u : (unsigned)c),
+                               dim3(256), 0, stream, src, ch0, c, per, runlen, part);
+        else
+            hipLaunchKernelGGL(gpfq_canon_squares_kernel, dim3((unsigned)((HW * c + 255) / 256), (unsigned)segs), dim3(256), 0, stream,
+                               src, ch0, c, (int)segs, per, part);
+        hipLaunchKernelGGL(gpfq_canon_rows_kernel, dim3((unsigned)N, (unsigned)c), dim3(256), 0, stream,
+                           src, N, ch0, c, (int)segs, part, nrm32, nrm_cs);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_gram_decide(const double *gram, const float *nrm32, const float *Wt, int64_t ldw, const AlphabetArg &A,
                               int N, int64_t C, double slack, int8_t *qidx, float *Qt, int32_t *uncertified,
                               float *q32_hist, const DecideBatch &bs, const FixSrc *src, void *fix_ws, const int *negflag,

@@ -503,6 +503,8 @@ hipError_t launch_gram_conv(const ConvGramArgs &a, hipStream_t stream)
     src.X = a.act_w; src.Xq = a.act_q; src.ld = 0; src.m = m; src.planes = 1; src.plane = a.pix > 1 ? 1 : p.plane; src.pix = a.pix > 1 ? a.pix : 1;
     src.n = (int)a.n; src.H = p.H; src.W = p.W; src.oh = p.oh; src.ow = p.ow;
     src.kw = a.kw; src.sh = a.sh; src.sw = a.sw; src.rh = a.rh; src.rw = a.rw; src.pt = a.pt; src.pl = a.pl;
+    e = launch_canonical_norms(src, (int)K, a.nch, nrm, K, fixws, stream);      // few channels: norms in an order fixed by the dimensions
+    if (e != hipSuccess) return e;
     return launch_gram_decide(gram, nrm, a.Wt, K, a.A, (int)K, a.F, a.slack, a.qidx, a.Qt, a.uncertified, q32h, bs, &src, fixws, negflag,
                               stream, a.big);
 }

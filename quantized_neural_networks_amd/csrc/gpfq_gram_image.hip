@@ -839,6 +839,8 @@ hipError_t launch_gram_image(const ImageGramArgs &a, hipStream_t stream)
     src.n = p.n; src.H = p.H; src.W = p.W; src.oh = p.oh; src.ow = p.SPR * S;
     src.kw = 3; src.sh = src.sw = src.rh = src.rw = 1; src.pt = src.pl = p.pad;
     src.m = (int64_t)p.grows * src.ow;
+    e = launch_canonical_norms(src, 9, a.nch, nrm, 9, fixws, stream);           // few channels: norms in an order fixed by the dimensions
+    if (e != hipSuccess) return e;
     return launch_gram_decide(gram, nrm, a.Wt, 9, a.A, 9, a.F, a.slack, a.qidx, a.Qt, a.uncertified, q32h, bs, &src, fixws, negflag,
                               stream, a.big);
 }
@@ -956,6 +958,8 @@ hipError_t launch_gram_image_nhwc(const ImageGramArgs &a, hipStream_t stream)
     src.n = p.n; src.H = p.H; src.W = p.W; src.oh = p.H; src.ow = p.W;
     src.kw = 3; src.sh = src.sw = src.rh = src.rw = 1; src.pt = src.pl = 1;
     src.m = (int64_t)a.n * a.H * a.W;
+    e = launch_canonical_norms(src, 9, a.nch, nrm, 9, fixws, stream);           // few channels: norms in an order fixed by the dimensions
+    if (e != hipSuccess) return e;
     return launch_gram_decide(gram, nrm, a.Wt, 9, a.A, 9, a.F, a.slack, a.qidx, a.Qt, a.uncertified, q32h, bs, &src, fixws, negflag,
                               stream, a.big);
 }

@@ -152,6 +152,12 @@ struct FixSrc {
     int kw, sh, sw, rh, rw, pt, pl;
 };
 size_t gram_fix_bytes();
+// Row norms of the patch rows of layers with few channel images, in a summation order fixed by the layer's dimensions (so that
+// image-sharded records + all-reduce and the one-call form decide from the same norms); overwrites nrm32[ch * nrm_cs + t].
+// No-op unless canonical_norms_apply(); fix_ws as for launch_gram_decide (used before it).
+constexpr int kCanonNormMaxChannels = 15;
+bool canonical_norms_apply(const FixSrc &src, int64_t nch);
+hipError_t launch_canonical_norms(const FixSrc &src, int N, int64_t nch, float *nrm32, int64_t nrm_cs, void *fix_ws, hipStream_t stream);
 // decide pass + (src != NULL) two rounds of device-side repair of the chains it could not certify;
 // fix_ws: gram_fix_bytes() of scratch.  Chains still flagged afterwards are the caller's to rerun.
 hipError_t launch_gram_decide(const double *gram, const float *nrm32, const float *Wt, int64_t ldw, const AlphabetArg &A,

@@ -678,6 +678,65 @@ def test_conv7x7_stride2_shift_sums(oracle_mod, n, H, W, Cin, F, kind):
         assert torch.equal(Qs, out["Q"].permute(2, 3, 0, 1).reshape(Cin, F, 49)[c_lo:c_hi])
 
 
+@pytest.mark.parametrize("geom", [
+    dict(k=7, stride=2, padding="VALID", n=24, H=41, W=37, Cin=3, F=6),      # ResNet50's conv1 in small (shift-sum records)
+    dict(k=3, stride=1, padding="SAME", n=40, H=12, W=12, Cin=2, F=9),       # fused 3x3 records
+    dict(k=3, stride=1, padding="VALID", n=33, H=14, W=10, Cin=15, F=4),     # the most channels that take the fixed-order norms
+    dict(k=5, stride=1, padding="VALID", n=19, H=20, W=20, Cin=3, F=5),      # generic plane kernel
+    dict(k=3, stride=2, padding="SAME", n=21, H=15, W=17, Cin=1, F=7),       # one channel, padded taps on two sides only
+])
+def test_records_form_decides_from_norms_of_a_fixed_summation_order(geom):
+    """Fewer channels than ranks: the records are summed over image shards in whatever order the all-reduce takes, and the float32
+    rounding of a row norm sqrt(sum of squares) (:80) would follow the LAST bit of that sum.  Layers of at most 15 channels therefore
+    take their norms from a pass over the activations whose order is fixed by the layer's dimensions, in the one-call form and in the
+    from-records form alike (launch_canonical_norms): the result may not depend on how the records were summed -- here three
+    unequal image shards summed in two orders, and records whose squared-norm entries are off by 2^-6 (which moves hundreds of
+    decisions where the norm IS taken from the record: the 16-channel control at the end)."""
+    from quantized_neural_networks_amd import hip, layer
+    k, st, padding, n, H, W, Cin, F = (geom[x] for x in ("k", "stride", "padding", "n", "H", "W", "Cin", "F"))
+    K = k * k
+
+    def run(Cin):
+        r = np.random.default_rng(K + n + Cin)
+        act_w = r.random((n, H, W, Cin)).astype(np.float32)
+        act_q = np.maximum(act_w + 0.05 * r.standard_normal(act_w.shape), 0).astype(np.float32)
+        Wd = torch.from_numpy((r.standard_normal((k, k, Cin, F)) / k).astype(np.float32)).cuda()
+        alphabet, _ = layer.layer_alphabet(Wd, np.linspace(-1, 1, 8), 4)
+        aw, aq = torch.from_numpy(act_w).cuda(), torch.from_numpy(act_q).cuda()
+        if not hip.conv_records_supported(n, H, W, Cin, (k, k), (st, st), (1, 1), padding):
+            pytest.skip("no plane kernel for this geometry")
+        out = layer.quantize_conv2d(Wd, aw, aq, alphabet, strides=(st, st), padding=padding, rate=(1, 1), want_resid=False)
+        want = out["Q"].permute(2, 3, 0, 1).reshape(Cin, F, K)
+        recs, negs = [], []
+        for lo, hi in ((0, 5), (5, n - 4), (n - 4, n)):
+            pw_, pq_ = hip.channel_planes(aw[lo:hi].contiguous(), 0, Cin), hip.channel_planes(aq[lo:hi].contiguous(), 0, Cin)
+            rec_, neg_ = hip.conv_channel_records(pw_, pq_, (k, k), (st, st), (1, 1), padding)
+            recs.append(rec_); negs.append(neg_)
+        neg = torch.maximum(torch.maximum(negs[0], negs[1]), negs[2])
+        off = (recs[0] + recs[1]) + recs[2]
+        t = torch.arange(K, device="cuda")
+        off[:, (t * K + t) * 2 + 1] *= 1.0 + 2.0 ** -6                 # <Xq_t, Xq_t>: the entry the norms used to be taken from
+        Wt_all = Wd.permute(2, 3, 0, 1).reshape(Cin, F, K).contiguous()
+        got = []
+        for rec in ((recs[0] + recs[1]) + recs[2], (recs[2] + recs[1]) + recs[0], off):
+            idx = torch.empty((Cin, F, K), dtype=hip.index_dtype(len(alphabet)), device="cuda")
+            Qs = torch.empty((Cin, F, K), dtype=torch.float32, device="cuda")
+            unc = torch.zeros((Cin, F), dtype=torch.int32, device="cuda")
+            hip.conv_channels_from_records(rec, neg, hip.channel_planes(aw, 0, Cin), hip.channel_planes(aq, 0, Cin), Wt_all,
+                                           alphabet, (k, k), (st, st), (1, 1), padding, idx, Qs, unc)
+            assert int(unc.sum()) == 0
+            got.append(Qs)
+        return want, got
+
+    want, got = run(Cin)
+    for Qs in got:
+        assert torch.equal(Qs, want)
+    if geom["Cin"] == 15:
+        want, got = run(16)                                            # control: beyond the limit the record's entry is the norm
+        assert torch.equal(got[0], want) and torch.equal(got[1], want)
+        assert int((got[2] != want).sum()) > 0
+
+
 @pytest.mark.parametrize("stride,bits", [(1, 2), (2, np.log2(3)), (1, 4)])
 def test_conv1x1_shortcut_equals_general_path(oracle_mod, stride, bits):
     """1x1 kernels take the MSQ shortcut; it must give what the general per-channel path gives,
