@@ -115,6 +115,9 @@ def main():
     kname = [""]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     ev_ag = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]   # N > 1: the all-gather
+    # the recurrence kernel alone: events the C library records immediately around that launch (gpfq_set_main_kernel_events);
+    # `ev` brackets the whole gpfq_quantize_neurons call, i.e. the record pre-pass (~50 us) as well
+    ev_k = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     st = {"C_total": C_total, "Wd": Wd}      # the layer being stepped (the weak-scaling companion swaps in its own)
 
@@ -130,10 +133,12 @@ def main():
         alphabet, _ = layer.layer_alphabet(Wd, unit_alphabet, args.alphabet_scalar, group, alphabet_free_work)   # N > 1: counting sharded over ranks
         Wt, nrm = pre["Wt"], pre["nrm"]
         if i_timed is not None:
+            hip.set_main_kernel_events(*ev_k[i_timed])
             ev[i_timed][0].record()          # same stream the kernel is launched on (torch current stream)
         r = hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm, want_values=False)
         if i_timed is not None:
             ev[i_timed][1].record()
+            hip.set_main_kernel_events(None, None)
         kname[0] = hip.last_dense_kernel()
         # one all-gather of the indices (packed to 2 bits per weight for the ternary alphabet when N > 1),
         # then values + transpose to the Keras layout in one pass
@@ -167,8 +172,10 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    call_ms = [a.elapsed_time(b) for a, b in ev]
     kernel_name = kname[0]
+    # (only the block-pipelined family records the inner events; any other kernel is timed by the events around the call)
+    kernel_ms = [a.elapsed_time(b) for a, b in ev_k] if kernel_name.startswith("gpfq_blk_kernel") else call_ms
     # N > 1: what the collective saw -- backend, the world size of the group the all-gather ran on, the all-gather's own
     # duration (HIP events around it on its stream; it waits for the slowest rank's kernel, so rank 0's figure includes the
     # skew) and every rank's kernel time, gathered over the same group
@@ -244,6 +251,7 @@ def main():
                 "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS,
                 "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
                 "kernel_ms_avg": k_avg_s * 1e3, "kernel_ms_min": float(np.min(kernel_ms)),
+                "call_ms_avg": float(np.mean(call_ms)),     # the whole gpfq_quantize_neurons call: record pre-pass + this kernel
                 "algorithmic_flops_per_launch": alg_flops,
                 "frac_of_measured_issue_rate": achieved_tf / FP64_MEASURED_ISSUE_TFLOPS,
                 "measured_issue_rate_tflops": FP64_MEASURED_ISSUE_TFLOPS,
@@ -256,7 +264,8 @@ def main():
                                    "no committed rocprofv3 --pmc pass for this kernel and shape (profiles/traffic.json)"),
                 "note": "skinny dot products with the residual on chip: the binding resource is FP64-rate vector issue "
                         "(per weight and sample one f64 fma, one f32->f64 convert, one f64 add, three f32 ops on two samples each -- two for the symmetric ternary alphabet), not HBM; "
-                        "flops per launch = 6 m N C_local (SURVEY 8d); duration = HIP events around the launch on its stream",
+                        "flops per launch = 6 m N C_local (SURVEY 8d); duration = HIP events recorded by the library immediately around this "
+                        "kernel's launch on its stream (gpfq_set_main_kernel_events; call_ms_avg also holds the record pre-pass)",
             },
         }
         if collective is not None:

@@ -100,6 +100,13 @@ size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path);
  * the first call); diagnostics for benchmarks and tests. */
 const char *gpfq_last_dense_kernel(void);
 
+/* Measurement hook: two hipEvent_t of the caller (NULL, NULL to clear; per calling thread), recorded on the launch stream
+ * immediately before and after the launch of a dense layer's MAIN kernel -- the recurrence, without the pre-passes
+ * that share the gpfq_quantize_neurons call -- so that a benchmark times exactly the kernel its roofline statement
+ * names (bench.py).  Only the block-pipelined kernel family (gpfq_blk_kernel) records them; with any other family
+ * the events are left as they were.  Results never depend on it. */
+int gpfq_set_main_kernel_events(void *start_event, void *stop_event);
+
 /*
  * Process-wide tuning/test hooks; results never depend on them, only which kernel family runs.  Each option is one atomic
  * integer: a call running on another thread sees the old or the new value of each, never a torn one -- the calls stay

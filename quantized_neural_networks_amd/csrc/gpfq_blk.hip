@@ -1650,7 +1650,10 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
         const int *pw = BlkSplit<S, NSW>::pw;
         for (int w = 0; w < 12; ++w) K.pw[w] = (unsigned char)(w < NSW ? pw[w] : 0);
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NSW + 1)), (size_t)L.total, stream, K, a.A);
+    {
+        MainKernelEvents ev(stream);       // (a benchmark's events around this launch alone, when it asked for them)
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NSW + 1)), (size_t)L.total, stream, K, a.A);
+    }
     return hipGetLastError();
 }
 

@@ -19,6 +19,7 @@ namespace {
 
 thread_local char g_err[512] = "";
 thread_local const char *g_dense_kernel = "";
+thread_local hipEvent_t g_main_ev[2] = {nullptr, nullptr};
 
 int fail(int code, const char *fmt, ...)
 {
@@ -74,6 +75,8 @@ int make_alphabet(const double *alphabet, int M, int zero_idx, HostAlphabet *H)
 
 namespace gpfq {
 void note_dense_kernel(const char *name) { g_dense_kernel = name; }
+MainKernelEvents::MainKernelEvents(hipStream_t s) : stream(s) { if (g_main_ev[0]) (void)hipEventRecord(g_main_ev[0], stream); }
+MainKernelEvents::~MainKernelEvents() { if (g_main_ev[1]) (void)hipEventRecord(g_main_ev[1], stream); }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): it is raised when a launch needs more than
 // any launch before it on that device, not once per launch.
@@ -98,6 +101,13 @@ extern "C" {
 int gpfq_version(void) { return 302; }
 
 const char *gpfq_last_dense_kernel(void) { return g_dense_kernel; }
+
+int gpfq_set_main_kernel_events(void *start, void *stop)
+{
+    g_main_ev[0] = static_cast<hipEvent_t>(start);
+    g_main_ev[1] = static_cast<hipEvent_t>(stop);
+    return GPFQ_OK;
+}
 
 const char *gpfq_last_error(void) { return g_err; }
 

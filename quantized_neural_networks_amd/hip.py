@@ -29,6 +29,7 @@ SYMBOLS = {
     "gpfq_row_norms": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "gpfq_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
     "gpfq_last_dense_kernel": (ctypes.c_char_p, []),
+    "gpfq_set_main_kernel_events": (_int, [_vp, _vp]),
     "gpfq_set_option": (_int, [ctypes.c_char_p, _int]),
     "gpfq_quantize_neurons": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _int, _int, _i64, _i64, _i64,
                                      _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp]),
@@ -545,6 +546,20 @@ def conv_channels_from_records(records, negflags, act_w_cm, act_q_cm, Wt_all, al
 def last_dense_kernel():
     """Name of the dense kernel family the last quantize_neurons() call dispatched (diagnostics)."""
     return load().gpfq_last_dense_kernel().decode()
+
+
+def set_main_kernel_events(start=None, stop=None):
+    """Measurement hook (gpfq_set_main_kernel_events): two torch.cuda.Event(enable_timing=True) that the block-pipelined dense
+    kernel records around its own launch -- the recurrence without the pre-passes of the same quantize_neurons() call.  None, None
+    clears.  torch creates an event's handle at its first record(): the events are recorded once here so that the handle exists."""
+    if start is None or stop is None:
+        _check(load().gpfq_set_main_kernel_events(None, None), "gpfq_set_main_kernel_events")
+        return
+    for e in (start, stop):
+        if not e.cuda_event:
+            e.record()
+    _check(load().gpfq_set_main_kernel_events(ctypes.c_void_p(start.cuda_event), ctypes.c_void_p(stop.cuda_event)),
+           "gpfq_set_main_kernel_events")
 
 
 def exact_fallbacks(result):
