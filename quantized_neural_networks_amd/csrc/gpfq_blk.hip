@@ -47,6 +47,7 @@
 #include <cstring>
 #include <type_traits>
 
+#include <cstdlib>
 #include "gpfq_device.hpp"
 #include "gpfq_launch.hpp"
 #include "gpfq_roles.hpp"
@@ -306,10 +307,33 @@ template <> struct BlkSplit<16, 11> { static constexpr int pw_[11] = {2, 2, 1, 1
 
 // (the four-group narrow shapes with FOUR sweep wavefronts of eight pairs were measured slower than with eight: 4096 x 512 on 1024 samples
 //  1.90 against 1.63 ms, 4096 x 1024 1.94 against 1.70 -- the sweeps are not negligible even there)
-template <int S, int NSW> constexpr bool blk_split_has(int k)
+// The four-group narrow shapes on rows of 769..1024 samples (G = 4, one or two neurons per lane, eight sweep wavefronts): their slot is the
+// chain of decisions, and every pair on the two sweep wavefronts that share the decision wavefront's SIMD lengthens it -- 4096 x 512 on
+// 1024 samples, splits from the environment (tools/split_sweep.sh, a diagnostic build): 4,4,4,4,4,4,4,4 1.72 ms; 3,4,4,5,3,4,4,5 1.61;
+// PairSplit<32> = 2,4,4,4,3,5,5,5 1.56; 2,5,5,4,2,5,5,4 **1.42**; 1,5,5,5,1,5,5,5 1.43-1.45.  (Leaving that SIMD to the decision
+// wavefront ALONE -- twelve wavefronts launched, the two SIMD mates ending at once, nine sweep wavefronts of 3-4 pairs on the other
+// three SIMDs -- was slower than the default: 1.75 against 1.63 ms, and 1.80 against 1.42 on 768-sample rows.  The shorter rows'
+// splits and the one- / two-group shapes' are at their optimum: equal splits are 5-15 % slower everywhere.)
+struct BlkSplitQuad32 { static constexpr int pw[8] = {2, 5, 5, 4, 2, 5, 5, 4}; };
+// (four neurons per workgroup on rows of 1537..2048 samples, two steps per slot -- cfg3's predictions layer, 4096 x 1000 on 2048 samples:
+//  1,2,2,3,2,2,2,2 2.70-2.75 ms against PairSplit<16>'s 2.81-2.87; the other splits tried there were slower than either)
+struct BlkSplitFour16 { static constexpr int pw[8] = {1, 2, 2, 3, 2, 2, 2, 2}; };
+template <int G, int S, int NSW, int NL> constexpr const int *blk_split()
 {
+    if constexpr (G == 4 && NL < 4 && S == 32 && NSW == 8) return BlkSplitQuad32::pw;
+    else if constexpr (G == 1 && NL == 4 && S == 16 && NSW == 8) return BlkSplitFour16::pw;
+    else return BlkSplit<S, NSW>::pw;
+}
+
+template <int G, int S, int NSW, int NL> constexpr bool blk_split_has(int k)
+{
+#ifdef GPFQ_BLK_SPLIT_ENV
+    // diagnostic build: the split of the 8-wavefront shapes comes from the environment (GPFQ_BLK_SPLIT="2,2,2,2,2,2,2,2"), every pair
+    // count up to one more than an even split is instantiated
+    if (NSW == 8 && k <= (S + NSW - 1) / NSW + 1) return true;
+#endif
     for (int w = 0; w < NSW; ++w)
-        if (BlkSplit<S, NSW>::pw[w] == k) return true;
+        if (blk_split<G, S, NSW, NL>()[w] == k) return true;
     return false;
 }
 
@@ -1450,7 +1474,7 @@ gpfq_blk_kernel(BlkK K, AlphabetArg A)
         for (int w = 0; w < NSW; ++w) { pbase += (w < wave) ? KQ * (int)K.pw[w] : 0; pw = (w == wave) ? (int)K.pw[w] : pw; }
         // (one instantiation of the role per pair count that the shape's split holds)
 #define GPFQ_BLK_ROLE(PW_)                                                                                             \
-        if constexpr (blk_split_has<S, NSW>(PW_)) {                                                                    \
+        if constexpr (blk_split_has<G, S, NSW, NL>(PW_)) {                                                                    \
             if (pw == PW_) blk_sweep_role<G, PW_, MP, B, NSW, SYM, NL>(K, lds, L, wave, lane, pbase);                   \
         }
         GPFQ_BLK_ROLE(1) GPFQ_BLK_ROLE(2) GPFQ_BLK_ROLE(3) GPFQ_BLK_ROLE(4) GPFQ_BLK_ROLE(5) GPFQ_BLK_ROLE(6)
@@ -1647,8 +1671,18 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
     K.sym_a = SYM ? blk_sym_a(a) : 0.f; K.Xq = a.Xq; K.ldx = a.ld;
     if (!blk_uniform(a.A, &K.uni_a0, &K.uni_step, &K.uni_inv, &K.uni_c0, &K.uni_plus, &K.uni_minus)) return hipErrorInvalidValue;
     {
-        const int *pw = BlkSplit<S, NSW>::pw;
+        const int *pw = blk_split<G, S, NSW, NL>();
         for (int w = 0; w < 12; ++w) K.pw[w] = (unsigned char)(w < NSW ? pw[w] : 0);
+#ifdef GPFQ_BLK_SPLIT_ENV
+        if (const char *env = NSW == 8 ? getenv("GPFQ_BLK_SPLIT") : nullptr) {
+            int v[8], n = 0, sum = 0;
+            for (const char *c = env; *c && n < 8; ++c)
+                if (*c >= '0' && *c <= '9') { v[n] = *c - '0'; sum += v[n]; ++n; }
+            bool ok = n == 8 && sum == S;
+            for (int w = 0; ok && w < 8; ++w) ok = v[w] >= 1 && v[w] <= (S + NSW - 1) / NSW + 1;
+            if (ok) for (int w = 0; w < 8; ++w) K.pw[w] = (unsigned char)v[w];
+        }
+#endif
     }
     {
         MainKernelEvents ev(stream);       // (a benchmark's events around this launch alone, when it asked for them)

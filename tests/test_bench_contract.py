@@ -32,11 +32,47 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert 0 < roof["frac"] <= 1.0 and roof["unit"] in ("TFLOP/s", "GB/s") and roof["kernel"]
     assert roof["kernel_ms_avg"] > 0 and roof["algorithmic_flops_per_launch"] == 6.0 * 512 * 256 * 512
     assert roof["compulsory_bytes_per_launch"] == (2 * 256 * 512 + 2 * 256 * 512) * 4 and "hbm_equiv" in roof
+    # the kernel's own events (recorded by the library around its launch) lie inside the events around the whole call
+    assert 0 < roof["kernel_ms_min"] <= roof["kernel_ms_avg"] <= roof["call_ms_avg"]
     cpu = out["cpu_baseline"]
     for key in ["value", "unit", "cores", "kind", "sample"]:
         assert key in cpu, key
     assert cpu["kind"] in ("port", "reference") and cpu["value"] > 0
     assert out["parity_sample"]["neurons_with_index_mismatch"] == 0
+
+
+@pytest.mark.gpu
+def test_main_kernel_events_bracket_the_recurrence_kernel_alone():
+    """gpfq_set_main_kernel_events: the block-pipelined kernel records the caller's two events around its own launch -- inside the
+    events around the gpfq_quantize_neurons call, which also holds the record pre-pass; cleared, nothing is recorded; a kernel
+    family that does not take part leaves them alone."""
+    import numpy as np
+    import torch
+    from quantized_neural_networks_amd import hip
+    r = np.random.default_rng(5)
+    N, m, C = 512, 1024, 1024
+    X = torch.from_numpy(r.random((N, m)).astype(np.float32)).cuda()
+    Wt = torch.from_numpy(r.standard_normal((C, N)).astype(np.float32)).cuda()
+    alphabet = np.array([-0.7, 0.0, 0.7])
+    mk = lambda: torch.cuda.Event(enable_timing=True)
+    hip.quantize_neurons(X, X, Wt, alphabet, want_values=False)                      # warm
+    assert hip.last_dense_kernel().startswith("gpfq_blk_kernel")
+    a, b, k0, k1 = mk(), mk(), mk(), mk()
+    hip.set_main_kernel_events(k0, k1)
+    try:
+        a.record()
+        ref = hip.quantize_neurons(X, X, Wt, alphabet, want_values=False)
+        b.record()
+    finally:
+        hip.set_main_kernel_events(None, None)
+    torch.cuda.synchronize()
+    inner, outer = k0.elapsed_time(k1), a.elapsed_time(b)
+    assert 0 < inner < outer
+    assert a.elapsed_time(k0) > 0 and k1.elapsed_time(b) >= 0                        # a < k0 < k1 <= b on the stream
+    # cleared: a further call records nothing into the old events, and results never depend on the hook
+    again = hip.quantize_neurons(X, X, Wt, alphabet, want_values=False)
+    torch.cuda.synchronize()
+    assert k0.elapsed_time(k1) == inner and torch.equal(ref["idx"], again["idx"])
 
 
 @pytest.mark.gpu
