@@ -1674,13 +1674,14 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
         const int *pw = blk_split<G, S, NSW, NL>();
         for (int w = 0; w < 12; ++w) K.pw[w] = (unsigned char)(w < NSW ? pw[w] : 0);
 #ifdef GPFQ_BLK_SPLIT_ENV
-        if (const char *env = NSW == 8 ? getenv("GPFQ_BLK_SPLIT") : nullptr) {
-            int v[8], n = 0, sum = 0;
-            for (const char *c = env; *c && n < 8; ++c)
+        // (eleven sweep wavefronts: permutations of the shape's own pair counts only -- GPFQ_BLK_SPLIT11)
+        if (const char *env = NSW == 8 ? getenv("GPFQ_BLK_SPLIT") : (NSW == 11 ? getenv("GPFQ_BLK_SPLIT11") : nullptr)) {
+            int v[12], n = 0, sum = 0;
+            for (const char *c = env; *c && n < NSW; ++c)
                 if (*c >= '0' && *c <= '9') { v[n] = *c - '0'; sum += v[n]; ++n; }
-            bool ok = n == 8 && sum == S;
-            for (int w = 0; ok && w < 8; ++w) ok = v[w] >= 1 && v[w] <= (S + NSW - 1) / NSW + 1;
-            if (ok) for (int w = 0; w < 8; ++w) K.pw[w] = (unsigned char)v[w];
+            bool ok = n == NSW && sum == S;
+            for (int w = 0; ok && w < NSW; ++w) ok = v[w] >= 1 && blk_split_has<G, S, NSW, NL>(v[w]);
+            if (ok) for (int w = 0; w < NSW; ++w) K.pw[w] = (unsigned char)v[w];
         }
 #endif
     }

@@ -1,14 +1,14 @@
-# usage (GPU box): bash tools/split_sweep.sh  -- pair splits of the 8-wavefront shapes from the environment (diagnostic build -DGPFQ_BLK_SPLIT_ENV)
+# usage (GPU box): bash tools/split_sweep.sh  -- pair splits from the environment (diagnostic build -DGPFQ_BLK_SPLIT_ENV):
+# GPFQ_BLK_SPLIT for the 8-wavefront shapes (any counts up to one more than an even split), GPFQ_BLK_SPLIT11 for the 11-wavefront
+# shapes (permutations of the shape's own counts)
 export GPFQ_DIAG="-DGPFQ_BLK_SPLIT_ENV"
 G='pipe mode|rror'
-run() { # shape splits...
-  sh="$1"; shift
+run() { # var shape splits...
+  var="$1"; sh="$2"; shift; shift
   echo "== $sh"
   for sp in "$@"; do
-    if [ "$sp" = "-" ]; then unset GPFQ_BLK_SPLIT; else export GPFQ_BLK_SPLIT="$sp"; fi
+    if [ "$sp" = "-" ]; then unset $var; else export $var="$sp"; fi
     echo -n "  split ${sp}: "; PIPE_MODES=2 PIPE_VARIANTS=0 PIPE_SWEEPS=0 timeout 600 python tools/pipe_probe.py $sh 2>&1 | grep -E "$G" | sed -e 's/.*\]: //' | cut -c1-40
   done
 }
-run "4096 1000 2048 4 5 8" - 12232222 12231223 13221322 12321232 12232222 11331133
-run "4096 1024 1536 4 5 8" - 11221122 12211221 21122112
-run "4096 2048 2048 4 5 8" - 25542554 15551555
+run GPFQ_BLK_SPLIT11 "4096 4096 1024 1.585 3 0" - 23333333333 32333333333 33233333333 33323333333 33332333333 33333233333 33333323333 33333332333 33333333233 33333333323 33333333332 -
