@@ -730,7 +730,7 @@ size_t gram_fix_bytes() { return al256(sizeof(FixState)); }
 // boundary (~1e-9 of the rows).  Layers of at most kCanonNormMaxChannels channels -- the ones that are sharded by IMAGES when there are
 // fewer channels than ranks -- therefore take their norms from here, in the one-call form and in the from-records form alike:
 //   pass 1: per pixel and channel the squares of all images, sequentially in image order, in `segs` fixed image ranges;
-//   pass 2: per patch row the pixel sums of its tap lattice, 256 strided walkers + a fixed tree.
+//   pass 2: the ranges of a pixel added in range order; per patch row the pixel sums of its tap lattice, 256 strided walkers + a fixed tree.
 // Every rank holds all the activations (the repair pass reads them), so there is nothing to exchange.  Scratch: FixState::part
 // (idle until the decide pass has listed its chains).
 constexpr int64_t kCanonScratch = (int64_t)kFixMax * kFixBlocks * 2;      // doubles
@@ -802,24 +802,37 @@ gpfq_canon_squares_v4_kernel(FixSrc src, int64_t ch0, int cb, int per, int64_t r
     }
 }
 
+// The image ranges of an element, added in range order (in place, into range 0).
 __global__ void __launch_bounds__(256)
-gpfq_canon_rows_kernel(FixSrc src, int N, int64_t ch0, int cb, int segs, const double *__restrict__ part, float *__restrict__ nrm32,
-                       int64_t nrm_cs)
+gpfq_canon_collapse_kernel(int64_t count, int segs, double *__restrict__ part)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    double v = part[e];
+    for (int s = 1; s < segs; ++s) v += part[(int64_t)s * count + e];
+    part[e] = v;
+}
+
+__global__ void __launch_bounds__(256)
+gpfq_canon_rows_kernel(FixSrc src, int N, int64_t ch0, const double *__restrict__ sq, float *__restrict__ nrm32, int64_t nrm_cs)
 {
     __shared__ double sm[4];
     const int t = blockIdx.x, c = blockIdx.y;
     const int ky = t / src.kw, kx = t - ky * src.kw;
-    const int64_t HW = (int64_t)src.H * src.W;
     const int npos = src.oh * src.ow;
+    const double *p = sq + (int64_t)c * src.H * src.W;
     double acc = 0.0;
-    for (int i = threadIdx.x; i < npos; i += 256) {
+    // (taps outside the image add a literal zero: the load is clamped and unconditional, so that four of them are in flight)
+    auto tap = [&](int i) -> double {
         const int oy = i / src.ow, ox = i - oy * src.ow;
         const int iy = oy * src.sh + ky * src.rh - src.pt, ix = ox * src.sw + kx * src.rw - src.pl;
-        if (iy < 0 || iy >= src.H || ix < 0 || ix >= src.W) continue;
-        const double *p = part + (int64_t)c * HW + (int64_t)iy * src.W + ix;
-        double v = p[0];
-        for (int s = 1; s < segs; ++s) v += p[(int64_t)s * cb * HW];
-        acc += v;
+        const bool in = i < npos && iy >= 0 && iy < src.H && ix >= 0 && ix < src.W;
+        const double v = p[in ? iy * src.W + ix : 0];
+        return in ? v : 0.0;
+    };
+    for (int i = threadIdx.x; i < npos; i += 1024) {
+        const double v0 = tap(i), v1 = tap(i + 256), v2 = tap(i + 512), v3 = tap(i + 768);
+        acc += v0; acc += v1; acc += v2; acc += v3;
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
@@ -860,8 +873,9 @@ hipError_t launch_canonical_norms(const FixSrc &src, int N, int64_t nch, float *
         else
             hipLaunchKernelGGL(gpfq_canon_squares_kernel, dim3((unsigned)((HW * c + 255) / 256), (unsigned)segs), dim3(256), 0, stream,
                                src, ch0, c, (int)segs, per, part);
-        hipLaunchKernelGGL(gpfq_canon_rows_kernel, dim3((unsigned)N, (unsigned)c), dim3(256), 0, stream,
-                           src, N, ch0, c, (int)segs, part, nrm32, nrm_cs);
+        if (segs > 1)
+            hipLaunchKernelGGL(gpfq_canon_collapse_kernel, dim3((unsigned)((HW * c + 255) / 256)), dim3(256), 0, stream, HW * c, (int)segs, part);
+        hipLaunchKernelGGL(gpfq_canon_rows_kernel, dim3((unsigned)N, (unsigned)c), dim3(256), 0, stream, src, N, ch0, part, nrm32, nrm_cs);
     }
     return hipGetLastError();
 }
