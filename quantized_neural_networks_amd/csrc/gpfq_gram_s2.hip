@@ -275,6 +275,28 @@ struct S2Combine {
     int64_t part_per_channel;                                       // doubles
 };
 
+// First stage of the combine: a launch region's workgroup blocks ([4 classes][kS2Slots][16 roles][kS2Acc] doubles each, ~1300 per
+// channel at 4096 images) added in chunks of kS2Chunk, in place into the chunk's first block.  The second stage reads ONE double per
+// block and entry, 69 KB apart -- over all blocks that was 88 MB per channel fetched a sector at a time (0.37 ms of conv1's 12.7);
+// here the blocks are read once, whole lines at a time.
+constexpr int kS2Chunk = 32;
+constexpr int kS2Block = 4 * kS2Slots * 16 * kS2Acc;
+__global__ void __launch_bounds__(256)
+gpfq_gram_s2_chunks_kernel(double *__restrict__ part, S2Combine c)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kS2Block) return;
+    const int64_t ch = blockIdx.z;
+    int l = 0, j = blockIdx.y;                                      // chunk j of launch l
+    while (l < c.nlaunch && j >= (c.L[l].nwg + kS2Chunk - 1) / kS2Chunk) { j -= (c.L[l].nwg + kS2Chunk - 1) / kS2Chunk; ++l; }
+    if (l >= c.nlaunch) return;
+    const int g0 = j * kS2Chunk, g1 = g0 + kS2Chunk < c.L[l].nwg ? g0 + kS2Chunk : c.L[l].nwg;
+    double *p = part + ch * c.part_per_channel + c.L[l].off + i;
+    double v = p[(int64_t)g0 * kS2Block];
+    for (int g = g0 + 1; g < g1; ++g) v += p[(int64_t)g * kS2Block];
+    p[(int64_t)g0 * kS2Block] = v;
+}
+
 // Regions -> the K = 49 Gram record of a channel (layout of gpfq_gram.hip: [t][s][G1, G2] lower triangle, then the squared X-row norms)
 // + the float32 row norms.  Entry (t, s): every region in which row t qualifies, in launch / slot / workgroup order.
 __global__ void __launch_bounds__(256)
@@ -310,7 +332,7 @@ gpfq_gram_s2_combine_kernel(const double *__restrict__ part, S2Combine c, double
                     if (!(col >= axt && col < axt + c.ow)) continue;
                 }
                 double w = 0.0;
-                for (int g = lane; g < L.nwg; g += 64)
+                for (int g = lane * kS2Chunk; g < L.nwg; g += 64 * kS2Chunk)        // (the chunk sums: gpfq_gram_s2_chunks_kernel)
                     w += pc[L.off + ((((int64_t)g * 4 + ptc) * kS2Slots + sl) * 16 + role) * kS2Acc + acc];
                 v += wave_sum(w);
             }
@@ -428,6 +450,9 @@ hipError_t launch_gram_s2(const float *act_w, const float *act_q, int64_t n, int
     else hipLaunchKernelGGL(gpfq_gram_s2_kernel<false>, dim3((unsigned)maxwg, (unsigned)P.nlaunch, (unsigned)nch), dim3(kS2Threads), P.lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    int nchunks = 0;
+    for (int l = 0; l < P.nlaunch; ++l) nchunks += (P.nwg[l] + kS2Chunk - 1) / kS2Chunk;
+    hipLaunchKernelGGL(gpfq_gram_s2_chunks_kernel, dim3((unsigned)((kS2Block + 255) / 256), (unsigned)nchunks, (unsigned)nch), dim3(256), 0, stream, part, c);
     const int64_t rec = gram_record(kS2K * kS2K);
     hipLaunchKernelGGL(gpfq_gram_s2_combine_kernel, dim3((unsigned)((rec + 3) / 4), (unsigned)nch), dim3(256), 0, stream, part, c, gram, nrm32);
     return hipGetLastError();
