@@ -284,7 +284,7 @@ __device__ __forceinline__ int decide_chain(const double *__restrict__ gram, con
 // pass over the data forms the exact dot products of the step that stopped each chain, the chain resumes.
 constexpr int kFixMax = 1024;      // chains repaired per round (more stay flagged for the caller)
 constexpr int kFixBlocks = 256;    // column walkers per listed chain
-constexpr int kFixSlots = 64;      // listed chains in flight per launch (the kernels loop over the list)
+constexpr int kFixSlots = 8;       // listed chains in flight per launch (the kernels loop over the list; a launch that finds no list costs its empty workgroups: 64 x 256 of them were 7 us, twice per conv layer)
 constexpr int kFixRounds = 2;      // short walks (conv channels): flags are rare
 constexpr int kFixRoundsLong = 12; // long walks: the bound grows with t, a chain may stop several times
 struct FixState {
@@ -940,7 +940,7 @@ hipError_t launch_gram_decide(const double *gram, const float *nrm32, const floa
         hipLaunchKernelGGL(gpfq_gram_fix_kernel, dim3(kFixBlocks, kFixSlots), dim3(256), 0, stream,
                            *src, Wt, ldw, N, C, uncertified, q32_hist, bs, fix, round);
         if (wave_chain)
-            GPFQ_WAVE_CHAIN(gpfq_gram_resume_wave_kernel, dim3(kFixSlots * 4), dim3(64),
+            GPFQ_WAVE_CHAIN(gpfq_gram_resume_wave_kernel, dim3(256), dim3(64),
                             gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, fix, round, negflag);
         else if (big)
             hipLaunchKernelGGL((gpfq_gram_resume_kernel<AlphabetBig, int16_t>), dim3(kFixMax / 64), dim3(64), 0, stream,
