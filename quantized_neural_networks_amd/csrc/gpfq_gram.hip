@@ -493,12 +493,12 @@ __device__ __forceinline__ void fix_fetch(const FixSrc &src, int64_t ch, int s, 
     }
     const int ky = s / src.kw, kx = s - ky * src.kw;
     const int iy = oy * src.sh + ky * src.rh - src.pt, ix = ox * src.sw + kx * src.rw - src.pl;
-    x = 0.f; xq = 0.f;
-    if (iy >= 0 && iy < src.H && ix >= 0 && ix < src.W) {
-        const int64_t o = ch * src.plane + ((b * src.H + iy) * src.W + ix) * src.pix;
-        x = src.X[o];
-        xq = src.Xq[o];
-    }
+    const bool in = iy >= 0 && iy < src.H && ix >= 0 && ix < src.W;
+    // (unconditional loads, so that several can be in flight: an out-of-image tap reads pixel (0, 0) of its image instead)
+    const int64_t o = ch * src.plane + ((b * src.H + (in ? iy : 0)) * src.W + (in ? ix : 0)) * src.pix;
+    const float vx = src.X[o], vq = src.Xq[o];
+    x = in ? vx : 0.f;
+    xq = in ? vq : 0.f;
 }
 
 // Exact dot products of the stopped step of every listed chain: per column the residual is rebuilt with
@@ -528,7 +528,18 @@ gpfq_gram_fix_kernel(FixSrc src, const float *__restrict__ Wt, int64_t ldw, int 
         }
         double u = 0.0;
         float x, xq;
-        for (int s = 0; s < t0; ++s) {
+        // (four steps' operands requested before the first is used: the taps of an NHWC tensor are 4-byte reads a pixel apart, and a
+        //  chain of t0 dependent round trips per column was the whole cost of a repair round -- 75 us for ONE listed chain of a
+        //  512-channel 7x7 layer; out-of-image taps read the image's first pixel and are replaced by the literal zero afterwards)
+        int s = 0;
+        for (; s + 4 <= t0; s += 4) {
+            float xs[4], qs[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fix_fetch(src, ch, s + k, i, b, oy, ox, xs[k], qs[k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u += (double)__fsub_rn(__fmul_rn(w[s + k], xs[k]), __fmul_rn(qh[s + k], qs[k]));
+        }
+        for (; s < t0; ++s) {
             fix_fetch(src, ch, s, i, b, oy, ox, x, xq);
             u += (double)__fsub_rn(__fmul_rn(w[s], x), __fmul_rn(qh[s], xq));
         }
