@@ -27,6 +27,7 @@
 #include "gpfq_device.hpp"
 #include "gpfq_gram_tile.hpp"
 #include "gpfq_launch.hpp"
+#include "gpfq_roles.hpp"
 
 namespace gpfq {
 
@@ -200,11 +201,14 @@ gpfq_gram_reduce_few_kernel(const double *__restrict__ part, int nparts, int N, 
 // element-wise dot products dot_u = <Xq_t0, u>, dot_uw = <Xq_t0, u + w X_t0> (:86-89), later steps are
 // certified as usual.
 // Alph / Idx: AlphabetArg with int8 indices, or AlphabetBig (65..256 members) with int16 indices.
-template <class Alph, class Idx>
+// SUB > 1: SUB adjacent lanes run the chain of ONE neuron together -- the O(t) sums of a step are split over them (lane `sub` takes
+// s = sub, sub + SUB, ...) and added by DPP, identical bits in all of them; everything else is replicated, the outputs leave through
+// sub-lane 0 (the recorded values qh are written by every sub-lane, so that each reads back its own stores).
+template <class Alph, class Idx, int SUB = 1>
 __device__ __forceinline__ int decide_chain(const double *__restrict__ gram, const float *__restrict__ nrm32,
                                             const float *__restrict__ w, float *__restrict__ qh, const Alph &A, int N,
                                             double slack, Idx *__restrict__ qidx, float *__restrict__ Qt,
-                                            int t0, double dot_u, double dot_uw, bool nonneg)
+                                            int t0, double dot_u, double dot_uw, bool nonneg, int sub = 0)
 {
     const double *nx2 = gram + (int64_t)N * N * 2;
     const double c = 0x1p-22 * slack;                   // slack = 1 in production; tests shrink margins with it
@@ -239,11 +243,12 @@ __device__ __forceinline__ int decide_chain(const double *__restrict__ gram, con
             }
         } else if (!((double)nrm < 1e-16)) {                                           // not rule (i)
             double acc = 0.0, B = 0.0;
-            for (int s = 0; s < t; ++s) {
+            for (int s = sub; s < t; s += SUB) {
                 const double *g = gram + ((int64_t)t * N + s) * 2;
                 acc += (double)w[s] * g[0] - (double)qh[s] * g[1];
                 B += fabs((double)w[s]) * g[0] + fabs((double)qh[s]) * g[1];
             }
+            if constexpr (SUB > 1) { acc = sub_sum<SUB>(acc); B = sub_sum<SUB>(B); }
             B = nonneg ? B * upg : nq * R;
             const double a_tt = nonneg ? gram[((int64_t)t * N + t) * 2] * upg : nq * nx;     // <|Xq_t|, |X_t|>
             const double err0 = c * B + 0x1p-128 * nq;          // second term: products rounded in the subnormal range
@@ -274,8 +279,8 @@ __device__ __forceinline__ int decide_chain(const double *__restrict__ gram, con
         }
         R += fabs((double)w[t]) * nx + fabs((double)q32) * nq;
         qh[t] = q32;
-        if (qidx) qidx[t] = (Idx)idx;
-        if (Qt) Qt[t] = q32;
+        if (qidx && sub == 0) qidx[t] = (Idx)idx;
+        if (Qt && sub == 0) Qt[t] = q32;
     }
     return 0;
 }
@@ -309,6 +314,33 @@ gpfq_gram_decide_kernel(const double *__restrict__ gram, const float *__restrict
                                q32_hist + ch * bs.hist_cs + j * N, A, N, slack,
                                qidx ? qidx + ch * bs.out_cs + j * N : nullptr, Qt ? Qt + ch * bs.out_cs + j * N : nullptr,
                                -1, 0.0, 0.0, negflag && negflag[ch] == 0);
+    uncertified[ch * bs.unc_cs + j] = r;
+    if (r && fix) {
+        const int k = atomicAdd(&fix->count[0], 1);
+        if (k < kFixMax) fix->list[0][k] = (int32_t)(ch * C + j);
+    }
+}
+
+// Walks of 16..64 steps (5x5, 7x7 kernels): eight lanes per neuron.  conv1 of ResNet50 has 3 x 64 chains of 49 steps -- three
+// wavefronts with one thread per neuron, 0.26 ms of a latency chain.
+constexpr int kDecideSub = 8;
+template <class Alph, class Idx>
+__global__ void __launch_bounds__(64)
+gpfq_gram_decide_sub_kernel(const double *__restrict__ gram, const float *__restrict__ nrm32,
+                            const float *__restrict__ Wt, int64_t ldw, Alph A, int N, int64_t C,
+                            double slack, Idx *__restrict__ qidx, float *__restrict__ Qt,
+                            int32_t *__restrict__ uncertified, float *__restrict__ q32_hist, DecideBatch bs,
+                            FixState *__restrict__ fix, const int *__restrict__ negflag)
+{
+    const int64_t j = (int64_t)blockIdx.x * (64 / kDecideSub) + threadIdx.x / kDecideSub;
+    const int sub = threadIdx.x % kDecideSub;
+    if (j >= C) return;                                            // (whole groups of kDecideSub lanes leave together)
+    const int64_t ch = blockIdx.y;
+    const int r = decide_chain<Alph, Idx, kDecideSub>(gram + ch * bs.gram_cs, nrm32 + ch * bs.nrm_cs, Wt + ch * bs.w_cs + j * ldw,
+                               q32_hist + ch * bs.hist_cs + j * N, A, N, slack,
+                               qidx ? qidx + ch * bs.out_cs + j * N : nullptr, Qt ? Qt + ch * bs.out_cs + j * N : nullptr,
+                               -1, 0.0, 0.0, negflag && negflag[ch] == 0, sub);
+    if (sub) return;
     uncertified[ch * bs.unc_cs + j] = r;
     if (r && fix) {
         const int k = atomicAdd(&fix->count[0], 1);
@@ -943,6 +975,9 @@ hipError_t launch_gram_decide(const double *gram, const float *nrm32, const floa
         hipLaunchKernelGGL((gpfq_gram_decide_kernel<AlphabetBig, int16_t>), dim3((unsigned)((C + 63) / 64), (unsigned)bs.nch), dim3(64), 0,
                            stream, gram, nrm32, Wt, ldw, *big, N, C, slack, reinterpret_cast<int16_t *>(qidx), Qt, uncertified, q32_hist,
                            bs, fix, negflag);
+    else if (N >= 16)
+        hipLaunchKernelGGL((gpfq_gram_decide_sub_kernel<AlphabetArg, int8_t>), dim3((unsigned)((C + 64 / kDecideSub - 1) / (64 / kDecideSub)), (unsigned)bs.nch),
+                           dim3(64), 0, stream, gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, bs, fix, negflag);
     else
         hipLaunchKernelGGL((gpfq_gram_decide_kernel<AlphabetArg, int8_t>), dim3((unsigned)((C + 63) / 64), (unsigned)bs.nch), dim3(64), 0,
                            stream, gram, nrm32, Wt, ldw, A, N, C, slack, qidx, Qt, uncertified, q32_hist, bs, fix, negflag);

@@ -1,6 +1,7 @@
 # usage (GPU box): bash tools/split_sweep.sh  -- pair splits from the environment (diagnostic build -DGPFQ_BLK_SPLIT_ENV):
 # GPFQ_BLK_SPLIT for the 8-wavefront shapes (any counts up to one more than an even split), GPFQ_BLK_SPLIT11 for the 11-wavefront
-# shapes (permutations of the shape's own counts)
+# shapes (counts from two below the shape's largest up to it).  Edit the run lines for the shape at hand; the sweeps of round 4 are
+# recorded in profiles/r04/README.md and in gpfq_blk.hip next to the tables they produced.
 export GPFQ_DIAG="-DGPFQ_BLK_SPLIT_ENV"
 G='pipe mode|rror'
 run() { # var shape splits...
@@ -11,4 +12,9 @@ run() { # var shape splits...
     echo -n "  split ${sp}: "; PIPE_MODES=2 PIPE_VARIANTS=0 PIPE_SWEEPS=0 timeout 600 python tools/pipe_probe.py $sh 2>&1 | grep -E "$G" | sed -e 's/.*\]: //' | cut -c1-40
   done
 }
-run GPFQ_BLK_SPLIT11 "4096 4096 1024 1.585 3 0" - 23333333333 32333333333 33233333333 33323333333 33332333333 33333233333 33333323333 33333332333 33333333233 33333333323 33333333332 -
+run GPFQ_BLK_SPLIT11 "4096 4096 2048 4 5 0" - 46666666666 66666666655 66656665666 66566656665 65666566656 -
+run GPFQ_BLK_SPLIT11 "4096 4096 4096 3 4 0" - 46666666666 66666666655 66656665666 -
+run GPFQ_BLK_SPLIT11 "4096 4096 1536 4 5 0" 45445445445 55445444445 45454544454 55535553444 44544454445
+run GPFQ_BLK_SPLIT11 "4096 4096 3000 3 4 0" 45445445445 55445444445 44544454445
+run GPFQ_BLK_SPLIT11 "4096 4096 768 1.585 3 0" - 22232223222 22322232222 23222322222 33313331222
+run GPFQ_BLK_SPLIT11 "4096 4096 512 1.585 3 0" - 
