@@ -127,9 +127,9 @@ int gpfq_set_main_kernel_events(void *start_event, void *stop_event);
  *   "blk_sweep_waves"   0 (default: by shape -- eleven for rows of 769..1024 samples, eight for shorter rows), 8 or 11: sweep
  *                  wavefronts per workgroup of the block form's 16-neuron four-step shapes (with the decision wavefront two or
  *                  three wavefronts per SIMD; same bits: DESIGN.md)
- *   "blk_quad_groups"   1 (default): layers of 129..2048 neurons on rows of 257..1024 samples take four neuron groups per sweep
+ *   "blk_quad_groups"   2 (default): layers of at most 2048 neurons on rows of 257..1024 samples take four neuron groups per sweep
  *                  wavefront with one or two neurons per lane (4 / 8 neurons per workgroup, dot products on the matrix unit);
- *                  2: layers of at most 128 neurons too; 0: the one- / two-group shapes of round 3
+ *                  1: only layers of 129..2048 neurons; 0: the one- / two-group shapes of round 3
  *   "blk_four_groups"   1 (default): layers of at most 1024 neurons on rows of 769..2048 samples take 4 neurons per workgroup; 0: 8
  *   "blk_wide_groups"   1 (default): rows of 1025..2048 samples in layers of more than 2048 neurons take 16 neurons per workgroup
  *                  (eleven sweep wavefronts, one round of workgroups); 0: 8 neurons per workgroup as narrower layers do

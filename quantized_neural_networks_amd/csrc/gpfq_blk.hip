@@ -1507,7 +1507,7 @@ void blk_set_sweep_waves(int nw) { g_blk_nw.store(nw == 11 ? 11 : (nw == 8 ? 8 :
 // C: neurons of the call.  Rows of 769..1024 samples are the one shape whose slot is bound by the sweeps (nine sample pairs
 // on three of the SIMDs), not by the chain of decisions: up to 2048 neurons -- one round of 256 workgroups with 8 neurons
 // each -- the sweeps are halved by giving a workgroup 8 neurons instead of 16 (4096 x 2048, m = 1024: 4.0 -> 2.9 ms).
-static std::atomic<int> g_blk_quad{1};    // four neuron groups x 1 / 2 neurons per lane for layers of 129..2048 neurons on rows of 257..1024 samples
+static std::atomic<int> g_blk_quad{2};    // four neuron groups x 1 / 2 neurons per lane for layers of at most 2048 neurons on rows of 257..1024 samples (1: 129..2048 only)
 void blk_set_quad_groups(int on) { g_blk_quad.store(on < 0 ? 0 : (on > 2 ? 2 : on), std::memory_order_relaxed); }
 static std::atomic<int> g_blk_pairs{1};   // two-neuron workgroups for layers of at most 512 neurons
 void blk_set_pair_groups(int on) { g_blk_pairs.store(on ? 1 : 0, std::memory_order_relaxed); }
@@ -1529,8 +1529,10 @@ static BlkShape blk_shape(int64_t m, int64_t C)
     // step's partial dot products over all 64 lanes (six dependent stages per row); here the matrix instruction leaves two row
     // rotations per slot, and the short rows no longer put 16 neurons on a workgroup (a layer of 1024 neurons filled 64 CUs):
     // 4096 x 512 on 1024 samples 1.74 -> 1.56 ms, x 1024 2.10 -> 1.65, x 2048 2.44 -> 1.97; 4096 x 1024 on 768 samples 2.69 -> 1.48,
-    // on 512 samples 1.96 -> 1.38 (profiles/r04/latency_shapes.txt).  At most 128 neurons: the one-neuron shapes stay (1.57 both ways).
-    const int quad = g_blk_quad.load(std::memory_order_relaxed);         // 1 (default): 129..2048 neurons; 2: every layer of at most 2048; 0: off
+    // on 512 samples 1.96 -> 1.38 (profiles/r04/latency_shapes.txt).  At most 128 neurons: 1.57 both ways at first; with the pair split of
+    // BlkSplitQuad32 the four-group form is ahead there too (4096 x 128 on 1024 samples 1.58 -> 1.40 ms, on 768 1.62 -> 1.39, on 512 1.37 ->
+    // 1.33; 4096 x 10 1.62 -> 1.50; cfg1's Dense(784 -> 128) 0.279 -> 0.271) and is the default for every layer of at most 2048 neurons.
+    const int quad = g_blk_quad.load(std::memory_order_relaxed);         // 2 (default): every layer of at most 2048 neurons; 1: 129..2048 only; 0: off
     if (quad && C <= 2048 && (quad >= 2 || C > 128) && m > 256 && m <= 1024) {
         const int nl = C > 1024 ? 2 : 1;
         if (m <= 512) return {4, 16, 4, 512, 8, nl};

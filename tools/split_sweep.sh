@@ -12,9 +12,7 @@ run() { # var shape splits...
     echo -n "  split ${sp}: "; PIPE_MODES=2 PIPE_VARIANTS=0 PIPE_SWEEPS=0 timeout 600 python tools/pipe_probe.py $sh 2>&1 | grep -E "$G" | sed -e 's/.*\]: //' | cut -c1-40
   done
 }
-run GPFQ_BLK_SPLIT11 "4096 4096 2048 4 5 0" - 46666666666 66666666655 66656665666 66566656665 65666566656 -
-run GPFQ_BLK_SPLIT11 "4096 4096 4096 3 4 0" - 46666666666 66666666655 66656665666 -
-run GPFQ_BLK_SPLIT11 "4096 4096 1536 4 5 0" 45445445445 55445444445 45454544454 55535553444 44544454445
-run GPFQ_BLK_SPLIT11 "4096 4096 3000 3 4 0" 45445445445 55445444445 44544454445
-run GPFQ_BLK_SPLIT11 "4096 4096 768 1.585 3 0" - 22232223222 22322232222 23222322222 33313331222
-run GPFQ_BLK_SPLIT11 "4096 4096 512 1.585 3 0" - 
+run GPFQ_BLK_SPLIT "4096 4096 768 1.585 3 0" - 24332433 14431443 23342334 13441344 24422442 -
+run GPFQ_BLK_SPLIT "4096 4096 512 1.585 3 0" - 13221322 12321232 22222222 12231223 -
+run GPFQ_BLK_SPLIT "4096 2048 1536 4 5 0" - 24332433 14431443 13441344
+run GPFQ_BLK_SPLIT "4096 4096 1536 4 5 0" -
