@@ -1171,7 +1171,20 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             const double u_a0 = K.uni_a0, u_step = K.uni_step, u_inv = K.uni_inv, u_c0 = K.uni_c0, u_kmax = (double)(M - 1);
             const unsigned long long u_plus = K.uni_plus, u_minus = K.uni_minus;
             const int u_zero = K.zero_idx;
+            const float sym_a32 = (float)sym_top;
             auto pick = [&](double tt, double &kd) -> float {     // nearest member of the uniform alphabet, by arithmetic
+#ifndef GPFQ_BLK_NO_SYMPICK
+                if constexpr (SYM && NB <= 8) {
+                    // {-a, 0, a} / {-a, a}, exactly symmetric (blk_sym_a): two comparisons with the boundaries -a/2, a/2 (or 0) instead of
+                    // the progression's arithmetic -- ~10 instructions fewer per decision on the wavefront whose chain is the floor of the
+                    // narrow shapes (4096 x 512 on 1024 samples 1.416 -> 1.38-1.39 ms, same box).  Not in the 16-neuron shapes, whose
+                    // slot is the sweeps': there the same change measured 2.5 % SLOWER (3.04-3.10 against 2.98-3.01 ms).
+                    // (A tie goes to the lower index as argmin does; a decision that close is never certified anyway.)
+                    const bool up = tt > sym_hb, mid = tt > -sym_hb;
+                    kd = up ? u_kmax : (mid ? 1.0 : 0.0);
+                    return up ? sym_a32 : (mid ? 0.f : -sym_a32);
+                }
+#endif
                 kd = fmin(fmax(rint(fma(tt, u_inv, u_c0)), 0.0), u_kmax);
                 const int ki = (int)kd;
                 const int adj = (int)((unsigned)(u_plus >> ki) & 1u) - (int)((unsigned)(u_minus >> ki) & 1u);
