@@ -906,10 +906,7 @@ hipError_t launch_canonical_norms(const FixSrc &src, int N, int64_t nch, float *
         // one contiguous run of elements per image: a channel plane, or the whole NHWC tensor when the pass takes all its channels
         const int64_t runlen = src.pix > 1 ? HW * src.pix : HW;
         const bool nhwc_all = src.pix > 1 && src.plane == 1 && ch0 == 0 && c == src.pix;
-        bool v4 = (src.pix == 1 || nhwc_all) && runlen % 4 == 0 && ((uintptr_t)src.Xq & 15) == 0 && (src.pix > 1 || src.plane % 4 == 0);
-#ifdef GPFQ_CANON_GENERIC
-        v4 = false;
-#endif
+        const bool v4 = (src.pix == 1 || nhwc_all) && runlen % 4 == 0 && ((uintptr_t)src.Xq & 15) == 0 && (src.pix > 1 || src.plane % 4 == 0);
         if (v4)
             hipLaunchKernelGGL(gpfq_canon_squares_v4_kernel, dim3((unsigned)((runlen / 4 + 255) / 256), (unsigned)segs, src.pix > 1 ? 1u : (unsigned)c),
                                dim3(256), 0, stream, src, ch0, c, per, runlen, part);
