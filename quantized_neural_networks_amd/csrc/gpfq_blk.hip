@@ -1180,6 +1180,9 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                     // narrow shapes (4096 x 512 on 1024 samples 1.416 -> 1.38-1.39 ms, same box).  Not in the 16-neuron shapes, whose
                     // slot is the sweeps': there the same change measured 2.5 % SLOWER (3.04-3.10 against 2.98-3.01 ms).
                     // (A tie goes to the lower index as argmin does; a decision that close is never certified anyway.)
+                    // (Tried on top and dropped: the chain restated for these alphabets -- broadcasts, the weight-only decision of rule
+                    //  (ii) and rule (i) formed before the chain, quotient as one fma, q selected as float64 without the conversion:
+                    //  bit-identical and SLOWER, 1.65 against 1.42 ms; what hipcc makes of the straightforward form is the better chain.)
                     const bool up = tt > sym_hb, mid = tt > -sym_hb;
                     kd = up ? u_kmax : (mid ? 1.0 : 0.0);
                     return up ? sym_a32 : (mid ? 0.f : -sym_a32);
