@@ -192,6 +192,32 @@ def test_cfg5_resnet50_conv1_full_size(hip, oracle_mod):
     assert hip.patch_out_dim(230, 7, 2, 1, False) == 112
     _conv_properties(layer, W, act_w, act_q, alphabet, out, 3, kw)
     _conv_slack_ab(hip, layer, W, act_w, act_q, alphabet, out, kw)
+    # fewer channels than GPUs (3 < 8): the records over eight unequal image shards, summed in rank order and in reverse -- what an
+    # all-reduce may do --, then every rank's second half.  The row norms come from a fixed-order pass over the activations
+    # (launch_canonical_norms), so the whole tensor equals the one-call result whatever the order
+    bounds = [0, 500, 1012, 1536, 2048, 2500, 3072, 3584, 4096]
+    recs, negs = [], []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        rec_, neg_ = hip.conv_channel_records(hip.channel_planes(act_w[lo:hi].contiguous(), 0, 3),
+                                              hip.channel_planes(act_q[lo:hi].contiguous(), 0, 3), (7, 7), (2, 2), (1, 1), "VALID")
+        recs.append(rec_); negs.append(neg_)
+    neg = torch.stack(negs).max(dim=0).values
+    fwd = recs[0].clone()
+    for r_ in recs[1:]:
+        fwd += r_
+    bwd = recs[-1].clone()
+    for r_ in recs[-2::-1]:
+        bwd += r_
+    pw_all, pq_all = hip.channel_planes(act_w, 0, 3), hip.channel_planes(act_q, 0, 3)
+    Wt_all = W.permute(2, 3, 0, 1).reshape(3, 64, 49).contiguous()
+    want = out["Q"].permute(2, 3, 0, 1).reshape(3, 64, 49)
+    for rec in (fwd, bwd):
+        idx = torch.empty((3, 64, 49), dtype=hip.index_dtype(len(alphabet)), device=dev)
+        Qs = torch.empty((3, 64, 49), dtype=torch.float32, device=dev)
+        unc = torch.zeros((3, 64), dtype=torch.int32, device=dev)
+        hip.conv_channels_from_records(rec, neg, pw_all, pq_all, Wt_all, alphabet, (7, 7), (2, 2), (1, 1), "VALID", idx, Qs, unc)
+        assert int(unc.sum()) == 0 and torch.equal(Qs, want)
+    del pw_all, pq_all, recs
     # 49 x 51.4 M x 4 B = 10 GB per patch matrix: two on the device, two copies on the host for the oracle
     _conv_sample(hip, oracle_mod, act_w, act_q, W, alphabet, out, 7, 2, "VALID", [(1, [0, 21, 42, 63])], host_gib_needed=48)
 
