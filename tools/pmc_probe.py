@@ -1,11 +1,12 @@
 """Run the cfg2 dense kernel a few times (for rocprofv3 --pmc passes).
-usage: pmc_probe.py M mode lanes_per_neuron variant tile_steps blk_sweep_waves"""
+usage: pmc_probe.py M mode lanes_per_neuron variant tile_steps blk_sweep_waves      (env PMC_C / PMC_M: another width / row length)"""
+import os
 import sys
 import numpy as np, torch
 sys.path.insert(0, ".")
 from quantized_neural_networks_amd import hip
 arg = lambda i, d: int(sys.argv[i]) if len(sys.argv) > i else d
-N = C = 4096; m = 1024; M = arg(1, 3)
+N = 4096; C = int(os.environ.get("PMC_C", "4096")); m = int(os.environ.get("PMC_M", "1024")); M = arg(1, 3)
 W = (np.random.default_rng(0).standard_normal((N, C)) / np.sqrt(N)).astype(np.float32)
 G = np.random.default_rng(1).standard_normal((N, m))
 X = np.maximum(G, 0).astype(np.float32)
