@@ -20,7 +20,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
   `roofline`      the dominant kernel against the resource that binds it -- FP64-rate vector issue: algorithmic flops
                   (6 m per weight) / the kernel's HIP-event time / the FP64 vector peak (spec) -- plus,
                   labelled as secondary, the 8d HBM-equivalent figure, the compulsory traffic and the PMC-measured one;
-  `cpu_baseline`  the C oracle port on all host cores over a bounded sample of the same layer.
+  `cpu_baseline`  the C oracle port on all host cores over a bounded sample of the same layer;
+  `cpu_baseline_numpy`  the reference-shaped one: the NumPy restatement over a process pool (a child process).
 """
 import argparse
 import json
@@ -68,6 +69,8 @@ def main():
     ap.add_argument("--bits", type=float, default=float(np.log2(3)))
     ap.add_argument("--alphabet-scalar", type=float, default=3.0)
     ap.add_argument("--cpu-sample", type=int, default=512, help="neurons timed on the host cores (0 = skip)")
+    ap.add_argument("--numpy-sample", type=int, default=-1,
+                    help="neurons of the NumPy process-pool baseline (the reference-shaped one); -1 = 2 x host cores, 0 = skip")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,6 +116,7 @@ def main():
 
     kernel_ms = []
     kname = [""]
+    knames = [""] * args.steps                 # per timed step: the inner events are only recorded by the block-pipelined family
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     ev_ag = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]   # N > 1: the all-gather
     # the recurrence kernel alone: events the C library records immediately around that launch (gpfq_set_main_kernel_events);
@@ -140,6 +144,8 @@ def main():
             ev[i_timed][1].record()
             hip.set_main_kernel_events(None, None)
         kname[0] = hip.last_dense_kernel()
+        if i_timed is not None:
+            knames[i_timed] = kname[0]
         # one all-gather of the indices (packed to 2 bits per weight for the ternary alphabet when N > 1),
         # then values + transpose to the Keras layout in one pass
         if world > 1:
@@ -175,7 +181,8 @@ def main():
     call_ms = [a.elapsed_time(b) for a, b in ev]
     kernel_name = kname[0]
     # (only the block-pipelined family records the inner events; any other kernel is timed by the events around the call)
-    kernel_ms = [a.elapsed_time(b) for a, b in ev_k] if kernel_name.startswith("gpfq_blk_kernel") else call_ms
+    # (a step whose kernel is not of that family falls back to ITS call events: ADVICE r04)
+    kernel_ms = [ev_k[i][0].elapsed_time(ev_k[i][1]) if knames[i].startswith("gpfq_blk_kernel") else call_ms[i] for i in range(args.steps)]
     # N > 1: what the collective saw -- backend, the world size of the group the all-gather ran on, the all-gather's own
     # duration (HIP events around it on its stream; it waits for the slowest rank's kernel, so rank 0's figure includes the
     # skew) and every rank's kernel time, gathered over the same group
@@ -252,6 +259,8 @@ def main():
                 "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
                 "kernel_ms_avg": k_avg_s * 1e3, "kernel_ms_min": float(np.min(kernel_ms)),
                 "call_ms_avg": float(np.mean(call_ms)),     # the whole gpfq_quantize_neurons call: record pre-pass + this kernel
+                # the same fraction on the bracket rounds 1-3 quoted (events around the whole call): comparable across rounds
+                "frac_call": alg_flops / (float(np.mean(call_ms)) / 1e3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                 "algorithmic_flops_per_launch": alg_flops,
                 "frac_of_measured_issue_rate": achieved_tf / FP64_MEASURED_ISSUE_TFLOPS,
                 "measured_issue_rate_tflops": FP64_MEASURED_ISSUE_TFLOPS,
@@ -274,6 +283,8 @@ def main():
             out["weak_scaling_companion"] = weak
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"], out["parity_sample"] = _cpu_baseline(W, X, Xq, unit_alphabet, args, idx, last)
+            if args.numpy_sample != 0:
+                out["cpu_baseline_numpy"] = _cpu_baseline_numpy(W, X, Xq, unit_alphabet, args, idx)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -316,6 +327,39 @@ def _cpu_baseline(W, X, Xq, unit_alphabet, args, idx_gpu, last):
                      f"{dt:.2f} s wall on {threads} threads, in-memory arrays (no HDF5)"}
     parity = {"neurons_checked": n, "neurons_with_index_mismatch": bad, "max_resid_rel_err": rel}
     return cpu, parity
+
+
+def _cpu_baseline_numpy(W, X, Xq, unit_alphabet, args, idx_gpu):
+    """The reference-shaped baseline (north_star: "the reference's NumPy/TensorFlow CPU path timed on the same box's host cores";
+    BASELINE.md 3): the NumPy restatement of _quantize_neuron_parallel (oracle.neuron_numpy, explicit casts) over a process pool
+    of os.cpu_count() workers, one neuron per task as the reference's executor.submit fan-out (:549-556), in-memory arrays
+    instead of HDF5, on >= 2 x cores neurons of the same layer.  Runs in a CHILD process that never touches the GPU (forking a
+    pool from this GPU-initialised process would not be safe); its indices are compared with the GPU's."""
+    import shutil
+    import subprocess
+    import tempfile
+    import oracle
+    cores = os.cpu_count() or 1
+    n = min(W.shape[1], 2 * cores if args.numpy_sample < 0 else args.numpy_sample)
+    alphabet, _ = oracle.layer_alphabet(W, unit_alphabet, args.alphabet_scalar)
+    d = tempfile.mkdtemp(prefix="gpfq_numpy_pool_")
+    try:
+        np.save(os.path.join(d, "W.npy"), np.ascontiguousarray(W[:, :n]))
+        np.save(os.path.join(d, "X.npy"), X)
+        np.save(os.path.join(d, "Xq.npy"), Xq)
+        np.save(os.path.join(d, "alphabet.npy"), alphabet)
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", PYTHONPATH=ROOT)
+        subprocess.run([sys.executable, "-m", "oracle.numpy_pool", d, str(cores)], check=True, cwd=ROOT, env=env, timeout=600)
+        with open(os.path.join(d, "result.json")) as f:
+            res = json.load(f)
+        io = np.load(os.path.join(d, "idx.npy"))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    bad = int((idx_gpu[:, :n].t().cpu().numpy() != io).any(axis=1).sum())
+    return {"value": n * W.shape[0] / res["seconds"], "unit": "weights/s", "cores": cores, "kind": "port (NumPy, process pool)",
+            "sample": f"{n} of {W.shape[1]} neurons of the same layer, one neuron per task over {cores} worker processes "
+                      f"(1 BLAS thread each), {res['seconds']:.2f} s wall, in-memory arrays (the reference reads HDF5 per step: slower)",
+            "neurons_with_index_mismatch_vs_gpu": bad}
 
 
 if __name__ == "__main__":

@@ -33,9 +33,19 @@ EXTRA_FLAGS = {"gpfq_pipe.hip": ["-fno-slp-vectorize"], "gpfq_blk.hip": ["-fno-s
 # diagnostic builds (never the shipped library): GPFQ_DIAG="-DGPFQ_BLK_STAMPS" adds in-kernel phase stamps to gpfq_blk.hip,
 # "-DGPFQ_WIDE_STAMPS" to the several-wavefronts-per-neuron kernel of gpfq_wide.hip (printed from the kernel),
 # "-DGPFQ_S2_SKIP=n" leaves a phase of gpfq_gram_s2_kernel out (wrong sums: timing experiments only)
+# A diagnostic build lives beside the shipped library, in csrc/diag_<hash of the flags>/ (round 5): several variants can be built in the
+# CPU container, travel to the GPU box together and be timed there without a compiler run (the box's minutes are the scarce resource);
+# objects of sources that take no diagnostic flag are shared with the shipped build.
+DIAG_SOURCES = ("gpfq_blk.hip", "gpfq_wide.hip", "gpfq_gram_s2.hip", "gpfq_gram_image.hip")
 if os.environ.get("GPFQ_DIAG"):
-    for _src in ("gpfq_blk.hip", "gpfq_wide.hip", "gpfq_gram_s2.hip", "gpfq_gram_image.hip"):
+    for _src in DIAG_SOURCES:
         EXTRA_FLAGS[_src] = EXTRA_FLAGS.get(_src, []) + os.environ["GPFQ_DIAG"].split()
+    _tag = hashlib.sha256(" ".join(os.environ["GPFQ_DIAG"].split()).encode()).hexdigest()[:10]
+    DIAG_DIR = os.path.join(CSRC, "diag_" + _tag)
+    LIB = os.path.join(DIAG_DIR, "libgpfq_hip.so")
+    STAMP = LIB + ".sha"
+else:
+    DIAG_DIR = None
 
 
 def _sha(paths, extra=""):
@@ -65,7 +75,8 @@ def _stale():
 
 
 def _compile(hipcc, src, verbose):
-    obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+    objdir = DIAG_DIR if (DIAG_DIR and src in DIAG_SOURCES) else OBJDIR
+    obj = os.path.join(objdir, src.replace(".hip", ".o"))
     stamp = obj + ".sha"
     flags = FLAGS + EXTRA_FLAGS.get(src, [])
     want = _sha([os.path.join(CSRC, f) for f in [src] + HEADERS], repr(flags))
@@ -108,7 +119,9 @@ def build(force=False, verbose=False):
             return LIB
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
         os.makedirs(OBJDIR, exist_ok=True)
-        if force:
+        if DIAG_DIR:
+            os.makedirs(DIAG_DIR, exist_ok=True)
+        if force and not DIAG_DIR:
             for f in os.listdir(OBJDIR):
                 os.remove(os.path.join(OBJDIR, f))
         with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:

@@ -882,7 +882,9 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         STAMP(st3);
         dma_wait();                                               // this wavefront's share of the next tile has landed
         STAMP(st4);
+#ifndef GPFQ_BLK_X_NOBAR               // timing experiment (WRONG results): no barrier between the slots, no slow path -- what free-running wavefronts could reach
         slot_barrier();
+#endif
         // (tried: the sweeps of the narrow shapes sleeping 128 .. 512 cycles here, a head start for the decision wavefront's reads:
         //  1.62 / 1.68 / 1.68 against 1.64 ms at 4096 x 512 -- nothing)
         STAMP(st5);
@@ -893,6 +895,9 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         // ---- slow path: neurons of block b stopped at an uncertifiable step (rare) ----
         {
         int ctl = lds_ld<int>(lds, L.off_ctl + 4 * (b & 1));      // (requested first: it is waited for alone)
+#ifdef GPFQ_BLK_X_NOBAR
+        ctl = -1;
+#endif
         if constexpr (kHoist) {
             if (b + 1 < nslots) { preload_wq(b + 1); preload_rows(b + 1); }
         }
@@ -1376,7 +1381,11 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         using F_ = std::false_type;
         hnext = hnext == 2 ? 0 : hnext + 1;
         STAMP(dt1);
+#ifdef GPFQ_BLK_X_NOBAR
+        ctl_now = -1;
+#else
         slot_barrier();
+#endif
         STAMP(dt2);
 #ifdef GPFQ_BLK_STAMPS
         dacc_work += dt1 - dt0; dacc_bar += dt2 - dt1; dacc_pro += dta - dt0; dacc_chain += dtb - dta;

@@ -558,6 +558,28 @@ class Model:
         self._input_shape = tuple(self._input.shape[1:])
         self.built = True
 
+    def graph_tables(self):
+        """(inbound, last_use) of a graph network, by position in ``self.layers`` (creation = topological order): ``inbound[k]`` lists
+        the positions of the layers whose outputs layer k consumes (empty for the InputLayer), ``last_use[k]`` is the position of
+        the last layer that consumes layer k's output (``len(self.layers)`` for a model output: never released).  What an
+        incremental walk over the graph needs to keep exactly the live tensors (quantized_network._capture_incremental_graph)."""
+        if not self._functional:
+            raise NotImplementedError("graph_tables of a truncated view")
+        tabs = getattr(self, "_tables", None)
+        if tabs is None:
+            pos = {id(l): k for k, l in enumerate(self.layers)}
+            inbound, last = [], list(range(len(self.layers)))
+            for k, layer in enumerate(self.layers):
+                inb = layer.inbound_nodes[0].inbound_layers
+                idx = [pos[id(p)] for p in (inb if isinstance(inb, (list, tuple)) else [inb])]
+                inbound.append(idx)
+                for p in idx:
+                    last[p] = max(last[p], k)
+            for t in self.outputs:
+                last[pos[id(t.layer)]] = len(self.layers)
+            tabs = self._tables = (inbound, last)
+        return tabs
+
     # -- Keras surface of a full model ---------------------------------------------------
     @property
     def input(self):

@@ -126,6 +126,23 @@ class _LazyStats(dict):
     def values(self):
         return [self[k] for k in self.keys()]
 
+    # (dict(stats), stats.copy(), pickle and ** read the underlying storage, not __getitem__: hand them host arrays -- ADVICE r04.
+    #  Until a layer's statistics are read its index tensor stays in HBM: N x C bytes per Dense layer, 103 MB for VGG16's fc1.)
+    def to_host(self):
+        for k in list(self.keys()):
+            self[k]
+        return self
+
+    def copy(self):
+        return dict(self.to_host())
+
+    def __iter__(self):
+        self.to_host()
+        return dict.__iter__(self)
+
+    def __reduce__(self):
+        return (dict, (dict(self.to_host()),))
+
 
 class QuantizedNeuralNetwork:
     """Wrapper around a Keras-style model that quantizes its Dense layers (reference :331-590)."""
@@ -254,8 +271,12 @@ class QuantizedNeuralNetwork:
         """Samples per forward chunk of the incremental capture: 2^25 input elements' worth, at least 512 and at most 16384 -- 16384 for
         the MNIST MLP (784 features), 8192 for CIFAR10 images (the reference's 5000 calibration images are one piece: no
         concatenation after every layer), 512 for ImageNet ones.  (Fixed at 512 until round 3: the MNIST run's
-        25000 samples went through every layer in 49 pieces, 294 launches of ~10 us of host time each for 7 ms of kernels.)  It does
-        not depend on the number of ranks, so a sample's chunk has the same shape in a sharded run."""
+        25000 samples went through every layer in 49 pieces, 294 launches of ~10 us of host time each for 7 ms of kernels.)
+        With a process group that shards the capture the chunk is capped so that every rank gets work: the largest power of two
+        <= n / (2 world), at least 128 (with the uncapped grid 5000 CIFAR10 images were ONE chunk -- rank 0 ran every
+        forward pass and the gather moved world x 8192 padded rows).  The grid depends on the GROUP SIZE, not on the rank: all ranks
+        of a run cut the same chunks; a single-process run that is to be compared bit for bit with a sharded one pins
+        `_capture_chunk` to the sharded run's value (chunk shapes can decide which GEMM / convolution kernel runs)."""
         if self._capture_chunk is not None:
             return int(self._capture_chunk)
         raw, _ = self._raw_inputs()
@@ -263,15 +284,36 @@ class QuantizedNeuralNetwork:
         c = 512
         while c < 16384 and 2 * c * feat <= (1 << 25):
             c *= 2
+        world, _ = _layer._group_info(self.process_group)
+        if world > 1 and self.shard_capture:
+            cap = 128
+            while 2 * cap * 2 * world <= raw.shape[0]:
+                cap *= 2
+            c = min(c, cap)
         return c
 
     def _incremental_capture_possible(self):
-        return (getattr(self, "incremental_capture", True) and hasattr(self.trained_net, "forward_upto")
-                and hasattr(self.quantized_net, "forward_upto") and len(self.trained_net.layers) == len(self.quantized_net.layers))
+        if not getattr(self, "incremental_capture", True) or len(self.trained_net.layers) != len(self.quantized_net.layers):
+            return False
+        if hasattr(self.trained_net, "forward_upto") and hasattr(self.quantized_net, "forward_upto"):
+            return True
+        return self._graph_capture_possible()
+
+    def _graph_capture_possible(self):
+        """Graph (functional-API) networks of the torch-backed shim: both networks expose their graph tables and every layer is a
+        shim layer (a real tf.keras Model keeps the reference's truncated-Model capture)."""
+        return all(getattr(n, "_functional", False) and hasattr(n, "graph_tables") and not hasattr(n, "forward_upto")
+                   for n in (self.trained_net, self.quantized_net))
 
     def _raw_inputs(self):
         if getattr(self, "_raw", None) is None:
             whole = getattr(self.get_data, "_all_inputs", None)
+            # (only when the feeder's batches ARE slices of its array: a subclass that overrides __getitem__ / _slice -- scaling,
+            #  augmentation, lazy loading -- is iterated batch by batch as the reference does: ADVICE r04)
+            cls = type(self.get_data)
+            if whole is not None and not (getattr(cls, "__getitem__", None) is _SliceSequence.__getitem__
+                                          and getattr(cls, "_slice", None) is _SliceSequence._slice):
+                whole = None
             if whole is not None:
                 # this module's own Sequences slice one array: the batches back to back ARE that array (no 313-way concatenate)
                 arr, sizes = whole()
@@ -282,34 +324,56 @@ class QuantizedNeuralNetwork:
                 self._raw = (self._to_device(batches[0] if len(batches) == 1 else np.concatenate(batches, axis=0)), sizes)
         return self._raw
 
+    # layers that act on every element (or every sample's own row) with no reduction over samples and no workspace: called on the
+    # whole block of samples at once (chunks + torch.cat would copy a 13 GB ResNet50 activation a second time for nothing)
+    _WHOLE_BLOCK_LAYERS = {"Activation", "ReLU", "Add", "BatchNormalization", "ZeroPadding2D", "Dropout", "Flatten", "InputLayer"}
+
     @torch.no_grad()
     def _advance(self, layer, x):
+        """layer.call on a block of samples in chunks of the capture grid; x: a tensor, or a list of tensors for a merging layer."""
         step = self._chunk_samples()
-        if x.shape[0] <= step:
+        multi = isinstance(x, (list, tuple))
+        n = (x[0] if multi else x).shape[0]
+        if n <= step or layer.__class__.__name__ in self._WHOLE_BLOCK_LAYERS:
             return layer.call(x)
-        return torch.cat([layer.call(x[i:i + step]) for i in range(0, x.shape[0], step)])
+        if multi:
+            return torch.cat([layer.call([t[i:i + step] for t in x]) for i in range(0, n, step)])
+        return torch.cat([layer.call(x[i:i + step]) for i in range(0, n, step)])
 
     def _capture_shard(self, n):
-        """(world, lo, hi, per): this rank's block [lo, hi) of the n samples -- whole chunks of the rank-independent grid,
-        `per` samples per rank in the gathered layout; world == 1 when the capture is not sharded."""
+        """(world, lo, hi, blocks): this rank's block [lo, hi) of the n samples and every rank's block (`blocks[r]` = (lo_r, hi_r)) --
+        whole chunks of the grid, dealt as evenly as whole chunks allow (the first n_chunks mod world ranks hold one more);
+        world == 1 when the capture is not sharded."""
         world, rank = _layer._group_info(self.process_group)
         if world == 1 or not self.shard_capture:
-            return 1, 0, n, n
+            return 1, 0, n, [(0, n)]
         chunk = self._chunk_samples()
         n_chunks = -(-n // chunk)
-        c_lo, c_hi = _layer.shard_bounds(n_chunks, world, rank)
-        return world, min(c_lo * chunk, n), min(c_hi * chunk, n), -(-n_chunks // world) * chunk
+        base, extra = divmod(n_chunks, world)
+        blocks, c = [], 0
+        for r in range(world):
+            c_hi = c + base + (1 if r < extra else 0)
+            blocks.append((min(c * chunk, n), min(c_hi * chunk, n)))
+            c = c_hi
+        return world, blocks[rank][0], blocks[rank][1], blocks
 
-    def _gather_samples(self, x, n, world, per):
-        """The ranks' sample blocks -> all n samples on every rank (one all-gather; blocks padded to `per` samples)."""
+    def _gather_samples(self, x, n, world, blocks):
+        """The ranks' sample blocks -> all n samples on every rank: one all-gather of blocks padded to the LARGEST block (at most one
+        chunk more than the smallest), then the blocks' own rows back to back (the counts follow from the grid: no exchange)."""
         if world == 1:
             return x
         import torch.distributed as dist
-        pad = torch.zeros((per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        pad[:x.shape[0]] = x
+        per = max(hi - lo for lo, hi in blocks)
+        if x.shape[0] == per:
+            pad = x.contiguous()
+        else:
+            pad = torch.zeros((per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            pad[:x.shape[0]] = x
         out = torch.empty((world * per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(out, pad, group=self.process_group)
-        return out[:n]
+        if all(hi - lo == per for lo, hi in blocks):
+            return out[:n]
+        return torch.cat([out[r * per:r * per + (hi - lo)] for r, (lo, hi) in enumerate(blocks) if hi > lo])
 
     # Look-ahead of the ANALOG network.  The analog activations at the input of the next layer to be quantized do not depend on
     # the layer being quantized now (only the quantized network's do: :461-462), so as soon as a layer's inputs are captured the
@@ -367,10 +431,53 @@ class QuantizedNeuralNetwork:
         ahead["w"].record_stream(main)                            # allocated on the side stream, consumed (and later freed) on this one
         return ahead["w"]
 
-    def _capture_incremental(self, layer_idx, transpose):
+    def _capture_incremental_graph(self, layer_idx, transpose):
+        """The incremental capture on a GRAPH network (Keras-ResNet50's topology: skip connections, layers with several consumers).
+        The reference rebuilds two truncated Models per layer and re-runs them from the input in 16-image batches
+        (:456-462, :483-484): O(L^2) layer evaluations -- for ResNet50's 53 conv layers tens of seconds of forward passes around
+        37 ms of quantization.  Here the frontier is the set of LIVE tensors of both networks after layer k (every output that a
+        later layer still consumes: a residual branch stays alive until its Add), keyed by layer position; capturing layer l's
+        inputs runs layers k+1 .. l-1 once, each on the outputs of its inbound layers, and releases a tensor after its last
+        consumer.  While the two networks still agree (same input tensors, same weights) they share one tensor."""
         raw, sizes = self._raw_inputs()
         n = raw.shape[0]
-        world, lo, hi, per = self._capture_shard(n)
+        world, lo, hi, blocks = self._capture_shard(n)
+        tl, ql = self.trained_net.layers, self.quantized_net.layers
+        inbound, last_use = self.trained_net.graph_tables()
+        if self.quantized_net.graph_tables()[0] != inbound:
+            raise NotImplementedError("the quantized network's graph differs from the analog one's")
+        src = inbound[layer_idx]
+        if len(src) != 1:
+            raise NotImplementedError(f"layer {layer_idx} has {len(src)} inbound layers")
+        fr = getattr(self, "_frontier", None)
+        if fr is None or not fr.get("graph") or fr["k"] > layer_idx - 1:
+            mine = raw[lo:hi]
+            fr = dict(graph=True, k=0, w={0: mine}, q={0: mine})    # layer 0 is the InputLayer: its output is the data
+        fw, fq = fr["w"], fr["q"]
+        for k in range(fr["k"] + 1, layer_idx):
+            xw, xq = [fw[p] for p in inbound[k]], [fq[p] for p in inbound[k]]
+            shared = all(a is b for a, b in zip(xw, xq)) and all(torch.equal(a, b) for a, b in zip(tl[k]._weights, ql[k]._weights))
+            one = len(xw) == 1 and not isinstance(tl[k].inbound_nodes[0].inbound_layers, (list, tuple))
+            w = self._advance(tl[k], xw[0] if one else xw)
+            q = w if shared else self._advance(ql[k], xq[0] if one else xq)
+            fw[k], fq[k] = w, q
+            for p in inbound[k]:
+                if last_use[p] == k:
+                    fw.pop(p, None)
+                    fq.pop(p, None)
+            fr["k"] = k
+        self._frontier = fr
+        w_in, q_in = fw[src[0]], fq[src[0]]
+        wX = self._assemble_capture(self._gather_samples(w_in, n, world, blocks), sizes, transpose)
+        qX = wX if q_in is w_in else self._assemble_capture(self._gather_samples(q_in, n, world, blocks), sizes, transpose)
+        return wX, qX
+
+    def _capture_incremental(self, layer_idx, transpose):
+        if not hasattr(self.trained_net, "forward_upto"):
+            return self._capture_incremental_graph(layer_idx, transpose)
+        raw, sizes = self._raw_inputs()
+        n = raw.shape[0]
+        world, lo, hi, blocks = self._capture_shard(n)
         fr = getattr(self, "_frontier", None)
         if fr is None or fr["k"] > layer_idx - 1:
             mine = raw[lo:hi]
@@ -405,13 +512,13 @@ class QuantizedNeuralNetwork:
                 q = w if same else self._advance(ql[k], fr["q"])
                 fr = dict(k=k, w=w, q=q)
         self._frontier = fr
-        full_w = raw if fr["k"] < 0 else self._gather_samples(fr["w"], n, world, per)
+        full_w = raw if fr["k"] < 0 else self._gather_samples(fr["w"], n, world, blocks)
         wX = self._assemble_capture(full_w, sizes, transpose)
         # both networks still agree up to here (first quantized layer): one tensor, as for layer 0 (:478-481)
         if fr["q"] is fr["w"]:
             qX = wX
         else:
-            qX = self._assemble_capture(self._gather_samples(fr["q"], n, world, per), sizes, transpose)
+            qX = self._assemble_capture(self._gather_samples(fr["q"], n, world, blocks), sizes, transpose)
         self._start_lookahead(fr, layer_idx)                      # the analog network runs on while this layer is quantized
         return wX, qX
 
@@ -419,6 +526,8 @@ class QuantizedNeuralNetwork:
         """Columns in the reference's layout (:491-495): batch b lands at offset b*(its own size)."""
         bs = self.get_data.batch_size
         n_batches = len(sizes)
+        if not transpose and act.shape[0] == n_batches * bs and all(k == bs for k in sizes):
+            return act                                           # full batches back to back ARE the captured block (read-only downstream)
         shape = (n_batches * bs,) + tuple(act.shape[1:])
         out = torch.zeros(shape[::-1] if transpose else shape, dtype=torch.float32, device=self.device)
         perm = tuple(range(act.dim() - 1, -1, -1))

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--n", "256", "--c", "512", "--m", "512", "--cpu-sample", "32"]
+           "--n", "256", "--c", "512", "--m", "512", "--cpu-sample", "32", "--numpy-sample", "16"]
     res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -39,6 +39,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert key in cpu, key
     assert cpu["kind"] in ("port", "reference") and cpu["value"] > 0
     assert out["parity_sample"]["neurons_with_index_mismatch"] == 0
+    # round 5: the reference-shaped baseline (NumPy restatement over a process pool, a child process) beside the C port, checked
+    # against the GPU's indices; and the fraction on the rounds-1-3 bracket (events around the whole call) beside `frac`
+    npb = out["cpu_baseline_numpy"]
+    assert npb["value"] > 0 and npb["cores"] >= 1 and npb["neurons_with_index_mismatch_vs_gpu"] == 0 and "process" in npb["kind"]
+    assert 0 < roof["frac_call"] <= roof["frac"]
 
 
 @pytest.mark.gpu

@@ -72,7 +72,7 @@ def test_small_graph_with_skip_connection(oracle_mod):
     X = r.random((40, 12, 12, 3)).astype(np.float32)
     y0 = np.zeros((40, 5), dtype=np.float32)
     q = qn.QuantizedCNN(network=net, batch_size=16, get_data=qn.CIFAR10Sequence(X, y0, 16), logger=Quiet(), bits=3, alphabet_scalar=4)
-    assert not q._incremental_capture_possible()          # graph network: the reference's truncated-Model capture
+    assert q._incremental_capture_possible() and q._graph_capture_possible()   # round 5: graph networks walk their live tensors
     rec = _record_captures(q)
     q.quantize_network()
     names = {l.name: k for k, l in enumerate(net.layers)}
@@ -125,3 +125,33 @@ def test_resnet50_topology_end_to_end_reduced_images(oracle_mod, tmp_path):
     K.save_model(q.quantized_net, path)
     back = K.load_model(path, device="cuda")
     assert torch.equal(back.predict_on_batch(X[:4]), q.quantized_net.predict_on_batch(X[:4]))
+
+
+def test_graph_incremental_capture_equals_the_recomputation_path_on_the_gpu():
+    """The incremental graph capture (live tensors of both networks, one evaluation per layer) against the reference's scheme (two
+    truncated Models per layer, re-run from the input: scripts/quantized_network.py:456-462) on the small ResNet50 topology, on the
+    GPU: every captured activation tensor and every quantized kernel bit for bit.  One feeder batch holds all images and one
+    capture chunk holds them too, so both schemes hand MIOpen / the GEMMs the same shapes (a convolution's algorithm, and with it
+    the last bits, can depend on the batch size; the partial-batch layout is compared on the CPU: tests/test_graph_capture_cpu.py)."""
+    from quantized_neural_networks_amd import keras_shim as K, quantized_network as qn
+    net = K.ResNet50(input_shape=(64, 64, 3), classes=10, seed=1)
+    g = np.random.default_rng(2)
+    for layer in net.layers:
+        if layer.__class__.__name__ == "BatchNormalization":
+            c = layer.get_weights()[0].shape[0]
+            layer.set_weights([g.uniform(0.8, 1.2, c), g.normal(0.1, 0.1, c), g.normal(0, 0.05, c), g.uniform(0.02, 0.06, c)])
+    X = (g.random((24, 64, 64, 3)) * 255 - 110).astype(np.float32)              # signed, like preprocessed images
+    runs = []
+    for incremental in (True, False):
+        q = qn.QuantizedCNN(network=net, batch_size=24, get_data=qn.CIFAR10Sequence(X, np.zeros((24, 10), np.float32), 24),
+                            logger=Quiet(), bits=np.log2(3), alphabet_scalar=3)
+        q.incremental_capture = incremental
+        assert q._incremental_capture_possible() == incremental
+        rec = _record_captures(q)
+        q.quantize_network()
+        runs.append((q, rec))
+    (qi, ri), (qr, rr) = runs
+    assert sorted(ri) == sorted(rr) and len(ri) == 54
+    for k in ri:
+        assert torch.equal(ri[k][0], rr[k][0]) and torch.equal(ri[k][1], rr[k][1]), net.layers[k].name
+        assert np.array_equal(qi.quantized_net.layers[k].get_weights()[0], qr.quantized_net.layers[k].get_weights()[0]), net.layers[k].name
