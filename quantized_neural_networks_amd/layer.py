@@ -225,6 +225,28 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
         Pw = hip.extract_patches(cm_w[c - c_lo].unsqueeze(-1), 0, (kh, kw), strides, rate, padding, out=Pw)
         Pq = Pw if same else hip.extract_patches(cm_q[c - c_lo].unsqueeze(-1), 0, (kh, kw), strides, rate, padding, out=Pq)
 
+    def rerun_flagged(Unc, with_resid):
+        """The (channel, filter) pairs the Gram path left flagged, through the verbatim flow on the channel's patch matrices: ONE
+        exact call per CHANNEL for all its flagged filters (round 5).  Normally about one pair in 10^4; but where the quantized
+        network's activations have drifted orders of magnitude away from the analog ones (the last blocks of a 50-layer network
+        whose 1 x 1 layers are plain MSQ: ResNet50's conv5_block3_2_conv flagged 179 000 of its 262 144 pairs) the prediction's
+        bound is wider than the alphabet's spacing for most walks -- one call per PAIR was 33 s of launches for that layer."""
+        flagged = torch.nonzero(Unc)                                   # one sync per layer
+        if flagged.numel() == 0:
+            return 0
+        by_c = {}
+        for c, f in flagged.tolist():
+            by_c.setdefault(c, []).append(f)
+        for c, fs in by_c.items():
+            patches(c)
+            fsel = torch.tensor(fs, dtype=torch.long, device=dev)
+            path = hip.GPFQ_PATH_ONCHIP if Pw.shape[1] <= hip.GPFQ_ONCHIP_MAX_M else hip.GPFQ_PATH_STREAM
+            r = hip.quantize_neurons(Pw, Pq, Wt_all[c].index_select(0, fsel).contiguous(), alphabet, path=path)
+            Qc[c, fsel], Ic[c, fsel] = r["Q"], r["idx"]
+            if with_resid:
+                Rc[c, fsel] = r["resid"]
+        return int(flagged.shape[0])
+
     # neuron-major filters [Cin][F][K]: row-major flattening of each kh x kw filter (:215), t = ky*kw + kx
     Wt_all = W.permute(2, 3, 0, 1).reshape(Cin, F, K).contiguous()
     rh, rw = rate if rate else (1, 1)
@@ -259,11 +281,7 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
             dist.all_reduce(neg, op=dist.ReduceOp.MAX, group=group)
             Unc = torch.zeros((Cin, F), dtype=torch.int32, device=dev)
             hip.conv_channels_from_records(rec, neg, *planes(), Wt_all, alphabet, (kh, kw), strides, rate, padding, Ic, Qc, Unc)
-            for c, f in torch.nonzero(Unc).tolist():                       # the same (rare) pairs on every rank
-                patches(c)
-                r = hip.quantize_neurons(Pw, Pq, Wt_all[c, f:f + 1], alphabet, path=hip.GPFQ_PATH_STREAM)
-                Qc[c, f], Ic[c, f] = r["Q"][0], r["idx"][0]
-                reruns += 1
+            reruns += rerun_flagged(Unc, False)                            # the same (rare) pairs on every rank
             replicated = True
     # the whole-shard Gram call for every conv layer (one launch chain instead of a Python loop over the
     # channels); with residual norms requested it builds patch matrices, which only pays for long ones
@@ -291,12 +309,7 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
             hip.quantize_conv_channels(*planes(), Wt_f, alphabet, (kh, kw), strides, rate, padding, i_f, q_f,
                                        r_f if want_resid else None, u_f)
             Ic[:, f_lo:f_hi], Qc[:, f_lo:f_hi], Rc[:, f_lo:f_hi], Unc[:, f_lo:f_hi] = i_f, q_f, r_f, u_f
-        flagged = torch.nonzero(Unc).tolist()                         # one sync per layer; ~1 filter in 10^4
-        reruns = len(flagged)
-        for c, f in flagged:
-            patches(c)
-            r = hip.quantize_neurons(Pw, Pq, Wt_all[c, f:f + 1], alphabet, path=hip.GPFQ_PATH_STREAM)
-            Qc[c, f], Ic[c, f], Rc[c, f] = r["Q"][0], r["idx"][0], r["resid"][0]
+        reruns = rerun_flagged(Unc, True)                             # one sync per layer; ~1 filter in 10^4
     else:
         for c in range(c_lo, c_hi):
             patches(c)

@@ -381,15 +381,14 @@ class QuantizedNeuralNetwork:
     # layer and, with a process group, under its index all-gather.  A latency-bound dense walk leaves most of the chip idle; a
     # conv layer's Gram kernels do not, and then the two simply share the GPU.  Same values: the same kernels on the same inputs.
     # Measured on one MI355X (tools/e2e_cnn.py, the CIFAR10 CNN at 5000 images): 48.0 ms without, 51 ms with -- on a single GPU the
-    # conv layers' kernels fill the chip and the second stream only adds launches, so the default (None) switches it on with a
-    # process group of more than one rank (where the all-gather and the shorter per-rank walks leave the GPU waiting) and off
-    # otherwise; True / False force it.
+    # conv layers' kernels fill the chip and the second stream only adds launches.  It should pay with a process group of more than
+    # one rank (the all-gather and the shorter per-rank walks leave the GPU waiting), but that has only ever run with several ranks
+    # sharing ONE GPU (tests/test_multirank_gpu.py forces it on and off: same bits): until a multi-GPU run has covered it the
+    # default is OFF (round 5); `lookahead_capture = True` switches it on.
     lookahead_capture = None
 
     def _lookahead_enabled(self):
-        if self.lookahead_capture is not None:
-            return bool(self.lookahead_capture)
-        return _layer._group_info(self.process_group)[0] > 1
+        return bool(self.lookahead_capture)
 
     def _next_quantized_layer(self, layer_idx):
         """Index of the next layer quantize_network() will quantize after `layer_idx`, or None."""

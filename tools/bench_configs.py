@@ -3,7 +3,13 @@ bench lines): cfg1 MNIST MLP layer, cfg3 VGG16 fc2/fc1, cfg4 CIFAR10 CNN conv + 
 synthetic activations of the right shapes.  Writes gpurun_out/configs.json
 (copied to profiles/r0N/configs.json).
 
-    python tools/bench_configs.py [--skip-fc1] [--resnet] [--alphabet-in-layer]
+    python tools/bench_configs.py [--skip-fc1] [--resnet] [--alphabet-in-layer] [--shapes] [--check profiles/r05/configs.json]
+
+--shapes: also the kernel-only times of the dense shapes behind gpfq_blk.hip's dispatch table (blk_shape): the latency-bound widths,
+the multi-GPU shards of the north-star layer, the long-row shapes.
+--check FILE (round 5, the perf guard): after measuring, every record is compared with the record of the same name in FILE (a committed
+profiles/r0N/configs.json); a layer more than 8 % (and more than 20 us) slower than its committed time fails the run (exit 1) -- a
+regression in one of the ~25 hand-tuned shapes no longer passes silently.  Box-to-box noise is +-3 %.
 """
 import json, os, sys, time
 import numpy as np, torch
@@ -85,6 +91,46 @@ def time_conv(name, cin, cout, hw, n, bits, scalar, dev, check=2, k=3, stride=1,
     return rec
 
 
+def time_shape(N, C, m, bits, scalar, dev, reps=5):
+    """Kernel-only time (pre-pass included) of one dense shape through the raw binding, best of `reps`, oracle on 4 neurons."""
+    W, X, Xq = synthetic(N, m, C, dev)
+    Wd = torch.from_numpy(W).to(dev)
+    unit = np.linspace(-1, 1, int(round(2 ** bits)))
+    alphabet, _ = layer.layer_alphabet(Wd, unit, scalar)
+    Wt = Wd.t().contiguous()
+    nrm = hip.row_norms(Xq)
+    out = hip.quantize_neurons(X, Xq, Wt, alphabet, nrm32=nrm, want_values=False)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); hip.quantize_neurons(X, Xq, Wt, alphabet, nrm32=nrm, want_values=False); b.record()
+        torch.cuda.synchronize(); best = min(best, a.elapsed_time(b))
+    _, io, _ = oracle.layer(W, X.cpu().numpy(), Xq.cpu().numpy(), alphabet, 0, 4)
+    bad = int((out["idx"][:4].cpu().numpy() != io).any(axis=1).sum())
+    rec = dict(config=f"shape {N} x {C} on {m} samples, M={len(unit)}", kind="dense kernel", N=N, m=m, C=C, M=len(unit), ms=best,
+               kernel=hip.last_dense_kernel()[:40], neurons_checked=4, neurons_with_index_mismatch=bad)
+    print(json.dumps(rec), flush=True)
+    return rec
+
+
+def check_against(recs, path, rel=0.08, abs_ms=0.020):
+    """The perf guard: records by name against a committed configs.json."""
+    ref = {r["config"]: r for r in json.load(open(path))["records"] if "ms" in r}
+    worse, seen = [], 0
+    for r in recs:
+        old = ref.get(r.get("config"))
+        if old is None or "ms" not in r:
+            continue
+        seen += 1
+        if r["ms"] > old["ms"] * (1 + rel) and r["ms"] > old["ms"] + abs_ms:
+            worse.append(f"{r['config']}: {r['ms']:.3f} ms against {old['ms']:.3f} committed (+{100 * (r['ms'] / old['ms'] - 1):.0f} %)")
+    print(f"perf guard: {seen} records compared with {path}, {len(worse)} more than {100 * rel:.0f} % slower")
+    for w in worse:
+        print("  SLOWER: " + w)
+    return not worse
+
+
 def main():
     dev = torch.device("cuda", 0)
     recs = []
@@ -127,12 +173,25 @@ def main():
             recs.append(r)
         recs.append(dict(config=f"cfg5 ResNet50, all {count5} conv layers (quantization only, synthetic activations of each layer's shape, one GPU)", ms=total5))
         print(json.dumps(recs[-1]))
+    if "--shapes" in sys.argv:
+        L3, L4 = float(np.log2(3)), 4.0
+        for N, C, m, bits, scalar in [(4096, 512, 1024, L3, 3), (4096, 1024, 1024, L3, 3), (4096, 2048, 1024, L3, 3), (4096, 4096, 1024, L3, 3),
+                                      (4096, 128, 1024, L3, 3), (4096, 10, 1024, L3, 3), (4096, 256, 1024, L3, 3),
+                                      (4096, 4096, 768, L3, 3), (4096, 4096, 512, L3, 3), (4096, 1024, 768, L3, 3), (4096, 1024, 512, L3, 3),
+                                      (4096, 4096, 1000, L4, 5), (4096, 4096, 1536, L4, 5), (4096, 4096, 2048, L4, 5), (4096, 2048, 1536, L4, 5),
+                                      (4096, 1000, 2048, L4, 5), (4096, 512, 2048, L4, 5), (4096, 128, 2048, L4, 5),
+                                      (4096, 4096, 3000, L4, 5), (4096, 4096, 4096, L4, 5), (4096, 1024, 3000, L4, 5), (4096, 4096, 5008, 3.0, 4),
+                                      (2048, 128, 5008, 3.0, 4), (784, 128, 512, L4, 5), (4096, 4096, 8192, L3, 3)]:
+            recs.append(time_shape(N, C, m, bits, scalar, dev))
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(dict(note="tools/bench_configs.py on one MI355X; best of 2-3 runs per layer; whole layer driver "
                         "(norms, kernel, assemble" + (", alphabet median" if "--alphabet-in-layer" in sys.argv else
                                                       "; the alphabet's median is formed up front, as the class surface does since round 4")
                         + ") with inputs resident in HBM", records=recs),
               open("gpurun_out/configs.json", "w"), indent=1)
+    if "--check" in sys.argv:
+        if not check_against(recs, sys.argv[sys.argv.index("--check") + 1]):
+            sys.exit(1)
 
 
 if __name__ == "__main__":
