@@ -346,79 +346,6 @@ template <int G, int S, int NSW, int NL> constexpr bool blk_split_has(int k)
     return false;
 }
 
-// ---- slow path of a sweep wavefront, OUT OF LINE (round 5) ---------------------------------------------
-// One exact round of block bb (see the header): the reference's two dot products of step bb B + S (:86, :89) on a COPY of the
-// residual (`uc`: [NL][2 PW] in the caller's private memory, written only on this rare path -- about one slot in 10^5), with the
-// block's already decided updates replayed into temporaries.  A real call (noinline): the loop of blk_sweep_role that holds the
-// residual in registers then carries none of this code's live ranges -- with the body inlined, hoisting the next slot's first LDS
-// requests above the wait for the control word made hipcc keep address registers across it and spill inside the hot loop (round 4).
-// Everything it needs travels by value (a reference to the kernel arguments would put them on the stack).
-struct BlkSlowArgs {
-    int tile_pitch, off_wq, off_x2, off_ctl, m;
-    const float *Xq;
-    int64_t ldx;
-};
-template <int G, int PW, int MP, int B, int NSW, bool SYM, int NL>
-__device__ __attribute__((noinline)) int blk_slow_round(BlkSlowArgs a, char *lds_generic, int wave, int lane, int pbase, int b, int S, const double *uc)
-{
-    constexpr int NB = NL * G, KQ = 64 / G;
-    constexpr int RSH = NL == 4 ? 0 : (NL == 2 ? 1 : 2);
-    constexpr int HDR = blk_hdr_bytes(B);
-    constexpr int RB = (int)blk_rec_bytes(MP, B, G);
-    lchar *lds = (lchar *)lds_generic;
-    const int ng = lane & (G - 1), kq = lane / G, row = lane >> 4;
-    const bool writer = (lane & 15 & ~(G - 1)) == 0 && (row & ((1 << RSH) - 1)) == 0;
-    const int nloc = NL * ng, nrow = row >> RSH;
-    const int o_x = HDR + 8 * (pbase + kq), o_q = o_x + 4 * MP;
-    const int o_wq = a.off_wq + nloc * B * 8;
-    const int o_x2 = a.off_x2 + (wave * NB + nloc + nrow) * 16;
-    const int nb_ = ((b + 1) & 1) * a.tile_pitch;                 // rows of block b are records of tile b + 1
-    const int cbq = (b & 1) * NB * B * 8;
-    double eu[NL], ew[NL];
-#pragma unroll
-    for (int n = 0; n < NL; ++n) { eu[n] = 0.0; ew[n] = 0.0; }
-#pragma unroll
-    for (int n = 0; n < NL; ++n) {
-        const float w = lds_ld<float2>(lds, o_wq + cbq + (n * B + S) * 8).x;
-#pragma unroll 1
-        for (int p = 0; p < PW; ++p) {
-            double t0 = uc[n * 2 * PW + 2 * p], t1 = uc[n * 2 * PW + 2 * p + 1];
-            for (int j = 0; j < S; ++j) {
-                const int rb = nb_ + j * RB;
-                const float2 x2 = lds_ld<float2>(lds, rb + o_x + 8 * p * KQ), q2 = lds_ld<float2>(lds, rb + o_q + 8 * p * KQ);
-                const float2 wq = lds_ld<float2>(lds, o_wq + cbq + (n * B + j) * 8);
-                if constexpr (SYM) {
-                    t0 += (double)__fmaf_rn(wq.y, q2.x, __fmul_rn(wq.x, x2.x));
-                    t1 += (double)__fmaf_rn(wq.y, q2.y, __fmul_rn(wq.x, x2.y));
-                } else {
-                    t0 += (double)__fsub_rn(__fmul_rn(wq.x, x2.x), __fmul_rn(wq.y, q2.x));
-                    t1 += (double)__fsub_rn(__fmul_rn(wq.x, x2.y), __fmul_rn(wq.y, q2.y));
-                }
-            }
-            const int rb = nb_ + S * RB;
-            const float2 x2 = lds_ld<float2>(lds, rb + o_x + 8 * p * KQ);
-            float2 q2;
-            if constexpr (SYM) {                              // the record holds a32 * Xq_t: the row itself from memory (rare path)
-                const int i0 = 2 * (pbase + p * KQ + kq);
-                const float *xr = a.Xq + ((int64_t)b * B + S) * a.ldx;
-                q2.x = i0 < a.m ? xr[i0] : 0.f;
-                q2.y = i0 + 1 < a.m ? xr[i0 + 1] : 0.f;
-            } else {
-                q2 = lds_ld<float2>(lds, rb + o_q + 8 * p * KQ);
-            }
-            eu[n] = fma((double)q2.x, t0, eu[n]);
-            eu[n] = fma((double)q2.y, t1, eu[n]);
-            ew[n] = fma((double)q2.x, t0 + (double)__fmul_rn(w, x2.x), ew[n]);
-            ew[n] = fma((double)q2.y, t1 + (double)__fmul_rn(w, x2.y), ew[n]);
-        }
-    }
-    const double vu = fold_klanes_n<G, NL>(eu), vw = fold_klanes_n<G, NL>(ew);
-    if (writer) lds_st<double2>(lds, o_x2, make_double2(vu, vw));
-    slot_barrier();                                               // partials published
-    slot_barrier();                                               // chains resumed, control word rewritten
-    return lds_ld<int>(lds, a.off_ctl + 4 * (b & 1));
-}
-
 // ---- sweep wavefront -------------------------------------------------------------------------------
 template <int G, int PW, int MP, int B, int NSW, bool SYM, int NL>
 __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic, const BlkLds &L, int wave, int lane, int pbase)
@@ -605,40 +532,6 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             ctl = lds_ld<int>(lds, L.off_ctl + 4 * (b & 1));
         }
     };
-    // Round 5 (fused shapes): the slot's first LDS requests -- the block's sixteen (w, q), the first update rows, the first row of the
-    // dot products -- are issued right BEHIND the read of the slow path's control word, after the barrier that ends the slot before:
-    // one LDS round trip behind every barrier instead of two in sequence.  The slow path is an out-of-line call on a copy of the
-    // residual (blk_slow_round), so none of its live ranges reach this loop; when it ran, the requests are simply issued again
-    // (it rewrote decisions of the block).
-#ifdef GPFQ_BLK_NO_HOIST               // diagnostic build: round 4's order (control word, wait, then the requests at the top of the slot)
-    constexpr bool kHoistF = false;
-#else
-    constexpr bool kHoistF = kFused;
-#endif
-#ifdef GPFQ_BLK_NO_OOL                 // diagnostic build: the slow path inlined as in round 4
-    constexpr bool kOutOfLine = false;
-#else
-    constexpr bool kOutOfLine = kFused;
-#endif
-    float2 fwq[kFused ? B : 1][NL], x2n = make_float2(0.f, 0.f), q2n = make_float2(0.f, 0.f);
-    double2 dcur = make_double2(0.0, 0.0);
-    // (only what the slot's FIRST step consumes crosses the barrier: the later steps' (w, q) are requested at the top of the slot and
-    //  have a whole pair-step to arrive -- with all sixteen carried round the loop hipcc spilled seven of them into the hot loop)
-    auto first_requests = [&](int bb, int s0, int s1) {           // for slot bb: (w, q) of block bb - 1 (steps s0 .. s1 - 1), rows of tile bb
-        if constexpr (kFused) {
-            const int tb = (bb & 1) * L.tile_pitch, pq = ((bb - 1) & 1) * NB * B * 8;
-#pragma unroll
-            for (int s = 0; s < B; ++s)
-#pragma unroll
-                for (int n = 0; n < NL; ++n)
-                    if (s >= s0 && s < s1) fwq[s][n] = lds_ld<float2>(lds, o_wq + pq + (n * B + s) * 8);
-            if (s0 == 0) {
-                x2n = lds_ld<float2>(lds, tb + o_x); q2n = lds_ld<float2>(lds, tb + o_q);
-                dcur = lds_ld<double2>(lds, tb + ng * RB + o_d);
-            }
-        }
-    };
-    if constexpr (kHoistF) first_requests(0, 0, 1);
     for (int b = 0; b < nslots; ++b) {
         STAMP(st0);
 #ifdef GPFQ_BLK_STAMPS
@@ -694,8 +587,17 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             //  s_waitcnt vmcnt(0) into the loop, which waits for the LDS-DMA pieces in flight: 2.98 -> 3.26 ms, and 5.0 ms with the
             //  requests hoisted across the barrier.  profiles/r04/README.md)
             const int rbm = tbase + ng * RB + o_d;
-            if constexpr (kHoistF) first_requests(b, 1, B);
-            else first_requests(b, 0, B);
+            float2 fwq[B][NL], x2n, q2n;
+            double2 dcur;
+            auto first_requests = [&]() {
+#pragma unroll
+                for (int s = 0; s < B; ++s)
+#pragma unroll
+                    for (int n = 0; n < NL; ++n) fwq[s][n] = lds_ld<float2>(lds, o_wq + pbq + (n * B + s) * 8);
+                x2n = lds_ld<float2>(lds, tbase + o_x); q2n = lds_ld<float2>(lds, tbase + o_q);
+                dcur = lds_ld<double2>(lds, rbm);
+            };
+            first_requests();
             double2 dprev = make_double2(0.0, 0.0);
             double acc[NL];
 #pragma unroll
@@ -999,28 +901,6 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         if constexpr (kHoist) {
             if (b + 1 < nslots) { preload_wq(b + 1); preload_rows(b + 1); }
         }
-        if constexpr (kHoistF || kOutOfLine) {
-            if constexpr (kHoistF) {
-                if (b + 1 < nslots) first_requests(b + 1, 0, 1);
-            }
-            int S = __builtin_amdgcn_readfirstlane(ctl);
-            if constexpr (!kOutOfLine) {
-                if (S >= 0) {
-                    slow_path(b, ctl);
-                    if (kHoistF && b + 1 < nslots) first_requests(b + 1, 0, 1);
-                }
-            } else
-            if (S >= 0) {
-                double uc[NL * 2 * PW];                           // the residual as it stands before block b, for the out-of-line rounds
-#pragma unroll
-                for (int n = 0; n < NL; ++n)
-#pragma unroll
-                    for (int e = 0; e < 2 * PW; ++e) uc[n * 2 * PW + e] = u[n][e];
-                const BlkSlowArgs sa{L.tile_pitch, L.off_wq, L.off_x2, L.off_ctl, K.m, K.Xq, K.ldx};
-                while (S >= 0) S = __builtin_amdgcn_readfirstlane(blk_slow_round<G, PW, MP, B, NSW, SYM, NL>(sa, lds_generic, wave, lane, pbase, b, S, uc));
-                if (kHoistF && b + 1 < nslots) first_requests(b + 1, 0, 1);  // (the slow path has rewritten decisions of block b)
-            }
-        } else
         if (__builtin_amdgcn_readfirstlane(ctl) >= 0) {
             slow_path(b, ctl);
             if constexpr (kHoist) {
@@ -1243,20 +1123,13 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                 flush(flushed, flush_hi);
                 flushed = flush_hi;
             }
-            // (the record headers: requested a slot ago, see prefetch_headers)
+            // (the record headers: requested before the last barrier, see prefetch_headers)
             double2 hp[B], hi_[BI];
             const double2 o01 = g01;
 #pragma unroll
             for (int j = 0; j + 1 < B; ++j) hi_[j] = ghi[j];
 #pragma unroll
             for (int s = 0; s < B; ++s) hp[s] = ghp[s];
-#ifndef GPFQ_BLK_LATE_HDR
-            // Round 5: the NEXT tile's headers are requested here, behind this slot's own reads, and arrive under the chain.  Until
-            // round 4 they were the last thing before the slot's barrier -- whose s_waitcnt lgkmcnt(0) then waited out their whole
-            // LDS round trip with every sweep wavefront of a narrow layer already parked at that barrier: the decision wavefront IS
-            // the slot there.  (They landed a slot ago: tile b + 1's headers are issued at the top of slot b - 1.)
-            if (b + 1 < K.nblk) prefetch_headers(hnext);
-#endif
             __builtin_amdgcn_sched_barrier(0);
             // ---- (1) arithmetic
             double wd[B];
@@ -1411,9 +1284,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             }
             ctl_now = smin < B ? smin : -1;
             if (lane == 0) lds_st<int>(lds, L.off_ctl + 4 * (b & 1), ctl_now);
-#ifdef GPFQ_BLK_LATE_HDR              // diagnostic build: round 3/4's place for the header prefetch (see the early one above)
             if (b + 1 < K.nblk) prefetch_headers(hnext);          // the next tile's headers (landed a slot ago): the LDS is quiet now
-#endif
         } else {
             STAMP(dta);
             STAMP(dtb);
