@@ -118,6 +118,9 @@ def build(force=False, verbose=False):
         if not force and not _stale():                  # another process built it while this one waited
             return LIB
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        # (the stamp is the hash of the tree as it stands NOW: a source edited while the compilers run leaves the library stale, not
+        #  "fresh" with an object of the old text -- it happened in round 5)
+        stamp_hash = tree_hash()
         os.makedirs(OBJDIR, exist_ok=True)
         if DIAG_DIR:
             os.makedirs(DIAG_DIR, exist_ok=True)
@@ -133,7 +136,7 @@ def build(force=False, verbose=False):
         subprocess.check_call(cmd, cwd=CSRC)
         tmp_stamp = STAMP + ".tmp.%d" % os.getpid()
         with open(tmp_stamp, "w") as f:
-            f.write(tree_hash())
+            f.write(stamp_hash)
         if os.path.exists(STAMP):
             os.remove(STAMP)                            # never a fresh stamp beside a stale library
         os.replace(tmp_lib, LIB)
