@@ -57,7 +57,8 @@ namespace gpfq {
 namespace {
 
 struct BlkStats {          // first 64 bytes of a record header (all float64); see gpfq_pipe.hip's PipeRec
-    double rden, G, cb, ca, Ea, nrm, pad0, pad1;
+    double rden, G, cb, ca, Ea, nrm;
+    double sE1, sE2;       // round 5: sums of the band's E1 / E2 over ALL its distances (rounded up): the quick certification's bound
 };
 struct BandEntry {         // distance d = 1 .. 2B-1 at header offset 64 + 32 (d - 1)
     double H1, H2, E1, E2; // <Xq_t, X_{t-d}>, <Xq_t, Xq_{t-d}>, 2^-23 (1+2^-20) sum|Xq_t X_{t-d}|, ... sum|Xq_t Xq_{t-d}|
@@ -197,6 +198,10 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
         st.cb = 0x1p-23 * s1 * st.rden * up;
         st.ca = 0x1p-149 * s2 * st.rden * up;
         st.Ea = 0x1p-149 * s2 * up;
+        double e1 = 0.0, e2 = 0.0;                                // (the band entries' own E1, E2: same products, summed; `up` twice covers the sums' roundings)
+#pragma unroll
+        for (int d = 1; d <= ND; ++d) { e1 += total(5 + 4 * (d - 1)); e2 += total(6 + 4 * (d - 1)); }
+        st.sE1 = 0x1p-23 * e1 * up * up; st.sE2 = 0x1p-23 * e2 * up * up;
         *reinterpret_cast<BlkStats *>(rb) = st;
         *reinterpret_cast<BlkStats *>(hdrs + t * hdr) = st;
     } else if (threadIdx.x <= ND) {
@@ -1166,14 +1171,19 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             const int rbm = tbase + sm * RB;
             const double2 o23 = lds_ld<double2>(lds, rbm + 16);
             const double rEa = lds_ld<double>(lds, rbm + 32);
+#ifndef GPFQ_BLK_NO_QUICK_CERT
+            const double2 o67 = lds_ld<double2>(lds, rbm + 48);   // (sE1, sE2): the quick certification's bound (below)
+#else
             double2 ep[B], ei_[BI];
 #pragma unroll
             for (int j = 0; j < B; ++j) ep[j] = lds_ld<double2>(lds, rbm + 64 + 32 * (B + sm - j - 1) + 16);
 #pragma unroll
             for (int j = 0; j + 1 < B; ++j) ei_[j] = lds_ld<double2>(lds, j < sm ? rbm + 64 + 32 * (sm - j - 1) + 16 : L.off_zero);
+#endif
             STAMP(dta);
             // ---- (2) the chain
             const double u_a0 = K.uni_a0, u_step = K.uni_step, u_inv = K.uni_inv, u_c0 = K.uni_c0, u_kmax = (double)(M - 1);
+            const double u_amax = fmax(fabs(u_a0), fabs(fma(u_kmax, u_step, u_a0))) * (1.0 + 0x1p-20);   // >= every |member| (and its float32 rounding)
             const unsigned long long u_plus = K.uni_plus, u_minus = K.uni_minus;
             const int u_zero = K.zero_idx;
             const float sym_a32 = (float)sym_top;
@@ -1201,8 +1211,10 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             };
             float q32s[B];
             double qd[B];
+#ifdef GPFQ_BLK_NO_QUICK_CERT
             double du_m = 0.0;
             unsigned any_run = anyP, any_m = anyP;
+#endif
 #pragma unroll
             for (int s = 0; s < B; ++s) {
                 // (1/nrm^2, G and <Xq_s, Xq_j> of step s from the sub-lane that owns it)
@@ -1218,10 +1230,29 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                 q32 = rden_s == 0.0 ? 0.f : q32;                  // rule (i): the pre-pass stores 1 / nrm^2 = 0 for nrm < 1e-16
                 q32s[s] = q32;
                 qd[s] = (double)q32;
+#ifdef GPFQ_BLK_NO_QUICK_CERT
                 du_m = sm == s ? du : du_m;
                 any_m = sm == s ? any_run : any_m;
                 any_run |= __float_as_uint(wc[s]) | __float_as_uint(q32);
+#endif
             }
+#ifndef GPFQ_BLK_NO_QUICK_CERT
+            // The own step's predicted dot product, from the lane's OWN band entries (zeros beyond the own step: a product with zero
+            // adds nothing), in the chain's order -- the same bits as the chain's du of step sm, without selecting it out of the four
+            // (round 5: two conditional moves per step of the chain, on the wavefront whose instruction count is a narrow layer's time).
+            double du_m = Am;
+#pragma unroll
+            for (int j = 0; j + 1 < B; ++j) du_m = fma(-qd[j], hi_[j].y, du_m);
+#endif
+#ifndef GPFQ_BLK_LATE_HDR
+            // The NEXT tile's headers (landed a slot ago) are requested here, behind the chain: the LDS is quiet (in a narrow layer the
+            // sweeps are parked at the barrier) and the reads return under the certification.  Until round 4 they were the last thing
+            // before the slot's barrier, whose s_waitcnt lgkmcnt(0) then waited out their round trip on the slot's critical path.
+            // (Requested at the TOP of the slot instead they land in the post-barrier burst and delay the partial sums the chain
+            //  waits for: 1.49 against 1.38 ms at 4096 x 512 on 1024 samples, profiles/r05/blk_variants_ab.txt.)
+            if (b + 1 < K.nblk) prefetch_headers(hnext);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             // ---- (3) certification of the own step
             const bool valid_m = sm < nvalid;
             const float w_m = valid_m ? w_own_raw : 0.f;
@@ -1234,41 +1265,106 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             double kd_m;
             const float qk32 = pick(tt_m, kd_m);                  // (the chain's arithmetic on the chain's operands: the same bits)
             const int ki = (int)kd_m;
-            const int oe = L.off_e + 8 * (1 + ki);                // table with two sentinels on either side: a[k-1], a[k], a[k+1]
-            const double a_lo = lds_ld<double>(lds, oe), a_k = lds_ld<double>(lds, oe + 8), a_hi = lds_ld<double>(lds, oe + 16);
-#pragma unroll
-            for (int j = 0; j < B; ++j) {
-                ePm = fma(fabs((double)wprev[j]), ep[j].x, ePm); ePm = fma(fabs((double)qprev[j]), ep[j].y, ePm);
+            double a_lo, a_k, a_hi;                               // a[k-1], a[k], a[k+1] (-inf / +inf beyond the ends)
+#ifndef GPFQ_BLK_TABLE_NEIGHBOURS
+            if constexpr (SYM) {
+                // {-a, 0, a} / {-a, a}, exactly symmetric in float64 (blk_sym_a): the members ARE (k - (M - 1) / 2) * gap with gap = a or
+                // 2 a, every one of these products and sums exact -- no table read behind the pick (a dependent LDS round trip on the
+                // wavefront whose latency chain is a narrow layer's slot: round 5)
+                const double kInfD = __longlong_as_double(0x7ff0000000000000LL);
+                const double gap = M == 3 ? sym_top : 2.0 * sym_top;
+                a_k = fma(kd_m, gap, -sym_top);
+                a_lo = ki == 0 ? -kInfD : a_k - gap;
+                a_hi = ki == M - 1 ? kInfD : a_k + gap;
+            } else
+#endif
+            {
+                const int oe = L.off_e + 8 * (1 + ki);            // table with two sentinels on either side
+                a_lo = lds_ld<double>(lds, oe); a_k = lds_ld<double>(lds, oe + 8); a_hi = lds_ld<double>(lds, oe + 16);
             }
-            double eps = ePm;
-#pragma unroll
-            for (int j = 0; j + 1 < B; ++j) { eps = fma(fabs(wd[j]), ei_[j].x, eps); eps = fma(fabs(qd[j]), ei_[j].y, eps); }
-            // (each of the up to 2B-1 pending increments may lose up to Ea = 2^-149 sum|Xq_t| to subnormal float32 products)
-            eps += ((any_m << 1) != 0u) ? (double)(2 * B - 1) * rEa : 0.0;
-            const bool du_exact = eps == 0.0;                     // every pending increment orthogonal to Xq_t element-wise
-            const bool msq = du_exact & small;                    // rule (ii), certain
-            const bool sure = du_exact | (fabs(du_m) - eps >= 1e-10);   // ... or certainly not rule (ii)
-            // twice the modelling error of the prediction (quotient units) + float64 slack
-            const double delta2 = 2.0 * (fma(fabs(wdm), rcb, rca) + eps * rden)
-                                  + 0x1p-43 * (fabs(Dm) + fabs(du_m - Dm) + fabs(wGm)) * rden;
             const double d_k = fabs(a_k - tt_m), d_lo = fabs(a_lo - tt_m), d_hi = fabs(a_hi - tt_m);
-            const bool far = (d_lo - d_k > delta2) & (d_hi - d_k > delta2);      // beyond the bound from both boundaries
-            const bool first = (d_k < d_lo) & (d_k <= d_hi);                     // exact t (rule (ii)): argmin's first minimum (:57)
-            const bool cert = (msq ? first : far) & sure;
-            const bool ok = rule1 | cert | !valid_m;
+            const double slack43 = 0x1p-43 * (fabs(Dm) + fabs(du_m - Dm) + fabs(wGm)) * rden;      // float64 slack of the prediction
+            const double base2 = 2.0 * fma(fabs(wdm), rcb, rca) + slack43;
+            // The certification proper needs eps = sum over the pending increments of |w_j| E1 + |q_j| E2 (fourteen products on seven
+            // band entries read from the tile, each at a sub-lane-dependent address): a third of this wavefront's instructions -- and
+            // this wavefront IS the slot of every narrow layer.  Round 5: first a bound on that bound -- the largest pending |w| times
+            // the sum of ALL the band's E1 plus the alphabet's largest |member| times the sum of its E2 (two numbers the pre-pass
+            // leaves in the header: BlkStats::sE1 / sE2) -- which certifies all but about one slot in 10^4; only when some lane fails
+            // it does the whole wavefront take the exact bound below (and with it rule (ii)'s certain case, which the quick test
+            // never accepts: eps_q > 0 whenever the row has any overlap with its band).  eps_q >= eps term by term, so a decision
+            // the quick test certifies is one the exact test certifies.
+            bool ok;
+#ifndef GPFQ_BLK_NO_QUICK_CERT
+            float wmx = fmaxf(fabsf(wprev[0]), fabsf(wc[0]));
+#pragma unroll
+            for (int j = 1; j < B; ++j) wmx = fmaxf(wmx, fmaxf(fabsf(wprev[j]), fabsf(wc[j])));
+            const double eps_q = fma((double)wmx, o67.x, u_amax * o67.y) + (double)(2 * B - 1) * rEa;
+            const bool sure_q = fabs(du_m) - eps_q >= 1e-10;                     // certainly not rule (ii)
+            const double delta2_q = base2 + 2.0 * eps_q * rden;
+            const bool far_q = (d_lo - d_k > delta2_q) & (d_hi - d_k > delta2_q);
+            ok = rule1 | (far_q & sure_q) | !valid_m;
+            if (__ballot(!ok) != 0ull)
+#endif
+            {
+#ifndef GPFQ_BLK_NO_QUICK_CERT
+                double2 ep[B], ei_[BI];
+#pragma unroll
+                for (int j = 0; j < B; ++j) ep[j] = lds_ld<double2>(lds, rbm + 64 + 32 * (B + sm - j - 1) + 16);
+#pragma unroll
+                for (int j = 0; j + 1 < B; ++j) ei_[j] = lds_ld<double2>(lds, j < sm ? rbm + 64 + 32 * (sm - j - 1) + 16 : L.off_zero);
+#endif
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    ePm = fma(fabs((double)wprev[j]), ep[j].x, ePm); ePm = fma(fabs((double)qprev[j]), ep[j].y, ePm);
+                }
+                double eps = ePm;
+#pragma unroll
+                for (int j = 0; j + 1 < B; ++j) { eps = fma(fabs(wd[j]), ei_[j].x, eps); eps = fma(fabs(qd[j]), ei_[j].y, eps); }
+#ifndef GPFQ_BLK_NO_QUICK_CERT
+                unsigned any_m = anyP;                                // any nonzero pending (w, q) before the own step
+#pragma unroll
+                for (int j = 0; j + 1 < B; ++j) any_m |= j < sm ? (__float_as_uint(wc[j]) | __float_as_uint(q32s[j])) : 0u;
+#endif
+                // (each of the up to 2B-1 pending increments may lose up to Ea = 2^-149 sum|Xq_t| to subnormal float32 products)
+                eps += ((any_m << 1) != 0u) ? (double)(2 * B - 1) * rEa : 0.0;
+                const bool du_exact = eps == 0.0;                     // every pending increment orthogonal to Xq_t element-wise
+                const bool msq = du_exact & small;                    // rule (ii), certain
+                const bool sure = du_exact | (fabs(du_m) - eps >= 1e-10);   // ... or certainly not rule (ii)
+                // twice the modelling error of the prediction (quotient units) + float64 slack
+                const double delta2 = base2 + 2.0 * eps * rden;
+                const bool far = (d_lo - d_k > delta2) & (d_hi - d_k > delta2);      // beyond the bound from both boundaries
+                const bool first = (d_k < d_lo) & (d_k <= d_hi);                     // exact t (rule (ii)): argmin's first minimum (:57)
+                const bool cert = (msq ? first : far) & sure;
+                ok = rule1 | cert | !valid_m;
+            }
             // first step of each neuron that is not certain: the R sub-lanes of a neuron sit side by side, sub-lane sm at bit sm
             const unsigned long long bad = __ballot(!ok);
+            const float q_m = rule1 ? 0.f : qk32;
+            const bool st = r < B;                                // (sub-lanes B.. repeat sub-lanes 0..B-1)
+#ifndef GPFQ_BLK_NO_QUICK_CERT
+            if (bad == 0ull) {
+                // every step of every neuron certified (all but about one slot in 10^4): no chain stops, nothing to select
+                STAMP(dtb);
+#pragma unroll
+                for (int s = 0; s < B; ++s) qc[s] = q32s[s];
+                const float qpub = SYM ? (q_m > 0.f ? -1.f : (q_m < 0.f ? 1.f : 0.f)) : q_m;
+                lds_st<float2>(lds, st ? o_wq + cbq + 8 * sm : o_dummy, make_float2(w_m, qpub));
+                lds_st<int2>(lds, (st & valid_m) ? o_out + ((oslot0 + sm) % kOutSteps) * 8 : o_dummy,
+                             make_int2(rule1 ? K.zero_idx : ki, __float_as_int(q_m)));
+                ctl_now = -1;
+                if (lane == 0) lds_st<int>(lds, L.off_ctl + 4 * (b & 1), -1);
+            } else
+#endif
+            {
             const unsigned field = (unsigned)(bad >> (lane & ~(R - 1))) & ((1u << B) - 1u);
             stop = field ? __builtin_ctz(field) : B;
             STAMP(dtb);
 #pragma unroll
             for (int s = 0; s < B; ++s) qc[s] = s < stop ? q32s[s] : 0.f;
             const bool keep = sm < stop;
-            const float q_m = rule1 ? 0.f : qk32;
             const float q_st = keep ? q_m : 0.f;
             // what the sweeps multiply the (scaled) Xq row with: q, or minus its sign; (w, 0) for a step still to be decided
             const float qpub = SYM ? (q_st > 0.f ? -1.f : (q_st < 0.f ? 1.f : 0.f)) : q_st;
-            const bool st = r < B;                                // (sub-lanes B.. repeat sub-lanes 0..B-1)
             lds_st<float2>(lds, st ? o_wq + cbq + 8 * sm : o_dummy, make_float2(w_m, qpub));
             lds_st<int2>(lds, (st & keep & valid_m) ? o_out + ((oslot0 + sm) % kOutSteps) * 8 : o_dummy,
                          make_int2(rule1 ? K.zero_idx : ki, __float_as_int(q_m)));
@@ -1284,7 +1380,10 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             }
             ctl_now = smin < B ? smin : -1;
             if (lane == 0) lds_st<int>(lds, L.off_ctl + 4 * (b & 1), ctl_now);
+            }
+#ifdef GPFQ_BLK_LATE_HDR
             if (b + 1 < K.nblk) prefetch_headers(hnext);          // the next tile's headers (landed a slot ago): the LDS is quiet now
+#endif
         } else {
             STAMP(dta);
             STAMP(dtb);
