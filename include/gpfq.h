@@ -127,6 +127,8 @@ int gpfq_set_main_kernel_events(void *start_event, void *stop_event);
  *   "blk_sweep_waves"   0 (default: by shape -- eleven for rows of 769..1024 samples, eight for shorter rows), 8 or 11: sweep
  *                  wavefronts per workgroup of the block form's 16-neuron four-step shapes (with the decision wavefront two or
  *                  three wavefronts per SIMD; same bits: DESIGN.md)
+ *   "blk_quad_waves"    0 (default: by shape), 7 or 8: sweep wavefronts per workgroup of the four-group narrow shapes on rows of at most
+ *                  768 samples (seven = two wavefronts per SIMD with the decision wavefront; the default for layers of at most 1024 neurons)
  *   "blk_quad_groups"   2 (default): layers of at most 2048 neurons on rows of 257..1024 samples take four neuron groups per sweep
  *                  wavefront with one or two neurons per lane (4 / 8 neurons per workgroup, dot products on the matrix unit);
  *                  1: only layers of 129..2048 neurons; 0: the one- / two-group shapes of round 3

@@ -72,12 +72,7 @@ __host__ __device__ constexpr int blk_hdr_bytes(int B) { return (64 + (2 * B - 1
 // up to 256 workgroups on the chip that EACH pull the whole record stream out of the L2s: 256 x 66 KiB per slot of four steps was
 // 10 TB/s, the bound of those shapes (profiles/r03/blk_phase_stamps.txt); a lane converts its two samples for two or four neurons.
 __host__ __device__ constexpr bool blk_row64(int G, int B) { return B > 1 && G > 1; }
-// (Tried in round 3: 128 bytes of skew between the rows of a record, so that the X and Xq rows of an update do not sit a multiple
-//  of 4 KiB apart.  SQ_LDS_BANK_CONFLICT did not move -- 3.2e8 against 3.4e8 cycles per launch: a 128-byte span of a row covers all
-//  32 banks, two rows per ds_read2st64_b64 are two passes wherever they lie -- and neither did the time.
-//  Round 4: the matrix form reads the float64 rows of FOUR records in one ds_read_b128 (lane = neuron group + 4 k): with records a
-//  multiple of 128 bytes apart (mod 256) groups 0 / 2 and 1 / 3 meet on the same banks.  Headers 64 bytes longer make those reads
-//  conflict-free -- measured: 3.08 against 3.01-3.02 ms on the same box, no gain; the LDS pipeline is not what a slot waits for.)
+// (record skews against LDS bank conflicts were measured twice and bought nothing: DESIGN_HISTORY.md, "gpfq_blk.hip notes" 1)
 __host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B, int G) { return blk_hdr_bytes(B) + (blk_row64(G, B) ? 16 : 12) * mp; }
 
 // ---- pre-pass ---------------------------------------------------------------------------------
@@ -306,29 +301,31 @@ template <> struct BlkSplit<4, 4>   { static constexpr int pw_[4] = {1, 1, 1, 1}
 template <> struct BlkSplit<32, 11> { static constexpr int pw_[11] = {3, 3, 3, 3, 3, 3, 3, 2, 3, 3, 3}; static constexpr const int *pw = pw_; };
 template <> struct BlkSplit<24, 11> { static constexpr int pw_[11] = {2, 2, 2, 2, 2, 2, 2, 1, 3, 3, 3}; static constexpr const int *pw = pw_; };
 
-// (round 4, measured with the split from the environment -- tools/split_sweep.sh: 48 pairs as 5,4,4,4,5,4,4,4,5,5,4 put 15 pairs on SIMD 0
-//  and 8 on SIMD 3; 4,5,4,4,5,4,4,5,4,4,5 -- 13 / 13 / 13 / 9 + the decision wavefront -- takes 4096 x 4096 on 1536 samples from 5.61 to
-//  4.83-5.04 ms and on 3000 samples from 12.76 to 11.52-11.65; 64 pairs: the short wavefront first, 6.57 -> 6.43 ms on 2048 samples and
-//  14.17 -> 13.71 on 4096, within 1 % in a second run; 5s and 6s mixed were no better)
+// (the eleven-wavefront 48- and 64-pair tables come from measured sweeps, tools/split_sweep.sh: DESIGN_HISTORY.md, "gpfq_blk.hip notes" 2)
 template <> struct BlkSplit<64, 11> { static constexpr int pw_[11] = {4, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6}; static constexpr const int *pw = pw_; };
 template <> struct BlkSplit<48, 11> { static constexpr int pw_[11] = {4, 5, 4, 4, 5, 4, 4, 5, 4, 4, 5}; static constexpr const int *pw = pw_; };
 template <> struct BlkSplit<16, 11> { static constexpr int pw_[11] = {2, 2, 1, 1, 2, 2, 1, 1, 1, 1, 2}; static constexpr const int *pw = pw_; };
 
-// (the four-group narrow shapes with FOUR sweep wavefronts of eight pairs were measured slower than with eight: 4096 x 512 on 1024 samples
-//  1.90 against 1.63 ms, 4096 x 1024 1.94 against 1.70 -- the sweeps are not negligible even there)
 // The four-group narrow shapes on rows of 769..1024 samples (G = 4, one or two neurons per lane, eight sweep wavefronts): their slot is the
-// chain of decisions, and every pair on the two sweep wavefronts that share the decision wavefront's SIMD lengthens it -- 4096 x 512 on
-// 1024 samples, splits from the environment (tools/split_sweep.sh, a diagnostic build): 4,4,4,4,4,4,4,4 1.72 ms; 3,4,4,5,3,4,4,5 1.61;
-// PairSplit<32> = 2,4,4,4,3,5,5,5 1.56; 2,5,5,4,2,5,5,4 **1.42**; 1,5,5,5,1,5,5,5 1.43-1.45.  (Leaving that SIMD to the decision
-// wavefront ALONE -- twelve wavefronts launched, the two SIMD mates ending at once, nine sweep wavefronts of 3-4 pairs on the other
-// three SIMDs -- was slower than the default: 1.75 against 1.63 ms, and 1.80 against 1.42 on 768-sample rows.  The shorter rows'
-// splits and the one- / two-group shapes' are at their optimum: equal splits are 5-15 % slower everywhere.)
+// chain of decisions, and every pair on the two sweep wavefronts that share the decision wavefront's SIMD lengthens it: 2,5,5,4,2,5,5,4 is
+// the measured optimum (1.42 against 1.56-1.72 ms for the other splits at 4096 x 512; four sweep wavefronts, or the decision wavefront
+// alone on its SIMD, are slower: DESIGN_HISTORY.md, "gpfq_blk.hip notes" 3).
 struct BlkSplitQuad32 { static constexpr int pw[8] = {2, 5, 5, 4, 2, 5, 5, 4}; };
 // (four neurons per workgroup on rows of 1537..2048 samples, two steps per slot -- cfg3's predictions layer, 4096 x 1000 on 2048 samples:
 //  1,2,2,3,2,2,2,2 2.70-2.75 ms against PairSplit<16>'s 2.81-2.87; the other splits tried there were slower than either)
 struct BlkSplitFour16 { static constexpr int pw[8] = {1, 2, 2, 3, 2, 2, 2, 2}; };
+// Round 5: the four-group narrow shapes on rows of at most 768 samples take SEVEN sweep wavefronts -- eight wavefronts per workgroup, two per
+// SIMD, 256 registers per wavefront; the decision wavefront, wavefront 7, shares SIMD 3 with sweep wavefront 3, which holds the fewest pairs.
+// 4096 x 1024 on 768 samples 1.39 -> 1.20-1.22 ms, on 512 samples 1.26 -> 1.19, cfg1's Dense(784 -> 128) 0.267 -> 0.239; rows of 769..1024
+// samples keep eight (their five-pair wavefronts at two per SIMD become the slot: 1.39 / 1.40-1.44 ms at 4096 x 512, 1.93 / 2.08 at 4096 x
+// 2048): profiles/r05/quad_seven_wavefronts_ab.txt.
+template <int S> struct BlkSplit7;
+template <> struct BlkSplit7<24> { static constexpr int pw[7] = {4, 4, 4, 1, 4, 4, 3}; };
+template <> struct BlkSplit7<16> { static constexpr int pw[7] = {3, 3, 2, 1, 3, 2, 2}; };
 template <int G, int S, int NSW, int NL> constexpr const int *blk_split()
 {
+    if constexpr (NSW == 7) return BlkSplit7<S>::pw;
+    else
     if constexpr (G == 4 && NL < 4 && S == 32 && NSW == 8) return BlkSplitQuad32::pw;
     else if constexpr (G == 1 && NL == 4 && S == 16 && NSW == 8) return BlkSplitFour16::pw;
     else return BlkSplit<S, NSW>::pw;
@@ -444,9 +441,8 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     // D's; 400-900 cycles each with the LDS busiest right after the barrier -- profiles/r03/blk_phase_stamps.txt).
     // Phase D on the matrix unit (round 4; G = 4 neuron groups x B = 4 steps x NL = 4 neurons per lane, row t + B as float64), and with it
     // the two phases FUSED pair by pair (kFused): see the slot loop.
-    // (NL = 4, 2 or 1 neurons per lane: 16, 8 or 4 per workgroup.  Tried with TWO steps per slot -- rows of 1025..2048 samples, half of every
-    //  4 x 4 x 4 block idle -- for layers of at most 2048 neurons: bit-identical and slower than the one- / two-group shapes, 4096 x 1000 on
-    //  2048 samples 3.23 against 2.86 ms, 4096 x 512 3.04 against 2.19: profiles/r04/README.md)
+    // (NL = 4, 2 or 1 neurons per lane: 16, 8 or 4 per workgroup; four steps per slot only -- with two, half of every 4 x 4 x 4 block idles and
+    //  the form measured slower than the one- / two-group shapes: DESIGN_HISTORY.md, "gpfq_blk.hip notes" 4)
     constexpr bool kMfmaD = G == 4 && B == 4 && blk_row64(G, B) && !kNoMfmaD;
     constexpr bool kFused = kMfmaD && !kNoFused;
     constexpr bool kPreloadAll = PW * B <= 8 && PW <= 5 && !kFused;
@@ -587,10 +583,9 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             // it cost a slot an LDS round trip nothing hid, a row of matrix instructions issued at the lowest priority while the
             // other wavefronts of the SIMD were still updating, and the fold behind it (profiles/r04/blk_phase_stamps.txt: 980 -
             // 2300 cycles per slot for 640 - 1150 cycles of matrix work).  The block's sixteen (w, q) are read once per slot.
-            // (Tried: the slot's first requests hoisted above the wait for the slow path's control word -- one LDS round trip instead of two
-            //  behind every barrier.  hipcc then held address registers across the slow path's code and spilled; a spill's reload puts an
-            //  s_waitcnt vmcnt(0) into the loop, which waits for the LDS-DMA pieces in flight: 2.98 -> 3.26 ms, and 5.0 ms with the
-            //  requests hoisted across the barrier.  profiles/r04/README.md)
+            // (The slot's first requests stay BEHIND the wait for the slow path's control word: hoisted in front of it -- with the slow
+            //  path inlined, round 4, or as an out-of-line call without a spill, round 5 -- the kernel is 10-20 % slower:
+            //  DESIGN_HISTORY.md, "gpfq_blk.hip notes" 5; profiles/r05/blk_variants_ab.txt.)
             const int rbm = tbase + ng * RB + o_d;
             float2 fwq[B][NL], x2n, q2n;
             double2 dcur;
@@ -627,9 +622,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             for (int p = 0; p < PW; ++p) {
                 // issue priority falls with progress through the slot (the laggard of a SIMD is served first, see below)
                 {
-                    // (tried, both measured slower: one level higher for the younger wavefronts of a SIMD, which it serves last at equal
-                    //  priority -- per pair 3.22 - 3.27 against 3.26 ms in the build that had it, the wave-uniform branches made hipcc
-                    //  spill; ONE constant level per wavefront by age instead of levels by progress 3.14 against 3.07 ms)
+                    // (priorities by wavefront AGE instead of progress measured slower: DESIGN_HISTORY.md, "gpfq_blk.hip notes" 6)
                     const int pr = 2 - (3 * p) / PW;
                     if (p == 0 || pr != 2 - (3 * (p - 1)) / PW) {
                         const int v = pr;
@@ -890,8 +883,6 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 #ifndef GPFQ_BLK_X_NOBAR               // timing experiment (WRONG results): no barrier between the slots, no slow path -- what free-running wavefronts could reach
         slot_barrier();
 #endif
-        // (tried: the sweeps of the narrow shapes sleeping 128 .. 512 cycles here, a head start for the decision wavefront's reads:
-        //  1.62 / 1.68 / 1.68 against 1.64 ms at 4096 x 512 -- nothing)
         STAMP(st5);
 #ifdef GPFQ_BLK_STAMPS
         acc_dma += st1 - st0; acc_u += st2 - st1; acc_d += st3 - st2; acc_w += st4 - st3; acc_b += st5 - st4;
@@ -1038,12 +1029,16 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     // The record HEADERS a slot's decisions read (row statistics + Gram band: a few hundred bytes per step, about thirty LDS reads
     // per lane) were requested from the tile in LDS right after the slot's barrier -- exactly when every sweep wavefront requests
     // its operands: 2300 of the decision wavefront's 3500 cycles per slot were that queue (profiles/r03/blk_phase_stamps.txt).
-    // They do not depend on anything the slot computes.  Tried first: global loads one slot ahead (the same bytes the LDS-DMA
-    // fetches) -- they queue in the CU's vector-memory path behind the DMA pieces of eight sweep wavefronts and came back just as
-    // late.  So the headers travel once more, compact (1.5 KiB per tile), by LDS-DMA into a ring of three buffers TWO slots ahead,
+    // They do not depend on anything the slot computes (global loads one slot ahead came back just as late, behind the DMA pieces:
+    // DESIGN_HISTORY.md, "gpfq_blk.hip notes" 8).  So the headers travel once more, compact (1.5 KiB per tile), by LDS-DMA into a ring of three buffers TWO slots ahead,
     // and this wavefront reads tile b + 1's at the END of slot b, when the LDS is quiet: after the barrier only the sweeps'
     // partial sums and the block's weights are read.
     const int smh = lane & (B - 1);                               // this lane's step of a block
+    // Seven-sweep-wavefront shapes (two wavefronts per SIMD, 256 registers each): the next tile's headers are requested behind the
+    // chain and arrive under the certification.  Everywhere else that placement costs registers this role does not have at three
+    // wavefronts per SIMD (hipcc spills 19-29 of them: cfg1's Dense(784 -> 128) 0.355 against 0.262 ms), and they are requested
+    // behind the slot's stores instead (below).
+    constexpr bool kHdrChain = NSW == 7;
     constexpr int BI = B > 1 ? B - 1 : 1, HDRB = blk_hdr_bytes(B);
     // Only what the predicted dot products need: the bounds (E1, E2, cb, ca, Ea) are read from the tile in LDS while the chain
     // computes -- they are consumed by the certification after it, off the critical path.
@@ -1060,11 +1055,6 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 #pragma unroll
         for (int j = 0; j + 1 < B; ++j) ghi[j] = lds_ld<double2>(lds, j < smh ? rm + 64 + 32 * (smh - j - 1) : L.off_zero);
     };
-    // (Round 4, tried and dropped: the next slot's first reads -- the sweeps' partial sums, the block's weights -- requested BEFORE the
-    //  barrier whenever an LDS counter says that every sweep wavefront has finished its slot (in a narrow layer they wait ~2000 cycles
-    //  for this wavefront).  Bit-identical; the prologue stamp fell from 2046 to 1424 cycles, the kernel from 2.08 to 1.99 ms in the
-    //  stamped build and by nothing measurable in the shipped one (1.65 against 1.56-1.64 ms at 4096 x 512 on 1024 samples): what this
-    //  wavefront waits for is not the LDS but its own ~700 instructions per slot at one issue per 5-6 cycles.)
     slot_barrier();                                               // (tile 0 and the headers of tiles 0, 1 landed)
     prefetch_headers(0);
     int hnext = 1;                                                // (b + 1) % 3
@@ -1171,15 +1161,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             const int rbm = tbase + sm * RB;
             const double2 o23 = lds_ld<double2>(lds, rbm + 16);
             const double rEa = lds_ld<double>(lds, rbm + 32);
-#ifndef GPFQ_BLK_NO_QUICK_CERT
             const double2 o67 = lds_ld<double2>(lds, rbm + 48);   // (sE1, sE2): the quick certification's bound (below)
-#else
-            double2 ep[B], ei_[BI];
-#pragma unroll
-            for (int j = 0; j < B; ++j) ep[j] = lds_ld<double2>(lds, rbm + 64 + 32 * (B + sm - j - 1) + 16);
-#pragma unroll
-            for (int j = 0; j + 1 < B; ++j) ei_[j] = lds_ld<double2>(lds, j < sm ? rbm + 64 + 32 * (sm - j - 1) + 16 : L.off_zero);
-#endif
             STAMP(dta);
             // ---- (2) the chain
             const double u_a0 = K.uni_a0, u_step = K.uni_step, u_inv = K.uni_inv, u_c0 = K.uni_c0, u_kmax = (double)(M - 1);
@@ -1195,9 +1177,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                     // narrow shapes (4096 x 512 on 1024 samples 1.416 -> 1.38-1.39 ms, same box).  Not in the 16-neuron shapes, whose
                     // slot is the sweeps': there the same change measured 2.5 % SLOWER (3.04-3.10 against 2.98-3.01 ms).
                     // (A tie goes to the lower index as argmin does; a decision that close is never certified anyway.)
-                    // (Tried on top and dropped: the chain restated for these alphabets -- broadcasts, the weight-only decision of rule
-                    //  (ii) and rule (i) formed before the chain, quotient as one fma, q selected as float64 without the conversion:
-                    //  bit-identical and SLOWER, 1.65 against 1.42 ms; what hipcc makes of the straightforward form is the better chain.)
+                    // (the chain restated by hand for these alphabets was slower: DESIGN_HISTORY.md, "gpfq_blk.hip notes" 10)
                     const bool up = tt > sym_hb, mid = tt > -sym_hb;
                     kd = up ? u_kmax : (mid ? 1.0 : 0.0);
                     return up ? sym_a32 : (mid ? 0.f : -sym_a32);
@@ -1211,10 +1191,6 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             };
             float q32s[B];
             double qd[B];
-#ifdef GPFQ_BLK_NO_QUICK_CERT
-            double du_m = 0.0;
-            unsigned any_run = anyP, any_m = anyP;
-#endif
 #pragma unroll
             for (int s = 0; s < B; ++s) {
                 // (1/nrm^2, G and <Xq_s, Xq_j> of step s from the sub-lane that owns it)
@@ -1230,29 +1206,19 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                 q32 = rden_s == 0.0 ? 0.f : q32;                  // rule (i): the pre-pass stores 1 / nrm^2 = 0 for nrm < 1e-16
                 q32s[s] = q32;
                 qd[s] = (double)q32;
-#ifdef GPFQ_BLK_NO_QUICK_CERT
-                du_m = sm == s ? du : du_m;
-                any_m = sm == s ? any_run : any_m;
-                any_run |= __float_as_uint(wc[s]) | __float_as_uint(q32);
-#endif
             }
-#ifndef GPFQ_BLK_NO_QUICK_CERT
             // The own step's predicted dot product, from the lane's OWN band entries (zeros beyond the own step: a product with zero
             // adds nothing), in the chain's order -- the same bits as the chain's du of step sm, without selecting it out of the four
             // (round 5: two conditional moves per step of the chain, on the wavefront whose instruction count is a narrow layer's time).
             double du_m = Am;
 #pragma unroll
             for (int j = 0; j + 1 < B; ++j) du_m = fma(-qd[j], hi_[j].y, du_m);
-#endif
-#ifndef GPFQ_BLK_LATE_HDR
-            // The NEXT tile's headers (landed a slot ago) are requested here, behind the chain: the LDS is quiet (in a narrow layer the
-            // sweeps are parked at the barrier) and the reads return under the certification.  Until round 4 they were the last thing
-            // before the slot's barrier, whose s_waitcnt lgkmcnt(0) then waited out their round trip on the slot's critical path.
-            // (Requested at the TOP of the slot instead they land in the post-barrier burst and delay the partial sums the chain
-            //  waits for: 1.49 against 1.38 ms at 4096 x 512 on 1024 samples, profiles/r05/blk_variants_ab.txt.)
-            if (b + 1 < K.nblk) prefetch_headers(hnext);
-            __builtin_amdgcn_sched_barrier(0);
-#endif
+            // (seven-sweep-wavefront shapes, two wavefronts per SIMD and 256 registers each: the next tile's headers are requested
+            //  HERE, behind the chain, and arrive under the certification; see kHdrChain)
+            if constexpr (kHdrChain) {
+                if (b + 1 < K.nblk) prefetch_headers(hnext);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // ---- (3) certification of the own step
             const bool valid_m = sm < nvalid;
             const float w_m = valid_m ? w_own_raw : 0.f;
@@ -1266,7 +1232,6 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             const float qk32 = pick(tt_m, kd_m);                  // (the chain's arithmetic on the chain's operands: the same bits)
             const int ki = (int)kd_m;
             double a_lo, a_k, a_hi;                               // a[k-1], a[k], a[k+1] (-inf / +inf beyond the ends)
-#ifndef GPFQ_BLK_TABLE_NEIGHBOURS
             if constexpr (SYM) {
                 // {-a, 0, a} / {-a, a}, exactly symmetric in float64 (blk_sym_a): the members ARE (k - (M - 1) / 2) * gap with gap = a or
                 // 2 a, every one of these products and sums exact -- no table read behind the pick (a dependent LDS round trip on the
@@ -1277,7 +1242,6 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                 a_lo = ki == 0 ? -kInfD : a_k - gap;
                 a_hi = ki == M - 1 ? kInfD : a_k + gap;
             } else
-#endif
             {
                 const int oe = L.off_e + 8 * (1 + ki);            // table with two sentinels on either side
                 a_lo = lds_ld<double>(lds, oe); a_k = lds_ld<double>(lds, oe + 8); a_hi = lds_ld<double>(lds, oe + 16);
@@ -1294,7 +1258,6 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             // never accepts: eps_q > 0 whenever the row has any overlap with its band).  eps_q >= eps term by term, so a decision
             // the quick test certifies is one the exact test certifies.
             bool ok;
-#ifndef GPFQ_BLK_NO_QUICK_CERT
             float wmx = fmaxf(fabsf(wprev[0]), fabsf(wc[0]));
 #pragma unroll
             for (int j = 1; j < B; ++j) wmx = fmaxf(wmx, fmaxf(fabsf(wprev[j]), fabsf(wc[j])));
@@ -1304,15 +1267,12 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             const bool far_q = (d_lo - d_k > delta2_q) & (d_hi - d_k > delta2_q);
             ok = rule1 | (far_q & sure_q) | !valid_m;
             if (__ballot(!ok) != 0ull)
-#endif
             {
-#ifndef GPFQ_BLK_NO_QUICK_CERT
                 double2 ep[B], ei_[BI];
 #pragma unroll
                 for (int j = 0; j < B; ++j) ep[j] = lds_ld<double2>(lds, rbm + 64 + 32 * (B + sm - j - 1) + 16);
 #pragma unroll
                 for (int j = 0; j + 1 < B; ++j) ei_[j] = lds_ld<double2>(lds, j < sm ? rbm + 64 + 32 * (sm - j - 1) + 16 : L.off_zero);
-#endif
 #pragma unroll
                 for (int j = 0; j < B; ++j) {
                     ePm = fma(fabs((double)wprev[j]), ep[j].x, ePm); ePm = fma(fabs((double)qprev[j]), ep[j].y, ePm);
@@ -1320,11 +1280,9 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                 double eps = ePm;
 #pragma unroll
                 for (int j = 0; j + 1 < B; ++j) { eps = fma(fabs(wd[j]), ei_[j].x, eps); eps = fma(fabs(qd[j]), ei_[j].y, eps); }
-#ifndef GPFQ_BLK_NO_QUICK_CERT
                 unsigned any_m = anyP;                                // any nonzero pending (w, q) before the own step
 #pragma unroll
                 for (int j = 0; j + 1 < B; ++j) any_m |= j < sm ? (__float_as_uint(wc[j]) | __float_as_uint(q32s[j])) : 0u;
-#endif
                 // (each of the up to 2B-1 pending increments may lose up to Ea = 2^-149 sum|Xq_t| to subnormal float32 products)
                 eps += ((any_m << 1) != 0u) ? (double)(2 * B - 1) * rEa : 0.0;
                 const bool du_exact = eps == 0.0;                     // every pending increment orthogonal to Xq_t element-wise
@@ -1341,7 +1299,6 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             const unsigned long long bad = __ballot(!ok);
             const float q_m = rule1 ? 0.f : qk32;
             const bool st = r < B;                                // (sub-lanes B.. repeat sub-lanes 0..B-1)
-#ifndef GPFQ_BLK_NO_QUICK_CERT
             if (bad == 0ull) {
                 // every step of every neuron certified (all but about one slot in 10^4): no chain stops, nothing to select
                 STAMP(dtb);
@@ -1354,7 +1311,6 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                 ctl_now = -1;
                 if (lane == 0) lds_st<int>(lds, L.off_ctl + 4 * (b & 1), -1);
             } else
-#endif
             {
             const unsigned field = (unsigned)(bad >> (lane & ~(R - 1))) & ((1u << B) - 1u);
             stop = field ? __builtin_ctz(field) : B;
@@ -1381,9 +1337,18 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             ctl_now = smin < B ? smin : -1;
             if (lane == 0) lds_st<int>(lds, L.off_ctl + 4 * (b & 1), ctl_now);
             }
-#ifdef GPFQ_BLK_LATE_HDR
-            if (b + 1 < K.nblk) prefetch_headers(hnext);          // the next tile's headers (landed a slot ago): the LDS is quiet now
-#endif
+            // The next tile's headers (landed a slot ago) are requested HERE, when the LDS is quiet -- but no longer waited for at the
+            // slot's barrier: the stores above must have reached the LDS before the barrier, the reads need not have returned.  So
+            // the stores are waited for first (an LDS store completes in tens of cycles), then the reads are issued, and this
+            // wavefront's barrier is a bare s_barrier: the reads' round trip -- which every sweep wavefront of a narrow layer sat
+            // out at that barrier: the decision wavefront IS their slot -- overlaps the barrier and the next slot's first reads.
+            // (Round 5.  Requested behind the chain instead they hide as well, but 32 more live registers through the certification
+            //  made hipcc spill 19-29 registers in this role at three wavefronts per SIMD: cfg1's Dense(784 -> 128) 0.355 against
+            //  0.262 ms; requested at the top of the slot they land in the post-barrier burst: +8 %.  profiles/r05/.)
+            if constexpr (!kHdrChain) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (b + 1 < K.nblk) prefetch_headers(hnext);
+            }
         } else {
             STAMP(dta);
             STAMP(dtb);
@@ -1483,7 +1448,8 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 #ifdef GPFQ_BLK_X_NOBAR
         ctl_now = -1;
 #else
-        slot_barrier();
+        if (kHdrChain || b >= K.nblk) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the last slot's only store; chain-prefetch shapes: the stores)
+        asm volatile("s_barrier" ::: "memory");
 #endif
         STAMP(dt2);
 #ifdef GPFQ_BLK_STAMPS
@@ -1633,6 +1599,8 @@ void blk_set_sweep_waves(int nw) { g_blk_nw.store(nw == 11 ? 11 : (nw == 8 ? 8 :
 // each -- the sweeps are halved by giving a workgroup 8 neurons instead of 16 (4096 x 2048, m = 1024: 4.0 -> 2.9 ms).
 static std::atomic<int> g_blk_quad{2};    // four neuron groups x 1 / 2 neurons per lane for layers of at most 2048 neurons on rows of 257..1024 samples (1: 129..2048 only)
 void blk_set_quad_groups(int on) { g_blk_quad.store(on < 0 ? 0 : (on > 2 ? 2 : on), std::memory_order_relaxed); }
+static std::atomic<int> g_blk_quad_nw{0}; // sweep wavefronts of the four-group narrow shapes on rows of at most 768 samples: 7, 8, or 0 = by shape
+void blk_set_quad_waves(int nw) { g_blk_quad_nw.store(nw == 7 ? 7 : (nw == 8 ? 8 : 0), std::memory_order_relaxed); }
 static std::atomic<int> g_blk_pairs{1};   // two-neuron workgroups for layers of at most 512 neurons
 void blk_set_pair_groups(int on) { g_blk_pairs.store(on ? 1 : 0, std::memory_order_relaxed); }
 
@@ -1659,8 +1627,10 @@ static BlkShape blk_shape(int64_t m, int64_t C)
     const int quad = g_blk_quad.load(std::memory_order_relaxed);         // 2 (default): every layer of at most 2048 neurons; 1: 129..2048 only; 0: off
     if (quad && C <= 2048 && (quad >= 2 || C > 128) && m > 256 && m <= 1024) {
         const int nl = C > 1024 ? 2 : 1;
-        if (m <= 512) return {4, 16, 4, 512, 8, nl};
-        if (m <= 768) return {4, 24, 4, 768, 8, nl};
+        const int qw = g_blk_quad_nw.load(std::memory_order_relaxed);
+        const int qnw = qw ? qw : (nl == 1 ? 7 : 8);                  // (seven sweep wavefronts: see BlkSplit7; rows beyond 768 samples keep eight)
+        if (m <= 512) return {4, 16, 4, 512, qnw, nl};
+        if (m <= 768) return {4, 24, 4, 768, qnw, nl};
         return {4, 32, 4, 1024, 8, nl};
     }
     if (C <= 128 && g_blk_pairs.load(std::memory_order_relaxed) != 0 && g_blk_single.load(std::memory_order_relaxed) != 0) {
@@ -1855,6 +1825,10 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // (four neuron groups with one or two neurons per lane: the narrow forms of the fused matrix shape)
+    if (sh.G == 4 && sh.NL < 4 && sh.NW == 7) {                    // (rows of at most 768 samples: blk_shape)
+        if (sh.S == 16) return sh.NL == 1 ? launch_blk_inst<4, 16, 4, 7, 1>(a, sh, stream) : launch_blk_inst<4, 16, 4, 7, 2>(a, sh, stream);
+        return sh.NL == 1 ? launch_blk_inst<4, 24, 4, 7, 1>(a, sh, stream) : launch_blk_inst<4, 24, 4, 7, 2>(a, sh, stream);
+    }
     if (sh.G == 4 && sh.NL < 4) {
         if (sh.S == 16) return sh.NL == 1 ? launch_blk_inst<4, 16, 4, 8, 1>(a, sh, stream) : launch_blk_inst<4, 16, 4, 8, 2>(a, sh, stream);
         if (sh.S == 24) return sh.NL == 1 ? launch_blk_inst<4, 24, 4, 8, 1>(a, sh, stream) : launch_blk_inst<4, 24, 4, 8, 2>(a, sh, stream);

@@ -217,6 +217,10 @@ int gpfq_set_option(const char *key, int value)
     if (!std::strcmp(key, "blk_pair_groups")) { gpfq::blk_set_pair_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_single_groups")) { gpfq::blk_set_single_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_quad_groups")) { gpfq::blk_set_quad_groups(value); return GPFQ_OK; }
+    if (!std::strcmp(key, "blk_quad_waves")) {
+        if (value != 0 && value != 7 && value != 8) return fail(GPFQ_ERR_INVALID_ARG, "blk_quad_waves must be 0 (by shape), 7 or 8");
+        gpfq::blk_set_quad_waves(value); return GPFQ_OK;
+    }
     if (!std::strcmp(key, "blk_sweep_waves")) {
         if (value != 0 && value != 8 && value != 11) return fail(GPFQ_ERR_INVALID_ARG, "blk_sweep_waves must be 0 (by shape), 8 or 11");
         gpfq::blk_set_sweep_waves(value); return GPFQ_OK;
