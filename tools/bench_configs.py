@@ -33,7 +33,7 @@ def time_dense(name, N, m, C, bits, scalar, dev, check=8):
     unit = np.linspace(-1, 1, int(round(2 ** bits)))
     best = 1e9
     alphabet, rad = layer.layer_alphabet(Wd, unit, scalar)       # (before the timed region, as the class surface forms it: see time_conv)
-    for _ in range(3):
+    for _ in range(5):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         if "--alphabet-in-layer" in sys.argv:
             alphabet, rad = layer.layer_alphabet(Wd, unit, scalar)
@@ -51,7 +51,7 @@ def time_dense(name, N, m, C, bits, scalar, dev, check=8):
     return rec
 
 
-def time_conv(name, cin, cout, hw, n, bits, scalar, dev, check=2, k=3, stride=1, padding="SAME", reps=2, first=False):
+def time_conv(name, cin, cout, hw, n, bits, scalar, dev, check=2, k=3, stride=1, padding="SAME", reps=4, first=False):
     g = torch.Generator(device=dev).manual_seed(2)
     act_w = torch.rand((n, hw, hw, cin), device=dev, generator=g)
     # first: the layer is the network's first, both networks see the data itself (scripts/quantized_network.py:478-481)
@@ -154,9 +154,9 @@ def main():
         # one layer of each spatial size (the net has 3/4/6/3 of the 3x3 ones) + conv1 (7x7/2 on the padded 230x230 input)
         n = 4096
         recs.append(time_conv("cfg5 ResNet50 conv1 7x7/2 VALID (3->64 @230x230 padded input), 4096 images, ternary, scalar 3",
-                              3, 64, 230, n, np.log2(3), 3, dev, k=7, stride=2, padding="VALID", reps=2))
+                              3, 64, 230, n, np.log2(3), 3, dev, k=7, stride=2, padding="VALID", reps=4))
         recs.append(time_conv("cfg5 ResNet50 conv1 7x7/2 VALID as the FIRST layer it is (both networks see the images), 4096 images, ternary, scalar 3 [not in the total]",
-                              3, 64, 230, n, np.log2(3), 3, dev, k=7, stride=2, padding="VALID", reps=2, first=True))
+                              3, 64, 230, n, np.log2(3), 3, dev, k=7, stride=2, padding="VALID", reps=4, first=True))
         conv1_ms = recs[-2]["ms"]
         # every other conv layer of the net by distinct shape (cin, cout, input size, kernel, stride) x how often it occurs:
         # 16 3x3 layers, 36 1x1 layers (four of them the stride-2 first convolutions of a stage, four the stride-2 shortcuts)
@@ -167,7 +167,7 @@ def main():
         total5, count5 = conv1_ms, 1
         for cin, cout, hw, k, stride, times in inventory:
             r = time_conv(f"cfg5 ResNet50 {k}x{k}/{stride} conv ({cin}->{cout} @{hw}x{hw}) x{times}, 4096 images, ternary, scalar 3",
-                          cin, cout, hw, n, np.log2(3), 3, dev, k=k, stride=stride, reps=3)
+                          cin, cout, hw, n, np.log2(3), 3, dev, k=k, stride=stride, reps=5)
             r["occurrences"] = times
             total5 += times * r["ms"]; count5 += times
             recs.append(r)
@@ -184,7 +184,7 @@ def main():
                                       (2048, 128, 5008, 3.0, 4), (784, 128, 512, L4, 5), (4096, 4096, 8192, L3, 3)]:
             recs.append(time_shape(N, C, m, bits, scalar, dev))
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(dict(note="tools/bench_configs.py on one MI355X; best of 2-3 runs per layer; whole layer driver "
+    json.dump(dict(note="tools/bench_configs.py on one MI355X; best of 4-5 runs per layer; whole layer driver "
                         "(norms, kernel, assemble" + (", alphabet median" if "--alphabet-in-layer" in sys.argv else
                                                       "; the alphabet's median is formed up front, as the class surface does since round 4")
                         + ") with inputs resident in HBM", records=recs),
