@@ -320,6 +320,7 @@ struct BlkSplitFour16 { static constexpr int pw[8] = {1, 2, 2, 3, 2, 2, 2, 2}; }
 // samples keep eight (their five-pair wavefronts at two per SIMD become the slot: 1.39 / 1.40-1.44 ms at 4096 x 512, 1.93 / 2.08 at 4096 x
 // 2048): profiles/r05/quad_seven_wavefronts_ab.txt.
 template <int S> struct BlkSplit7;
+template <> struct BlkSplit7<32> { static constexpr int pw[7] = {5, 5, 5, 2, 5, 5, 5}; };
 template <> struct BlkSplit7<24> { static constexpr int pw[7] = {4, 4, 4, 1, 4, 4, 3}; };
 template <> struct BlkSplit7<16> { static constexpr int pw[7] = {3, 3, 2, 1, 3, 2, 2}; };
 template <int G, int S, int NSW, int NL> constexpr const int *blk_split()
@@ -587,14 +588,21 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             //  path inlined, round 4, or as an out-of-line call without a spill, round 5 -- the kernel is 10-20 % slower:
             //  DESIGN_HISTORY.md, "gpfq_blk.hip notes" 5; profiles/r05/blk_variants_ab.txt.)
             const int rbm = tbase + ng * RB + o_d;
-            float2 fwq[B][NL], x2n, q2n;
+            // Operand rows are requested PF pair-steps ahead of their use: one everywhere -- except in the seven-sweep-wavefront shapes (two
+            // wavefronts per SIMD, 256 registers), where a pair-step's handful of instructions no longer covers an LDS round trip and the
+            // sweep's own chain of them would become the slot: two (round 5).
+            constexpr int PF = NSW == 7 ? 2 : 1, NPS = PW * B;
+            float2 fwq[B][NL], xbuf[PF], qbuf[PF];
             double2 dcur;
+            auto row_off = [&](int i, bool q) { return tbase + (i % B) * RB + (q ? o_q : o_x) + 8 * (i / B) * KQ; };   // pair-step i = pair * B + step
             auto first_requests = [&]() {
 #pragma unroll
                 for (int s = 0; s < B; ++s)
 #pragma unroll
                     for (int n = 0; n < NL; ++n) fwq[s][n] = lds_ld<float2>(lds, o_wq + pbq + (n * B + s) * 8);
-                x2n = lds_ld<float2>(lds, tbase + o_x); q2n = lds_ld<float2>(lds, tbase + o_q);
+#pragma unroll
+                for (int i = 0; i < PF; ++i)
+                    if (i < NPS) { xbuf[i] = lds_ld<float2>(lds, row_off(i, false)); qbuf[i] = lds_ld<float2>(lds, row_off(i, true)); }
                 dcur = lds_ld<double2>(lds, rbm);
             };
             first_requests();
@@ -634,11 +642,13 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
                 if (p > 0) dcur = lds_ld<double2>(lds, rbm + DB * p * KQ);       // (consumed under the NEXT pair's updates, or at the end)
 #pragma unroll
                 for (int st = 0; st < B; ++st) {
-                    const float2 x2 = x2n, q2 = q2n;
-                    const int sn = st + 1 < B ? st + 1 : 0, pn = st + 1 < B ? p : p + 1;
-                    if (pn < PW) {
-                        x2n = lds_ld<float2>(lds, tbase + sn * RB + o_x + 8 * pn * KQ);
-                        q2n = lds_ld<float2>(lds, tbase + sn * RB + o_q + 8 * pn * KQ);
+                    const int ips = p * B + st;                                  // this pair-step; its operands sit in buffer ips % PF
+                    const float2 x2 = xbuf[ips % PF], q2 = qbuf[ips % PF];
+                    const int pn = (ips + 1) / B, sn = (ips + 1) % B;            // (the GPFQ_BLK_X_LDS2 experiment re-reads the next one)
+                    (void)pn; (void)sn;
+                    if (ips + PF < NPS) {
+                        xbuf[ips % PF] = lds_ld<float2>(lds, row_off(ips + PF, false));
+                        qbuf[ips % PF] = lds_ld<float2>(lds, row_off(ips + PF, true));
                     }
                     if (p < PTS) {
 #pragma unroll
@@ -1631,7 +1641,7 @@ static BlkShape blk_shape(int64_t m, int64_t C)
         const int qnw = qw ? qw : (nl == 1 ? 7 : 8);                  // (seven sweep wavefronts: see BlkSplit7; rows beyond 768 samples keep eight)
         if (m <= 512) return {4, 16, 4, 512, qnw, nl};
         if (m <= 768) return {4, 24, 4, 768, qnw, nl};
-        return {4, 32, 4, 1024, 8, nl};
+        return {4, 32, 4, 1024, qw == 7 ? 7 : 8, nl};                 // (rows of 769..1024 samples: seven only when the option forces it)
     }
     if (C <= 128 && g_blk_pairs.load(std::memory_order_relaxed) != 0 && g_blk_single.load(std::memory_order_relaxed) != 0) {
         if (m > 256 && m <= 512) return {1, 4, 4, 512, 4, 1};
@@ -1827,7 +1837,8 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     // (four neuron groups with one or two neurons per lane: the narrow forms of the fused matrix shape)
     if (sh.G == 4 && sh.NL < 4 && sh.NW == 7) {                    // (rows of at most 768 samples: blk_shape)
         if (sh.S == 16) return sh.NL == 1 ? launch_blk_inst<4, 16, 4, 7, 1>(a, sh, stream) : launch_blk_inst<4, 16, 4, 7, 2>(a, sh, stream);
-        return sh.NL == 1 ? launch_blk_inst<4, 24, 4, 7, 1>(a, sh, stream) : launch_blk_inst<4, 24, 4, 7, 2>(a, sh, stream);
+        if (sh.S == 24) return sh.NL == 1 ? launch_blk_inst<4, 24, 4, 7, 1>(a, sh, stream) : launch_blk_inst<4, 24, 4, 7, 2>(a, sh, stream);
+        return sh.NL == 1 ? launch_blk_inst<4, 32, 4, 7, 1>(a, sh, stream) : launch_blk_inst<4, 32, 4, 7, 2>(a, sh, stream);
     }
     if (sh.G == 4 && sh.NL < 4) {
         if (sh.S == 16) return sh.NL == 1 ? launch_blk_inst<4, 16, 4, 8, 1>(a, sh, stream) : launch_blk_inst<4, 16, 4, 8, 2>(a, sh, stream);
