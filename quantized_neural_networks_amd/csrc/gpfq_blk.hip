@@ -209,11 +209,23 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
     }
 }
 
+// Who writes a block's outputs from the LDS ring to memory (round 5).  The sweep wavefronts, block b - 1 at the top of slot b, one wavefront per
+// slot in turn, wherever the decision wavefront IS the slot -- the four-group shapes with one neuron per lane: its own flush (eight slots'
+// worth at a time, 64-bit address arithmetic on operands hipcc spills at three wavefronts per SIMD) cost those shapes 9-12 % while the sweeps
+// idle at the barrier.  Everywhere else the decision wavefront, which has the slack there (profiles/r05/sweep_side_flush*.txt).
+#if defined(GPFQ_BLK_SWEEP_FLUSH_ALL)          // diagnostic builds: every shape one way or the other
+template <int G, int NL> constexpr bool blk_sweep_flush() { return true; }
+#elif defined(GPFQ_BLK_SWEEP_FLUSH_NONE)
+template <int G, int NL> constexpr bool blk_sweep_flush() { return false; }
+#else
+template <int G, int NL> constexpr bool blk_sweep_flush() { return G == 4 && NL == 1; }
+#endif
+
 // LDS carve-up (byte offsets), shared by host and device.
 struct BlkLds {
     int tile_bytes, tile_pitch, off_w, off_d, off_wq, off_x2, off_e, off_out, off_ctl, off_zero, off_hr, hr_pitch, total;
 };
-constexpr int kOutSteps = 32;                                    // steps of outputs staged in LDS between flushes
+constexpr int kOutSteps = 32;                                    // steps of outputs staged in LDS (a ring: block b's leave it in slot b + 1)
 
 // Partial sums have one slot per sweep wavefront, rounded up to the decision wavefront's 64 / NB sub-lanes per neuron
 // (sub-lane r adds slots r, r + R, ...; a slot no wavefront writes stays zero).
@@ -232,7 +244,7 @@ __host__ __device__ inline BlkLds blk_lds(int mp, int nb, int B, int nsw, int G)
     L.off_wq = o;   o += 2 * nb * B * 8;                        // [2][NB][B] (w, q) f32 decisions of the block
     L.off_x2 = o;   o += nw * nb * 16;                          // [NW][NB] (f64, f64)   exact partials (slow path)
     L.off_e = o;    o += 68 * 8;                                // [2 + 64 + 2] f64      -inf, -inf, alphabet, +inf, +inf
-    L.off_out = o;  o += nb * kOutSteps * 8;                    // [NB][32] (idx i32, q f32) until the flush
+    L.off_out = o;  o += nb * kOutSteps * 8;                    // [NB][32] (idx i32, q f32) until a sweep wavefront writes them out
     L.off_ctl = o;  o += 16;                                    // [2] (by slot parity) smallest step a neuron of the block is stopped at, -1: none; [2] dummy
     L.off_zero = o; o += 32;                                    // zeros (band entries a step does not have)
     o = (o + 15) & ~15;
@@ -539,6 +551,17 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 #ifdef GPFQ_BLK_STAMPS
         if (b) acc_t += st0 - st5;                                // from the barrier to the top of the next slot: control word, next operands
 #endif
+        // (blk_sweep_flush shapes) block b - 1's outputs -- final since the barrier, slow path included -- go from the LDS ring to memory
+        // here, by one sweep wavefront per slot in turn: lane = (neuron, step), a byte and a float each
+        if (blk_sweep_flush<G, NL>() && b >= 1 && wave == b % NSW && lane < NB * B) {
+            const int nn = lane / B, sidx = lane % B;
+            const int64_t t = (int64_t)(b - 1) * B + sidx, jn = jbase + nn;
+            if (t < N && jn < K.C) {
+                const int2 v = lds_ld<int2>(lds, L.off_out + (nn * kOutSteps + (int)(t % kOutSteps)) * 8);
+                if (K.qidx) K.qidx[jn * N + t] = (int8_t)v.x;
+                if (K.Qt) K.Qt[jn * N + t] = __int_as_float(v.y);
+            }
+        }
         if (b + 1 < nslots) load_weights(b + 1);                  // the block's weights: one piece
         load_headers(b + 2, hbuf); hbuf = hbuf == 2 ? 0 : hbuf + 1;
         const int bn = b + 1 < nslots ? b + 1 : b;                // (the last slot rewrites its own tile with the same bytes)
@@ -995,8 +1018,9 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         return mn;
     };
 
-    // Steps [t0, t1) of this workgroup's outputs from the LDS ring to memory: a lane takes 8 consecutive steps of one
-    // neuron (32-byte runs of indices, 128-byte runs of values per neuron)
+    // (not blk_sweep_flush shapes) Steps [t0, t1) of this workgroup's outputs from the LDS ring to memory: a lane takes 8 consecutive steps
+    // of one neuron (32-byte runs of indices, 128-byte runs of values per neuron)
+    constexpr bool kOwnFlush = !blk_sweep_flush<G, NL>();
     auto flush = [&](int64_t t0, int64_t t1) {
         for (int e = lane; e < NB * (kOutSteps / 8); e += 64) {
             const int nn = e / (kOutSteps / 8), c = e % (kOutSteps / 8);
@@ -1035,6 +1059,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             }
         }
     };
+    int64_t flushed = 0, flush_hi = 0;                            // steps [0, flushed) are in memory; [flushed, flush_hi) are due
 
     // The record HEADERS a slot's decisions read (row statistics + Gram band: a few hundred bytes per step, about thirty LDS reads
     // per lane) were requested from the tile in LDS right after the slot's barrier -- exactly when every sweep wavefront requests
@@ -1073,13 +1098,12 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     // ahead of them it takes 6800 and the sweeps, which have the slack, fill the gaps.
     __builtin_amdgcn_s_setprio(3);
 
-    int64_t flushed = 0, flush_hi = 0;                            // steps [0, flushed) are in memory; [flushed, flush_hi) are due
     unsigned long long dt0 = 0, dt1 = 0, dt2 = 0, dta = 0, dtb = 0, dacc_work = 0, dacc_bar = 0, dacc_pro = 0, dacc_chain = 0, dacc_tail = 0;
     (void)dt0; (void)dt1; (void)dt2; (void)dta; (void)dtb; (void)dacc_work; (void)dacc_bar; (void)dacc_pro; (void)dacc_chain; (void)dacc_tail;
     for (int b = 0; b < nslots; ++b) {
         STAMP(dt0);
 #ifdef GPFQ_BLK_STAMPS
-        if (b) dacc_tail += dt0 - dt2;                            // after the barrier: header prefetch, output flush
+        if (b) dacc_tail += dt0 - dt2;                            // after the barrier
 #endif
         const int tbase = (b & 1) * L.tile_pitch;
         const int cbq = (b & 1) * NB * B * 8;
@@ -1124,9 +1148,11 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 #pragma unroll
             for (int s = 0; s < B; ++s) wc[s] = lds_ld<float>(lds, o_w + (b & 1) * NB * B * 4 + 4 * s);
             const float w_own_raw = lds_ld<float>(lds, o_w + (b & 1) * NB * B * 4 + 4 * sm);
-            if (flush_hi > flushed) {                             // (outputs of earlier slots: under the latency of the reads above)
-                flush(flushed, flush_hi);
-                flushed = flush_hi;
+            if constexpr (kOwnFlush) {
+                if (flush_hi > flushed) {                         // (outputs of earlier slots: under the latency of the reads above)
+                    flush(flushed, flush_hi);
+                    flushed = flush_hi;
+                }
             }
             // (the record headers: requested before the last barrier, see prefetch_headers)
             double2 hp[B], hi_[BI];
@@ -1526,14 +1552,18 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             slot_barrier();                                       // chains resumed, control word rewritten
         }
 
-        // block b is final: it becomes "the previous block"; the output ring is flushed when it is full -- at the top of the next
-        // slot, AFTER that slot's LDS reads have been requested (they are what the slot waits for)
+        // block b is final: it becomes "the previous block"; its outputs leave the LDS ring in the next slot (a sweep wavefront's job) or,
+        // where this wavefront flushes, when the ring is full -- at the top of a slot, behind that slot's first LDS reads
 #pragma unroll
         for (int j = 0; j < B; ++j) { wprev[j] = (b < K.nblk) ? wc[j] : 0.f; qprev[j] = (b < K.nblk) ? qc[j] : 0.f; }
-        const int64_t done = min((int64_t)(b + 1) * B, N);
-        if (b < K.nblk && (done - flushed >= kOutSteps - B + 1 || done == N)) { flush_hi = done; }
+        if constexpr (kOwnFlush) {
+            const int64_t done = min((int64_t)(b + 1) * B, N);
+            if (b < K.nblk && (done - flushed >= kOutSteps - B + 1 || done == N)) { flush_hi = done; }
+        }
     }
-    if (flush_hi > flushed) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); flush(flushed, flush_hi); }
+    if constexpr (kOwnFlush) {
+        if (flush_hi > flushed) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); flush(flushed, flush_hi); }
+    }
 
     if (K.fallback_count && n_fallback) atomicAdd(K.fallback_count, n_fallback);   // rare
 #ifdef GPFQ_BLK_STAMPS
