@@ -83,17 +83,21 @@ __host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B, int G) { 
 template <int B, bool R64>
 __global__ void __launch_bounds__(256)
 gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t N, int m, int mp,
-                     const float *__restrict__ nrm32, char *__restrict__ recs, char *__restrict__ hdrs, float sym_a)
+                     const float *__restrict__ nrm32, char *__restrict__ recs, char *__restrict__ hdrs, float sym_a,
+                     int nsl, int64_t slice_bytes)
 {
+    // (cluster form, nsl > 1: mp = nsl record rows of mp / nsl samples each, slice s's record stream slice_bytes behind slice s - 1's;
+    //  the statistics and the Gram band are the whole row's and go into every slice's record)
     constexpr int GREC = R64 ? 2 : 1;                         // (any G with this row format: the record size depends on nothing else)
     constexpr int ND = 2 * B - 1, NV = 3 + 4 * ND;
     __shared__ double sm[4][((NV + 3) & ~3) + 1];
     const int64_t t = blockIdx.x;
     constexpr int hdr = blk_hdr_bytes(B);
-    char *rb = recs + t * blk_rec_bytes(mp, B, GREC);
+    const int mps = nsl > 1 ? mp / nsl : mp;                  // samples of a record row
+    char *rb = recs + t * blk_rec_bytes(mps, B, GREC);
     float  *ox = reinterpret_cast<float *>(rb + hdr);
-    float  *oq = ox + mp;
-    double *od = reinterpret_cast<double *>(rb + hdr + 8 * (int64_t)mp);
+    float  *oq = ox + mps;
+    double *od = reinterpret_cast<double *>(rb + hdr + 8 * (int64_t)mps);
     const bool has_prev = t >= B && t - B < N, has_cur = t < N, has_next = t + B < N;
     const float *px = X + (t - B) * ld, *pq = Xq + (t - B) * ld;
     const float *cx = X + t * ld, *cq = Xq + t * ld;
@@ -132,13 +136,17 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
             float4 bx4[ND], bq4[ND];
 #pragma unroll
             for (int d = 1; d <= ND; ++d) { bx4[d - 1] = row(X, t - d); bq4[d - 1] = row(Xq, t - d); }
-            *reinterpret_cast<float4 *>(ox + i) = xp;
-            *reinterpret_cast<float4 *>(oq + i) = sym_a != 0.f ? make_float4(__fmul_rn(sym_a, qp.x), __fmul_rn(sym_a, qp.y), __fmul_rn(sym_a, qp.z), __fmul_rn(sym_a, qp.w)) : qp;
+            const int sl = nsl > 1 ? i / mps : 0, il = i - sl * mps;      // slice and sample of the slice (mps is a multiple of four)
+            const int64_t so = (int64_t)sl * slice_bytes;
+            float *oxs = reinterpret_cast<float *>(reinterpret_cast<char *>(ox) + so), *oqs = reinterpret_cast<float *>(reinterpret_cast<char *>(oq) + so);
+            double *ods = reinterpret_cast<double *>(reinterpret_cast<char *>(od) + so);
+            *reinterpret_cast<float4 *>(oxs + il) = xp;
+            *reinterpret_cast<float4 *>(oqs + il) = sym_a != 0.f ? make_float4(__fmul_rn(sym_a, qp.x), __fmul_rn(sym_a, qp.y), __fmul_rn(sym_a, qp.z), __fmul_rn(sym_a, qp.w)) : qp;
             if constexpr (R64) {
-                *reinterpret_cast<double2 *>(od + i) = make_double2((double)qn.x, (double)qn.y);
-                *reinterpret_cast<double2 *>(od + i + 2) = make_double2((double)qn.z, (double)qn.w);
+                *reinterpret_cast<double2 *>(ods + il) = make_double2((double)qn.x, (double)qn.y);
+                *reinterpret_cast<double2 *>(ods + il + 2) = make_double2((double)qn.z, (double)qn.w);
             } else {
-                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(od) + i) = qn;
+                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(ods) + il) = qn;
             }
             float b1[ND], b2[ND];
 #pragma unroll
@@ -157,10 +165,14 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
     } else {
         for (int i = threadIdx.x; i < mp; i += 256) {
             const bool in = i < m;
-            ox[i] = (has_prev && in) ? px[i] : 0.f;
-            oq[i] = (has_prev && in) ? (sym_a != 0.f ? __fmul_rn(sym_a, pq[i]) : pq[i]) : 0.f;   // symmetric form: f32(a Xq), see BlkK::sym_a
-            if constexpr (R64) od[i] = (double)((has_next && in) ? nq[i] : 0.f);
-            else reinterpret_cast<float *>(od)[i] = (has_next && in) ? nq[i] : 0.f;
+            const int sl = nsl > 1 ? i / mps : 0, il = i - sl * mps;
+            const int64_t so = (int64_t)sl * slice_bytes;
+            float *oxs = reinterpret_cast<float *>(reinterpret_cast<char *>(ox) + so), *oqs = reinterpret_cast<float *>(reinterpret_cast<char *>(oq) + so);
+            double *ods = reinterpret_cast<double *>(reinterpret_cast<char *>(od) + so);
+            oxs[il] = (has_prev && in) ? px[i] : 0.f;
+            oqs[il] = (has_prev && in) ? (sym_a != 0.f ? __fmul_rn(sym_a, pq[i]) : pq[i]) : 0.f;   // symmetric form: f32(a Xq), see BlkK::sym_a
+            if constexpr (R64) ods[il] = (double)((has_next && in) ? nq[i] : 0.f);
+            else reinterpret_cast<float *>(ods)[il] = (has_next && in) ? nq[i] : 0.f;
             if (has_cur && in) {
                 float b1[ND], b2[ND];
 #pragma unroll
@@ -197,14 +209,14 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
 #pragma unroll
         for (int d = 1; d <= ND; ++d) { e1 += total(5 + 4 * (d - 1)); e2 += total(6 + 4 * (d - 1)); }
         st.sE1 = 0x1p-23 * e1 * up * up; st.sE2 = 0x1p-23 * e2 * up * up;
-        *reinterpret_cast<BlkStats *>(rb) = st;
+        for (int sl = 0; sl < (nsl > 1 ? nsl : 1); ++sl) *reinterpret_cast<BlkStats *>(rb + (int64_t)sl * slice_bytes) = st;
         *reinterpret_cast<BlkStats *>(hdrs + t * hdr) = st;
     } else if (threadIdx.x <= ND) {
         const int d = threadIdx.x;
         BandEntry e;
         e.H1 = total(3 + 4 * (d - 1)); e.H2 = total(4 + 4 * (d - 1));
         e.E1 = 0x1p-23 * total(5 + 4 * (d - 1)) * up; e.E2 = 0x1p-23 * total(6 + 4 * (d - 1)) * up;
-        *reinterpret_cast<BandEntry *>(rb + 64 + 32 * (d - 1)) = e;
+        for (int sl = 0; sl < (nsl > 1 ? nsl : 1); ++sl) *reinterpret_cast<BandEntry *>(rb + (int64_t)sl * slice_bytes + 64 + 32 * (d - 1)) = e;
         *reinterpret_cast<BandEntry *>(hdrs + t * hdr + 64 + 32 * (d - 1)) = e;
     }
 }
@@ -284,6 +296,16 @@ struct BlkK {
     // float32(alphabet[k]) is the next float32 above / below (in the integer order of the bit patterns) float32(a0 + k step).
     unsigned long long uni_plus, uni_minus;
     unsigned char pw[12];       // sample pairs per k-lane of sweep wavefront w (BlkSplit: a launch parameter)
+    // Cluster form (round 5, rows beyond what one workgroup's registers hold; CL instantiations only): `nsl` workgroups -- the SLICES of a
+    // cluster -- hold MP samples each of the same NB neurons; slice s streams its own records (recs + s slice_bytes: the same layout
+    // over its samples, the headers' statistics and Gram band over the WHOLE row) and the decision wavefronts exchange their partial dot
+    // products through `mbox` once per slot (cl_exchange), then take the same decisions from the same bits.  0: the classic form.
+    int nsl;
+    int64_t slice_bytes;
+    unsigned long long *mbox;   // [cluster][2][nsl][64 lanes][4] 8-byte words (payload32 | tag32 << 32), zeroed before the launch
+    int64_t u_ld;               // row pitch of u_out (the whole row's sample count)
+    double slack;               // float64 slack of a predicted dot product, relative: 2^-43 per 1024 samples of a row
+    int *cl_err;                // set when an exchange timed out (a slice of the cluster never arrived): results are then invalid
 };
 
 #ifdef GPFQ_BLK_NO_MFMA            // diagnostic build: phase D on the vector unit everywhere (A/B timing of round 4's matrix form)
@@ -303,6 +325,110 @@ constexpr bool kNoFused = false;
 #else
 #define STAMP(var) do { } while (0)
 #endif
+
+// ---- cluster form: the exchange between the decision wavefronts of a cluster's slices (CL instantiations) ----
+// Every slice publishes KV float64 values per lane and reads all slices' back, summed in slice order -- the same bits in every slice, so the
+// slices take the same decisions without another word passing between them.  A value travels as two 8-byte words (32 bits of payload, the
+// exchange's sequence number above them: the LL protocol of the collectives libraries), so a word is valid or visibly stale by itself and no
+// fence orders anything; agent-scope accesses (sc1) meet in the memory side of the L2s.  Two buffers by the parity of the sequence
+// number: a slice publishes exchange k + 1 only after it has read everybody's k, i.e. after everybody has read k - 1.  The slices of a
+// cluster are co-resident by construction of the grid (gpfq_blk_kernel); should one never arrive, the wait gives up after ~3 s of
+// s_memrealtime, raises BlkK::cl_err and the launch runs to its end on garbage instead of hanging the device.
+struct ClState { int64_t cl; int slice; unsigned seq; bool dead; };
+typedef unsigned cl_u32x4 __attribute__((ext_vector_type(4)));
+
+// Loads of the exchange: 16 bytes per lane, issued back to back and waited for together; device scope (sc1), like the stores -- right
+// wherever the slices of a cluster run.  (They sit in ONE XCD, whose L2 every one of their stores passes through, so polling that L2
+// would do: sc0 loads alone hit the CU's own cache and never see the data -- 722 against 28 ms at 4096 x 4096 on 8192 samples until the
+// fallback to sc1 after 256 polls, profiles/r05/cluster_form.txt; diagnostic build -DGPFQ_CL_NEAR_INV: the CU's cache invalidated before
+// every near poll.)
+#if defined(GPFQ_CL_NEAR_INV)
+constexpr int kClNearPolls = 256;
+#else
+constexpr int kClNearPolls = 0;
+#endif
+template <bool FAR> __device__ __forceinline__ cl_u32x4 cl_load16(const unsigned long long *p)
+{
+    cl_u32x4 r;
+    if constexpr (FAR) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r) : "v"(p) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=&v"(r) : "v"(p) : "memory");
+    return r;
+}
+
+// publish: the lane's KV values of exchange cs.seq + 1 (which this call makes the current one)
+template <int KV>
+__device__ __forceinline__ void cl_publish(const BlkK &K, ClState &cs, int lane, const double (&v)[KV])
+{
+    const unsigned seq = ++cs.seq;
+    unsigned long long *buf = K.mbox + ((cs.cl * 2 + (int64_t)(seq & 1u)) * (int64_t)K.nsl) * 256;       // [slice][lane][4]
+    unsigned long long *mine = buf + ((int64_t)cs.slice * 64 + lane) * 4;
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        const cl_u32x4 w = {(unsigned)__double2loint(v[k]), seq, (unsigned)__double2hiint(v[k]), seq};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(mine + 2 * k), "v"(w) : "memory");
+    }
+}
+
+// gather: every slice's values of the current exchange, added in slice order (CLB slices per batch of loads)
+template <int KV, int CLB>
+__device__ __forceinline__ void cl_gather(const BlkK &K, ClState &cs, int lane, double (&v)[KV])
+{
+    const unsigned seq = cs.seq;
+    const unsigned long long *buf = K.mbox + ((cs.cl * 2 + (int64_t)(seq & 1u)) * (int64_t)K.nsl) * 256;
+    double tot[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) tot[k] = 0.0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int polls = 0;
+    for (int s0 = 0; s0 < K.nsl; s0 += CLB) {
+        cl_u32x4 w[CLB][KV];
+        for (;;) {
+            const bool far = polls >= kClNearPolls;
+#if defined(GPFQ_CL_NEAR_INV)
+            if (!far) asm volatile("buffer_inv sc1" ::: "memory");
+#endif
+#pragma unroll
+            for (int i = 0; i < CLB; ++i) {
+                const unsigned long long *p = buf + ((int64_t)(s0 + i < K.nsl ? s0 + i : cs.slice) * 64 + lane) * 4;    // (beyond the cluster: the own words, ignored below)
+#pragma unroll
+                for (int k = 0; k < KV; ++k) w[i][k] = far ? cl_load16<true>(p + 2 * k) : cl_load16<false>(p + 2 * k);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < CLB; ++i)
+#pragma unroll
+                for (int k = 0; k < KV; ++k) {
+                    asm volatile("" : "+v"(w[i][k]));               // (the loads have landed: nothing below moves above the wait)
+                    ok &= (w[i][k].y == seq) & (w[i][k].w == seq);
+                }
+            if (__ballot(!ok) == 0ull || cs.dead) break;
+            ++polls;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {
+                cs.dead = true;
+                if (lane == 0 && K.cl_err) __hip_atomic_store(K.cl_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int i = 0; i < CLB; ++i)
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                const double x = __hiloint2double((int)w[i][k].z, (int)w[i][k].x);
+                tot[k] += (s0 + i < K.nsl) ? x : 0.0;
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < KV; ++k) v[k] = tot[k];
+}
+
+template <int KV, int CLB>
+__device__ __forceinline__ void cl_exchange(const BlkK &K, ClState &cs, int lane, double (&v)[KV])
+{
+    cl_publish<KV>(K, cs, lane, v);
+    cl_gather<KV, CLB>(K, cs, lane, v);
+}
 
 // Sample-pair split over the sweep wavefronts: PairSplit for eight of them (the decision wavefront, wavefront 8, shares
 // SIMD 0 with wavefronts 0 and 4); with eleven the twelve wavefronts of a workgroup are three per SIMD.
@@ -362,8 +488,8 @@ template <int G, int S, int NSW, int NL> constexpr bool blk_split_has(int k)
 }
 
 // ---- sweep wavefront -------------------------------------------------------------------------------
-template <int G, int PW, int MP, int B, int NSW, bool SYM, int NL>
-__device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic, const BlkLds &L, int wave, int lane, int pbase)
+template <int G, int PW, int MP, int B, int NSW, bool SYM, int NL, bool CL>
+__device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic, const BlkLds &L, int wave, int lane, int pbase, const ClState &cs)
 {
     constexpr int NB = NL * G, KQ = 64 / G, NW = blk_slots(NSW, NB);   // NL neurons per lane (4; 2 in the narrow-layer shapes)
     constexpr int RSH = NL == 4 ? 0 : (NL == 2 ? 1 : 2);          // folded sums: neuron i of the lane ends up in rows i << RSH .. of the wavefront
@@ -374,7 +500,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     const bool writer = (lane & 15 & ~(G - 1)) == 0 && (row & ((1 << RSH) - 1)) == 0;   // one lane per (neuron, ng) publishes the folded sums
     const int nloc = NL * ng;                                     // first of this lane's NL neurons
     const int nrow = row >> RSH;                                  // the neuron (of the lane's NL) whose folded sums this row holds
-    const int64_t jbase = (int64_t)blockIdx.x * NB;
+    const int64_t jbase = (CL ? cs.cl : (int64_t)blockIdx.x) * NB;   // (cluster form: K is the slice's view -- its records, its samples of Xq, its m)
     const unsigned ldsT_addr = lds_addr(lds_generic), ldsW_addr = lds_addr(lds_generic + L.off_w);
     const int64_t N = K.N;
     const int nslots = K.nblk + 1;
@@ -971,7 +1097,11 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const int i = 2 * (pbase + p * KQ + kq) + e;
-                        if (i < K.m) K.u_out[jn * (int64_t)K.m + i] = u[n][2 * p + e];
+                        if constexpr (CL) {
+                            if (i < K.m) K.u_out[jn * K.u_ld + (int64_t)cs.slice * MP + i] = u[n][2 * p + e];
+                        } else {
+                            if (i < K.m) K.u_out[jn * (int64_t)K.m + i] = u[n][2 * p + e];
+                        }
                     }
             }
         }
@@ -979,8 +1109,8 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 }
 
 // ---- decision wavefront ------------------------------------------------------------------------------
-template <int G, int MP, int B, int NSW, bool SYM, int NL>
-__device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_generic, const BlkLds &L, int lane)
+template <int G, int MP, int B, int NSW, bool SYM, int NL, bool CL>
+__device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_generic, const BlkLds &L, int lane, ClState &cs)
 {
     constexpr int NB = NL * G, R = blk_sublanes(NB), NW = blk_slots(NSW, NB);
     constexpr int RB = (int)blk_rec_bytes(MP, B, G);
@@ -989,7 +1119,8 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     // same decisions, same stores to the same addresses) and is left out of the counters
     const bool shadow = lane / R >= NB;
     const int n = shadow ? NB - 1 : lane / R, r = lane % R;
-    const int64_t jn = (int64_t)blockIdx.x * NB + n;
+    const int64_t wg = CL ? cs.cl : (int64_t)blockIdx.x;          // the workgroup's neurons: wg NB .. (cluster form: the cluster's)
+    const int64_t jn = wg * NB + n;
     const bool active = jn < K.C;
     const int64_t N = K.N;
     const int M = K.M;
@@ -1024,7 +1155,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     auto flush = [&](int64_t t0, int64_t t1) {
         for (int e = lane; e < NB * (kOutSteps / 8); e += 64) {
             const int nn = e / (kOutSteps / 8), c = e % (kOutSteps / 8);
-            const int64_t j = (int64_t)blockIdx.x * NB + nn, ts = t0 + 8 * c;
+            const int64_t j = wg * NB + nn, ts = t0 + 8 * c;
             if (j >= K.C || ts >= t1) continue;
             int idx8[8]; float q8[8];
 #pragma unroll
@@ -1109,6 +1240,8 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         const int cbq = (b & 1) * NB * B * 8;
         float  wc[B], qc[B];                                      // this block: weights, decisions (as float32 values)
         double D[B];
+        double DmT = 0.0;                                         // (cluster form) the own step's D over all slices: the slow path's D[s]
+        (void)DmT;
         int stop = B;                                             // first step of the block this neuron could not certify
         // ---- the slot's decisions, in three parts (round 3).  Until round 2 a decision was ~100 instructions issued B times in
         // sequence by this one wavefront (3300 cycles per slot of four: the floor of every narrow layer).  Only a sliver of that is
@@ -1181,6 +1314,15 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                     for (int w = 0; w + span < NW; w += 2 * span) t[w] += t[w + span];
                 Dm = t[0];
             }
+            if constexpr (CL) {
+                // cluster form: this slice's partial sums of (neuron, step) leave for the other slices -- what does not depend on D is
+                // formed under their flight
+                static_assert(!CL || (R == B && NB * B == 64), "cluster form: lane = (neuron, step)");
+                __builtin_amdgcn_sched_barrier(0);
+                const double xv[1] = {Dm};
+                cl_publish<1>(K, cs, lane, xv);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int j = 0; j < B; ++j) {
                 const double wj = (double)wprev[j], qj = (double)qprev[j];
@@ -1189,6 +1331,15 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             double Aw = cPm;                                      // + this block's weights before the own step
 #pragma unroll
             for (int j = 0; j + 1 < B; ++j) Aw = fma(wd[j], hi_[j].x, Aw);
+            if constexpr (CL) {
+                // ... and every slice's come back, added in slice order: the same bits in every slice
+                __builtin_amdgcn_sched_barrier(0);
+                double xv[1] = {Dm};
+                cl_gather<1, 8>(K, cs, lane, xv);
+                Dm = xv[0];
+                DmT = Dm;
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const double Am = Dm + Aw;
             double A[B];
 #pragma unroll
@@ -1283,7 +1434,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                 a_lo = lds_ld<double>(lds, oe); a_k = lds_ld<double>(lds, oe + 8); a_hi = lds_ld<double>(lds, oe + 16);
             }
             const double d_k = fabs(a_k - tt_m), d_lo = fabs(a_lo - tt_m), d_hi = fabs(a_hi - tt_m);
-            const double slack43 = 0x1p-43 * (fabs(Dm) + fabs(du_m - Dm) + fabs(wGm)) * rden;      // float64 slack of the prediction
+            const double slack43 = (CL ? K.slack : 0x1p-43) * (fabs(Dm) + fabs(du_m - Dm) + fabs(wGm)) * rden;      // float64 slack of the prediction
             const double base2 = 2.0 * fma(fabs(wdm), rcb, rca) + slack43;
             // The certification proper needs eps = sum over the pending increments of |w_j| E1 + |q_j| E2 (fourteen products on seven
             // band entries read from the tile, each at a sub-lane-dependent address): a third of this wavefront's instructions -- and
@@ -1428,7 +1579,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             const double tt = msq ? wd : tq;
             // twice the modelling error of the prediction (quotient units) + float64 slack
             const double delta2 = 2.0 * (fma(fabs(wd), rcb, rca) + eps * rden)
-                                  + 0x1p-43 * (fabs(D[s]) + fabs(corr) + fabs(wG)) * rden;
+                                  + (CL ? K.slack : 0x1p-43) * (fabs(D[s]) + fabs(corr) + fabs(wG)) * rden;
             int idx_l;
             double q_l;
             bool cert;
@@ -1498,12 +1649,17 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             if (S < 0) break;
             slot_barrier();                                       // exact partials published
             // (the hot path only forms the own step's D: here every sub-lane needs all of them, sub-lane r adding slots r, r + R, ...)
+            if constexpr (CL) {                                   // (the sums over all slices, from the sub-lanes that own the steps)
+#pragma unroll
+                for (int s = 0; s < B; ++s) D[s] = quad_bcast(DmT, s);
+            } else {
 #pragma unroll
             for (int s = 0; s < B; ++s) {
                 double d = 0.0;
 #pragma unroll
                 for (int q = 0; q < NW / R; ++q) d += lds_ld<double>(lds, o_d + ((((b & 1) * NW + q * R) * B) + s) * NB * 8);
                 D[s] = sub_sum<R>(d);
+            }
             }
             double du = 0.0, dw = 0.0;
 #pragma unroll
@@ -1512,6 +1668,11 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                 du += v.x; dw += v.y;
             }
             du = sub_sum<R>(du); dw = sub_sum<R>(dw);
+            if constexpr (CL) {                                   // the exact dot products over all slices
+                double xv[2] = {du, dw};
+                cl_exchange<2, 4>(K, cs, lane, xv);
+                du = xv[0]; dw = xv[1];
+            }
             const bool mine = active && stop == S;
             if (mine) {
                 const int64_t t = (int64_t)b * B + S;
@@ -1575,7 +1736,12 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 #pragma unroll
         for (int q = 0; q < NW / R; ++q) tot += lds_ld<double>(lds, o_d + q * R * B * NB * 8);
         tot = sub_sum<R>(tot);
-        if (active && r == 0) K.resid[jn] = sqrt(tot);
+        if constexpr (CL) {
+            double xv[1] = {tot};
+            cl_exchange<1, 8>(K, cs, lane, xv);
+            tot = xv[0];
+        }
+        if (active && r == 0 && (!CL || cs.slice == 0)) K.resid[jn] = sqrt(tot);
     }
 }
 
@@ -1585,11 +1751,30 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 // wavefronts (rows of MP = (128 / G) * S samples), B steps per slot.
 // NL neurons per lane of a sweep wavefront: NL * G neurons per workgroup (4; 2 for layers of at most 512 neurons, which
 // then fill twice the CUs with half the element-wise work per slot -- a narrow layer is bound by the time of ONE slot).
-template <int G, int S, int B, int NSW, bool SYM, int NL>
+// CL (cluster form): workgroup id -> (cluster, slice) with a cluster's slices side by side in ONE XCD's queue (workgroups go to the
+// XCDs round-robin by id): id = ((cluster / 8) nsl + slice) 8 + cluster % 8.  Workgroups are dispatched in id order, so whenever a
+// slice is resident every slice before it in the queue is resident or done -- the oldest cluster with work left is always complete on
+// the chip (nsl <= 16 <= the 32 CUs of an XCD) and the exchange cannot deadlock, whatever the mapping of ids to XCDs really is.
+template <int G, int S, int B, int NSW, bool SYM, int NL, bool CL = false>
 __global__ void __launch_bounds__(64 * (NSW + 1))
-gpfq_blk_kernel(BlkK K, AlphabetArg A)
+gpfq_blk_kernel(BlkK K_, AlphabetArg A)
 {
     constexpr int NB = NL * G, KQ = 64 / G, MP = 2 * KQ * S;
+    ClState cs{0, 0, 0u, false};
+    BlkK Kc;                                                      // (cluster form: the slice's view of the launch)
+    if constexpr (CL) {
+        Kc = K_;
+        const int id = (int)blockIdx.x, j = id >> 3;
+        cs.slice = j % Kc.nsl;
+        cs.cl = (int64_t)(j / Kc.nsl) * 8 + (id & 7);
+        if (cs.cl * NB >= Kc.C) return;                           // (the last group of eight clusters may be short)
+        Kc.recs += (int64_t)cs.slice * Kc.slice_bytes;
+        Kc.Xq += (int64_t)cs.slice * MP;                          // (the symmetric form's slow path reads the row itself)
+        const int left = Kc.m - cs.slice * MP;
+        Kc.m = left < 0 ? 0 : (left > MP ? MP : left);
+        if (cs.slice != 0) { Kc.qidx = nullptr; Kc.Qt = nullptr; Kc.fallback_count = nullptr; }     // slice 0 writes the cluster's outputs
+    }
+    const BlkK &K = CL ? Kc : K_;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const BlkLds L = blk_lds(MP, NB, B, NSW, G);
     const int tid = threadIdx.x;
@@ -1614,17 +1799,17 @@ gpfq_blk_kernel(BlkK K, AlphabetArg A)
         // (one instantiation of the role per pair count that the shape's split holds)
 #define GPFQ_BLK_ROLE(PW_)                                                                                             \
         if constexpr (blk_split_has<G, S, NSW, NL>(PW_)) {                                                                    \
-            if (pw == PW_) blk_sweep_role<G, PW_, MP, B, NSW, SYM, NL>(K, lds, L, wave, lane, pbase);                   \
+            if (pw == PW_) blk_sweep_role<G, PW_, MP, B, NSW, SYM, NL, CL>(K, lds, L, wave, lane, pbase, cs);           \
         }
         GPFQ_BLK_ROLE(1) GPFQ_BLK_ROLE(2) GPFQ_BLK_ROLE(3) GPFQ_BLK_ROLE(4) GPFQ_BLK_ROLE(5) GPFQ_BLK_ROLE(6)
 #undef GPFQ_BLK_ROLE
     } else {
-        blk_decision_role<G, MP, B, NSW, SYM, NL>(K, lds, L, lane);
+        blk_decision_role<G, MP, B, NSW, SYM, NL, CL>(K, lds, L, lane, cs);
     }
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-struct BlkShape { int G, S, B, mp, NW, NL; };      // NL: neurons per lane (4 G or 2 G neurons per workgroup)
+struct BlkShape { int G, S, B, mp, NW, NL, NS; };  // NL: neurons per lane (4 G or 2 G neurons per workgroup); NS: slices of the cluster form (0: classic; mp = samples of a slice)
 static std::atomic<int> g_blk_single{1};  // one neuron per workgroup for layers of at most 128 neurons (blk_set_single_groups)
 void blk_set_single_groups(int on) { g_blk_single.store(on ? 1 : 0, std::memory_order_relaxed); }
 static std::atomic<int> g_blk_nw{0};      // sweep wavefronts of the 16-neuron B = 4 shapes: 8, 11, or 0 = by shape (blk_set_sweep_waves)
@@ -1644,8 +1829,19 @@ void blk_set_quad_waves(int nw) { g_blk_quad_nw.store(nw == 7 ? 7 : (nw == 8 ? 8
 static std::atomic<int> g_blk_pairs{1};   // two-neuron workgroups for layers of at most 512 neurons
 void blk_set_pair_groups(int on) { g_blk_pairs.store(on ? 1 : 0, std::memory_order_relaxed); }
 
+// Cluster form (round 5): rows beyond `g_blk_cluster` samples -- 5120 by default, what the classic shapes hold -- up to 16384 are cut into
+// slices of 1024 samples, one workgroup of the headline shape <4,32,4> x 11 each, that exchange their partial dot products once per slot
+// (cl_exchange).  0: off (those rows keep the several-wavefronts-per-neuron kernel); values from 1024 up move the threshold (tests, A/B).
+static std::atomic<int> g_blk_cluster{5120};
+void blk_set_cluster(int v) { g_blk_cluster.store(v <= 0 ? 0 : (v < 1024 ? 5120 : v), std::memory_order_relaxed); }
+constexpr int64_t kClusterMaxM = 16384;
+
 static BlkShape blk_shape(int64_t m, int64_t C)
 {
+    {
+        const int clm = g_blk_cluster.load(std::memory_order_relaxed);
+        if (clm && m > clm && m <= kClusterMaxM) return {4, 32, 4, 1024, 11, 4, (int)((m + 1023) / 1024)};
+    }
     // Round 4 (dot products on the matrix unit, fused with the updates pair by pair): rows of 769..1024 samples take ELEVEN sweep wavefronts
     // (three per SIMD: 2.97 against 3.13 ms at 4096 x 4096 x 1024 -- the per-wavefront fold that made eleven lose until round 3 is gone);
     // shorter rows keep eight (768 samples: 2.53 against 2.63 ms; 512: 1.96 against 1.98)
@@ -1755,11 +1951,16 @@ static bool blk_uniform(const AlphabetArg &A, double *a0, double *step, double *
 }
 
 // workspace: [records of slots 0..nblk, + one record of DMA over-read][compact headers of the same records, + 2 KiB of over-read]
-static size_t blk_recs_bytes(int64_t nblk, const BlkShape &sh)
+static size_t blk_recs_bytes(int64_t nblk, const BlkShape &sh)          // (cluster form: of ONE slice)
 {
     return ((size_t)((nblk + 1) * sh.B + 1) * (size_t)blk_rec_bytes(sh.mp, sh.B, sh.G) + 255) & ~(size_t)255;
 }
+// cluster form: the exchange buffers, [cluster][2][slice][64 lanes][4 words]; clusters in whole groups of eight
+static int64_t blk_clusters(int64_t C, const BlkShape &sh) { return (((C + 4 * sh.G - 1) / (4 * sh.G)) + 7) / 8 * 8; }
+static size_t blk_mbox_bytes(int64_t C, const BlkShape &sh) { return sh.NS ? (size_t)blk_clusters(C, sh) * 2 * sh.NS * 64 * 4 * 8 : 0; }
 static size_t blk_hdrs_bytes(int64_t nblk, int B) { return (size_t)((nblk + 1) * B + 1) * (size_t)blk_hdr_bytes(B) + 2048; }
+static size_t blk_hdrs_off(int64_t nblk, const BlkShape &sh) { return blk_recs_bytes(nblk, sh) * (size_t)(sh.NS ? sh.NS : 1); }     // compact headers: behind the last record stream
+static size_t blk_mbox_off(int64_t nblk, const BlkShape &sh) { return blk_hdrs_off(nblk, sh) + ((blk_hdrs_bytes(nblk, sh.B) + 255) & ~(size_t)255); }
 
 bool blk_supported(const PipeArgs &a)
 {
@@ -1772,7 +1973,7 @@ bool blk_supported(const PipeArgs &a)
     return a.N + 64 < (1LL << 31) / 64;
 }
 
-size_t blk_workspace_bytes(int64_t N, int64_t m)
+size_t blk_workspace_bytes(int64_t N, int64_t m, int64_t Cn)
 {
     // (the record layout depends on the row length and, through the steps per slot, on the width class of the layer: the largest)
     size_t need = 0;
@@ -1780,7 +1981,8 @@ size_t blk_workspace_bytes(int64_t N, int64_t m)
         const BlkShape sh = blk_shape(m, C);
         if (!sh.G) continue;
         const int64_t nblk = (N + sh.B - 1) / sh.B;
-        const size_t b = blk_recs_bytes(nblk, sh) + blk_hdrs_bytes(nblk, sh.B);
+        // (cluster form: a record stream per slice, the compact headers once, the exchange buffers + the error word)
+        const size_t b = blk_recs_bytes(nblk, sh) * (size_t)(sh.NS ? sh.NS : 1) + ((blk_hdrs_bytes(nblk, sh.B) + 255) & ~(size_t)255) + blk_mbox_bytes(Cn, sh);
         if (b > need) need = b;
     }
     return need;
@@ -1798,18 +2000,29 @@ static float blk_sym_a(const PipeArgs &a)
     return hi;
 }
 
-template <int G, int S, int B, int NSW, bool SYM, int NL>
+template <int G, int S, int B, int NSW, bool SYM, int NL, bool CL = false>
 static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStream_t stream)
 {
     constexpr int NB = NL * G;
     const BlkLds L = blk_lds(sh.mp, NB, B, NSW, G);
-    const unsigned grid = (unsigned)((a.C + NB - 1) / NB);
-    auto *kern = gpfq_blk_kernel<G, S, B, NSW, SYM, NL>;
+    const unsigned grid = CL ? (unsigned)(blk_clusters(a.C, sh) * sh.NS) : (unsigned)((a.C + NB - 1) / NB);
+    auto *kern = gpfq_blk_kernel<G, S, B, NSW, SYM, NL, CL>;
     hipError_t e = ensure_dynamic_lds((const void *)kern, (size_t)L.total);
     if (e != hipSuccess) return e;
     BlkK K;
+    const int64_t nblk_ = (a.N + B - 1) / B;
     K.recs = static_cast<const char *>(a.workspace); K.Wt = a.Wt; K.ldw = a.ldw;
-    K.hdrs = K.recs + blk_recs_bytes((a.N + B - 1) / B, sh);
+    K.hdrs = K.recs + blk_hdrs_off(nblk_, sh);
+    K.nsl = CL ? sh.NS : 0; K.slice_bytes = (int64_t)blk_recs_bytes(nblk_, sh); K.mbox = nullptr; K.cl_err = nullptr;
+    K.u_ld = a.m; K.slack = 0x1p-43 * (double)(sh.NS > 1 ? sh.NS : 1);
+    if constexpr (CL) {
+        char *mb = static_cast<char *>(a.workspace) + blk_mbox_off(nblk_, sh);
+        const size_t mbytes = blk_mbox_bytes(a.C, sh);
+        e = hipMemsetAsync(mb, 0, mbytes, stream);                 // sequence numbers start at 1: a zero word is "not yet written"
+        if (e != hipSuccess) return e;
+        K.mbox = reinterpret_cast<unsigned long long *>(mb);
+        K.cl_err = a.fallback_count ? reinterpret_cast<int *>(a.fallback_count + 1) : nullptr;   // (second word of the call's counter block, zeroed with it)
+    }
     K.N = a.N; K.C = a.C; K.m = (int)a.m; K.M = a.A.M; K.zero_idx = a.A.zero_idx; K.nblk = (int)((a.N + B - 1) / B);
     K.qidx = a.qidx; K.Qt = a.Qt; K.resid = a.resid; K.u_out = a.u_out; K.fallback_count = a.fallback_count;
     K.stamps = a.fallback_count ? a.fallback_count + 8 : nullptr;      // (diagnostic build: the unused row-statistics area behind the counter block)
@@ -1857,11 +2070,21 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     const int64_t nblk = (a.N + sh.B - 1) / sh.B;
     const int64_t nrec = (nblk + 1) * sh.B + 1;
     const bool r64 = blk_row64(sh.G, sh.B);
+    if (sh.NS) {                                                   // cluster form: NS slices of the headline shape
+        note_dense_kernel("gpfq_blk_kernel, cluster form (rows cut into 1024-sample slices: one workgroup of 11 sweep wavefronts + 1 decision wavefront per slice, partial dot products exchanged once per slot)");
+        const float sym_a = blk_sym_a(a);
+        hipLaunchKernelGGL((gpfq_blk_prep_kernel<4, true>), dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp * sh.NS,
+                           a.nrm32, static_cast<char *>(a.workspace), static_cast<char *>(a.workspace) + blk_hdrs_off(nblk, sh), sym_a,
+                           sh.NS, (int64_t)blk_recs_bytes(nblk, sh));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        return sym_a != 0.f ? launch_blk_sym<4, 32, 4, 11, true, 4, true>(a, sh, stream) : launch_blk_sym<4, 32, 4, 11, false, 4, true>(a, sh, stream);
+    }
     auto *prep = sh.B == 4 ? (r64 ? gpfq_blk_prep_kernel<4, true> : gpfq_blk_prep_kernel<4, false>)
                            : (sh.B == 2 ? (r64 ? gpfq_blk_prep_kernel<2, true> : gpfq_blk_prep_kernel<2, false>) : gpfq_blk_prep_kernel<1, false>);
     const float sym_a = blk_has_sym(sh.S, sh.NW) ? blk_sym_a(a) : 0.f;   // (exactly the launches launch_blk_inst gives the symmetric form)
     hipLaunchKernelGGL(prep, dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp,
-                       a.nrm32, static_cast<char *>(a.workspace), static_cast<char *>(a.workspace) + blk_recs_bytes(nblk, sh), sym_a);
+                       a.nrm32, static_cast<char *>(a.workspace), static_cast<char *>(a.workspace) + blk_recs_bytes(nblk, sh), sym_a, 1, (int64_t)0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // (four neuron groups with one or two neurons per lane: the narrow forms of the fused matrix shape)

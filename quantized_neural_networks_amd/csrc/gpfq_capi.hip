@@ -151,9 +151,9 @@ static bool auto_wants_gram(int64_t N, int64_t m, int64_t C, bool want_u)
 // on-chip workspace: [fallback counter, 64 B][RowStats x N][iteration records of the pipelined kernel]
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t onchip_stats_bytes(int64_t N) { return al256(64 + (size_t)N * sizeof(gpfq::RowStats)); }
-static size_t onchip_workspace_bytes(int64_t N, int64_t m)
+static size_t onchip_workspace_bytes(int64_t N, int64_t m, int64_t C)
 {
-    const size_t p = gpfq::pipe_workspace_bytes(N, m), b = gpfq::blk_workspace_bytes(N, m);
+    const size_t p = gpfq::pipe_workspace_bytes(N, m), b = gpfq::blk_workspace_bytes(N, m, C);
     return onchip_stats_bytes(N) + (p > b ? p : b);
 }
 
@@ -167,7 +167,7 @@ static size_t auto_gram_workspace_bytes(int64_t N, int64_t m, int64_t C)
 size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path)
 {
     if (N < 0 || m < 0 || C < 0) return 0;
-    size_t need = resolve_path(m, path) == GPFQ_PATH_ONCHIP ? onchip_workspace_bytes(N, m)
+    size_t need = resolve_path(m, path) == GPFQ_PATH_ONCHIP ? onchip_workspace_bytes(N, m, C)
                                                              : gpfq::stream_workspace_bytes(N, m, C, /*need_u=*/true);
     if (path == GPFQ_PATH_AUTO && auto_wants_gram(N, m, C, false)) {
         const size_t g = auto_gram_workspace_bytes(N, m, C);
@@ -217,6 +217,10 @@ int gpfq_set_option(const char *key, int value)
     if (!std::strcmp(key, "blk_pair_groups")) { gpfq::blk_set_pair_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_single_groups")) { gpfq::blk_set_single_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_quad_groups")) { gpfq::blk_set_quad_groups(value); return GPFQ_OK; }
+    if (!std::strcmp(key, "blk_cluster")) {
+        if (value < 0 || (value > 1 && value < 1024)) return fail(GPFQ_ERR_INVALID_ARG, "blk_cluster must be 0 (off), 1 (default: rows beyond 5120 samples) or a row length >= 1024");
+        gpfq::blk_set_cluster(value); return GPFQ_OK;
+    }
     if (!std::strcmp(key, "blk_quad_waves")) {
         if (value != 0 && value != 7 && value != 8) return fail(GPFQ_ERR_INVALID_ARG, "blk_quad_waves must be 0 (by shape), 7 or 8");
         gpfq::blk_set_quad_waves(value); return GPFQ_OK;
@@ -348,10 +352,12 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
             // width (4096 x 2048, m = 1024: 2.5 vs 5.4 ms; 4096 x 128, m = 2048: 2.9 vs 4.5; 2048 x 128, m = 4096: 2.3 vs 2.5).
             // Round 3: two-neuron workgroups (layers of at most 512 neurons, rows of up to 5120 samples) make it the fastest for narrow
             // layers as well (784 x 128, m = 512, 16 levels; 2048 x 128, m = 5008: tools/blk_ab.sh latency, profiles/r03/).
-            const bool fits = m > 256 && M <= 64 && m <= 5120;
+            // Round 5: rows of 5121..16384 samples too -- the cluster form (gpfq_blk.hip: slices of 1024 samples over several workgroups;
+            // blk_supported() says no when the option blk_cluster switches it off)
+            const bool fits = m > 256 && M <= 64 && m <= 16384;
             const bool want = g_pipe == 1;
             if ((g_pipe == 2 || (g_pipe < 0 && !forced_old && fits)) && N > 0 && m > 0 && gpfq::blk_supported(pa) && workspace &&
-                (uintptr_t)workspace % 16 == 0 && workspace_bytes >= onchip_workspace_bytes(N, m)) {
+                (uintptr_t)workspace % 16 == 0 && workspace_bytes >= onchip_workspace_bytes(N, m, C)) {
                 pa.workspace = static_cast<char *>(workspace) + onchip_stats_bytes(N);
                 pa.fallback_count = static_cast<unsigned long long *>(workspace);
                 gpfq::note_dense_kernel("gpfq_blk_kernel (4 to 11 sweep wavefronts + 1 decision wavefront per workgroup, blocks of steps per slot)");
@@ -359,7 +365,7 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
                 return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_neurons(block-pipelined)");
             }
             if (want && N > 0 && m > 0 && gpfq::pipe_supported(pa) && workspace && (uintptr_t)workspace % 16 == 0 &&
-                workspace_bytes >= onchip_workspace_bytes(N, m)) {
+                workspace_bytes >= onchip_workspace_bytes(N, m, C)) {
                 pa.workspace = static_cast<char *>(workspace) + onchip_stats_bytes(N);
                 pa.fallback_count = static_cast<unsigned long long *>(workspace);
                 gpfq::note_dense_kernel("gpfq_pipe_kernel (8 sweep wavefronts over the sample axis + 1 decision wavefront per workgroup)");

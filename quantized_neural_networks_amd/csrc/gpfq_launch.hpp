@@ -78,7 +78,7 @@ struct PipeArgs {
 };
 // Block form (gpfq_blk.hip): B steps per slot; same arguments.
 bool blk_supported(const PipeArgs &a);
-size_t blk_workspace_bytes(int64_t N, int64_t m);
+size_t blk_workspace_bytes(int64_t N, int64_t m, int64_t C);   // (C: the cluster form's exchange buffers are per 16 neurons)
 hipError_t launch_blk(const PipeArgs &a, hipStream_t stream);
 void blk_set_four_groups(int on);   // 4-neuron workgroups for layers of at most 1024 neurons (speed only)
 void blk_set_single_groups(int on); // 1-neuron workgroups for layers of at most 128 neurons (speed only)
@@ -86,6 +86,7 @@ void blk_set_pair_groups(int on);   // 2-neuron workgroups for layers of at most
 void blk_set_wide_groups(int on);   // 16-neuron workgroups for rows beyond 1024 samples (speed only)
 void blk_set_quad_groups(int on);   // four neuron groups x 1 / 2 neurons per lane for layers of at most 2048 neurons on rows of 257..1024 samples; 2 (default): every such layer, 1: 129..2048 neurons only, 0: off (speed only)
 void blk_set_quad_waves(int nw);    // sweep wavefronts of the four-group narrow shapes on rows of at most 768 samples: 0 (default) = by shape (seven for layers of at most 1024 neurons, else eight), 7 or 8 force it (speed only)
+void blk_set_cluster(int v);        // cluster form (rows cut into 1024-sample slices over several workgroups): rows beyond v samples, up to 16384; default 5120; 0: off (speed only)
 void blk_set_sweep_waves(int nw);   // sweep wavefronts of the 16-neuron four-step shapes: 0 (default) = by shape (eleven for rows of 769..1024 samples, eight below), 8 or 11 force it (speed only)
 bool pipe_supported(const PipeArgs &a);
 size_t pipe_workspace_bytes(int64_t N, int64_t m);

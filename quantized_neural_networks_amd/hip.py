@@ -569,6 +569,14 @@ def exact_fallbacks(result):
     return 0 if ws is None or ws.numel() < 8 else int(ws[:8].view(torch.int64).item())
 
 
+def cluster_timeouts(result):
+    """Nonzero when an exchange of the block kernel's cluster form (rows beyond 5120 samples: several workgroups per group of
+    neurons) gave up waiting for a slice that never arrived -- the results of that call are then invalid (forces a device
+    sync; diagnostics and tests)."""
+    ws = result.get("workspace")
+    return 0 if ws is None or ws.numel() < 16 else int(ws[8:12].view(torch.int32).item())
+
+
 def set_option(key, value):
     _check(load().gpfq_set_option(key.encode(), int(value)), f"gpfq_set_option({key})")
 

@@ -1,0 +1,123 @@
+"""The block kernel's cluster form (gpfq_blk.hip, round 5): rows beyond 5120 samples are cut into 1024-sample slices, one workgroup
+each, whose decision wavefronts exchange their partial dot products once per slot.  Same contract as every dense kernel
+(scripts/quantized_network.py:91-121): bit-exact indices, values and residual vectors against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RESID_RTOL = 1e-5
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from quantized_neural_networks_amd import hip as h
+    h.load()
+    return h
+
+
+def _synthetic(N, m, C, seed=0):
+    W = (np.random.default_rng(seed).standard_normal((N, C)) / np.sqrt(N)).astype(np.float32)
+    G = np.random.default_rng(seed + 1).standard_normal((N, m))
+    X = np.maximum(G, 0).astype(np.float32)
+    Xq = np.maximum(G + 0.1 * np.random.default_rng(seed + 2).standard_normal((N, m)), 0).astype(np.float32)
+    return W, X, Xq
+
+
+def _run(hip, W, X, Xq, alphabet, want_u=True):
+    r = hip.quantize_neurons(_dev(X), _dev(Xq), _dev(W.T), alphabet, want_u=want_u, path=1)
+    torch.cuda.synchronize()
+    assert hip.cluster_timeouts(r) == 0
+    return r, {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in r.items()}
+
+
+# (threshold, m): the option moves the threshold down so that clusters of two and three slices run too; 9000 / 16384: more slices than one
+# batch of the exchange's reads; 5121 and 8192: as dispatched
+@pytest.mark.parametrize("threshold,m", [(1024, 1100), (1024, 2049), (2048, 3000), (1, 5121), (1, 6000), (1, 8192), (1, 9000), (1, 16384)])
+@pytest.mark.parametrize("C,levels", [(5, 3), (70, 2), (200, 4), (33, 16)])
+def test_cluster_form_vs_oracle(hip, oracle_mod, threshold, m, C, levels):
+    N = 23 if m > 6000 else 37                                    # (not a multiple of the block of four steps)
+    W, X, Xq = _synthetic(N, m, C, seed=m + C)
+    Xq[N - 2] = 0                                                 # a dead row: rule (i)
+    alphabet, _ = oracle_mod.layer_alphabet(W, np.linspace(-1, 1, levels), 2)
+    Q, idx, resid = oracle_mod.layer(W, X, Xq, alphabet)
+    try:
+        hip.set_option("blk_cluster", threshold)
+        r, out = _run(hip, W, X, Xq, alphabet)
+        name = hip.last_dense_kernel()
+    finally:
+        hip.set_option("blk_cluster", 1)
+    assert "cluster form" in name, name
+    assert np.array_equal(out["idx"], idx)
+    assert np.array_equal(out["Q"], Q.astype(np.float32))
+    np.testing.assert_allclose(out["resid"], resid, rtol=RESID_RTOL)
+    for j in (0, C - 1):
+        _, _, u = oracle_mod.neuron(W[:, j], X, Xq, alphabet)
+        assert np.array_equal(out["u"][j], u), j                 # the residual vector, bit for bit, across the slices
+
+
+def test_cluster_form_off_keeps_the_wide_kernel(hip, oracle_mod):
+    N, m, C = 19, 6000, 9
+    W, X, Xq = _synthetic(N, m, C, seed=5)
+    alphabet, _ = oracle_mod.layer_alphabet(W, np.linspace(-1, 1, 3), 3)
+    _, idx, _ = oracle_mod.layer(W, X, Xq, alphabet)
+    try:
+        hip.set_option("blk_cluster", 0)
+        _, out = _run(hip, W, X, Xq, alphabet, want_u=False)
+        assert "cluster form" not in hip.last_dense_kernel()
+        assert np.array_equal(out["idx"], idx)
+    finally:
+        hip.set_option("blk_cluster", 1)
+    _, out = _run(hip, W, X, Xq, alphabet, want_u=False)
+    assert "cluster form" in hip.last_dense_kernel()
+    assert np.array_equal(out["idx"], idx)
+
+
+@pytest.mark.parametrize("m", [5200, 8192])
+def test_cluster_form_slow_path_is_exercised(hip, oracle_mod, m):
+    """Weights on the alphabet's boundaries against identical activations of both networks (tests/test_hip_parity.py,
+    test_role_split_slow_path_is_exercised): the look-ahead cannot certify many decisions, and the exact dot products of the slow path
+    are sums over ALL slices -- a second exchange per round."""
+    r0 = np.random.default_rng(29)
+    N, C = 48, 40
+    G = r0.standard_normal((N, m))
+    X = np.maximum(G, 0).astype(np.float32)
+    step = 0.125
+    alphabet = step * np.arange(-3, 4, dtype=np.float64)
+    W = (step / 2 * r0.integers(-7, 8, (N, C))).astype(np.float32)
+    Q, idx, resid = oracle_mod.layer(W, X, X, alphabet)
+    r, out = _run(hip, W, X, X, alphabet)
+    assert "cluster form" in hip.last_dense_kernel()
+    assert np.array_equal(out["idx"], idx) and np.array_equal(out["Q"], Q.astype(np.float32))
+    assert hip.exact_fallbacks(r) > 0
+    # the symmetric form ({-a, 0, a}, {-a, a}): its slow path reads the row itself from memory, at the slice's offset
+    Xq = np.maximum(G + 0.25 * r0.standard_normal((N, m)), 0).astype(np.float32)
+    for members in (3, 2):
+        alph = step * (np.arange(-1, 2, dtype=np.float64) if members == 3 else np.array([-1.0, 1.0]))
+        Ws = (step / 2 * r0.integers(-3, 4, (N, C))).astype(np.float32)
+        for Xq_ in (Xq, X):
+            Qs, idxs, _ = oracle_mod.layer(Ws, X, Xq_, alph)
+            r, out = _run(hip, Ws, X, Xq_, alph)
+            assert np.array_equal(out["idx"], idxs), members
+            assert np.array_equal(out["Q"], Qs.astype(np.float32))
+            if Xq_ is X:
+                assert hip.exact_fallbacks(r) > 0
+
+
+def test_cluster_form_full_width_layer(hip, oracle_mod):
+    """Dense(1024 -> 4096) on 8192 samples, ternary: every cluster of the launch (256 x 8 workgroups: eight rounds of the chip) against
+    the oracle on a sample of neurons spread over the clusters; the launch contains slow-path decisions."""
+    N, m, C = 1024, 8192, 4096
+    W, X, Xq = _synthetic(N, m, C, seed=11)
+    alphabet, _ = oracle_mod.layer_alphabet(W, np.linspace(-1, 1, 3), 3)
+    pick = np.arange(0, C, 37)
+    _, idx, resid = oracle_mod.layer(W[:, pick], X, Xq, alphabet)
+    r, out = _run(hip, W, X, Xq, alphabet, want_u=False)
+    assert "cluster form" in hip.last_dense_kernel()
+    assert np.array_equal(out["idx"][pick], idx)
+    np.testing.assert_allclose(out["resid"][pick], resid, rtol=RESID_RTOL)

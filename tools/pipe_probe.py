@@ -62,6 +62,7 @@ def main():
     hip.set_option("blk_single_groups", int(os.environ.get("BLK_SINGLE", "1")))  # <= 128 neurons: 1 neuron per workgroup
     hip.set_option("blk_quad_groups", int(os.environ.get("BLK_QUAD", "2")))   # <= 2048 neurons on rows of 257..1024 samples: four neuron groups x 1 / 2 neurons per lane (fused matrix form); 1: 129..2048 only; 2: narrower layers too
     hip.set_option("blk_quad_waves", int(os.environ.get("BLK_QUAD_NW", "0")))  # four-group narrow shapes on rows <= 768 samples: 7 / 8 sweep wavefronts (0: by shape)
+    hip.set_option("blk_cluster", int(os.environ.get("BLK_CLUSTER", "1")))     # cluster form: 1 = rows beyond 5120 samples, 0 = off, >= 1024: rows beyond that
     hip.set_option("blk_wide_groups", int(os.environ.get("BLK_WIDE", "1")))   # rows > 1024 samples, > 2048 neurons: 16 neurons per workgroup
     base = run(pipe=0)
     print(f"shape N={N} C={C} m={m} M={M}; row-group kernel fallbacks={hip.exact_fallbacks(base)}")
@@ -88,6 +89,8 @@ def main():
         rel_r = float(((r["resid"] - base["resid"]).abs() / base["resid"].clamp_min(1e-300)).max())
         bad_u = int((r["u"] != base["u"]).sum()) if want_u else -1
         fb = hip.exact_fallbacks(r)
+        if hip.cluster_timeouts(r):
+            print("  !! cluster form: an exchange timed out")
         if os.environ.get("GPFQ_DIAG") and mode == 2:
             st = r["workspace"][64:64 + 48 * 8].view(torch.int64).cpu().numpy()
             ns = max(int(st[5]), 1)
@@ -98,7 +101,7 @@ def main():
             print(f"    decision wave: work {st[16]/ns:.0f} (prologue {st[18]/ns:.0f}, chain + certification {st[19]/ns:.0f}), barrier {st[17]/ns:.0f}, barrier -> next slot {st[20]/ns:.0f} cycles per slot")
         tmin, tavg = timed(lambda: hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm, want_values=False,
                                                         path=hip.GPFQ_PATH_ONCHIP))
-        print(f"  pipe mode={mode} variant={variant} ts={ts or 'auto'} sweeps={sw} [{hip.last_dense_kernel()[:16]}]: min {tmin:.3f} ms avg {tavg:.3f} ms  "
+        print(f"  pipe mode={mode} variant={variant} ts={ts or 'auto'} sweeps={sw} [{hip.last_dense_kernel()[:30]}]: min {tmin:.3f} ms avg {tavg:.3f} ms  "
               f"mismatch idx={bad_i} Q={bad_q} u={bad_u} max resid rel diff={rel_r:.2e}  exact fallbacks={fb}")
     hip.set_option("pipe", -1); hip.set_option("tile_steps", 0); hip.set_option("variant", 0); hip.set_option("blk_sweep_waves", 0)
 
