@@ -60,12 +60,15 @@ struct BlkStats {          // first 64 bytes of a record header (all float64); s
     double rden, G, cb, ca, Ea, nrm;
     double sE1, sE2;       // round 5: sums of the band's E1 / E2 over ALL its distances (rounded up): the quick certification's bound
 };
-struct BandEntry {         // distance d = 1 .. 2B-1 at header offset 64 + 32 (d - 1)
+struct BandEntry {         // distance d = 1 .. 2B-1 (cluster form: 3B-1) at header offset 64 + 32 (d - 1)
     double H1, H2, E1, E2; // <Xq_t, X_{t-d}>, <Xq_t, Xq_{t-d}>, 2^-23 (1+2^-20) sum|Xq_t X_{t-d}|, ... sum|Xq_t Xq_{t-d}|
 };
 static_assert(sizeof(BlkStats) == 64 && sizeof(BandEntry) == 32, "header layout");
 
-__host__ __device__ constexpr int blk_hdr_bytes(int B) { return (64 + (2 * B - 1) * 32 + 127) & ~127; }
+// (cluster form, CL: the partial dot products travel between the slices for a slot, so a decision's D is TWO slots old and the band
+//  covers the 3B - 1 increments then pending)
+__host__ __device__ constexpr int blk_band(int B, bool CL = false) { return CL ? 3 * B - 1 : 2 * B - 1; }
+__host__ __device__ constexpr int blk_hdr_bytes(int B, bool CL = false) { return (64 + blk_band(B, CL) * 32 + 127) & ~127; }
 // The row t + B travels as float64 (the sweep's dot products then need no conversion) -- except in the one-step-per-slot shapes,
 // which are bound by the record stream itself: there it stays float32 (12 instead of 16 bytes per sample) and is converted in the sweep.
 // -- and in the shapes with one neuron group per sweep wavefront (G = 1: 4 or 2 neurons per workgroup, the narrow layers), which put
@@ -73,14 +76,14 @@ __host__ __device__ constexpr int blk_hdr_bytes(int B) { return (64 + (2 * B - 1
 // 10 TB/s, the bound of those shapes (profiles/r03/blk_phase_stamps.txt); a lane converts its two samples for two or four neurons.
 __host__ __device__ constexpr bool blk_row64(int G, int B) { return B > 1 && G > 1; }
 // (record skews against LDS bank conflicts were measured twice and bought nothing: DESIGN_HISTORY.md, "gpfq_blk.hip notes" 1)
-__host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B, int G) { return blk_hdr_bytes(B) + (blk_row64(G, B) ? 16 : 12) * mp; }
+__host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B, int G, bool CL = false) { return blk_hdr_bytes(B, CL) + (blk_row64(G, B) ? 16 : 12) * mp; }
 
 // ---- pre-pass ---------------------------------------------------------------------------------
 // One workgroup per slot record t: statistics of row t, its Gram band against rows t-1 .. t-(2B-1), float32 copies
 // of rows t-B, the float64 copy of Xq row t+B; zero-padded to mp samples.  One pass over the samples with all 3 + 4 (2B-1)
 // sums in registers and ONE workgroup reduction.  The launch is bound by its float64 arithmetic (about 60 operations per
 // sample of a row: seven band distances x four sums): 49 us for 4096 rows of 1024 samples.
-template <int B, bool R64>
+template <int B, bool R64, bool CL = false>
 __global__ void __launch_bounds__(256)
 gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t N, int m, int mp,
                      const float *__restrict__ nrm32, char *__restrict__ recs, char *__restrict__ hdrs, float sym_a,
@@ -89,19 +92,20 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
     // (cluster form, nsl > 1: mp = nsl record rows of mp / nsl samples each, slice s's record stream slice_bytes behind slice s - 1's;
     //  the statistics and the Gram band are the whole row's and go into every slice's record)
     constexpr int GREC = R64 ? 2 : 1;                         // (any G with this row format: the record size depends on nothing else)
-    constexpr int ND = 2 * B - 1, NV = 3 + 4 * ND;
+    constexpr int ND = blk_band(B, CL), NV = 3 + 4 * ND;
+    constexpr int DN = CL ? 2 * B : B;                        // the float64 row of a record: row t + DN (cluster form: two slots ahead)
     __shared__ double sm[4][((NV + 3) & ~3) + 1];
     const int64_t t = blockIdx.x;
-    constexpr int hdr = blk_hdr_bytes(B);
+    constexpr int hdr = blk_hdr_bytes(B, CL);
     const int mps = nsl > 1 ? mp / nsl : mp;                  // samples of a record row
-    char *rb = recs + t * blk_rec_bytes(mps, B, GREC);
+    char *rb = recs + t * blk_rec_bytes(mps, B, GREC, CL);
     float  *ox = reinterpret_cast<float *>(rb + hdr);
     float  *oq = ox + mps;
     double *od = reinterpret_cast<double *>(rb + hdr + 8 * (int64_t)mps);
-    const bool has_prev = t >= B && t - B < N, has_cur = t < N, has_next = t + B < N;
+    const bool has_prev = t >= B && t - B < N, has_cur = t < N, has_next = t + DN < N;
     const float *px = X + (t - B) * ld, *pq = Xq + (t - B) * ld;
     const float *cx = X + t * ld, *cq = Xq + t * ld;
-    const float *nq = Xq + (t + B) * ld;
+    const float *nq = Xq + (t + DN) * ld;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double up = 1.0 + 0x1p-20;
 
@@ -131,7 +135,7 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
                 if (i + 3 >= m) { w.y = i + 1 < m ? w.y : 0.f; w.z = i + 2 < m ? w.z : 0.f; w.w = 0.f; }   // (m % 4 != 0: the row's tail)
                 return w;
             };
-            const float4 xp = row(X, t - B), qp = row(Xq, t - B), qn = row(Xq, t + B);
+            const float4 xp = row(X, t - B), qp = row(Xq, t - B), qn = row(Xq, t + DN);
             const float4 xc = row(X, t), qc4 = row(Xq, t);
             float4 bx4[ND], bq4[ND];
 #pragma unroll
@@ -226,11 +230,12 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
 // worth at a time, 64-bit address arithmetic on operands hipcc spills at three wavefronts per SIMD) cost those shapes 9-12 % while the sweeps
 // idle at the barrier.  Everywhere else the decision wavefront, which has the slack there (profiles/r05/sweep_side_flush*.txt).
 #if defined(GPFQ_BLK_SWEEP_FLUSH_ALL)          // diagnostic builds: every shape one way or the other
-template <int G, int NL> constexpr bool blk_sweep_flush() { return true; }
+template <int G, int NL, bool CL = false> constexpr bool blk_sweep_flush() { return true; }
 #elif defined(GPFQ_BLK_SWEEP_FLUSH_NONE)
-template <int G, int NL> constexpr bool blk_sweep_flush() { return false; }
+template <int G, int NL, bool CL = false> constexpr bool blk_sweep_flush() { return CL; }
 #else
-template <int G, int NL> constexpr bool blk_sweep_flush() { return G == 4 && NL == 1; }
+// (and the cluster form: its decision wavefront has no register to spare for the flush's addresses)
+template <int G, int NL, bool CL = false> constexpr bool blk_sweep_flush() { return (G == 4 && NL == 1) || CL; }
 #endif
 
 // LDS carve-up (byte offsets), shared by host and device.
@@ -244,11 +249,11 @@ constexpr int kOutSteps = 32;                                    // steps of out
 __host__ __device__ constexpr int blk_sublanes(int nb) { return 64 / nb > 8 ? 8 : 64 / nb; }   // R: lanes of the decision wavefront per neuron
 __host__ __device__ constexpr int blk_slots(int nsw, int nb) { return (nsw + blk_sublanes(nb) - 1) / blk_sublanes(nb) * blk_sublanes(nb); }
 
-__host__ __device__ inline BlkLds blk_lds(int mp, int nb, int B, int nsw, int G)
+__host__ __device__ inline BlkLds blk_lds(int mp, int nb, int B, int nsw, int G, bool CL = false)
 {
     BlkLds L;
     const int nw = blk_slots(nsw, nb);
-    L.tile_bytes = B * (int)blk_rec_bytes(mp, B, G);
+    L.tile_bytes = B * (int)blk_rec_bytes(mp, B, G, CL);
     L.tile_pitch = (L.tile_bytes + 1023) & ~1023;               // the DMA moves whole 1 KiB pieces
     int o = 2 * L.tile_pitch;
     L.off_w = o;    o += 2 * nb * B * 4;    o = (o + 15) & ~15; // [2][NB][B] f32        weights of the block
@@ -260,7 +265,7 @@ __host__ __device__ inline BlkLds blk_lds(int mp, int nb, int B, int nsw, int G)
     L.off_ctl = o;  o += 16;                                    // [2] (by slot parity) smallest step a neuron of the block is stopped at, -1: none; [2] dummy
     L.off_zero = o; o += 32;                                    // zeros (band entries a step does not have)
     o = (o + 15) & ~15;
-    L.hr_pitch = (B * blk_hdr_bytes(B) + 1023) & ~1023;         // the headers of a tile, whole 1 KiB DMA pieces
+    L.hr_pitch = (B * blk_hdr_bytes(B, CL) + 1023) & ~1023;     // the headers of a tile, whole 1 KiB DMA pieces
     L.off_hr = o;   o += 3 * L.hr_pitch;                        // [3] header ring: tile k in buffer k % 3 (lands two slots ahead)
     L.total = o;
     return L;
@@ -301,6 +306,7 @@ struct BlkK {
     // over its samples, the headers' statistics and Gram band over the WHOLE row) and the decision wavefronts exchange their partial dot
     // products through `mbox` once per slot (cl_exchange), then take the same decisions from the same bits.  0: the classic form.
     int nsl;
+    int cl_map;                 // 0: a cluster's slices in one XCD's queue; 1: consecutive workgroup ids (see gpfq_blk_kernel)
     int64_t slice_bytes;
     unsigned long long *mbox;   // [cluster][2][nsl][64 lanes][4] 8-byte words (payload32 | tag32 << 32), zeroed before the launch
     int64_t u_ld;               // row pitch of u_out (the whole row's sample count)
@@ -334,24 +340,17 @@ constexpr bool kNoFused = false;
 // number: a slice publishes exchange k + 1 only after it has read everybody's k, i.e. after everybody has read k - 1.  The slices of a
 // cluster are co-resident by construction of the grid (gpfq_blk_kernel); should one never arrive, the wait gives up after ~3 s of
 // s_memrealtime, raises BlkK::cl_err and the launch runs to its end on garbage instead of hanging the device.
-struct ClState { int64_t cl; int slice; unsigned seq; bool dead; };
+struct ClState { int64_t cl; int slice; unsigned seq; bool dead; int64_t rec_off; int m_sl; };   // rec_off: the slice's record stream; m_sl: its samples of the row
 typedef unsigned cl_u32x4 __attribute__((ext_vector_type(4)));
 
 // Loads of the exchange: 16 bytes per lane, issued back to back and waited for together; device scope (sc1), like the stores -- right
 // wherever the slices of a cluster run.  (They sit in ONE XCD, whose L2 every one of their stores passes through, so polling that L2
-// would do: sc0 loads alone hit the CU's own cache and never see the data -- 722 against 28 ms at 4096 x 4096 on 8192 samples until the
-// fallback to sc1 after 256 polls, profiles/r05/cluster_form.txt; diagnostic build -DGPFQ_CL_NEAR_INV: the CU's cache invalidated before
-// every near poll.)
-#if defined(GPFQ_CL_NEAR_INV)
-constexpr int kClNearPolls = 256;
-#else
-constexpr int kClNearPolls = 0;
-#endif
-template <bool FAR> __device__ __forceinline__ cl_u32x4 cl_load16(const unsigned long long *p)
+// would do -- but sc0 loads hit the CU's own cache and never see the data, with or without `buffer_inv sc0`, and behind `buffer_inv sc1`
+// they cost more than they save: 40.2 against 28.1 ms at 4096 x 4096 on 8192 samples, profiles/r05/cluster_form.txt.)
+__device__ __forceinline__ cl_u32x4 cl_load16(const unsigned long long *p)
 {
     cl_u32x4 r;
-    if constexpr (FAR) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r) : "v"(p) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=&v"(r) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r) : "v"(p) : "memory");
     return r;
 }
 
@@ -379,19 +378,14 @@ __device__ __forceinline__ void cl_gather(const BlkK &K, ClState &cs, int lane, 
 #pragma unroll
     for (int k = 0; k < KV; ++k) tot[k] = 0.0;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    int polls = 0;
     for (int s0 = 0; s0 < K.nsl; s0 += CLB) {
         cl_u32x4 w[CLB][KV];
         for (;;) {
-            const bool far = polls >= kClNearPolls;
-#if defined(GPFQ_CL_NEAR_INV)
-            if (!far) asm volatile("buffer_inv sc1" ::: "memory");
-#endif
 #pragma unroll
             for (int i = 0; i < CLB; ++i) {
                 const unsigned long long *p = buf + ((int64_t)(s0 + i < K.nsl ? s0 + i : cs.slice) * 64 + lane) * 4;    // (beyond the cluster: the own words, ignored below)
 #pragma unroll
-                for (int k = 0; k < KV; ++k) w[i][k] = far ? cl_load16<true>(p + 2 * k) : cl_load16<false>(p + 2 * k);
+                for (int k = 0; k < KV; ++k) w[i][k] = cl_load16(p + 2 * k);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             bool ok = true;
@@ -403,7 +397,6 @@ __device__ __forceinline__ void cl_gather(const BlkK &K, ClState &cs, int lane, 
                     ok &= (w[i][k].y == seq) & (w[i][k].w == seq);
                 }
             if (__ballot(!ok) == 0ull || cs.dead) break;
-            ++polls;
             if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {
                 cs.dead = true;
                 if (lane == 0 && K.cl_err) __hip_atomic_store(K.cl_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -493,14 +486,14 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 {
     constexpr int NB = NL * G, KQ = 64 / G, NW = blk_slots(NSW, NB);   // NL neurons per lane (4; 2 in the narrow-layer shapes)
     constexpr int RSH = NL == 4 ? 0 : (NL == 2 ? 1 : 2);          // folded sums: neuron i of the lane ends up in rows i << RSH .. of the wavefront
-    constexpr int HDR = blk_hdr_bytes(B);
-    constexpr int RB = (int)blk_rec_bytes(MP, B, G);
+    constexpr int HDR = blk_hdr_bytes(B, CL);
+    constexpr int RB = (int)blk_rec_bytes(MP, B, G, CL);
     lchar *lds = (lchar *)lds_generic;
     const int ng = lane & (G - 1), kq = lane / G, row = lane >> 4;
     const bool writer = (lane & 15 & ~(G - 1)) == 0 && (row & ((1 << RSH) - 1)) == 0;   // one lane per (neuron, ng) publishes the folded sums
     const int nloc = NL * ng;                                     // first of this lane's NL neurons
     const int nrow = row >> RSH;                                  // the neuron (of the lane's NL) whose folded sums this row holds
-    const int64_t jbase = (CL ? cs.cl : (int64_t)blockIdx.x) * NB;   // (cluster form: K is the slice's view -- its records, its samples of Xq, its m)
+    const int64_t jbase = (CL ? cs.cl : (int64_t)blockIdx.x) * NB;
     const unsigned ldsT_addr = lds_addr(lds_generic), ldsW_addr = lds_addr(lds_generic + L.off_w);
     const int64_t N = K.N;
     const int nslots = K.nblk + 1;
@@ -544,7 +537,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         glds16_s(K.recs + (int64_t)b1 * L.tile_bytes + ((int64_t)pc << 10), lane16,
                  ldsT_addr + (unsigned)(b1 & 1) * (unsigned)L.tile_pitch + ((unsigned)pc << 10));
 #endif
-        glds16_s(K.recs + (int64_t)b1 * L.tile_bytes + ((int64_t)pc << 10), lane16,
+        glds16_s(K.recs + (CL ? cs.rec_off : (int64_t)0) + (int64_t)b1 * L.tile_bytes + ((int64_t)pc << 10), lane16,
                  ldsT_addr + (unsigned)(b1 & 1) * (unsigned)L.tile_pitch + ((unsigned)pc << 10));
     };
     auto load_weights = [&](int b1) {
@@ -653,9 +646,10 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
                     float2 q2;
                     if constexpr (SYM) {                              // the record holds a32 * Xq_t: the row itself from memory (rare path)
                         const int i0 = 2 * (pbase + p * KQ + kq);
-                        const float *xr = K.Xq + ((int64_t)b * B + S) * K.ldx;
-                        q2.x = i0 < K.m ? xr[i0] : 0.f;
-                        q2.y = i0 + 1 < K.m ? xr[i0 + 1] : 0.f;
+                        const float *xr = K.Xq + ((int64_t)b * B + S) * K.ldx + (CL ? (int64_t)cs.slice * MP : (int64_t)0);   // (cluster form: the slice's samples)
+                        const int mrow = CL ? cs.m_sl : K.m;
+                        q2.x = i0 < mrow ? xr[i0] : 0.f;
+                        q2.y = i0 + 1 < mrow ? xr[i0 + 1] : 0.f;
                     } else {
                         q2 = lds_ld<float2>(lds, rb + o_q + 8 * p * KQ);
                     }
@@ -679,7 +673,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 #endif
         // (blk_sweep_flush shapes) block b - 1's outputs -- final since the barrier, slow path included -- go from the LDS ring to memory
         // here, by one sweep wavefront per slot in turn: lane = (neuron, step), a byte and a float each
-        if (blk_sweep_flush<G, NL>() && b >= 1 && wave == b % NSW && lane < NB * B) {
+        if (blk_sweep_flush<G, NL, CL>() && b >= 1 && wave == b % NSW && lane < NB * B && (!CL || cs.slice == 0)) {
             const int nn = lane / B, sidx = lane % B;
             const int64_t t = (int64_t)(b - 1) * B + sidx, jn = jbase + nn;
             if (t < N && jn < K.C) {
@@ -1098,7 +1092,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
                     for (int e = 0; e < 2; ++e) {
                         const int i = 2 * (pbase + p * KQ + kq) + e;
                         if constexpr (CL) {
-                            if (i < K.m) K.u_out[jn * K.u_ld + (int64_t)cs.slice * MP + i] = u[n][2 * p + e];
+                            if (i < cs.m_sl) K.u_out[jn * K.u_ld + (int64_t)cs.slice * MP + i] = u[n][2 * p + e];
                         } else {
                             if (i < K.m) K.u_out[jn * (int64_t)K.m + i] = u[n][2 * p + e];
                         }
@@ -1113,7 +1107,7 @@ template <int G, int MP, int B, int NSW, bool SYM, int NL, bool CL>
 __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_generic, const BlkLds &L, int lane, ClState &cs)
 {
     constexpr int NB = NL * G, R = blk_sublanes(NB), NW = blk_slots(NSW, NB);
-    constexpr int RB = (int)blk_rec_bytes(MP, B, G);
+    constexpr int RB = (int)blk_rec_bytes(MP, B, G, CL);
     lchar *lds = (lchar *)lds_generic;
     // neuron of the workgroup, sub-lane.  Four-neuron workgroups use 32 lanes; the other half shadows the last neuron (same reads,
     // same decisions, same stores to the same addresses) and is left out of the counters
@@ -1138,8 +1132,11 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     const double sym_top = SYM ? lds_ld<double>(lds, L.off_e + 8 * (2 + M - 1)) : 0.0;      // a;  a / 2 (0 for {-a, a})
     const double sym_hb = (SYM && M == 3) ? 0.5 * sym_top : 0.0;
     float wprev[B], qprev[B];                                     // block b-1 (final), this neuron
+    float wprev2[B], qprev2[B];                                   // (cluster form) block b-2: D is two slots old there
 #pragma unroll
-    for (int j = 0; j < B; ++j) { wprev[j] = 0.f; qprev[j] = 0.f; }
+    for (int j = 0; j < B; ++j) { wprev[j] = 0.f; qprev[j] = 0.f; wprev2[j] = 0.f; qprev2[j] = 0.f; }
+    double DmCur = 0.0;                                           // (cluster form) D of the own step of the slot's block, over all slices: gathered a slot ago
+    (void)wprev2; (void)qprev2; (void)DmCur;
     unsigned long long n_fallback = 0;
     auto wave_min_stop = [&](int v) -> int {                    // min over the wavefront of values in [0, B]
         int mn = B;
@@ -1151,12 +1148,12 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 
     // (not blk_sweep_flush shapes) Steps [t0, t1) of this workgroup's outputs from the LDS ring to memory: a lane takes 8 consecutive steps
     // of one neuron (32-byte runs of indices, 128-byte runs of values per neuron)
-    constexpr bool kOwnFlush = !blk_sweep_flush<G, NL>();
+    constexpr bool kOwnFlush = !blk_sweep_flush<G, NL, CL>();
     auto flush = [&](int64_t t0, int64_t t1) {
         for (int e = lane; e < NB * (kOutSteps / 8); e += 64) {
             const int nn = e / (kOutSteps / 8), c = e % (kOutSteps / 8);
             const int64_t j = wg * NB + nn, ts = t0 + 8 * c;
-            if (j >= K.C || ts >= t1) continue;
+            if (j >= K.C || ts >= t1 || (CL && cs.slice != 0)) continue;      // (cluster form: slice 0 writes the cluster's outputs)
             int idx8[8]; float q8[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -1205,7 +1202,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     // wavefronts per SIMD (hipcc spills 19-29 of them: cfg1's Dense(784 -> 128) 0.355 against 0.262 ms), and they are requested
     // behind the slot's stores instead (below).
     constexpr bool kHdrChain = NSW == 7;
-    constexpr int BI = B > 1 ? B - 1 : 1, HDRB = blk_hdr_bytes(B);
+    constexpr int BI = B > 1 ? B - 1 : 1, HDRB = blk_hdr_bytes(B, CL);
     // Only what the predicted dot products need: the bounds (E1, E2, cb, ca, Ea) are read from the tile in LDS while the chain
     // computes -- they are consumed by the certification after it, off the critical path.
     double2 g01 = make_double2(0.0, 0.0);                         // own step: (1/nrm^2, G)
@@ -1222,7 +1219,9 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         for (int j = 0; j + 1 < B; ++j) ghi[j] = lds_ld<double2>(lds, j < smh ? rm + 64 + 32 * (smh - j - 1) : L.off_zero);
     };
     slot_barrier();                                               // (tile 0 and the headers of tiles 0, 1 landed)
-    prefetch_headers(0);
+    // (cluster form: the headers are read at the top of the slot that uses them -- its chain no longer waits for the sweeps' partial sums,
+    //  so the post-barrier LDS burst costs it nothing, and 32 registers held across the barrier and the exchange made hipcc spill there)
+    if constexpr (!CL) prefetch_headers(0);
     int hnext = 1;                                                // (b + 1) % 3
     // The B dependent decisions of a slot are a latency chain on a SIMD that two sweep wavefronts keep busy: at equal priority
     // every instruction of the chain waits its turn behind theirs (9640 cycles per slot, the longest path of the workgroup);
@@ -1261,6 +1260,10 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         unsigned anyP = 0u;
 #pragma unroll
         for (int j = 0; j < B; ++j) anyP |= __float_as_uint(wprev[j]) | __float_as_uint(qprev[j]);
+        if constexpr (CL) {
+#pragma unroll
+            for (int j = 0; j < B; ++j) anyP |= __float_as_uint(wprev2[j]) | __float_as_uint(qprev2[j]);
+        }
         const int nvalid = (int)min((int64_t)B, N - (int64_t)b * B);            // steps beyond N pad the last block: no-ops
         const int oslot0 = (int)(((int64_t)b * B) % kOutSteps);
         const int o_dummy = L.off_ctl + 8;
@@ -1281,6 +1284,12 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 #pragma unroll
             for (int s = 0; s < B; ++s) wc[s] = lds_ld<float>(lds, o_w + (b & 1) * NB * B * 4 + 4 * s);
             const float w_own_raw = lds_ld<float>(lds, o_w + (b & 1) * NB * B * 4 + 4 * sm);
+            double2 hp2[CL ? B : 1];                              // (cluster form) own step against block b-2, distance 2B + sm - j: from the tile, not kept across the slots
+            if constexpr (CL) {
+                prefetch_headers(b % 3);                          // tile b's headers: buffer b % 3 of the ring
+#pragma unroll
+                for (int j = 0; j < B; ++j) hp2[j] = lds_ld<double2>(lds, tbase + sm * RB + 64 + 32 * (2 * B + sm - j - 1));
+            }
             if constexpr (kOwnFlush) {
                 if (flush_hi > flushed) {                         // (outputs of earlier slots: under the latency of the reads above)
                     flush(flushed, flush_hi);
@@ -1314,29 +1323,32 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                     for (int w = 0; w + span < NW; w += 2 * span) t[w] += t[w + span];
                 Dm = t[0];
             }
-            if constexpr (CL) {
-                // cluster form: this slice's partial sums of (neuron, step) leave for the other slices -- what does not depend on D is
-                // formed under their flight
-                static_assert(!CL || (R == B && NB * B == 64), "cluster form: lane = (neuron, step)");
-                __builtin_amdgcn_sched_barrier(0);
-                const double xv[1] = {Dm};
-                cl_publish<1>(K, cs, lane, xv);
-                __builtin_amdgcn_sched_barrier(0);
-            }
 #pragma unroll
             for (int j = 0; j < B; ++j) {
                 const double wj = (double)wprev[j], qj = (double)qprev[j];
                 cPm = fma(wj, hp[j].x, cPm); cPm = fma(-qj, hp[j].y, cPm);
             }
+            if constexpr (CL) {                                   // block b-2's increments are pending too
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    const double wj = (double)wprev2[j], qj = (double)qprev2[j];
+                    cPm = fma(wj, hp2[j].x, cPm); cPm = fma(-qj, hp2[j].y, cPm);
+                }
+            }
             double Aw = cPm;                                      // + this block's weights before the own step
 #pragma unroll
             for (int j = 0; j + 1 < B; ++j) Aw = fma(wd[j], hi_[j].x, Aw);
             if constexpr (CL) {
-                // ... and every slice's come back, added in slice order: the same bits in every slice
+                // cluster form: what the sweeps left in LDS is this slice's share of block b + 1's D (the records carry row t + 2B): it leaves
+                // for the other slices now and is gathered at the END of the slot, behind the stores, while this wavefront would wait at the
+                // barrier anyway; this block's D came back a slot ago (DmCur).  lane = (neuron, step).
+                static_assert(!CL || (R == B && NB * B == 64), "cluster form: lane = (neuron, step)");
                 __builtin_amdgcn_sched_barrier(0);
-                double xv[1] = {Dm};
-                cl_gather<1, 8>(K, cs, lane, xv);
-                Dm = xv[0];
+                if (b + 1 < K.nblk) {
+                    const double xv[1] = {Dm};
+                    cl_publish<1>(K, cs, lane, xv);
+                }
+                Dm = DmCur;
                 DmT = Dm;
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1448,7 +1460,12 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             float wmx = fmaxf(fabsf(wprev[0]), fabsf(wc[0]));
 #pragma unroll
             for (int j = 1; j < B; ++j) wmx = fmaxf(wmx, fmaxf(fabsf(wprev[j]), fabsf(wc[j])));
-            const double eps_q = fma((double)wmx, o67.x, u_amax * o67.y) + (double)(2 * B - 1) * rEa;
+            if constexpr (CL) {
+#pragma unroll
+                for (int j = 0; j < B; ++j) wmx = fmaxf(wmx, fabsf(wprev2[j]));
+            }
+            constexpr int NPEND = blk_band(B, CL);                // increments that may be pending at a decision
+            const double eps_q = fma((double)wmx, o67.x, u_amax * o67.y) + (double)NPEND * rEa;
             const bool sure_q = fabs(du_m) - eps_q >= 1e-10;                     // certainly not rule (ii)
             const double delta2_q = base2 + 2.0 * eps_q * rden;
             const bool far_q = (d_lo - d_k > delta2_q) & (d_hi - d_k > delta2_q);
@@ -1464,6 +1481,13 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                 for (int j = 0; j < B; ++j) {
                     ePm = fma(fabs((double)wprev[j]), ep[j].x, ePm); ePm = fma(fabs((double)qprev[j]), ep[j].y, ePm);
                 }
+                if constexpr (CL) {
+#pragma unroll
+                    for (int j = 0; j < B; ++j) {
+                        const double2 e2 = lds_ld<double2>(lds, rbm + 64 + 32 * (2 * B + sm - j - 1) + 16);
+                        ePm = fma(fabs((double)wprev2[j]), e2.x, ePm); ePm = fma(fabs((double)qprev2[j]), e2.y, ePm);
+                    }
+                }
                 double eps = ePm;
 #pragma unroll
                 for (int j = 0; j + 1 < B; ++j) { eps = fma(fabs(wd[j]), ei_[j].x, eps); eps = fma(fabs(qd[j]), ei_[j].y, eps); }
@@ -1471,7 +1495,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 #pragma unroll
                 for (int j = 0; j + 1 < B; ++j) any_m |= j < sm ? (__float_as_uint(wc[j]) | __float_as_uint(q32s[j])) : 0u;
                 // (each of the up to 2B-1 pending increments may lose up to Ea = 2^-149 sum|Xq_t| to subnormal float32 products)
-                eps += ((any_m << 1) != 0u) ? (double)(2 * B - 1) * rEa : 0.0;
+                eps += ((any_m << 1) != 0u) ? (double)NPEND * rEa : 0.0;
                 const bool du_exact = eps == 0.0;                     // every pending increment orthogonal to Xq_t element-wise
                 const bool msq = du_exact & small;                    // rule (ii), certain
                 const bool sure = du_exact | (fabs(du_m) - eps >= 1e-10);   // ... or certainly not rule (ii)
@@ -1534,7 +1558,15 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             //  0.262 ms; requested at the top of the slot they land in the post-barrier burst: +8 %.  profiles/r05/.)
             if constexpr (!kHdrChain) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (b + 1 < K.nblk) prefetch_headers(hnext);
+                if constexpr (!CL) { if (b + 1 < K.nblk) prefetch_headers(hnext); }
+            }
+            if constexpr (CL) {
+                // every slice's share of block b + 1's D, added in slice order: the same bits in every slice (published above)
+                if (b + 1 < K.nblk) {
+                    double xv[1] = {0.0};
+                    cl_gather<1, 8>(K, cs, lane, xv);
+                    DmCur = xv[0];
+                }
             }
         } else {
             STAMP(dta);
@@ -1568,7 +1600,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                 }
             }
             // (each of the up to 2B-1 pending increments may lose up to Ea = 2^-149 sum|Xq_t| to subnormal float32 products)
-            eps += ((anyinc << 1) != 0u) ? (double)(2 * B - 1) * rEa : 0.0;
+            eps += ((anyinc << 1) != 0u) ? (double)blk_band(B, CL) * rEa : 0.0;
             const double wd = (double)wc[s];
             const double du = D[s] + corr;                                       // predicted <Xq_t, u_{t-1}>
             const bool   du_exact = eps == 0.0;                                  // every pending increment orthogonal to Xq_t element-wise
@@ -1716,7 +1748,10 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         // block b is final: it becomes "the previous block"; its outputs leave the LDS ring in the next slot (a sweep wavefront's job) or,
         // where this wavefront flushes, when the ring is full -- at the top of a slot, behind that slot's first LDS reads
 #pragma unroll
-        for (int j = 0; j < B; ++j) { wprev[j] = (b < K.nblk) ? wc[j] : 0.f; qprev[j] = (b < K.nblk) ? qc[j] : 0.f; }
+        for (int j = 0; j < B; ++j) {
+            if constexpr (CL) { wprev2[j] = wprev[j]; qprev2[j] = qprev[j]; }
+            wprev[j] = (b < K.nblk) ? wc[j] : 0.f; qprev[j] = (b < K.nblk) ? qc[j] : 0.f;
+        }
         if constexpr (kOwnFlush) {
             const int64_t done = min((int64_t)(b + 1) * B, N);
             if (b < K.nblk && (done - flushed >= kOutSteps - B + 1 || done == N)) { flush_hi = done; }
@@ -1726,7 +1761,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         if (flush_hi > flushed) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); flush(flushed, flush_hi); }
     }
 
-    if (K.fallback_count && n_fallback) atomicAdd(K.fallback_count, n_fallback);   // rare
+    if (K.fallback_count && n_fallback && (!CL || cs.slice == 0)) atomicAdd(K.fallback_count, n_fallback);   // rare
 #ifdef GPFQ_BLK_STAMPS
     if (K.stamps && blockIdx.x == 0 && lane == 0) { K.stamps[16] = dacc_work; K.stamps[17] = dacc_bar; K.stamps[18] = dacc_pro; K.stamps[19] = dacc_chain; K.stamps[20] = dacc_tail; }
 #endif
@@ -1757,26 +1792,26 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 // the chip (nsl <= 16 <= the 32 CUs of an XCD) and the exchange cannot deadlock, whatever the mapping of ids to XCDs really is.
 template <int G, int S, int B, int NSW, bool SYM, int NL, bool CL = false>
 __global__ void __launch_bounds__(64 * (NSW + 1))
-gpfq_blk_kernel(BlkK K_, AlphabetArg A)
+gpfq_blk_kernel(BlkK K, AlphabetArg A)
 {
     constexpr int NB = NL * G, KQ = 64 / G, MP = 2 * KQ * S;
-    ClState cs{0, 0, 0u, false};
-    BlkK Kc;                                                      // (cluster form: the slice's view of the launch)
+    ClState cs{0, 0, 0u, false, 0, 0};
     if constexpr (CL) {
-        Kc = K_;
         const int id = (int)blockIdx.x, j = id >> 3;
-        cs.slice = j % Kc.nsl;
-        cs.cl = (int64_t)(j / Kc.nsl) * 8 + (id & 7);
-        if (cs.cl * NB >= Kc.C) return;                           // (the last group of eight clusters may be short)
-        Kc.recs += (int64_t)cs.slice * Kc.slice_bytes;
-        Kc.Xq += (int64_t)cs.slice * MP;                          // (the symmetric form's slow path reads the row itself)
-        const int left = Kc.m - cs.slice * MP;
-        Kc.m = left < 0 ? 0 : (left > MP ? MP : left);
-        if (cs.slice != 0) { Kc.qidx = nullptr; Kc.Qt = nullptr; Kc.fallback_count = nullptr; }     // slice 0 writes the cluster's outputs
+        if (K.cl_map == 0) {                                      // the slices of a cluster side by side in ONE XCD's queue
+            cs.slice = j % K.nsl;
+            cs.cl = (int64_t)(j / K.nsl) * 8 + (id & 7);
+        } else {                                                  // consecutive ids: the slices of a cluster go round the XCDs
+            cs.cl = id / K.nsl;
+            cs.slice = id - (int)cs.cl * K.nsl;
+        }
+        if (cs.cl * NB >= K.C) return;                            // (the last group of eight clusters may be short)
+        cs.rec_off = (int64_t)cs.slice * K.slice_bytes;
+        const int left = K.m - cs.slice * MP;
+        cs.m_sl = left < 0 ? 0 : (left > MP ? MP : left);
     }
-    const BlkK &K = CL ? Kc : K_;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const BlkLds L = blk_lds(MP, NB, B, NSW, G);
+    const BlkLds L = blk_lds(MP, NB, B, NSW, G, CL);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1829,18 +1864,37 @@ void blk_set_quad_waves(int nw) { g_blk_quad_nw.store(nw == 7 ? 7 : (nw == 8 ? 8
 static std::atomic<int> g_blk_pairs{1};   // two-neuron workgroups for layers of at most 512 neurons
 void blk_set_pair_groups(int on) { g_blk_pairs.store(on ? 1 : 0, std::memory_order_relaxed); }
 
-// Cluster form (round 5): rows beyond `g_blk_cluster` samples -- 5120 by default, what the classic shapes hold -- up to 16384 are cut into
-// slices of 1024 samples, one workgroup of the headline shape <4,32,4> x 11 each, that exchange their partial dot products once per slot
-// (cl_exchange).  0: off (those rows keep the several-wavefronts-per-neuron kernel); values from 1024 up move the threshold (tests, A/B).
-static std::atomic<int> g_blk_cluster{5120};
-void blk_set_cluster(int v) { g_blk_cluster.store(v <= 0 ? 0 : (v < 1024 ? 5120 : v), std::memory_order_relaxed); }
+// Cluster form (round 5): long rows -- up to 16384 samples -- are cut into slices of 1024 samples, one workgroup of the headline shape
+// <4,32,4> x 11 each, that exchange their partial dot products once per slot (cl_publish / cl_gather).  Option blk_cluster: 1 (default)
+// = by row length and width (blk_shape), 0 = off (rows beyond 5120 samples then keep the several-wavefronts-per-neuron kernel), a value
+// from 1024 up = every row beyond that many samples (tests, A/B).
+static std::atomic<int> g_blk_cluster{1};
+void blk_set_cluster(int v) { g_blk_cluster.store(v <= 0 ? 0 : (v < 1024 ? 1 : v), std::memory_order_relaxed); }
 constexpr int64_t kClusterMaxM = 16384;
+// Workgroup id -> (cluster, slice).  Workgroups go to the XCDs round-robin by id and every XCD starts its own in order.  Map 0 puts the
+// slices of a cluster side by side in ONE XCD's queue (the exchange stays inside that XCD's L2 domain); but an XCD's 32 CUs then hold
+// 32 / nsl whole clusters and 32 % nsl slices of the next one, which wait a whole round for their mates -- and so does every round after
+// (three slices: four rounds' time for three rounds of work).  Map 1, consecutive ids, strands at most one cluster of the whole chip.
+static std::atomic<int> g_blk_cluster_map{-1};     // -1: by the number of slices; 0 / 1 force a map (option blk_cluster_map)
+void blk_set_cluster_map(int v) { g_blk_cluster_map.store(v < 0 ? -1 : (v ? 1 : 0), std::memory_order_relaxed); }
+static int blk_cluster_map(int nsl)
+{
+    const int v = g_blk_cluster_map.load(std::memory_order_relaxed);
+    (void)nsl;
+    return v >= 0 ? v : 0;                             // (measured: the two maps take the same time at 3, 6, 7 and 8 slices: profiles/r05/cluster_form.txt)
+}
 
 static BlkShape blk_shape(int64_t m, int64_t C)
 {
     {
+        // By default (1): every row beyond 3072 samples -- a slot of the cluster form is the headline shape's (its exchange hides behind the
+        // chain of decisions), the classic shapes lose a third of that rate from 2049 samples up --, rows of 2049..3072 samples in layers
+        // of at most 1280 neurons (three slices: ten clusters per XCD and round, so such a layer is one round) and rows of 1537..2048
+        // samples in layers of 1025..2048 neurons (two slices, one round where the classic 8-neuron shape takes the same round with
+        // twice the sweep per workgroup): profiles/r05/cluster_form.txt.
         const int clm = g_blk_cluster.load(std::memory_order_relaxed);
-        if (clm && m > clm && m <= kClusterMaxM) return {4, 32, 4, 1024, 11, 4, (int)((m + 1023) / 1024)};
+        const bool take = clm == 1 ? (m > 3072 || (m > 2048 && C <= 1280) || (m > 1536 && m <= 2048 && C > 1024 && C <= 2048)) : (clm > 1 && m > clm);
+        if (take && m <= kClusterMaxM) return {4, 32, 4, 1024, 11, 4, (int)((m + 1023) / 1024)};
     }
     // Round 4 (dot products on the matrix unit, fused with the updates pair by pair): rows of 769..1024 samples take ELEVEN sweep wavefronts
     // (three per SIMD: 2.97 against 3.13 ms at 4096 x 4096 x 1024 -- the per-wavefront fold that made eleven lose until round 3 is gone);
@@ -1953,14 +2007,14 @@ static bool blk_uniform(const AlphabetArg &A, double *a0, double *step, double *
 // workspace: [records of slots 0..nblk, + one record of DMA over-read][compact headers of the same records, + 2 KiB of over-read]
 static size_t blk_recs_bytes(int64_t nblk, const BlkShape &sh)          // (cluster form: of ONE slice)
 {
-    return ((size_t)((nblk + 1) * sh.B + 1) * (size_t)blk_rec_bytes(sh.mp, sh.B, sh.G) + 255) & ~(size_t)255;
+    return ((size_t)((nblk + 1) * sh.B + 1) * (size_t)blk_rec_bytes(sh.mp, sh.B, sh.G, sh.NS != 0) + 255) & ~(size_t)255;
 }
 // cluster form: the exchange buffers, [cluster][2][slice][64 lanes][4 words]; clusters in whole groups of eight
 static int64_t blk_clusters(int64_t C, const BlkShape &sh) { return (((C + 4 * sh.G - 1) / (4 * sh.G)) + 7) / 8 * 8; }
 static size_t blk_mbox_bytes(int64_t C, const BlkShape &sh) { return sh.NS ? (size_t)blk_clusters(C, sh) * 2 * sh.NS * 64 * 4 * 8 : 0; }
-static size_t blk_hdrs_bytes(int64_t nblk, int B) { return (size_t)((nblk + 1) * B + 1) * (size_t)blk_hdr_bytes(B) + 2048; }
+static size_t blk_hdrs_bytes(int64_t nblk, int B, bool CL = false) { return (size_t)((nblk + 1) * B + 1) * (size_t)blk_hdr_bytes(B, CL) + 2048; }
 static size_t blk_hdrs_off(int64_t nblk, const BlkShape &sh) { return blk_recs_bytes(nblk, sh) * (size_t)(sh.NS ? sh.NS : 1); }     // compact headers: behind the last record stream
-static size_t blk_mbox_off(int64_t nblk, const BlkShape &sh) { return blk_hdrs_off(nblk, sh) + ((blk_hdrs_bytes(nblk, sh.B) + 255) & ~(size_t)255); }
+static size_t blk_mbox_off(int64_t nblk, const BlkShape &sh) { return blk_hdrs_off(nblk, sh) + ((blk_hdrs_bytes(nblk, sh.B, sh.NS != 0) + 255) & ~(size_t)255); }
 
 bool blk_supported(const PipeArgs &a)
 {
@@ -1982,7 +2036,7 @@ size_t blk_workspace_bytes(int64_t N, int64_t m, int64_t Cn)
         if (!sh.G) continue;
         const int64_t nblk = (N + sh.B - 1) / sh.B;
         // (cluster form: a record stream per slice, the compact headers once, the exchange buffers + the error word)
-        const size_t b = blk_recs_bytes(nblk, sh) * (size_t)(sh.NS ? sh.NS : 1) + ((blk_hdrs_bytes(nblk, sh.B) + 255) & ~(size_t)255) + blk_mbox_bytes(Cn, sh);
+        const size_t b = blk_recs_bytes(nblk, sh) * (size_t)(sh.NS ? sh.NS : 1) + ((blk_hdrs_bytes(nblk, sh.B, sh.NS != 0) + 255) & ~(size_t)255) + blk_mbox_bytes(Cn, sh);
         if (b > need) need = b;
     }
     return need;
@@ -2004,7 +2058,7 @@ template <int G, int S, int B, int NSW, bool SYM, int NL, bool CL = false>
 static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStream_t stream)
 {
     constexpr int NB = NL * G;
-    const BlkLds L = blk_lds(sh.mp, NB, B, NSW, G);
+    const BlkLds L = blk_lds(sh.mp, NB, B, NSW, G, CL);
     const unsigned grid = CL ? (unsigned)(blk_clusters(a.C, sh) * sh.NS) : (unsigned)((a.C + NB - 1) / NB);
     auto *kern = gpfq_blk_kernel<G, S, B, NSW, SYM, NL, CL>;
     hipError_t e = ensure_dynamic_lds((const void *)kern, (size_t)L.total);
@@ -2013,7 +2067,7 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
     const int64_t nblk_ = (a.N + B - 1) / B;
     K.recs = static_cast<const char *>(a.workspace); K.Wt = a.Wt; K.ldw = a.ldw;
     K.hdrs = K.recs + blk_hdrs_off(nblk_, sh);
-    K.nsl = CL ? sh.NS : 0; K.slice_bytes = (int64_t)blk_recs_bytes(nblk_, sh); K.mbox = nullptr; K.cl_err = nullptr;
+    K.nsl = CL ? sh.NS : 0; K.cl_map = blk_cluster_map(sh.NS); K.slice_bytes = (int64_t)blk_recs_bytes(nblk_, sh); K.mbox = nullptr; K.cl_err = nullptr;
     K.u_ld = a.m; K.slack = 0x1p-43 * (double)(sh.NS > 1 ? sh.NS : 1);
     if constexpr (CL) {
         char *mb = static_cast<char *>(a.workspace) + blk_mbox_off(nblk_, sh);
@@ -2073,7 +2127,7 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     if (sh.NS) {                                                   // cluster form: NS slices of the headline shape
         note_dense_kernel("gpfq_blk_kernel, cluster form (rows cut into 1024-sample slices: one workgroup of 11 sweep wavefronts + 1 decision wavefront per slice, partial dot products exchanged once per slot)");
         const float sym_a = blk_sym_a(a);
-        hipLaunchKernelGGL((gpfq_blk_prep_kernel<4, true>), dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp * sh.NS,
+        hipLaunchKernelGGL((gpfq_blk_prep_kernel<4, true, true>), dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp * sh.NS,
                            a.nrm32, static_cast<char *>(a.workspace), static_cast<char *>(a.workspace) + blk_hdrs_off(nblk, sh), sym_a,
                            sh.NS, (int64_t)blk_recs_bytes(nblk, sh));
         hipError_t e = hipGetLastError();

@@ -121,3 +121,25 @@ def test_cluster_form_full_width_layer(hip, oracle_mod):
     assert "cluster form" in hip.last_dense_kernel()
     assert np.array_equal(out["idx"][pick], idx)
     np.testing.assert_allclose(out["resid"][pick], resid, rtol=RESID_RTOL)
+
+
+@pytest.mark.parametrize("cmap", [0, 1])
+@pytest.mark.parametrize("m", [3000, 5121, 8192])
+def test_cluster_form_both_workgroup_maps(hip, oracle_mod, cmap, m):
+    """Workgroup id -> (cluster, slice): inside one XCD's queue (0) or consecutive ids (1: the slices of a cluster go round the XCDs and
+    the exchange crosses them); the default picks by the slice count.  Same bits either way; enough clusters for several rounds of the chip
+    would take a wide layer -- here 40 clusters of 3 / 6 / 8 slices."""
+    N, C = 29, 640
+    W, X, Xq = _synthetic(N, m, C, seed=m + cmap)
+    alphabet, _ = oracle_mod.layer_alphabet(W, np.linspace(-1, 1, 3), 3)
+    _, idx, resid = oracle_mod.layer(W, X, Xq, alphabet)
+    try:
+        hip.set_option("blk_cluster", 1024)
+        hip.set_option("blk_cluster_map", cmap)
+        _, out = _run(hip, W, X, Xq, alphabet, want_u=False)
+        assert "cluster form" in hip.last_dense_kernel()
+    finally:
+        hip.set_option("blk_cluster", 1)
+        hip.set_option("blk_cluster_map", -1)
+    assert np.array_equal(out["idx"], idx)
+    np.testing.assert_allclose(out["resid"], resid, rtol=RESID_RTOL)

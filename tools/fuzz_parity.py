@@ -44,6 +44,8 @@ while time.time() < t_end:
             N = int(rng.integers(200, 1025)); m = int(rng.integers(1, 2500))
         if rng.random() < 0.12:                     # 129..2048 neurons on rows of 257..1024 samples: the four-group matrix shapes (round 4)
             N = int(rng.integers(1, 60)); C = int(rng.choice([rng.integers(129, 400), rng.integers(1000, 1050), rng.integers(1900, 2049)])); m = int(rng.integers(257, 1025))
+        if rng.random() < 0.15:                     # rows of 2049..16384 samples: the block kernel's cluster form (1024-sample slices over several workgroups)
+            N = int(rng.integers(1, 60)); C = int(rng.choice([rng.integers(1, 60), rng.integers(100, 700), rng.integers(1000, 1400)])); m = int(rng.choice([rng.integers(2049, 5200), rng.integers(5121, 16385)]))
         if rng.random() < 0.12:                     # wide layers on long rows: 16 neurons per workgroup over eleven sweep wavefronts
             N = int(rng.integers(1, 40)); C = int(rng.integers(2049, 2400)); m = int(rng.integers(1025, 2049))
         kind = rng.choice(["relu", "sparse", "signed", "uniform"])
@@ -63,7 +65,8 @@ while time.time() < t_end:
         if path in (0, 1) and rng.random() < 0.5:   # the role-split kernels (one step / a block of steps per slot) wherever they apply
             opts = dict(pipe=int(rng.choice([1, 2])), blk_sweep_waves=int(rng.choice([0, 8, 11])), blk_wide_groups=int(rng.choice([1, 1, 0])), blk_four_groups=int(rng.choice([1, 1, 0])),
                         blk_pair_groups=int(rng.choice([1, 1, 0])), blk_single_groups=int(rng.choice([1, 1, 0])), blk_quad_groups=int(rng.choice([2, 2, 0, 1])), blk_quad_waves=int(rng.choice([0, 0, 7, 8])),
-                        variant=int(rng.choice([0, 0, 32])))
+                        variant=int(rng.choice([0, 0, 32])),
+                        blk_cluster=int(rng.choice([1, 1, 0, 1024, 2048])), blk_cluster_map=int(rng.choice([-1, 0, 1])))   # cluster form (round 5): by shape, off, from 1025 / 2049 samples up; both workgroup maps
         elif path == 1:
             opts = dict(lanes_per_neuron=int(rng.choice([0, 1, 16, 32, 64])), waves_per_neuron=int(rng.choice([0, 0, 2, 4, 8, 16])),
                         onchip_mode=int(rng.integers(0, 2)))
@@ -74,7 +77,7 @@ while time.time() < t_end:
                                      alphabet, path=path)
         finally:
             for k in opts:
-                hip.set_option(k, {"onchip_mode": 1, "pipe": -1, "blk_sweep_waves": 0, "blk_quad_waves": 0, "blk_wide_groups": 1, "blk_four_groups": 1, "blk_pair_groups": 1, "blk_single_groups": 1, "blk_quad_groups": 2}.get(k, 0))
+                hip.set_option(k, {"onchip_mode": 1, "pipe": -1, "blk_sweep_waves": 0, "blk_quad_waves": 0, "blk_wide_groups": 1, "blk_four_groups": 1, "blk_pair_groups": 1, "blk_single_groups": 1, "blk_quad_groups": 2, "blk_cluster": 1, "blk_cluster_map": -1}.get(k, 0))
         ok = np.array_equal(r["idx"].cpu().numpy(), io) and np.allclose(r["resid"].cpu().numpy(), ro, rtol=1e-5, atol=0)
         n_dense += 1
         if not ok:
