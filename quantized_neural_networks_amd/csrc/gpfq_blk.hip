@@ -481,9 +481,10 @@ template <int G, int S, int NSW, int NL> constexpr bool blk_split_has(int k)
 }
 
 // ---- sweep wavefront -------------------------------------------------------------------------------
-template <int G, int PW, int MP, int B, int NSW, bool SYM, int NL, bool CL>
+template <int G, int PW, int MP, int B, int NSW, bool SYM, int NL, int CLM>
 __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic, const BlkLds &L, int wave, int lane, int pbase, const ClState &cs)
 {
+    constexpr bool CL = CLM != 0;
     constexpr int NB = NL * G, KQ = 64 / G, NW = blk_slots(NSW, NB);   // NL neurons per lane (4; 2 in the narrow-layer shapes)
     constexpr int RSH = NL == 4 ? 0 : (NL == 2 ? 1 : 2);          // folded sums: neuron i of the lane ends up in rows i << RSH .. of the wavefront
     constexpr int HDR = blk_hdr_bytes(B, CL);
@@ -1103,9 +1104,10 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 }
 
 // ---- decision wavefront ------------------------------------------------------------------------------
-template <int G, int MP, int B, int NSW, bool SYM, int NL, bool CL>
+template <int G, int MP, int B, int NSW, bool SYM, int NL, int CLM>
 __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_generic, const BlkLds &L, int lane, ClState &cs)
 {
+    constexpr bool CL = CLM != 0;
     constexpr int NB = NL * G, R = blk_sublanes(NB), NW = blk_slots(NSW, NB);
     constexpr int RB = (int)blk_rec_bytes(MP, B, G, CL);
     lchar *lds = (lchar *)lds_generic;
@@ -1342,7 +1344,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                 // cluster form: what the sweeps left in LDS is this slice's share of block b + 1's D (the records carry row t + 2B): it leaves
                 // for the other slices now and is gathered at the END of the slot, behind the stores, while this wavefront would wait at the
                 // barrier anyway; this block's D came back a slot ago (DmCur).  lane = (neuron, step).
-                static_assert(!CL || (R == B && NB * B == 64), "cluster form: lane = (neuron, step)");
+                static_assert(!CL || (B == 4 && R % 4 == 0), "cluster form: a quad of lanes = the four steps of a neuron's block");
                 __builtin_amdgcn_sched_barrier(0);
                 if (b + 1 < K.nblk) {
                     const double xv[1] = {Dm};
@@ -1790,10 +1792,11 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 // XCDs round-robin by id): id = ((cluster / 8) nsl + slice) 8 + cluster % 8.  Workgroups are dispatched in id order, so whenever a
 // slice is resident every slice before it in the queue is resident or done -- the oldest cluster with work left is always complete on
 // the chip (nsl <= 16 <= the 32 CUs of an XCD) and the exchange cannot deadlock, whatever the mapping of ids to XCDs really is.
-template <int G, int S, int B, int NSW, bool SYM, int NL, bool CL = false>
+template <int G, int S, int B, int NSW, bool SYM, int NL, int CLM = 0>
 __global__ void __launch_bounds__(64 * (NSW + 1))
 gpfq_blk_kernel(BlkK K, AlphabetArg A)
 {
+    constexpr bool CL = CLM != 0;
     constexpr int NB = NL * G, KQ = 64 / G, MP = 2 * KQ * S;
     ClState cs{0, 0, 0u, false, 0, 0};
     if constexpr (CL) {
@@ -1834,17 +1837,17 @@ gpfq_blk_kernel(BlkK K, AlphabetArg A)
         // (one instantiation of the role per pair count that the shape's split holds)
 #define GPFQ_BLK_ROLE(PW_)                                                                                             \
         if constexpr (blk_split_has<G, S, NSW, NL>(PW_)) {                                                                    \
-            if (pw == PW_) blk_sweep_role<G, PW_, MP, B, NSW, SYM, NL, CL>(K, lds, L, wave, lane, pbase, cs);           \
+            if (pw == PW_) blk_sweep_role<G, PW_, MP, B, NSW, SYM, NL, CLM>(K, lds, L, wave, lane, pbase, cs);          \
         }
         GPFQ_BLK_ROLE(1) GPFQ_BLK_ROLE(2) GPFQ_BLK_ROLE(3) GPFQ_BLK_ROLE(4) GPFQ_BLK_ROLE(5) GPFQ_BLK_ROLE(6)
 #undef GPFQ_BLK_ROLE
     } else {
-        blk_decision_role<G, MP, B, NSW, SYM, NL, CL>(K, lds, L, lane, cs);
+        blk_decision_role<G, MP, B, NSW, SYM, NL, CLM>(K, lds, L, lane, cs);
     }
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-struct BlkShape { int G, S, B, mp, NW, NL, NS; };  // NL: neurons per lane (4 G or 2 G neurons per workgroup); NS: slices of the cluster form (0: classic; mp = samples of a slice)
+struct BlkShape { int G, S, B, mp, NW, NL, NS; };  // NL: neurons per lane (4 G or 2 G neurons per workgroup); NS: 0 = classic; >= 2: slices of the cluster form (mp = samples of a slice)
 static std::atomic<int> g_blk_single{1};  // one neuron per workgroup for layers of at most 128 neurons (blk_set_single_groups)
 void blk_set_single_groups(int on) { g_blk_single.store(on ? 1 : 0, std::memory_order_relaxed); }
 static std::atomic<int> g_blk_nw{0};      // sweep wavefronts of the 16-neuron B = 4 shapes: 8, 11, or 0 = by shape (blk_set_sweep_waves)
@@ -1868,6 +1871,8 @@ void blk_set_pair_groups(int on) { g_blk_pairs.store(on ? 1 : 0, std::memory_ord
 // <4,32,4> x 11 each, that exchange their partial dot products once per slot (cl_publish / cl_gather).  Option blk_cluster: 1 (default)
 // = by row length and width (blk_shape), 0 = off (rows beyond 5120 samples then keep the several-wavefronts-per-neuron kernel), a value
 // from 1024 up = every row beyond that many samples (tests, A/B).
+static std::atomic<int> g_blk_cluster_nl{0};      // cluster form: neurons per lane, 0 = by width; 1 / 2 / 4 force it (option blk_cluster_nl)
+void blk_set_cluster_nl(int v) { g_blk_cluster_nl.store(v == 1 || v == 2 || v == 4 ? v : 0, std::memory_order_relaxed); }
 static std::atomic<int> g_blk_cluster{1};
 void blk_set_cluster(int v) { g_blk_cluster.store(v <= 0 ? 0 : (v < 1024 ? 1 : v), std::memory_order_relaxed); }
 constexpr int64_t kClusterMaxM = 16384;
@@ -1888,13 +1893,25 @@ static BlkShape blk_shape(int64_t m, int64_t C)
 {
     {
         // By default (1): every row beyond 3072 samples -- a slot of the cluster form is the headline shape's (its exchange hides behind the
-        // chain of decisions), the classic shapes lose a third of that rate from 2049 samples up --, rows of 2049..3072 samples in layers
-        // of at most 1280 neurons (three slices: ten clusters per XCD and round, so such a layer is one round) and rows of 1537..2048
-        // samples in layers of 1025..2048 neurons (two slices, one round where the classic 8-neuron shape takes the same round with
-        // twice the sweep per workgroup): profiles/r05/cluster_form.txt.
+        // chain of decisions), the classic shapes lose a third of that rate from 2049 samples up --, and rows of 1537..3072 samples
+        // wherever the layer is ONE round of the chip (an XCD holds 32 / slices clusters at a time: up to 2048 neurons at two slices,
+        // 1280 at three): profiles/r05/cluster_form.txt.
         const int clm = g_blk_cluster.load(std::memory_order_relaxed);
-        const bool take = clm == 1 ? (m > 3072 || (m > 2048 && C <= 1280) || (m > 1536 && m <= 2048 && C > 1024 && C <= 2048)) : (clm > 1 && m > clm);
-        if (take && m <= kClusterMaxM) return {4, 32, 4, 1024, 11, 4, (int)((m + 1023) / 1024)};
+        const int ns_ = (int)((m + 1023) / 1024);
+        const bool one_round = ns_ <= 32 && ((C + 15) / 16 + 7) / 8 <= 32 / ns_;      // with 16 neurons per workgroup
+        const bool take = clm == 1 ? (m > 3072 || (m > 1536 && one_round)) : (clm > 1 && m > clm);
+        if (take && m <= kClusterMaxM) {
+            // neurons per workgroup: the fewest (4, 8, 16) with which the layer is still ONE round of the chip -- a slot of the 4- and
+            // 8-neuron shapes is the decision wavefront's (with the exchange's flight exposed), a slot of the 16-neuron shape the sweeps'
+            const int ns = (int)((m + 1023) / 1024);
+            const int cn = g_blk_cluster_nl.load(std::memory_order_relaxed);
+            // (measured, profiles/r05/cluster_form.txt: 8 neurons per workgroup wherever the layer is then still one round -- an XCD holds
+            //  32 / ns clusters at a time --, 16 otherwise; 4 per workgroup never beat 8)
+            int nl = 4;
+            if (cn == 1 || cn == 2) nl = cn;
+            else if (cn == 0 && ((C + 7) / 8 + 7) / 8 <= 32 / ns) nl = 2;
+            return {4, 32, 4, 1024, nl == 4 ? 11 : 8, nl, ns};
+        }
     }
     // Round 4 (dot products on the matrix unit, fused with the updates pair by pair): rows of 769..1024 samples take ELEVEN sweep wavefronts
     // (three per SIMD: 2.97 against 3.13 ms at 4096 x 4096 x 1024 -- the per-wavefront fold that made eleven lose until round 3 is gone);
@@ -2010,8 +2027,8 @@ static size_t blk_recs_bytes(int64_t nblk, const BlkShape &sh)          // (clus
     return ((size_t)((nblk + 1) * sh.B + 1) * (size_t)blk_rec_bytes(sh.mp, sh.B, sh.G, sh.NS != 0) + 255) & ~(size_t)255;
 }
 // cluster form: the exchange buffers, [cluster][2][slice][64 lanes][4 words]; clusters in whole groups of eight
-static int64_t blk_clusters(int64_t C, const BlkShape &sh) { return (((C + 4 * sh.G - 1) / (4 * sh.G)) + 7) / 8 * 8; }
-static size_t blk_mbox_bytes(int64_t C, const BlkShape &sh) { return sh.NS ? (size_t)blk_clusters(C, sh) * 2 * sh.NS * 64 * 4 * 8 : 0; }
+static int64_t blk_clusters(int64_t C, const BlkShape &sh) { return (((C + sh.NL * sh.G - 1) / (sh.NL * sh.G)) + 7) / 8 * 8; }
+static size_t blk_mbox_bytes(int64_t C, const BlkShape &sh) { return sh.NS > 1 ? (size_t)blk_clusters(C, sh) * 2 * sh.NS * 64 * 4 * 8 : 0; }
 static size_t blk_hdrs_bytes(int64_t nblk, int B, bool CL = false) { return (size_t)((nblk + 1) * B + 1) * (size_t)blk_hdr_bytes(B, CL) + 2048; }
 static size_t blk_hdrs_off(int64_t nblk, const BlkShape &sh) { return blk_recs_bytes(nblk, sh) * (size_t)(sh.NS ? sh.NS : 1); }     // compact headers: behind the last record stream
 static size_t blk_mbox_off(int64_t nblk, const BlkShape &sh) { return blk_hdrs_off(nblk, sh) + ((blk_hdrs_bytes(nblk, sh.B, sh.NS != 0) + 255) & ~(size_t)255); }
@@ -2031,7 +2048,7 @@ size_t blk_workspace_bytes(int64_t N, int64_t m, int64_t Cn)
 {
     // (the record layout depends on the row length and, through the steps per slot, on the width class of the layer: the largest)
     size_t need = 0;
-    for (int64_t C : {(int64_t)1 << 30, (int64_t)2048, (int64_t)1024, (int64_t)512}) {
+    for (int64_t C : {(int64_t)1 << 30, (int64_t)2048, (int64_t)1024, (int64_t)512, Cn > 0 ? Cn : (int64_t)1}) {   // (and the call's own width: the cluster form's neurons per workgroup)
         const BlkShape sh = blk_shape(m, C);
         if (!sh.G) continue;
         const int64_t nblk = (N + sh.B - 1) / sh.B;
@@ -2054,13 +2071,14 @@ static float blk_sym_a(const PipeArgs &a)
     return hi;
 }
 
-template <int G, int S, int B, int NSW, bool SYM, int NL, bool CL = false>
+template <int G, int S, int B, int NSW, bool SYM, int NL, int CLM = 0>
 static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStream_t stream)
 {
+    constexpr bool CL = CLM != 0;
     constexpr int NB = NL * G;
     const BlkLds L = blk_lds(sh.mp, NB, B, NSW, G, CL);
     const unsigned grid = CL ? (unsigned)(blk_clusters(a.C, sh) * sh.NS) : (unsigned)((a.C + NB - 1) / NB);
-    auto *kern = gpfq_blk_kernel<G, S, B, NSW, SYM, NL, CL>;
+    auto *kern = gpfq_blk_kernel<G, S, B, NSW, SYM, NL, CLM>;
     hipError_t e = ensure_dynamic_lds((const void *)kern, (size_t)L.total);
     if (e != hipSuccess) return e;
     BlkK K;
@@ -2069,7 +2087,7 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
     K.hdrs = K.recs + blk_hdrs_off(nblk_, sh);
     K.nsl = CL ? sh.NS : 0; K.cl_map = blk_cluster_map(sh.NS); K.slice_bytes = (int64_t)blk_recs_bytes(nblk_, sh); K.mbox = nullptr; K.cl_err = nullptr;
     K.u_ld = a.m; K.slack = 0x1p-43 * (double)(sh.NS > 1 ? sh.NS : 1);
-    if constexpr (CL) {
+    if constexpr (CLM == 1) {
         char *mb = static_cast<char *>(a.workspace) + blk_mbox_off(nblk_, sh);
         const size_t mbytes = blk_mbox_bytes(a.C, sh);
         e = hipMemsetAsync(mb, 0, mbytes, stream);                 // sequence numbers start at 1: a zero word is "not yet written"
@@ -2125,14 +2143,17 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     const int64_t nrec = (nblk + 1) * sh.B + 1;
     const bool r64 = blk_row64(sh.G, sh.B);
     if (sh.NS) {                                                   // cluster form: NS slices of the headline shape
-        note_dense_kernel("gpfq_blk_kernel, cluster form (rows cut into 1024-sample slices: one workgroup of 11 sweep wavefronts + 1 decision wavefront per slice, partial dot products exchanged once per slot)");
+        note_dense_kernel("gpfq_blk_kernel, cluster form (rows cut into 1024-sample slices: one workgroup of 8 or 11 sweep wavefronts + 1 decision wavefront per slice, partial dot products exchanged once per slot)");
         const float sym_a = blk_sym_a(a);
         hipLaunchKernelGGL((gpfq_blk_prep_kernel<4, true, true>), dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp * sh.NS,
                            a.nrm32, static_cast<char *>(a.workspace), static_cast<char *>(a.workspace) + blk_hdrs_off(nblk, sh), sym_a,
                            sh.NS, (int64_t)blk_recs_bytes(nblk, sh));
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        return sym_a != 0.f ? launch_blk_sym<4, 32, 4, 11, true, 4, true>(a, sh, stream) : launch_blk_sym<4, 32, 4, 11, false, 4, true>(a, sh, stream);
+#define GPFQ_BLK_CL(NSW_, NL_, M_) (sym_a != 0.f ? launch_blk_sym<4, 32, 4, NSW_, true, NL_, M_>(a, sh, stream) : launch_blk_sym<4, 32, 4, NSW_, false, NL_, M_>(a, sh, stream))
+        if (sh.NL == 4) return GPFQ_BLK_CL(11, 4, 1);
+        return sh.NL == 1 ? GPFQ_BLK_CL(8, 1, 1) : GPFQ_BLK_CL(8, 2, 1);
+#undef GPFQ_BLK_CL
     }
     auto *prep = sh.B == 4 ? (r64 ? gpfq_blk_prep_kernel<4, true> : gpfq_blk_prep_kernel<4, false>)
                            : (sh.B == 2 ? (r64 ? gpfq_blk_prep_kernel<2, true> : gpfq_blk_prep_kernel<2, false>) : gpfq_blk_prep_kernel<1, false>);

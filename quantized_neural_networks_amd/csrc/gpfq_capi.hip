@@ -218,6 +218,7 @@ int gpfq_set_option(const char *key, int value)
     if (!std::strcmp(key, "blk_single_groups")) { gpfq::blk_set_single_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_quad_groups")) { gpfq::blk_set_quad_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_cluster_map")) { gpfq::blk_set_cluster_map(value); return GPFQ_OK; }
+    if (!std::strcmp(key, "blk_cluster_nl")) { gpfq::blk_set_cluster_nl(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_cluster")) {
         if (value < 0 || (value > 1 && value < 1024)) return fail(GPFQ_ERR_INVALID_ARG, "blk_cluster must be 0 (off), 1 (default: by row length and width) or a row length >= 1024");
         gpfq::blk_set_cluster(value); return GPFQ_OK;

@@ -86,6 +86,7 @@ void blk_set_pair_groups(int on);   // 2-neuron workgroups for layers of at most
 void blk_set_wide_groups(int on);   // 16-neuron workgroups for rows beyond 1024 samples (speed only)
 void blk_set_quad_groups(int on);   // four neuron groups x 1 / 2 neurons per lane for layers of at most 2048 neurons on rows of 257..1024 samples; 2 (default): every such layer, 1: 129..2048 neurons only, 0: off (speed only)
 void blk_set_quad_waves(int nw);    // sweep wavefronts of the four-group narrow shapes on rows of at most 768 samples: 0 (default) = by shape (seven for layers of at most 1024 neurons, else eight), 7 or 8 force it (speed only)
+void blk_set_cluster_nl(int v);     // cluster form: neurons per lane of a workgroup, 0 (default) = by width, 1 / 2 / 4 force it (speed only)
 void blk_set_cluster_map(int v);    // cluster form: workgroup id -> (cluster, slice): -1 (default) by the slice count, 0 = a cluster inside one XCD, 1 = consecutive ids (speed only)
 void blk_set_cluster(int v);        // cluster form (rows cut into 1024-sample slices over several workgroups, up to 16384 samples): 1 (default) = by shape, 0 = off, v >= 1024 = every row beyond v samples (speed only)
 void blk_set_sweep_waves(int nw);   // sweep wavefronts of the 16-neuron four-step shapes: 0 (default) = by shape (eleven for rows of 769..1024 samples, eight below), 8 or 11 force it (speed only)

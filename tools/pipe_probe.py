@@ -63,6 +63,7 @@ def main():
     hip.set_option("blk_quad_groups", int(os.environ.get("BLK_QUAD", "2")))   # <= 2048 neurons on rows of 257..1024 samples: four neuron groups x 1 / 2 neurons per lane (fused matrix form); 1: 129..2048 only; 2: narrower layers too
     hip.set_option("blk_quad_waves", int(os.environ.get("BLK_QUAD_NW", "0")))  # four-group narrow shapes on rows <= 768 samples: 7 / 8 sweep wavefronts (0: by shape)
     hip.set_option("blk_cluster_map", int(os.environ.get("BLK_CLUSTER_MAP", "-1")))
+    hip.set_option("blk_cluster_nl", int(os.environ.get("BLK_CLUSTER_NL", "0")))    # cluster form: neurons per lane (0: by width)
     hip.set_option("blk_cluster", int(os.environ.get("BLK_CLUSTER", "1")))     # cluster form: 1 = rows beyond 5120 samples, 0 = off, >= 1024: rows beyond that
     hip.set_option("blk_wide_groups", int(os.environ.get("BLK_WIDE", "1")))   # rows > 1024 samples, > 2048 neurons: 16 neurons per workgroup
     base = run(pipe=0)
