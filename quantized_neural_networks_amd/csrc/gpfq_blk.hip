@@ -1899,7 +1899,7 @@ static BlkShape blk_shape(int64_t m, int64_t C)
         const int clm = g_blk_cluster.load(std::memory_order_relaxed);
         const int ns_ = (int)((m + 1023) / 1024);
         const bool one_round = ns_ <= 32 && ((C + 15) / 16 + 7) / 8 <= 32 / ns_;      // with 16 neurons per workgroup
-        const bool take = clm == 1 ? (m > 3072 || (m > 1536 && one_round)) : (clm > 1 && m > clm);
+        const bool take = clm == 1 ? (m > 3072 || (m > 1536 && one_round && (m > 2048 || C > 128))) : (clm > 1 && m > clm);   // (at most 128 neurons on rows of at most 2048 samples: the one-neuron workgroups stay ahead, 1.98 / 2.07 ms)
         if (take && m <= kClusterMaxM) {
             // neurons per workgroup: the fewest (4, 8, 16) with which the layer is still ONE round of the chip -- a slot of the 4- and
             // 8-neuron shapes is the decision wavefront's (with the exchange's flight exposed), a slot of the 16-neuron shape the sweeps'
