@@ -1880,13 +1880,17 @@ constexpr int64_t kClusterMaxM = 16384;
 // slices of a cluster side by side in ONE XCD's queue (the exchange stays inside that XCD's L2 domain); but an XCD's 32 CUs then hold
 // 32 / nsl whole clusters and 32 % nsl slices of the next one, which wait a whole round for their mates -- and so does every round after
 // (three slices: four rounds' time for three rounds of work).  Map 1, consecutive ids, strands at most one cluster of the whole chip.
-static std::atomic<int> g_blk_cluster_map{-1};     // -1: by the number of slices; 0 / 1 force a map (option blk_cluster_map)
+static std::atomic<int> g_blk_cluster_map{-1};     // -1: by the number of slices (blk_cluster_map below); 0 / 1 force a map (option blk_cluster_map)
 void blk_set_cluster_map(int v) { g_blk_cluster_map.store(v < 0 ? -1 : (v ? 1 : 0), std::memory_order_relaxed); }
 static int blk_cluster_map(int nsl)
 {
     const int v = g_blk_cluster_map.load(std::memory_order_relaxed);
-    (void)nsl;
-    return v >= 0 ? v : 0;                             // (measured: the two maps take the same time at 3, 6, 7 and 8 slices: profiles/r05/cluster_form.txt)
+    if (v >= 0) return v;
+    // The two maps take the same time at every slice count measured (profiles/r05/cluster_form.txt) -- the exchange hides behind the chain of
+    // decisions across XCDs as well as inside one.  But where the slice count divides 8 (or is 16), consecutive ids put slice s of EVERY
+    // cluster on XCD s mod 8: an XCD's 32 workgroups then stream one or two record streams instead of all of them, and the launch's HBM
+    // traffic is the headline's per slice (FETCH_SIZE at 4096 x 4096 on 8192 samples: 44.4 GB under map 0) -- so map 1 there.
+    return (nsl > 0 && (8 % nsl == 0 || nsl % 8 == 0)) ? 1 : 0;
 }
 
 static BlkShape blk_shape(int64_t m, int64_t C)
