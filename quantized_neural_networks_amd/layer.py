@@ -126,9 +126,15 @@ def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True):
     world, rank = _group_info(group)
     lo, hi = shard_bounds(C, world, rank)
     Wt = hip.neuron_major(W.contiguous(), lo, hi)            # neuron-major shard [C_local][N]
+    flag = None
     if hi > lo:
         r = hip.quantize_neurons(X, Xq, Wt, alphabet, want_values=False, want_resid=want_resid)
         i_loc, res_loc = r["idx"], r["resid"]
+        ws = r.get("workspace")
+        if ws is not None and ws.numel() >= 16:
+            # the block kernel's cluster form raises this word when an exchange between its workgroups timed out (hip.cluster_timeouts):
+            # a copy of it travels with the result, checked by the class surface at the end of quantize_network()
+            flag = ws[8:12].view(torch.int32).clone()
     else:
         i_loc = torch.empty((0, N), dtype=hip.index_dtype(len(alphabet)), device=W.device)
         res_loc = torch.empty((0,), dtype=torch.float64, device=W.device)
@@ -139,7 +145,7 @@ def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True):
         Q, idx = hip.assemble_kernel(all_gather_units(packed, C, group).contiguous(), alphabet, bits=bits, N=N)
     else:
         Q, idx = hip.assemble_kernel(i_loc, alphabet)
-    out = dict(Q=Q, idx=idx)
+    out = dict(Q=Q, idx=idx, cluster_err=flag)
     if want_resid is not False:
         out["resid"] = all_gather_units(res_loc, C, group)
     return out
