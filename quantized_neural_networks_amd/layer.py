@@ -145,7 +145,7 @@ def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True):
         Q, idx = hip.assemble_kernel(all_gather_units(packed, C, group).contiguous(), alphabet, bits=bits, N=N)
     else:
         Q, idx = hip.assemble_kernel(i_loc, alphabet)
-    out = dict(Q=Q, idx=idx, cluster_err=flag)
+    out = dict(Q=Q, idx=idx, cluster_err=flag if flag is not None else torch.zeros(1, dtype=torch.int32, device=W.device))
     if want_resid is not False:
         out["resid"] = all_gather_units(res_loc, C, group)
     return out
