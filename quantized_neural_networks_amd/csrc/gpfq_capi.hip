@@ -98,7 +98,7 @@ hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes)
 
 extern "C" {
 
-int gpfq_version(void) { return 303; }   // 303: gpfq_set_main_kernel_events joined the ABI (round 4); hip.load() checks it
+int gpfq_version(void) { return 304; }   // 304: options blk_cluster / blk_cluster_nl / blk_cluster_map, larger workspaces for long rows (round 5); 303: gpfq_set_main_kernel_events (round 4); hip.load() checks it
 
 const char *gpfq_last_dense_kernel(void) { return g_dense_kernel; }
 

@@ -83,7 +83,7 @@ def lib_path():
     return _build.LIB
 
 
-ABI_VERSION = 303                  # gpfq_version() of the library this binding was written against
+ABI_VERSION = 304                  # gpfq_version() of the library this binding was written against
 
 
 def load():
