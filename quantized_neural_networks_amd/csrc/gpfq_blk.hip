@@ -735,6 +735,8 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             // Operand rows are requested PF pair-steps ahead of their use: one everywhere -- except in the seven-sweep-wavefront shapes (two
             // wavefronts per SIMD, 256 registers), where a pair-step's handful of instructions no longer covers an LDS round trip and the
             // sweep's own chain of them would become the slot: two (round 5).
+            // (two and four pair-steps ahead in the eight-wavefront narrow shapes too: no change, 1.28-1.30 ms at 4096 x 512 on 1024 samples
+            //  either way -- profiles/r05/cluster_form.txt)
             constexpr int PF = NSW == 7 ? 2 : 1, NPS = PW * B;
             float2 fwq[B][NL], xbuf[PF], qbuf[PF];
             double2 dcur;
@@ -2175,7 +2177,8 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     if (sh.G == 4 && sh.NL < 4) {
         if (sh.S == 16) return sh.NL == 1 ? launch_blk_inst<4, 16, 4, 8, 1>(a, sh, stream) : launch_blk_inst<4, 16, 4, 8, 2>(a, sh, stream);
         if (sh.S == 24) return sh.NL == 1 ? launch_blk_inst<4, 24, 4, 8, 1>(a, sh, stream) : launch_blk_inst<4, 24, 4, 8, 2>(a, sh, stream);
-        // (eleven sweep wavefronts buy these shapes nothing: 4096 x 512 on 1024 samples 1.77 against 1.62 ms, 4096 x 2048 1.94 / 1.95)
+        // (eleven sweep wavefronts buy these shapes nothing: 4096 x 512 on 1024 samples 1.77 against 1.62 ms, 4096 x 2048 1.94 / 1.95 in round 4;
+        //  measured again on round 5's kernels, one neuron per lane: 1.326 against 1.285 -- profiles/r05/cluster_form.txt)
         return sh.NL == 1 ? launch_blk_inst<4, 32, 4, 8, 1>(a, sh, stream) : launch_blk_inst<4, 32, 4, 8, 2>(a, sh, stream);
     }
     if (sh.NL == 1) {                                              // one-neuron workgroups (layers of at most 128 neurons)
