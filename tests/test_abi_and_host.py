@@ -243,3 +243,33 @@ def test_accuracy_regression_entry_point_skips_cleanly_without_data(tmp_path, ca
     assert mod.main(["--published", str(pub), "--dataset", str(tmp_path / "mnist.npz"), "--model", str(tmp_path / "m.npz")]) == 0
     assert "skipped" in capsys.readouterr().out
     assert mod.main(["--published", str(tmp_path / "none.csv")]) == 0
+
+
+def test_cluster_form_options_and_workspace_sizing(lib):
+    """Host side of the block kernel's cluster form (no launch): the options validate their values, and gpfq_workspace_bytes() follows
+    them -- one record stream per 1024-sample slice, the exchange buffers per group of neurons."""
+    from quantized_neural_networks_amd import hip
+    ws = lambda N, m, C: int(lib.gpfq_workspace_bytes(N, m, C, hip.GPFQ_PATH_ONCHIP))
+    try:
+        assert lib.gpfq_set_option(b"blk_cluster", 500) != 0 and b"blk_cluster" in lib.gpfq_last_error()
+        assert lib.gpfq_set_option(b"blk_cluster", -1) != 0
+        for v in (0, 1, 1024, 4096):
+            assert lib.gpfq_set_option(b"blk_cluster", v) == 0
+        for key in (b"blk_cluster_nl", b"blk_cluster_map"):
+            assert lib.gpfq_set_option(key, 0) == 0
+        # default dispatch: 8192 samples = eight slices of the headline shape's records (16 B per sample and step + headers)
+        assert lib.gpfq_set_option(b"blk_cluster", 1) == 0
+        w8192, w1024 = ws(4096, 8192, 4096), ws(4096, 1024, 4096)
+        assert w8192 > 7 * w1024 and w8192 < 10 * w1024
+        assert ws(4096, 8192, 4096) == w8192                         # a pure function of its arguments and the options
+        assert ws(4096, 8192, 8192) > w8192                          # more neurons: more exchange buffers
+        # cluster form off: rows beyond 5120 samples need no block-kernel records at all
+        assert lib.gpfq_set_option(b"blk_cluster", 0) == 0
+        assert ws(4096, 8192, 4096) < w1024
+        # ... and forced from 1025 samples up, a 2048-sample row takes two slices' records
+        assert lib.gpfq_set_option(b"blk_cluster", 1024) == 0
+        assert ws(4096, 2048, 4096) > 1.9 * w1024
+    finally:
+        lib.gpfq_set_option(b"blk_cluster", 1)
+        lib.gpfq_set_option(b"blk_cluster_nl", 0)
+        lib.gpfq_set_option(b"blk_cluster_map", -1)
