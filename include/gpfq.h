@@ -120,7 +120,7 @@ int gpfq_set_main_kernel_events(void *start_event, void *stop_event);
  *                  LDS-staged rows instead of register prefetch; bit 2: Gram records of walks longer than 64
  *                  steps on the vector units instead of the matrix cores (v_mfma_f64_16x16x4_f64);
  *                  bit 4: pipelined kernel issues its LDS-DMA spread over the steps of a tile
- *   "pipe"         role-split dense kernels (alphabets <= 64): -1 (default) the block form (gpfq_blk.hip; rows of 257..16384
+ *   "pipe"         role-split dense kernels (alphabets <= 64): -1 (default) the block form (gpfq_blk.hip; rows of 257..28672
  *                  samples) where measured faster -- layers of 512+ neurons, and any width for rows of 769+ samples --,
  *                  0 never, 1 one step per slot (gpfq_pipe.hip, rows up to 2048) whenever it applies, 2 the block form
  *                  whenever it applies
@@ -133,7 +133,7 @@ int gpfq_set_main_kernel_events(void *start_event, void *stop_event);
  *                  wavefront with one or two neurons per lane (4 / 8 neurons per workgroup, dot products on the matrix unit);
  *                  1: only layers of 129..2048 neurons; 0: the one- / two-group shapes of round 3
  *   "blk_cluster"       the block form's CLUSTER FORM (a row cut into 1024-sample slices, one workgroup each, partial dot products exchanged
- *                  once per slot; rows of up to 16384 samples): 1 (default) by shape -- every row beyond 3072 samples, rows of 1537..3072
+ *                  once per slot; rows of up to GPFQ_ONCHIP_MAX_M samples): 1 (default) by shape -- every row beyond 3072 samples, rows of 1537..3072
  *                  samples in layers that are one round of the chip --, 0 off (rows beyond 5120 samples then take the wide kernel), a row
  *                  length >= 1024: every row beyond it (tests)
  *   "blk_cluster_nl"    that form's neurons per workgroup: 0 (default) 8 where the layer is then one round, else 16; 1 / 2 / 4 force 4 / 8 / 16

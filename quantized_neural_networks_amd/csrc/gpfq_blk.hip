@@ -1793,7 +1793,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 // CL (cluster form): workgroup id -> (cluster, slice) with a cluster's slices side by side in ONE XCD's queue (workgroups go to the
 // XCDs round-robin by id): id = ((cluster / 8) nsl + slice) 8 + cluster % 8.  Workgroups are dispatched in id order, so whenever a
 // slice is resident every slice before it in the queue is resident or done -- the oldest cluster with work left is always complete on
-// the chip (nsl <= 16 <= the 32 CUs of an XCD) and the exchange cannot deadlock, whatever the mapping of ids to XCDs really is.
+// the chip (nsl <= 28 <= the 32 CUs of an XCD) and the exchange cannot deadlock, whatever the mapping of ids to XCDs really is.
 template <int G, int S, int B, int NSW, bool SYM, int NL, int CLM = 0>
 __global__ void __launch_bounds__(64 * (NSW + 1))
 gpfq_blk_kernel(BlkK K, AlphabetArg A)
@@ -1869,7 +1869,7 @@ void blk_set_quad_waves(int nw) { g_blk_quad_nw.store(nw == 7 ? 7 : (nw == 8 ? 8
 static std::atomic<int> g_blk_pairs{1};   // two-neuron workgroups for layers of at most 512 neurons
 void blk_set_pair_groups(int on) { g_blk_pairs.store(on ? 1 : 0, std::memory_order_relaxed); }
 
-// Cluster form (round 5): long rows -- up to 16384 samples -- are cut into slices of 1024 samples, one workgroup of the headline shape
+// Cluster form (round 5): long rows -- up to 28672 samples -- are cut into slices of 1024 samples, one workgroup of the headline shape
 // <4,32,4> x 11 each, that exchange their partial dot products once per slot (cl_publish / cl_gather).  Option blk_cluster: 1 (default)
 // = by row length and width (blk_shape), 0 = off (rows beyond 5120 samples then keep the several-wavefronts-per-neuron kernel), a value
 // from 1024 up = every row beyond that many samples (tests, A/B).
@@ -1877,7 +1877,7 @@ static std::atomic<int> g_blk_cluster_nl{0};      // cluster form: neurons per l
 void blk_set_cluster_nl(int v) { g_blk_cluster_nl.store(v == 1 || v == 2 || v == 4 ? v : 0, std::memory_order_relaxed); }
 static std::atomic<int> g_blk_cluster{1};
 void blk_set_cluster(int v) { g_blk_cluster.store(v <= 0 ? 0 : (v < 1024 ? 1 : v), std::memory_order_relaxed); }
-constexpr int64_t kClusterMaxM = 16384;
+constexpr int64_t kClusterMaxM = 28672;      // = GPFQ_ONCHIP_MAX_M: 28 slices, still inside one XCD's 32 CUs
 // Workgroup id -> (cluster, slice).  Workgroups go to the XCDs round-robin by id and every XCD starts its own in order.  Map 0 puts the
 // slices of a cluster side by side in ONE XCD's queue (the exchange stays inside that XCD's L2 domain); but an XCD's 32 CUs then hold
 // 32 / nsl whole clusters and 32 % nsl slices of the next one, which wait a whole round for their mates -- and so does every round after

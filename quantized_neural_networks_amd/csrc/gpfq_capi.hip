@@ -354,9 +354,9 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
             // width (4096 x 2048, m = 1024: 2.5 vs 5.4 ms; 4096 x 128, m = 2048: 2.9 vs 4.5; 2048 x 128, m = 4096: 2.3 vs 2.5).
             // Round 3: two-neuron workgroups (layers of at most 512 neurons, rows of up to 5120 samples) make it the fastest for narrow
             // layers as well (784 x 128, m = 512, 16 levels; 2048 x 128, m = 5008: tools/blk_ab.sh latency, profiles/r03/).
-            // Round 5: rows of 5121..16384 samples too -- the cluster form (gpfq_blk.hip: slices of 1024 samples over several workgroups;
+            // Round 5: rows of 5121..28672 samples too -- the cluster form (gpfq_blk.hip: slices of 1024 samples over several workgroups;
             // blk_supported() says no when the option blk_cluster switches it off)
-            const bool fits = m > 256 && M <= 64 && m <= 16384;
+            const bool fits = m > 256 && M <= 64 && m <= GPFQ_ONCHIP_MAX_M;
             const bool want = g_pipe == 1;
             if ((g_pipe == 2 || (g_pipe < 0 && !forced_old && fits)) && N > 0 && m > 0 && gpfq::blk_supported(pa) && workspace &&
                 (uintptr_t)workspace % 16 == 0 && workspace_bytes >= onchip_workspace_bytes(N, m, C)) {

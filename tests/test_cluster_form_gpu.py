@@ -38,7 +38,7 @@ def _run(hip, W, X, Xq, alphabet, want_u=True):
 
 # (threshold, m): the option moves the threshold down so that clusters of two and three slices run too; 9000 / 16384: more slices than one
 # batch of the exchange's reads; 5121 and 8192: as dispatched
-@pytest.mark.parametrize("threshold,m", [(1024, 1100), (1024, 2049), (2048, 3000), (1, 5121), (1, 6000), (1, 8192), (1, 9000), (1, 16384)])
+@pytest.mark.parametrize("threshold,m", [(1024, 1100), (1024, 2049), (2048, 3000), (1, 5121), (1, 6000), (1, 8192), (1, 9000), (1, 16384), (1, 20001), (1, 28672)])
 @pytest.mark.parametrize("C,levels,nl", [(5, 3, 0), (70, 2, 4), (200, 4, 2), (33, 16, 1), (70, 3, 0), (33, 16, 4)])
 def test_cluster_form_vs_oracle(hip, oracle_mod, threshold, m, C, levels, nl):
     N = 23 if m > 6000 else 37                                    # (not a multiple of the block of four steps)
