@@ -1884,7 +1884,7 @@ constexpr int64_t kClusterMaxM = 28672;      // = GPFQ_ONCHIP_MAX_M: 28 slices, 
 // (three slices: four rounds' time for three rounds of work).  Map 1, consecutive ids, strands at most one cluster of the whole chip.
 static std::atomic<int> g_blk_cluster_map{-1};     // -1: by the number of slices (blk_cluster_map below); 0 / 1 force a map (option blk_cluster_map)
 void blk_set_cluster_map(int v) { g_blk_cluster_map.store(v < 0 ? -1 : (v ? 1 : 0), std::memory_order_relaxed); }
-static int blk_cluster_map(int nsl)
+static int blk_cluster_map(int nsl, int64_t clusters)
 {
     const int v = g_blk_cluster_map.load(std::memory_order_relaxed);
     if (v >= 0) return v;
@@ -1892,7 +1892,15 @@ static int blk_cluster_map(int nsl)
     // decisions across XCDs as well as inside one.  But where the slice count divides 8 (or is 16), consecutive ids put slice s of EVERY
     // cluster on XCD s mod 8: an XCD's 32 workgroups then stream one or two record streams instead of all of them, and the launch's HBM
     // traffic is the headline's per slice (FETCH_SIZE at 4096 x 4096 on 8192 samples: 44.4 GB under map 0) -- so map 1 there.
-    return (nsl > 0 && (8 % nsl == 0 || nsl % 8 == 0)) ? 1 : 0;
+    if (nsl > 0 && (8 % nsl == 0 || nsl % 8 == 0)) return 1;
+    // Other slice counts: whole clusters per round -- an XCD's 32 CUs hold 32 / nsl of them under map 0 (the rest of its CUs wait a round
+    // for their mates), the chip's 256 hold 256 / nsl under map 1.  The map with fewer rounds, map 1 on a tie.  (At 256 clusters the two
+    // tie for 3, 5, 6 and 7 slices -- which is why they measured equal there; 20 slices: 32 rounds against 22, 122.0 against 83.9 ms at
+    // 4096 x 4096 on 20000 samples; 28 slices of 64 clusters tie at 8 rounds, 40.3 against 37.3 ms: profiles/r05/cluster_form.txt.)
+    if (nsl <= 0 || nsl > 32) return 0;
+    const int64_t per0 = 32 / nsl, per1 = 256 / nsl;
+    const int64_t r0 = ((clusters + 7) / 8 + per0 - 1) / per0, r1 = (clusters + per1 - 1) / per1;
+    return r1 <= r0 ? 1 : 0;
 }
 
 static BlkShape blk_shape(int64_t m, int64_t C)
@@ -2091,7 +2099,7 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
     const int64_t nblk_ = (a.N + B - 1) / B;
     K.recs = static_cast<const char *>(a.workspace); K.Wt = a.Wt; K.ldw = a.ldw;
     K.hdrs = K.recs + blk_hdrs_off(nblk_, sh);
-    K.nsl = CL ? sh.NS : 0; K.cl_map = blk_cluster_map(sh.NS); K.slice_bytes = (int64_t)blk_recs_bytes(nblk_, sh); K.mbox = nullptr; K.cl_err = nullptr;
+    K.nsl = CL ? sh.NS : 0; K.cl_map = blk_cluster_map(sh.NS, (a.C + NB - 1) / NB); K.slice_bytes = (int64_t)blk_recs_bytes(nblk_, sh); K.mbox = nullptr; K.cl_err = nullptr;
     K.u_ld = a.m; K.slack = 0x1p-43 * (double)(sh.NS > 1 ? sh.NS : 1);
     if constexpr (CLM == 1) {
         char *mb = static_cast<char *>(a.workspace) + blk_mbox_off(nblk_, sh);
