@@ -1569,7 +1569,11 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                 // every slice's share of block b + 1's D, added in slice order: the same bits in every slice (published above)
                 if (b + 1 < K.nblk) {
                     double xv[1] = {0.0};
-                    cl_gather<1, 8>(K, cs, lane, xv);
+                    // (9+ slices in the 16-neuron shape: sixteen per batch of loads -- a batch is a trip to memory, and two of them no longer
+                    //  fit into this wavefront's wait at the barrier: 4096 x 4096 on 16384 samples 51.0 -> 48.0 ms, 4096 x 1024 on 28672
+                    //  37.3 -> 33.1; the 4- / 8-neuron shapes, whose slot is this wavefront's, spill with the second instantiation)
+                    if (NL == 4 && K.nsl > 8) cl_gather<1, NL == 4 ? 16 : 8>(K, cs, lane, xv);
+                    else cl_gather<1, 8>(K, cs, lane, xv);
                     DmCur = xv[0];
                 }
             }
