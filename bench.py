@@ -21,7 +21,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
                   (6 m per weight) / the kernel's HIP-event time / the FP64 vector peak (spec) -- plus,
                   labelled as secondary, the 8d HBM-equivalent figure, the compulsory traffic and the PMC-measured one;
   `cpu_baseline`  the C oracle port on all host cores over a bounded sample of the same layer;
-  `cpu_baseline_numpy`  the reference-shaped one: the NumPy restatement over a process pool (a child process).
+  `cpu_baseline_numpy`  the reference-shaped one: the NumPy restatement over a process pool (a child process);
+  `long_rows`     a secondary record outside the timed region: the same layer on --long-rows (8192) calibration samples, i.e. through
+                  the block kernel's cluster form -- kernel time by the library's own events and the same flop roofline.
 """
 import argparse
 import json
@@ -69,6 +71,8 @@ def main():
     ap.add_argument("--bits", type=float, default=float(np.log2(3)))
     ap.add_argument("--alphabet-scalar", type=float, default=3.0)
     ap.add_argument("--cpu-sample", type=int, default=512, help="neurons timed on the host cores (0 = skip)")
+    ap.add_argument("--long-rows", type=int, default=8192,
+                    help="also time the same layer on this many calibration samples (a secondary record: the block kernel's cluster form); 0 = skip")
     ap.add_argument("--numpy-sample", type=int, default=-1,
                     help="neurons of the NumPy process-pool baseline (the reference-shaped one); -1 = 2 x host cores, 0 = skip")
     args = ap.parse_args()
@@ -285,9 +289,46 @@ def main():
             out["cpu_baseline"], out["parity_sample"] = _cpu_baseline(W, X, Xq, unit_alphabet, args, idx, last)
             if args.numpy_sample != 0:
                 out["cpu_baseline_numpy"] = _cpu_baseline_numpy(W, X, Xq, unit_alphabet, args, idx)
+        if world == 1 and args.long_rows > m:
+            out["long_rows"] = _long_rows(N, C_total, args.long_rows, unit_alphabet, args, dev)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _long_rows(N, C, m_long, unit_alphabet, args, dev):
+    """Secondary record, outside the timed region of the headline: the same Dense(N -> C) layer on `m_long` calibration samples -- rows
+    that do not fit one workgroup's registers and run as the block kernel's CLUSTER FORM (1024-sample slices over several workgroups,
+    partial dot products exchanged once per slot: DESIGN 4.1).  Kernel time from the library's own events, three launches; never fails
+    the bench line (an exception is reported in place of the numbers)."""
+    try:
+        from quantized_neural_networks_amd import hip, layer
+        g = np.random.default_rng(7).standard_normal((N, m_long)).astype(np.float32)
+        X = torch.from_numpy(np.maximum(g, 0)).to(dev)
+        Xq = torch.from_numpy(np.maximum(g + 0.1 * np.random.default_rng(8).standard_normal((N, m_long)).astype(np.float32), 0)).to(dev)
+        del g
+        Wd = torch.from_numpy(weight_block(N, 0, C)).to(dev)
+        alphabet, _ = layer.layer_alphabet(Wd, unit_alphabet, args.alphabet_scalar, None)
+        Wt = hip.neuron_major(Wd, 0, C)
+        nrm = hip.row_norms(Xq)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+        hip.quantize_neurons(X, Xq, Wt, alphabet, nrm32=nrm, want_values=False)                     # warm-up
+        for a, b in evs:
+            hip.set_main_kernel_events(a, b)
+            r = hip.quantize_neurons(X, Xq, Wt, alphabet, nrm32=nrm, want_values=False)
+            hip.set_main_kernel_events(None, None)
+        torch.cuda.synchronize()
+        name = hip.last_dense_kernel()
+        ms = [a.elapsed_time(b) for a, b in evs] if name.startswith("gpfq_blk_kernel") else []
+        if not ms:
+            return {"m": m_long, "kernel": name, "note": "not the block kernel: no inner events"}
+        flops = 6.0 * m_long * N * C
+        k = float(np.mean(ms)) / 1e3
+        return {"workload": f"Dense({N}->{C}) on m={m_long} calibration samples, same alphabet", "kernel": name[:120], "kernel_ms_avg": k * 1e3,
+                "kernel_ms_min": float(np.min(ms)), "achieved_tflops": flops / k / 1e12, "frac_of_fp64_vector_peak": flops / k / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                "weights_per_s_kernel": N * C / k, "cluster_timeouts": hip.cluster_timeouts(r), "exact_fallbacks": hip.exact_fallbacks(r)}
+    except Exception as exc:                                          # a secondary record must not cost the headline line
+        return {"m": m_long, "error": repr(exc)[:300]}
 
 
 def _recorded_traffic(N, m, C_local, kernel_name):
