@@ -24,8 +24,8 @@ def _free_port():
 
 def _inputs(case, dev):
     g = torch.Generator(device=dev).manual_seed(11)
-    if case in ("dense", "dense_8bit"):
-        N, m, C = 300, 1024, 70                                  # 70 neurons: uneven shards
+    if case in ("dense", "dense_8bit", "dense_long"):
+        N, m, C = (120, 3100, 70) if case == "dense_long" else (300, 1024, 70)   # 70 neurons: uneven shards; dense_long: rows of the block kernel's cluster form (four slices per rank's launch)
         W = torch.randn((N, C), device=dev, generator=g) / np.sqrt(N)
         G = torch.randn((N, m), device=dev, generator=g)
         return dict(W=W, X=torch.relu(G), Xq=torch.relu(G + 0.1 * torch.randn((N, m), device=dev, generator=g)),
@@ -170,7 +170,7 @@ def _worker(rank, world, port, case, result_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,world", [("dense", 2), ("dense", 3), ("dense_big_median", 2), ("conv3x3", 2), ("conv5x5", 3),
+@pytest.mark.parametrize("case,world", [("dense", 2), ("dense", 3), ("dense_long", 2), ("dense_big_median", 2), ("conv3x3", 2), ("conv5x5", 3),
                                         ("dense_8bit", 3), ("conv3x3_8bit", 2), ("conv_filters_8bit", 2),
                                         ("network_mlp", 2), ("network_cnn", 2), ("network_cnn", 3), ("network_mlp_grid", 2),
                                         ("conv_filters", 2), ("conv_columns7", 3),    # fewer channels than ranks: image shards
