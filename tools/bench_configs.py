@@ -181,7 +181,9 @@ def main():
                                       (4096, 4096, 1000, L4, 5), (4096, 4096, 1536, L4, 5), (4096, 4096, 2048, L4, 5), (4096, 2048, 1536, L4, 5),
                                       (4096, 1000, 2048, L4, 5), (4096, 512, 2048, L4, 5), (4096, 128, 2048, L4, 5),
                                       (4096, 4096, 3000, L4, 5), (4096, 4096, 4096, L4, 5), (4096, 1024, 3000, L4, 5), (4096, 4096, 5008, 3.0, 4),
-                                      (2048, 128, 5008, 3.0, 4), (784, 128, 512, L4, 5), (4096, 4096, 8192, L3, 3)]:
+                                      (2048, 128, 5008, 3.0, 4), (784, 128, 512, L4, 5), (4096, 4096, 8192, L3, 3),
+                                      # round 5, the cluster form's own shapes: 8-neuron workgroups, slice counts that do not divide 8, the longest rows
+                                      (4096, 512, 4096, L4, 5), (4096, 4096, 6000, L4, 5), (4096, 4096, 12000, L3, 3), (4096, 1024, 28672, L3, 3)]:
             recs.append(time_shape(N, C, m, bits, scalar, dev))
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(dict(note="tools/bench_configs.py on one MI355X; best of 4-5 runs per layer; whole layer driver "
