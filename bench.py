@@ -129,16 +129,55 @@ def main():
 
     st = {"C_total": C_total, "Wd": Wd}      # the layer being stepped (the weak-scaling companion swaps in its own)
 
+    # The layer driver with nothing crossing to the host (round 6): the median of |W| stays a device scalar, one single-thread kernel forms
+    # rad * alphabet in device memory (layer.layer_alphabet_device), the block-pipelined kernel reads the Keras kernel itself and (one GPU)
+    # writes Q and the indices in the Keras layout: no host wait, no neuron-major copy, no assembly pass inside a step.  Shapes that kernel
+    # does not take (a --m below 257, ...) keep round 5's step: host alphabet, neuron-major copy, assembly.
+    lo0, hi0 = layer.shard_bounds(C_total, world, rank)
+    device_path = hip.dense_layer_supported(N, m, max(hi0 - lo0, 1), unit_alphabet)
+    statuses = []
+
     def step(i_timed=None):
         C_total, Wd = st["C_total"], st["Wd"]
         lo, hi = layer.shard_bounds(C_total, world, rank)
+        if not device_path:
+            return step_host(i_timed, C_total, Wd, lo, hi)
+        # (st["alphabet_pre"], secondary figure only: the alphabet formed before the loop, as _prefetch_medians does for a network)
+        dalpha = st.get("alphabet_pre") or layer.layer_alphabet_device(Wd, unit_alphabet, args.alphabet_scalar, group)   # N > 1: counting sharded over ranks
+        nrm = hip.row_norms(Xqd)
+        if i_timed is not None:
+            hip.set_main_kernel_events(*ev_k[i_timed])
+            ev[i_timed][0].record()          # same stream the kernel is launched on (torch current stream)
+        r = hip.quantize_dense_layer(Xd, Xqd, Wd, dalpha, lo, hi, nrm32=nrm, keras_out=(world == 1), want_values=(world == 1))
+        if i_timed is not None:
+            ev[i_timed][1].record()
+            hip.set_main_kernel_events(None, None)
+            statuses.append(r["workspace"][:16])     # (a view: the deferred status words of every timed step, read after the loop)
+        kname[0] = hip.last_dense_kernel()
+        if i_timed is not None:
+            knames[i_timed] = kname[0]
+        if world > 1:
+            # one all-gather of the indices (packed to 2 bits per weight for the ternary alphabet), then values + transpose to the Keras layout
+            packed, bits = hip.pack_indices(r["idx"], M)
+            if i_timed is not None:
+                ev_ag[i_timed][0].record()
+            gathered = layer.all_gather_units(packed, C_total, group)
+            if i_timed is not None:
+                ev_ag[i_timed][1].record()
+                st["gather_bytes"] = gathered.numel() * gathered.element_size()
+            Q, idx = hip.assemble_kernel_device(gathered.contiguous(), dalpha, bits=bits, N=N)
+        else:
+            Q, idx = r["Q"], r["idx"]
+        return Q, idx, r
+
+    def step_host(i_timed, C_total, Wd, lo, hi):
         pre = {}
 
         def alphabet_free_work():            # queued behind the median kernels, runs while the host waits for the radius
             pre["Wt"] = hip.neuron_major(Wd, lo, hi)
             pre["nrm"] = hip.row_norms(Xqd)
 
-        if st.get("alphabet_pre") is not None:   # (secondary figure only: the radius formed before the loop, as _prefetch_medians does for a network)
+        if st.get("alphabet_pre") is not None:
             alphabet = st["alphabet_pre"]
             alphabet_free_work()
         else:
@@ -146,7 +185,7 @@ def main():
         Wt, nrm = pre["Wt"], pre["nrm"]
         if i_timed is not None:
             hip.set_main_kernel_events(*ev_k[i_timed])
-            ev[i_timed][0].record()          # same stream the kernel is launched on (torch current stream)
+            ev[i_timed][0].record()
         r = hip.quantize_neurons(Xd, Xqd, Wt, alphabet, nrm32=nrm, want_values=False)
         if i_timed is not None:
             ev[i_timed][1].record()
@@ -154,8 +193,6 @@ def main():
         kname[0] = hip.last_dense_kernel()
         if i_timed is not None:
             knames[i_timed] = kname[0]
-        # one all-gather of the indices (packed to 2 bits per weight for the ternary alphabet when N > 1),
-        # then values + transpose to the Keras layout in one pass
         if world > 1:
             packed, bits = hip.pack_indices(r["idx"], M)
             if i_timed is not None:
@@ -191,8 +228,11 @@ def main():
     # Secondary figure (never `value`): the same steps with the layer's radius formed BEFORE the loop -- what a layer costs inside
     # QuantizedNeuralNetwork.quantize_network(), which queues the medians of all layers up front (_prefetch_medians)
     ms_prefetched = None
+    # deferred status of every timed step (a timed-out cluster exchange, a degenerate device alphabet): read now, after the timed region
+    bad_status = int(torch.stack([w.view(torch.int32)[2:4] for w in statuses]).ne(0).sum().item()) if statuses else 0
     if world == 1:
-        st["alphabet_pre"], _ = layer.layer_alphabet(Wd, unit_alphabet, args.alphabet_scalar, None)
+        st["alphabet_pre"] = (layer.layer_alphabet_device(Wd, unit_alphabet, args.alphabet_scalar, None) if device_path
+                              else layer.layer_alphabet(Wd, unit_alphabet, args.alphabet_scalar, None)[0])
         step(); fence()
         t0p = time.perf_counter()
         for _ in range(args.steps):
@@ -261,6 +301,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_medians_prefetched": ms_prefetched, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "step": ("device-resident alphabet: median(|W|) -> rad * alphabet on the device, row norms, record pre-pass, the block-pipelined kernel "
+                     "reading the Keras kernel and writing Q / indices in the Keras layout; no host wait inside a step" if device_path else
+                     "host alphabet (one host wait per step), neuron-major copy, row norms, record pre-pass, kernel, assembly pass"),
+            "deferred_status_nonzero_steps": bad_status,
             "config": {
                 "workload": (f"Dense({N}->{C_total}) whole-layer GPFQ, m={m} calibration samples, M={M} alphabet, "
                              f"alphabet_scalar={args.alphabet_scalar:g}"
@@ -304,7 +348,10 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"], out["parity_sample"] = _cpu_baseline(W, X, Xq, unit_alphabet, args, idx, last)
             if args.numpy_sample != 0:
-                out["cpu_baseline_numpy"] = _cpu_baseline_numpy(W, X, Xq, unit_alphabet, args, idx)
+                try:
+                    out["cpu_baseline_numpy"] = _cpu_baseline_numpy(W, X, Xq, unit_alphabet, args, idx)
+                except Exception as exc:                          # a secondary record must not cost the headline line
+                    out["cpu_baseline_numpy"] = {"error": repr(exc)[:300]}
         if world == 1 and args.long_rows > m:
             out["long_rows"] = _long_rows(N, C_total, args.long_rows, unit_alphabet, args, dev)
         print(json.dumps(out))
@@ -405,7 +452,9 @@ def _cpu_baseline_numpy(W, X, Xq, unit_alphabet, args, idx_gpu):
         np.save(os.path.join(d, "X.npy"), X)
         np.save(os.path.join(d, "Xq.npy"), Xq)
         np.save(os.path.join(d, "alphabet.npy"), alphabet)
-        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", PYTHONPATH=ROOT)
+        # (a CPU-only child: no profiler preload or tool library rides along when bench.py itself runs under rocprofv3)
+        env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTRACER"))}
+        env.update(OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", PYTHONPATH=ROOT)
         subprocess.run([sys.executable, "-m", "oracle.numpy_pool", d, str(cores)], check=True, cwd=ROOT, env=env, timeout=600)
         with open(os.path.join(d, "result.json")) as f:
             res = json.load(f)

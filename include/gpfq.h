@@ -56,6 +56,8 @@ extern "C" {
 #define GPFQ_ERR_WORKSPACE     (-3)   /* workspace missing or smaller than gpfq_workspace_bytes */
 #define GPFQ_ERR_LAUNCH        (-4)   /* HIP reported an error; text in gpfq_last_error()      */
 #define GPFQ_ERR_NO_DEVICE     (-5)   /* no gfx950 device visible                              */
+#define GPFQ_ERR_CLUSTER_TIMEOUT (-6) /* gpfq_call_status: an exchange of the block kernel's cluster form timed out, outputs invalid */
+#define GPFQ_ERR_ALPHABET      (-7)   /* gpfq_call_status: the device-resident alphabet was degenerate (radius 0 / inf / NaN), nothing computed */
 
 #define GPFQ_MAX_ALPHABET 256         /* alphabet members per call (bits <= 8, scripts/quantized_network.py:396: int(round(2**bits)));
                                          more than 64 members: int16 indices, the kernels that hold four alphabet registers per lane */
@@ -167,6 +169,23 @@ int gpfq_set_main_kernel_events(void *start_event, void *stop_event);
  *                  images use; 2: the shift form for every image of 4 x 4 or more (tests)
  */
 int gpfq_set_option(const char *key, int value);
+/* Round 6 additions to the option list above:
+ *   "blk_chip_ok"   -1 (default): the cluster form asks the device whether it is the whole chip its workgroup maps assume (256 compute
+ *                  units = 8 XCDs x 32, no compute-unit mask in the environment) and is not used otherwise; 0 / 1 force the answer (tests)
+ *   "blk_cluster_timeout_ms"  how long an exchange of the cluster form waits for a slice that does not arrive (default 3000)
+ *   "blk_cluster_fault"       tests: 1 = one slice of the first cluster never publishes -- every exchange of that cluster times out
+ *   "sync_errors"   1: gpfq_quantize_neurons (block-pipelined kernel) and gpfq_quantize_dense_layer wait for their launches and return
+ *                  gpfq_call_status() of the call; 0 (default): asynchronous, the caller checks gpfq_call_status itself
+ */
+
+/*
+ * Deferred errors of an asynchronous dense call (gpfq_quantize_neurons on the on-chip path, gpfq_quantize_dense_layer): waits for
+ * `stream` and reads the call's status words at the start of its workspace -- bytes 0..7 exact-fallback decisions (diagnostics),
+ * bytes 8..11 != 0: GPFQ_ERR_CLUSTER_TIMEOUT, bytes 12..15 != 0: GPFQ_ERR_ALPHABET.  The reference logs the failing unit and re-raises
+ * at once (scripts/quantized_network.py:563-565); the layer drivers of this package call this BEFORE a layer's result reaches
+ * set_weights and rerun the layer through the classic kernels (quantized_neural_networks_amd/layer.py).
+ */
+int gpfq_call_status(const void *workspace, void *stream);
 
 /*
  * The hot path: run the greedy recurrence for C independent neurons.
@@ -196,6 +215,48 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
                           int64_t N, int64_t m, int64_t C,
                           void *qidx, float *Qt, double *resid, double *u_out,
                           void *workspace, size_t workspace_bytes, int path, void *stream);
+
+/*
+ * The Dense layer driver as ONE call with nothing crossing to the host (round 6).  Replaces the body of _quantize_layer_parallel
+ * (scripts/quantized_network.py:523-574) between "the activations are there" and set_weights:
+ *
+ *   rad = alphabet_scalar * median(|W|); layer_alphabet = rad * alphabet          (:544-545)   gpfq_median_abs + gpfq_layer_alphabet_device
+ *   Q[:, j] = _quantize_neuron_parallel(W[:, j], ..., layer_alphabet) for every j  (:549-562)   gpfq_quantize_dense_layer
+ *
+ * gpfq_layer_alphabet_device forms, ON THE DEVICE, rad = float64(alphabet_scalar) * float64(*median32) (the reference's legacy-NumPy
+ * typing of :544), the members rad * unit_alphabet[k] (float64 products, :545) and what the block-pipelined kernel derives from them,
+ * into `dev_alphabet` (GPFQ_DEVICE_ALPHABET_BYTES of device memory, 16-byte aligned; float64 rad at byte 0, the M float64 members from
+ * byte 128) -- no launch of the layer waits for the radius to reach the host.
+ *   median32       [device] f32 [1]   from gpfq_median_abs (or the sharded protocol)
+ *   unit_alphabet  [host]   f64 [M]   linspace(-1, 1, M) (:396), 1 <= M <= 64
+ *
+ * gpfq_quantize_dense_layer quantizes neurons c_lo .. c_lo + C of the layer:
+ *   W      [device] f32 [N][ldc]   the Keras kernel itself (row = input feature; no neuron-major copy)
+ *   nrm32  [device] f32 [N] from gpfq_row_norms, or NULL: computed here
+ *   qidx, Q [device] outputs (either may be NULL): GPFQ_LAYOUT_KERAS: the whole layer's [N][ldo] arrays in the layout set_weights takes
+ *          (:562, :570), of which columns c_lo .. c_lo + C are written; GPFQ_LAYOUT_NEURON_MAJOR: this shard's [C][N] (what the all-gather
+ *          of a multi-GPU run exchanges; gpfq_assemble_kernel_device lays the gathered indices out)
+ *   resid  [device] f64 [C] residual norms (may be NULL)
+ *   workspace [device] >= gpfq_dense_layer_workspace_bytes(N, m, C), 16-byte aligned; its first 16 bytes are the call's status words
+ *          (gpfq_call_status)
+ * Only the block-pipelined kernel reads a device-resident alphabet: gpfq_dense_layer_supported() says whether this shape has one (rows of
+ * 257..GPFQ_ONCHIP_MAX_M samples, M <= 64, linspace-like unit alphabet); otherwise GPFQ_ERR_UNSUPPORTED, and the caller reads the radius
+ * back and uses gpfq_quantize_neurons.  A radius of 0 (more than half of the kernel is zero), infinity or NaN is only seen on the device:
+ * the kernel then writes nothing and raises the call's alphabet word -- gpfq_call_status returns GPFQ_ERR_ALPHABET.
+ */
+#define GPFQ_DEVICE_ALPHABET_BYTES 1024
+#define GPFQ_LAYOUT_NEURON_MAJOR 0
+#define GPFQ_LAYOUT_KERAS        1
+int gpfq_layer_alphabet_device(const float *median32, double alphabet_scalar, const double *unit_alphabet, int M,
+                               void *dev_alphabet, void *stream);
+int gpfq_dense_layer_supported(int64_t N, int64_t m, int64_t C, const double *unit_alphabet, int M);
+size_t gpfq_dense_layer_workspace_bytes(int64_t N, int64_t m, int64_t C);
+int gpfq_quantize_dense_layer(const float *X, const float *Xq, int64_t ld, const float *nrm32,
+                              const float *W, int64_t ldc, int64_t c_lo, int64_t C,
+                              const void *dev_alphabet, const double *unit_alphabet, int M,
+                              int64_t N, int64_t m,
+                              int8_t *qidx, float *Q, int out_layout, int64_t ldo, double *resid,
+                              void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * The same recurrence for SHORT walks over LONG rows (conv: N = kh*kw steps against patch matrices of
@@ -251,6 +312,9 @@ int gpfq_index_bits(int M);
 int gpfq_pack_indices(const int8_t *qidx, int64_t N, int64_t C, int bits, uint8_t *packed, void *stream);
 int gpfq_assemble_kernel(const void *qidx, int bits, const double *alphabet, int M, int64_t N, int64_t C,
                          float *Q, void *qidx_t, void *stream);
+/* ... with the members read from a device-resident alphabet (gpfq_layer_alphabet_device; M <= 64: bits = 2, 4 or 8) */
+int gpfq_assemble_kernel_device(const void *qidx, int bits, const void *dev_alphabet, int M, int64_t N, int64_t C,
+                                float *Q, void *qidx_t, void *stream);
 
 /*
  * median(|W|) of n float32 weights with NumPy's semantics (float32 result; even n -> float32 mean of

@@ -48,6 +48,7 @@
 #include <type_traits>
 
 #include <cstdlib>
+#include <mutex>
 #include "gpfq_device.hpp"
 #include "gpfq_launch.hpp"
 #include "gpfq_roles.hpp"
@@ -86,9 +87,11 @@ __host__ __device__ constexpr int64_t blk_rec_bytes(int64_t mp, int B, int G, bo
 template <int B, bool R64, bool CL = false>
 __global__ void __launch_bounds__(256)
 gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t N, int m, int mp,
-                     const float *__restrict__ nrm32, char *__restrict__ recs, char *__restrict__ hdrs, float sym_a,
-                     int nsl, int64_t slice_bytes)
+                     const float *__restrict__ nrm32, char *__restrict__ recs, char *__restrict__ hdrs,
+                     const DevAlphabet *__restrict__ alpha, int sym, int nsl, int64_t slice_bytes)
 {
+    // (symmetric form, BlkK: the records hold f32(a32 Xq) in place of Xq; a32 comes from the device alphabet)
+    const float sym_a = sym ? alpha->sym_a : 0.f;
     // (cluster form, nsl > 1: mp = nsl record rows of mp / nsl samples each, slice s's record stream slice_bytes behind slice s - 1's;
     //  the statistics and the Gram band are the whole row's and go into every slice's record)
     constexpr int GREC = R64 ? 2 : 1;                         // (any G with this row format: the record size depends on nothing else)
@@ -275,11 +278,14 @@ struct BlkK {
     const char *recs;
     const char *hdrs;           // the record headers once more, compact: [record][blk_hdr_bytes(B)] (the decision wavefront's copy)
     const float *Wt;
-    int64_t ldw;
+    int64_t ldw, ldt;           // weight of neuron j at step t: Wt[j ldw + t ldt] -- neuron-major rows (ldt = 1) or the Keras kernel itself (ldw = 1, ldt = its row pitch)
     int64_t N, C;
     int m, M, zero_idx, nblk;   // nblk = ceil(N / B) blocks, nblk + 1 slots
     int8_t *qidx;
     float *Qt;
+    int64_t o_sj, o_st;         // output element (neuron j, step t) at j o_sj + t o_st: neuron-major [C][N] (N, 1) or Keras layout [N][ldo] (1, ldo)
+    const DevAlphabet *alpha;   // the layer alphabet in device memory (gpfq_alphabet_setup_kernel); alpha->ok == 0: nothing runs, *alpha_err is raised
+    int *alpha_err;
     double *resid, *u_out;
     unsigned long long *fallback_count;
     unsigned long long *stamps;     // diagnostic build only (GPFQ_BLK_STAMPS): per-phase shader cycles of two wavefronts
@@ -288,18 +294,17 @@ struct BlkK {
     // f32(w x) - f32(q xq) is ONE fused multiply-add on the pre-scaled row: fma(-sg, f32(a32 xq), f32(w x)) rounds once, the
     // subtraction's rounding.  The pre-pass stores f32(a32 * Xq) in place of Xq and the decisions publish -sg in place of q:
     // 8 instead of 12 packed float32 instructions per sample pair of four neurons.  0: the general form.
-    float sym_a;
+    // (DevAlphabet::sym_a; the SYM instantiations.)
     const float *Xq;                // (symmetric form's slow path)
     int64_t ldx;
-    // The alphabet as an arithmetic progression (blk_uniform): member k = a0 + k step in float64, whose float32 rounding is
-    // float32(alphabet[k]) for every k (checked on the host); inv = 1 / step, c0 = -a0 / step (0, 0 for a single member).  The
-    // chain of decisions finds its candidate index and value by arithmetic; the certification looks the true members up.
-    double uni_a0, uni_step, uni_inv, uni_c0;
+    // The alphabet as an arithmetic progression (blk_uniform; DevAlphabet::a0, step, inv, c0): member k = a0 + k step in float64, whose
+    // float32 rounding is float32(alphabet[k]) for every k (checked where the DevAlphabet is formed); inv = 1 / step, c0 = -a0 / step
+    // (0, 0 for a single member).  The chain of decisions finds its candidate index and value by arithmetic; the certification looks the
+    // true members up.
     // ... up to one float32 ulp: alphabet[k] = rad (2k - M + 1) / (M - 1) is a small rational multiple of a float32 median, and such
     // values sit EXACTLY on float32 rounding ties a few per cent of the time -- the float64 product rad * linspace[k] and the fused
-    // a0 + k step then round to different neighbours (2 of 16 members of a typical 4-bit alphabet).  Bit k of uni_plus / uni_minus:
+    // a0 + k step then round to different neighbours (2 of 16 members of a typical 4-bit alphabet).  Bit k of DevAlphabet::plus / minus:
     // float32(alphabet[k]) is the next float32 above / below (in the integer order of the bit patterns) float32(a0 + k step).
-    unsigned long long uni_plus, uni_minus;
     unsigned char pw[12];       // sample pairs per k-lane of sweep wavefront w (BlkSplit: a launch parameter)
     // Cluster form (round 5, rows beyond what one workgroup's registers hold; CL instantiations only): `nsl` workgroups -- the SLICES of a
     // cluster -- hold MP samples each of the same NB neurons; slice s streams its own records (recs + s slice_bytes: the same layout
@@ -312,6 +317,8 @@ struct BlkK {
     int64_t u_ld;               // row pitch of u_out (the whole row's sample count)
     double slack;               // float64 slack of a predicted dot product, relative: 2^-43 per 1024 samples of a row
     int *cl_err;                // set when an exchange timed out (a slice of the cluster never arrived): results are then invalid
+    unsigned long long cl_timeout;  // ... after this many ticks of s_memrealtime (100 MHz; 3 s unless the option blk_cluster_timeout_ms says otherwise)
+    int cl_fault;               // tests (option blk_cluster_fault): slice 1 of cluster 0 never publishes
 };
 
 #ifdef GPFQ_BLK_NO_MFMA            // diagnostic build: phase D on the vector unit everywhere (A/B timing of round 4's matrix form)
@@ -360,6 +367,7 @@ template <int KV>
 __device__ __forceinline__ void cl_publish(const BlkK &K, ClState &cs, int lane, const double (&v)[KV])
 {
     const unsigned seq = ++cs.seq;
+    if (K.cl_fault && cs.cl == 0 && cs.slice == 1) return;          // (tests: the slice that never arrives)
     unsigned long long *buf = K.mbox + ((cs.cl * 2 + (int64_t)(seq & 1u)) * (int64_t)K.nsl) * 256;       // [slice][lane][4]
     unsigned long long *mine = buf + ((int64_t)cs.slice * 64 + lane) * 4;
 #pragma unroll
@@ -398,7 +406,7 @@ __device__ __forceinline__ void cl_gather(const BlkK &K, ClState &cs, int lane, 
                     ok &= (w[i][k].y == seq) & (w[i][k].w == seq);
                 }
             if (__ballot(!ok) == 0ull || cs.dead) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > K.cl_timeout) {
                 cs.dead = true;
                 if (lane == 0 && K.cl_err) __hip_atomic_store(K.cl_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
@@ -548,7 +556,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             const int i = i0 + lane;
             const int n = i / B, s = i - n * B;
             const int64_t jn = jbase + n, t = (int64_t)b1 * B + s;
-            if (i < NB * B && jn < K.C && t < N) glds4(K.Wt + jn * K.ldw + t, dw + 4 * (unsigned)i0);
+            if (i < NB * B && jn < K.C && t < N) glds4(K.Wt + jn * K.ldw + t * K.ldt, dw + 4 * (unsigned)i0);
         }
     };
 
@@ -680,8 +688,8 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             const int64_t t = (int64_t)(b - 1) * B + sidx, jn = jbase + nn;
             if (t < N && jn < K.C) {
                 const int2 v = lds_ld<int2>(lds, L.off_out + (nn * kOutSteps + (int)(t % kOutSteps)) * 8);
-                if (K.qidx) K.qidx[jn * N + t] = (int8_t)v.x;
-                if (K.Qt) K.Qt[jn * N + t] = __int_as_float(v.y);
+                if (K.qidx) K.qidx[jn * K.o_sj + t * K.o_st] = (int8_t)v.x;
+                if (K.Qt) K.Qt[jn * K.o_sj + t * K.o_st] = __int_as_float(v.y);
             }
         }
         if (b + 1 < nslots) load_weights(b + 1);                  // the block's weights: one piece
@@ -1155,6 +1163,47 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     // of one neuron (32-byte runs of indices, 128-byte runs of values per neuron)
     constexpr bool kOwnFlush = !blk_sweep_flush<G, NL, CL>();
     auto flush = [&](int64_t t0, int64_t t1) {
+        if (K.o_st != 1) {
+            // Keras layout [N][ldo] (round 6: the layer's outputs as set_weights takes them, scripts/quantized_network.py:562, :570 -- no
+            // transposing pass behind the kernel): a lane takes NJ consecutive NEURONS of one step -- NJ indices in one store, NJ values
+            // in NJ / 4; the lanes of the wavefront are consecutive steps, so the reads of the LDS ring do not conflict
+            constexpr int NJ = NB < 8 ? NB : 8, GJ = NB / NJ;
+            for (int e = lane; e < GJ * kOutSteps; e += 64) {
+                const int g = e / kOutSteps, c = e % kOutSteps;
+                const int64_t ts = t0 + c, j0 = wg * NB + g * NJ;
+                if (ts >= t1 || j0 >= K.C || (CL && cs.slice != 0)) continue;
+                int idxj[NJ]; float qj[NJ];
+#pragma unroll
+                for (int k = 0; k < NJ; ++k) {
+                    const int2 v = lds_ld<int2>(lds, L.off_out + ((g * NJ + k) * kOutSteps + (int)(ts % kOutSteps)) * 8);
+                    idxj[k] = v.x; qj[k] = __int_as_float(v.y);
+                }
+                const int64_t o = ts * K.o_st + j0;
+                const bool whole = j0 + NJ <= K.C && K.o_sj == 1;
+                if (K.qidx) {
+                    if (whole && NJ >= 4 && ((uintptr_t)(K.qidx + o) & (NJ - 1)) == 0) {
+                        unsigned lo = 0, hi = 0;
+#pragma unroll
+                        for (int k = 0; k < NJ; ++k) { if (k < 4) lo |= (unsigned)(idxj[k] & 0xff) << (8 * k); else hi |= (unsigned)(idxj[k] & 0xff) << (8 * (k - 4)); }
+                        if constexpr (NJ == 8) *reinterpret_cast<uint2 *>(K.qidx + o) = make_uint2(lo, hi);
+                        else *reinterpret_cast<unsigned *>(K.qidx + o) = lo;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < NJ; ++k) if (j0 + k < K.C) K.qidx[ts * K.o_st + (j0 + k) * K.o_sj] = (int8_t)idxj[k];
+                    }
+                }
+                if (K.Qt) {
+                    if (whole && NJ >= 4 && ((uintptr_t)(K.Qt + o) & 15) == 0) {
+#pragma unroll
+                        for (int k = 0; k + 3 < NJ; k += 4) *reinterpret_cast<float4 *>(K.Qt + o + k) = make_float4(qj[k], qj[k + 1], qj[k + 2], qj[k + 3]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < NJ; ++k) if (j0 + k < K.C) K.Qt[ts * K.o_st + (j0 + k) * K.o_sj] = qj[k];
+                    }
+                }
+            }
+            return;
+        }
         for (int e = lane; e < NB * (kOutSteps / 8); e += 64) {
             const int nn = e / (kOutSteps / 8), c = e % (kOutSteps / 8);
             const int64_t j = wg * NB + nn, ts = t0 + 8 * c;
@@ -1368,9 +1417,9 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             const double2 o67 = lds_ld<double2>(lds, rbm + 48);   // (sE1, sE2): the quick certification's bound (below)
             STAMP(dta);
             // ---- (2) the chain
-            const double u_a0 = K.uni_a0, u_step = K.uni_step, u_inv = K.uni_inv, u_c0 = K.uni_c0, u_kmax = (double)(M - 1);
+            const double u_a0 = K.alpha->a0, u_step = K.alpha->step, u_inv = K.alpha->inv, u_c0 = K.alpha->c0, u_kmax = (double)(M - 1);
             const double u_amax = fmax(fabs(u_a0), fabs(fma(u_kmax, u_step, u_a0))) * (1.0 + 0x1p-20);   // >= every |member| (and its float32 rounding)
-            const unsigned long long u_plus = K.uni_plus, u_minus = K.uni_minus;
+            const unsigned long long u_plus = K.alpha->plus, u_minus = K.alpha->minus;
             const int u_zero = K.zero_idx;
             const float sym_a32 = (float)sym_top;
             auto pick = [&](double tt, double &kd) -> float {     // nearest member of the uniform alphabet, by arithmetic
@@ -1801,10 +1850,17 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 // the chip (nsl <= 28 <= the 32 CUs of an XCD) and the exchange cannot deadlock, whatever the mapping of ids to XCDs really is.
 template <int G, int S, int B, int NSW, bool SYM, int NL, int CLM = 0>
 __global__ void __launch_bounds__(64 * (NSW + 1))
-gpfq_blk_kernel(BlkK K, AlphabetArg A)
+gpfq_blk_kernel(BlkK K)
 {
     constexpr bool CL = CLM != 0;
     constexpr int NB = NL * G, KQ = 64 / G, MP = 2 * KQ * S;
+    // The alphabet lives in device memory (DevAlphabet).  One that is not an arithmetic progression the chain can index -- only possible when
+    // it was formed on the device from a median that is zero or not finite -- runs nothing: the call's alphabet word is raised instead and the
+    // caller reruns the layer with a host alphabet (gpfq_call_status, layer.quantize_dense).  Uniform over the launch: no exchange is left waiting.
+    if (K.alpha->ok == 0) {
+        if (K.alpha_err && blockIdx.x == 0 && threadIdx.x == 0) *K.alpha_err = 1;
+        return;
+    }
     ClState cs{0, 0, 0u, false, 0, 0};
     if constexpr (CL) {
         const int id = (int)blockIdx.x, j = id >> 3;
@@ -1832,7 +1888,7 @@ gpfq_blk_kernel(BlkK K, AlphabetArg A)
     if (tid < 68) {
         const double kInf = __longlong_as_double(0x7ff0000000000000LL);
         const int k = tid - 2;
-        reinterpret_cast<double *>(lds + L.off_e)[tid] = k < 0 ? -kInf : (k < A.M ? A.a[k] : kInf);
+        reinterpret_cast<double *>(lds + L.off_e)[tid] = k < 0 ? -kInf : (k < K.M ? K.alpha->a[k] : kInf);
     }
     if (tid < 2) reinterpret_cast<int *>(lds + L.off_ctl)[tid] = -1;
     __syncthreads();
@@ -1880,9 +1936,38 @@ void blk_set_pair_groups(int on) { g_blk_pairs.store(on ? 1 : 0, std::memory_ord
 // from 1024 up = every row beyond that many samples (tests, A/B).
 static std::atomic<int> g_blk_cluster_nl{0};      // cluster form: neurons per lane, 0 = by width; 1 / 2 / 4 force it (option blk_cluster_nl)
 void blk_set_cluster_nl(int v) { g_blk_cluster_nl.store(v == 1 || v == 2 || v == 4 ? v : 0, std::memory_order_relaxed); }
+static std::atomic<int> g_blk_chip{-1};            // -1: ask the device; 0 / 1 force the answer of blk_chip_ok (option blk_chip_ok: tests)
+void blk_set_chip_ok(int v) { g_blk_chip.store(v < 0 ? -1 : (v ? 1 : 0), std::memory_order_relaxed); }
+static std::atomic<int> g_blk_cl_timeout_ms{3000};  // how long an exchange of the cluster form waits for a slice before it gives up (option blk_cluster_timeout_ms)
+void blk_set_cluster_timeout_ms(int v) { g_blk_cl_timeout_ms.store(v < 1 ? 1 : v, std::memory_order_relaxed); }
+static std::atomic<int> g_blk_cl_fault{0};         // tests: 1 = slice 1 of cluster 0 never publishes (forces the exchange's timeout; option blk_cluster_fault)
+void blk_set_cluster_fault(int v) { g_blk_cl_fault.store(v ? 1 : 0, std::memory_order_relaxed); }
 static std::atomic<int> g_blk_cluster{1};
 void blk_set_cluster(int v) { g_blk_cluster.store(v <= 0 ? 0 : (v < 1024 ? 1 : v), std::memory_order_relaxed); }
 constexpr int64_t kClusterMaxM = 28672;      // = GPFQ_ONCHIP_MAX_M: 28 slices, still inside one XCD's 32 CUs
+// The cluster form's co-residency argument (gpfq_blk_kernel) is about THIS chip: 256 compute units in 8 XCDs of 32, the workgroups of a
+// launch handed to the XCDs round-robin and started in order.  A device that shows anything else -- a partition of the chip (CPX / DPX / QPX
+// modes: 32 / 128 / 64 compute units), a compute-unit mask from the environment -- does not get the cluster shapes: its long rows keep the
+// classic shapes and the several-wavefronts-per-neuron kernel.  Asked once per device; no device (the CPU build container
+// sizing a workspace): the full chip is assumed.
+static bool blk_chip_ok()
+{
+    static std::atomic<int> cache[64];                       // per device: 0 unknown, 1 ok, 2 not
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return true; }
+    if (dev < 0 || dev >= 64) return false;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int cus = 0;
+        bool ok = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus == 256;
+        for (const char *name : {"HSA_CU_MASK", "ROC_GLOBAL_CU_MASK", "HSA_CU_MASK_SKIP_INIT"})
+            if (const char *e = getenv(name)) ok = ok && e[0] == 0;
+        v = ok ? 1 : 2;
+        cache[dev].store(v, std::memory_order_relaxed);
+    }
+    const int forced = g_blk_chip.load(std::memory_order_relaxed);      // (tests: option blk_chip_ok = 0 pretends the chip is partitioned)
+    return forced >= 0 ? forced != 0 : v == 1;
+}
 // Workgroup id -> (cluster, slice).  Workgroups go to the XCDs round-robin by id and every XCD starts its own in order.  Map 0 puts the
 // slices of a cluster side by side in ONE XCD's queue (the exchange stays inside that XCD's L2 domain); but an XCD's 32 CUs then hold
 // 32 / nsl whole clusters and 32 % nsl slices of the next one, which wait a whole round for their mates -- and so does every round after
@@ -1910,6 +1995,7 @@ static int blk_cluster_map(int nsl, int64_t clusters)
 
 static BlkShape blk_shape(int64_t m, int64_t C)
 {
+    if (m <= 0 || C <= 0) return {0, 0, 0, 0, 0, 0};               // (an empty calibration set has no shape: the slice count below would divide by zero)
     {
         // By default (1): every row beyond 3072 samples -- a slot of the cluster form is the headline shape's (its exchange hides behind the
         // chain of decisions), the classic shapes lose a third of that rate from 2049 samples up --, and rows of 1537..3072 samples
@@ -1918,7 +2004,7 @@ static BlkShape blk_shape(int64_t m, int64_t C)
         const int clm = g_blk_cluster.load(std::memory_order_relaxed);
         const int ns_ = (int)((m + 1023) / 1024);
         const bool one_round = ns_ <= 32 && ((C + 15) / 16 + 7) / 8 <= 32 / ns_;      // with 16 neurons per workgroup
-        const bool take = clm == 1 ? (m > 3072 || (m > 1536 && one_round && (m > 2048 || C > 128))) : (clm > 1 && m > clm);   // (at most 128 neurons on rows of at most 2048 samples: the one-neuron workgroups stay ahead, 1.98 / 2.07 ms)
+        const bool take = blk_chip_ok() && (clm == 1 ? (m > 3072 || (m > 1536 && one_round && (m > 2048 || C > 128))) : (clm > 1 && m > clm));   // (at most 128 neurons on rows of at most 2048 samples: the one-neuron workgroups stay ahead, 1.98 / 2.07 ms)
         if (take && m <= kClusterMaxM) {
             // neurons per workgroup: the fewest (4, 8, 16) with which the layer is still ONE round of the chip -- a slot of the 4- and
             // 8-neuron shapes is the decision wavefront's (with the exchange's flight exposed), a slot of the 16-neuron shape the sweeps'
@@ -2006,38 +2092,78 @@ static BlkShape blk_shape(int64_t m, int64_t C)
 }
 
 // The alphabet as an arithmetic progression, if it is one in the sense the chain of decisions needs: strictly ascending and
-// float32(fma(k, step, a0)) == float32(alphabet[k]) for every k, with step = (a[M-1] - a[0]) / (M - 1) -- the same fused operation
-// the kernel performs.  Everything the reference builds (rad * linspace(-1, 1, M), scripts/quantized_network.py:396, :545) is.
-static bool blk_uniform(const AlphabetArg &A, double *a0, double *step, double *inv, double *c0, unsigned long long *plus,
-                        unsigned long long *minus)
+// float32(fma(k, step, a0)) == float32(alphabet[k]) for every k (up to the one-ulp corrections of D.plus / D.minus), with
+// step = (a[M-1] - a[0]) / (M - 1) -- the same fused operation the kernel performs.  Everything the reference builds
+// (rad * linspace(-1, 1, M), scripts/quantized_network.py:396, :545) is, for a finite rad > 0.  Host and device (round 6: the device forms
+// the alphabet itself from the layer's median, gpfq_alphabet_device_kernel): fills D's progression fields from D.a[0..M), true if it is one.
+__host__ __device__ inline bool blk_fin(double x) { return fabs(x) <= 1.7976931348623157e308; }     // finite (false for NaN)
+__host__ __device__ inline bool blk_uniform(DevAlphabet &D)
 {
-    const int M = A.M;
-    *plus = *minus = 0ull;
-    if (M < 1 || M > 64 || !std::isfinite(A.a[0]) || !std::isfinite(A.a[M - 1])) return false;
-    *a0 = A.a[0];
-    if (M == 1) { *step = 0.0; *inv = 0.0; *c0 = 0.0; return true; }
-    *step = (A.a[M - 1] - A.a[0]) / (double)(M - 1);
-    if (!(*step > 0.0) || !std::isfinite(*step)) return false;
-    *inv = 1.0 / *step;
-    *c0 = -*a0 * *inv;
-    if (!std::isfinite(*inv) || !std::isfinite(*c0)) return false;
+    const int M = D.M;
+    const double *a = D.a;
+    D.plus = D.minus = 0ull;
+    D.a0 = D.step = D.inv = D.c0 = 0.0;
+    if (M < 1 || M > 64 || !blk_fin(a[0]) || !blk_fin(a[M - 1])) return false;
+    D.a0 = a[0];
+    D.amax = fmax(fabs(a[0]), fabs(a[M - 1]));
+    if (M == 1) return true;
+    D.step = (a[M - 1] - a[0]) / (double)(M - 1);
+    if (!(D.step > 0.0) || !blk_fin(D.step)) return false;
+    D.inv = 1.0 / D.step;
+    D.c0 = -D.a0 * D.inv;
+    if (!blk_fin(D.inv) || !blk_fin(D.c0)) return false;
     for (int k = 0; k < M; ++k) {
-        if (k > 0 && !(A.a[k - 1] < A.a[k])) return false;
-        if (A.a[k] == 0.0) {                                   // (the member 0 is returned as such, BlkK::zero_idx, if the progression passes through it)
-            if (!(std::fabs(std::fma((double)k, *step, *a0)) <= 0x1p-40 * std::fmax(std::fabs(A.a[0]), std::fabs(A.a[M - 1])))) return false;
+        if (k > 0 && !(a[k - 1] < a[k])) return false;
+        if (a[k] == 0.0) {                                     // (the member 0 is returned as such, BlkK::zero_idx, if the progression passes through it)
+            if (!(fabs(fma((double)k, D.step, D.a0)) <= 0x1p-40 * D.amax)) return false;
         } else {
-            const float want = (float)A.a[k], have = (float)std::fma((double)k, *step, *a0);
-            int32_t iw, ih;
-            std::memcpy(&iw, &want, 4); std::memcpy(&ih, &have, 4);
-            const int64_t d = (int64_t)iw - (int64_t)ih;
-            if (d == 1) *plus |= 1ull << k;
-            else if (d == -1) *minus |= 1ull << k;
+            const float want = (float)a[k], have = (float)fma((double)k, D.step, D.a0);
+            const int64_t d = (int64_t)__builtin_bit_cast(int32_t, want) - (int64_t)__builtin_bit_cast(int32_t, have);
+            if (d == 1) D.plus |= 1ull << k;
+            else if (d == -1) D.minus |= 1ull << k;
             else if (d != 0) return false;
         }
         // and the index arithmetic finds a member from its own value (monotone rounding does the rest)
-        if (std::rint(std::fma(A.a[k], *inv, *c0)) != (double)k) return false;
+        if (rint(fma(a[k], D.inv, D.c0)) != (double)k) return false;
     }
     return true;
+}
+
+// a32 of an exactly symmetric alphabet {-a, 0, a} or {-a, a} (DevAlphabet::sym_a; the SYM instantiations), else 0
+__host__ __device__ inline float blk_sym_of(const double *a, int M)
+{
+    if (M != 2 && M != 3) return 0.f;
+    // (exactly symmetric as float64 too: the decisions' nearest-member search takes its boundaries as -a/2 and a/2)
+    if (a[0] != -a[M - 1] || (M == 3 && a[1] != 0.0)) return 0.f;
+    const float hi = (float)a[M - 1];
+    if (!(hi > 0.f) || !blk_fin((double)hi)) return 0.f;
+    return hi;
+}
+
+// A host alphabet's DevAlphabet, computed on the host (launch_blk), stored into the call's workspace.
+__global__ void gpfq_alphabet_store_kernel(DevAlphabet *out, DevAlphabet D)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *out = D;
+}
+
+// The layer alphabet formed ON the device (gpfq_layer_alphabet_device): rad = float64(alphabet_scalar) * float64(float32 median) -- the
+// reference's legacy-NumPy product (:544: python scalar times np.float32 is a float64 product) --, members rad * unit[k] (:545: float64
+// products), and the progression the chain of decisions indexes.  `want_sym`: the caller will launch the symmetric-form instantiations
+// (the unit alphabet is {-1, 0, 1} / {-1, 1}): an alphabet that is then not exactly symmetric is not ok.
+__global__ void gpfq_alphabet_device_kernel(DevAlphabet *out, const float *__restrict__ median32, double alphabet_scalar, AlphabetArg unit, int want_sym)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    DevAlphabet D{};
+    D.M = unit.M; D.zero_idx = unit.zero_idx;
+    D.rad = alphabet_scalar * (double)median32[0];
+    for (int k = 0; k < unit.M && k < 64; ++k) D.a[k] = D.rad * unit.a[k];
+    bool ok = blk_fin(D.rad) && blk_uniform(D);
+    D.sym_a = blk_sym_of(D.a, D.M);
+    if (want_sym && D.sym_a == 0.f) ok = false;
+    // (the literal zero of rule (i) and the member 0: the caller's zero_idx is the unit alphabet's -- rad * 0 = 0 for every finite rad)
+    if (ok && D.zero_idx >= 0 && D.a[D.zero_idx] != 0.0) ok = false;
+    D.ok = ok ? 1 : 0;
+    *out = D;
 }
 
 // workspace: [records of slots 0..nblk, + one record of DMA over-read][compact headers of the same records, + 2 KiB of over-read]
@@ -2057,14 +2183,19 @@ bool blk_supported(const PipeArgs &a)
     const BlkShape sh = blk_shape(a.m, a.C);
     if (sh.G == 0 || a.N < 1 || a.m < 1) return false;
     if (a.A.M > 64 || !a.A.ascending) return false;
-    double a0, step, inv, c0;
-    unsigned long long up, dn;
-    if (!blk_uniform(a.A, &a0, &step, &inv, &c0, &up, &dn)) return false;      // (other alphabets keep the row-group kernels)
+    DevAlphabet D{};
+    D.M = a.A.M;
+    for (int k = 0; k < a.A.M; ++k) D.a[k] = a.A.a[k];
+    if (!blk_uniform(D)) return false;      // (other alphabets keep the row-group kernels)
     return a.N + 64 < (1LL << 31) / 64;
 }
 
+constexpr size_t kAlphaBlock = 1024;        // the call's DevAlphabet, in front of the records (a host alphabet is stored there; a device alphabet is the caller's block)
+static_assert(sizeof(DevAlphabet) <= kAlphaBlock, "alphabet block");
+
 size_t blk_workspace_bytes(int64_t N, int64_t m, int64_t Cn)
 {
+    if (m <= 0 || N < 0) return 0;          // (an empty calibration set: blk_shape has no shape for it -- and must not be asked)
     // (the record layout depends on the row length and, through the steps per slot, on the width class of the layer: the largest)
     size_t need = 0;
     for (int64_t C : {(int64_t)1 << 30, (int64_t)2048, (int64_t)1024, (int64_t)512, Cn > 0 ? Cn : (int64_t)1}) {   // (and the call's own width: the cluster form's neurons per workgroup)
@@ -2075,23 +2206,19 @@ size_t blk_workspace_bytes(int64_t N, int64_t m, int64_t Cn)
         const size_t b = blk_recs_bytes(nblk, sh) * (size_t)(sh.NS ? sh.NS : 1) + ((blk_hdrs_bytes(nblk, sh.B, sh.NS != 0) + 255) & ~(size_t)255) + blk_mbox_bytes(Cn, sh);
         if (b > need) need = b;
     }
-    return need;
+    return need ? need + kAlphaBlock : 0;
 }
 
-// a32 of a symmetric alphabet {-a, 0, a} or {-a, a} (BlkK::sym_a), else 0.  PipeArgs::variant bit 1 (option "variant" bit 5) keeps the general form (A/B timing).
+// a32 of a symmetric alphabet {-a, 0, a} or {-a, a} (DevAlphabet::sym_a), else 0.  PipeArgs::variant bit 1 (option "variant" bit 5) keeps the general form (A/B timing).
+// (device alphabets: a.A is the UNIT alphabet linspace(-1, 1, M) -- symmetric exactly when rad * unit is, for a finite rad > 0)
 static float blk_sym_a(const PipeArgs &a)
 {
-    const int M = a.A.M;
-    if ((a.variant & 2) || (M != 2 && M != 3)) return 0.f;
-    // (exactly symmetric as float64 too: the decisions' nearest-member search takes its boundaries as -a/2 and a/2)
-    if (a.A.a[0] != -a.A.a[M - 1] || (M == 3 && a.A.a[1] != 0.0)) return 0.f;
-    const float hi = (float)a.A.a[M - 1];
-    if (!(hi > 0.f) || !std::isfinite(hi)) return 0.f;
-    return hi;
+    if (a.variant & 2) return 0.f;
+    return blk_sym_of(a.A.a, a.A.M);
 }
 
 template <int G, int S, int B, int NSW, bool SYM, int NL, int CLM = 0>
-static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStream_t stream)
+static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, const DevAlphabet *alpha, hipStream_t stream)
 {
     constexpr bool CL = CLM != 0;
     constexpr int NB = NL * G;
@@ -2102,12 +2229,16 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
     if (e != hipSuccess) return e;
     BlkK K;
     const int64_t nblk_ = (a.N + B - 1) / B;
-    K.recs = static_cast<const char *>(a.workspace); K.Wt = a.Wt; K.ldw = a.ldw;
+    char *const wbase = static_cast<char *>(a.workspace) + kAlphaBlock;       // records, compact headers, exchange buffers: behind the alphabet block
+    K.recs = wbase; K.Wt = a.Wt; K.ldw = a.ldw; K.ldt = a.ldt;
     K.hdrs = K.recs + blk_hdrs_off(nblk_, sh);
+    K.alpha = alpha;
+    K.alpha_err = a.fallback_count ? reinterpret_cast<int *>(a.fallback_count + 1) + 1 : nullptr;   // (fourth 32-bit word of the call's counter block, zeroed with it)
     K.nsl = CL ? sh.NS : 0; K.cl_map = blk_cluster_map(sh.NS, (a.C + NB - 1) / NB); K.slice_bytes = (int64_t)blk_recs_bytes(nblk_, sh); K.mbox = nullptr; K.cl_err = nullptr;
     K.u_ld = a.m; K.slack = 0x1p-43 * (double)(sh.NS > 1 ? sh.NS : 1);
+    K.cl_timeout = 100000ull * (unsigned long long)g_blk_cl_timeout_ms.load(std::memory_order_relaxed); K.cl_fault = g_blk_cl_fault.load(std::memory_order_relaxed);
     if constexpr (CLM == 1) {
-        char *mb = static_cast<char *>(a.workspace) + blk_mbox_off(nblk_, sh);
+        char *mb = wbase + blk_mbox_off(nblk_, sh);
         const size_t mbytes = blk_mbox_bytes(a.C, sh);
         e = hipMemsetAsync(mb, 0, mbytes, stream);                 // sequence numbers start at 1: a zero word is "not yet written"
         if (e != hipSuccess) return e;
@@ -2116,9 +2247,9 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
     }
     K.N = a.N; K.C = a.C; K.m = (int)a.m; K.M = a.A.M; K.zero_idx = a.A.zero_idx; K.nblk = (int)((a.N + B - 1) / B);
     K.qidx = a.qidx; K.Qt = a.Qt; K.resid = a.resid; K.u_out = a.u_out; K.fallback_count = a.fallback_count;
+    K.o_sj = a.o_st == 1 ? a.N : a.o_sj; K.o_st = a.o_st;             // neuron-major [C][N] unless the caller asked for the Keras layout
     K.stamps = a.fallback_count ? a.fallback_count + 8 : nullptr;      // (diagnostic build: the unused row-statistics area behind the counter block)
-    K.sym_a = SYM ? blk_sym_a(a) : 0.f; K.Xq = a.Xq; K.ldx = a.ld;
-    if (!blk_uniform(a.A, &K.uni_a0, &K.uni_step, &K.uni_inv, &K.uni_c0, &K.uni_plus, &K.uni_minus)) return hipErrorInvalidValue;
+    K.Xq = a.Xq; K.ldx = a.ld;
     {
         const int *pw = blk_split<G, S, NSW, NL>();
         for (int w = 0; w < 12; ++w) K.pw[w] = (unsigned char)(w < NSW ? pw[w] : 0);
@@ -2136,7 +2267,7 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
     }
     {
         MainKernelEvents ev(stream);       // (a benchmark's events around this launch alone, when it asked for them)
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NSW + 1)), (size_t)L.total, stream, K, a.A);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NSW + 1)), (size_t)L.total, stream, K);
     }
     return hipGetLastError();
 }
@@ -2145,13 +2276,69 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, hipStrea
 constexpr bool blk_has_sym(int S, int NSW) { (void)S; (void)NSW; return true; }
 
 template <int G, int S, int B, int NSW = 8, int NL = 4>
-static hipError_t launch_blk_inst(const PipeArgs &a, const BlkShape &sh, hipStream_t stream)
+static hipError_t launch_blk_inst(const PipeArgs &a, const BlkShape &sh, const DevAlphabet *alpha, hipStream_t stream)
 {
     // (sweep-bound shapes gain 3-4 %, the others nothing)
     if constexpr (blk_has_sym(S, NSW)) {
-        if (blk_sym_a(a) != 0.f) return launch_blk_sym<G, S, B, NSW, true, NL>(a, sh, stream);
+        if (blk_sym_a(a) != 0.f) return launch_blk_sym<G, S, B, NSW, true, NL>(a, sh, alpha, stream);
     }
-    return launch_blk_sym<G, S, B, NSW, false, NL>(a, sh, stream);
+    return launch_blk_sym<G, S, B, NSW, false, NL>(a, sh, alpha, stream);
+}
+
+// One cluster-form launch in flight per device: the co-residency of a cluster's slices is argued for ONE such launch on the
+// chip; a second one on another stream (the class surface's look-ahead capture runs on one) would share the compute units with it and
+// could strand slices of both.  So a cluster launch on a stream other than the last one's first waits, on the device, for that one to end
+// (an event recorded behind every cluster launch); launches on one stream are ordered anyway.  The guard holds the lock from the wait to
+// the record, so two host threads cannot interleave theirs.
+struct ClusterLaunchGuard {
+    static std::mutex &mu() { static std::mutex m; return m; }
+    struct Last { hipEvent_t ev = nullptr; hipStream_t stream = nullptr; bool any = false; };
+    static Last &last(int dev) { static Last L[64]; return L[dev & 63]; }
+    std::unique_lock<std::mutex> lock;
+    hipStream_t stream;
+    int dev = 0;
+    hipError_t err = hipSuccess;
+    explicit ClusterLaunchGuard(hipStream_t s) : lock(mu()), stream(s)
+    {
+        err = hipGetDevice(&dev);
+        if (err != hipSuccess) return;
+        Last &l = last(dev);
+        if (!l.ev) err = hipEventCreateWithFlags(&l.ev, hipEventDisableTiming);
+        if (err == hipSuccess && l.any && l.stream != stream) err = hipStreamWaitEvent(stream, l.ev, 0);
+    }
+    ~ClusterLaunchGuard()
+    {
+        if (err != hipSuccess) return;
+        Last &l = last(dev);
+        if (hipEventRecord(l.ev, stream) == hipSuccess) { l.any = true; l.stream = stream; }
+    }
+};
+
+// The call's DevAlphabet: the caller's block (a.dev_alpha, formed on the device: gpfq_quantize_dense_layer), or the host alphabet a.A
+// with its progression computed here and stored in front of the records by one single-thread kernel.
+static hipError_t blk_alphabet(const PipeArgs &a, const DevAlphabet **alpha, hipStream_t stream)
+{
+    if (a.dev_alpha) { *alpha = a.dev_alpha; return hipSuccess; }
+    DevAlphabet D{};
+    D.M = a.A.M; D.zero_idx = a.A.zero_idx;
+    D.rad = std::nan("");
+    for (int k = 0; k < a.A.M && k < 64; ++k) D.a[k] = a.A.a[k];
+    if (!blk_uniform(D)) return hipErrorInvalidValue;               // (blk_supported said otherwise)
+    D.sym_a = blk_sym_a(a);
+    D.ok = 1;
+    DevAlphabet *dst = static_cast<DevAlphabet *>(a.workspace);
+    hipLaunchKernelGGL(gpfq_alphabet_store_kernel, dim3(1), dim3(64), 0, stream, dst, D);
+    *alpha = dst;
+    return hipGetLastError();
+}
+
+hipError_t launch_alphabet_device(const float *median32, double alphabet_scalar, const AlphabetArg &unit, void *dev_alphabet, hipStream_t stream)
+{
+    PipeArgs a{};
+    a.A = unit;
+    hipLaunchKernelGGL(gpfq_alphabet_device_kernel, dim3(1), dim3(64), 0, stream, static_cast<DevAlphabet *>(dev_alphabet), median32,
+                       alphabet_scalar, unit, blk_sym_a(a) != 0.f ? 1 : 0);
+    return hipGetLastError();
 }
 
 hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
@@ -2161,76 +2348,82 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     const int64_t nblk = (a.N + sh.B - 1) / sh.B;
     const int64_t nrec = (nblk + 1) * sh.B + 1;
     const bool r64 = blk_row64(sh.G, sh.B);
+    const DevAlphabet *alpha = nullptr;
+    hipError_t e = blk_alphabet(a, &alpha, stream);
+    if (e != hipSuccess) return e;
+    char *const wbase = static_cast<char *>(a.workspace) + kAlphaBlock;
     if (sh.NS) {                                                   // cluster form: NS slices of the headline shape
         note_dense_kernel("gpfq_blk_kernel, cluster form (rows cut into 1024-sample slices: one workgroup of 8 or 11 sweep wavefronts + 1 decision wavefront per slice, partial dot products exchanged once per slot)");
-        const float sym_a = blk_sym_a(a);
+        const int sym = blk_sym_a(a) != 0.f ? 1 : 0;
         hipLaunchKernelGGL((gpfq_blk_prep_kernel<4, true, true>), dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp * sh.NS,
-                           a.nrm32, static_cast<char *>(a.workspace), static_cast<char *>(a.workspace) + blk_hdrs_off(nblk, sh), sym_a,
+                           a.nrm32, wbase, wbase + blk_hdrs_off(nblk, sh), alpha, sym,
                            sh.NS, (int64_t)blk_recs_bytes(nblk, sh));
-        hipError_t e = hipGetLastError();
+        e = hipGetLastError();
         if (e != hipSuccess) return e;
-#define GPFQ_BLK_CL(NSW_, NL_, M_) (sym_a != 0.f ? launch_blk_sym<4, 32, 4, NSW_, true, NL_, M_>(a, sh, stream) : launch_blk_sym<4, 32, 4, NSW_, false, NL_, M_>(a, sh, stream))
+        ClusterLaunchGuard one_at_a_time(stream);
+        if (one_at_a_time.err != hipSuccess) return one_at_a_time.err;
+#define GPFQ_BLK_CL(NSW_, NL_, M_) (sym ? launch_blk_sym<4, 32, 4, NSW_, true, NL_, M_>(a, sh, alpha, stream) : launch_blk_sym<4, 32, 4, NSW_, false, NL_, M_>(a, sh, alpha, stream))
         if (sh.NL == 4) return GPFQ_BLK_CL(11, 4, 1);
         return sh.NL == 1 ? GPFQ_BLK_CL(8, 1, 1) : GPFQ_BLK_CL(8, 2, 1);
 #undef GPFQ_BLK_CL
     }
     auto *prep = sh.B == 4 ? (r64 ? gpfq_blk_prep_kernel<4, true> : gpfq_blk_prep_kernel<4, false>)
                            : (sh.B == 2 ? (r64 ? gpfq_blk_prep_kernel<2, true> : gpfq_blk_prep_kernel<2, false>) : gpfq_blk_prep_kernel<1, false>);
-    const float sym_a = blk_has_sym(sh.S, sh.NW) ? blk_sym_a(a) : 0.f;   // (exactly the launches launch_blk_inst gives the symmetric form)
+    const int sym = (blk_has_sym(sh.S, sh.NW) && blk_sym_a(a) != 0.f) ? 1 : 0;   // (exactly the launches launch_blk_inst gives the symmetric form)
     hipLaunchKernelGGL(prep, dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp,
-                       a.nrm32, static_cast<char *>(a.workspace), static_cast<char *>(a.workspace) + blk_recs_bytes(nblk, sh), sym_a, 1, (int64_t)0);
-    hipError_t e = hipGetLastError();
+                       a.nrm32, wbase, wbase + blk_recs_bytes(nblk, sh), alpha, sym, 1, (int64_t)0);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
     // (four neuron groups with one or two neurons per lane: the narrow forms of the fused matrix shape)
     if (sh.G == 4 && sh.NL < 4 && sh.NW == 7) {                    // (rows of at most 768 samples: blk_shape)
-        if (sh.S == 16) return sh.NL == 1 ? launch_blk_inst<4, 16, 4, 7, 1>(a, sh, stream) : launch_blk_inst<4, 16, 4, 7, 2>(a, sh, stream);
-        if (sh.S == 24) return sh.NL == 1 ? launch_blk_inst<4, 24, 4, 7, 1>(a, sh, stream) : launch_blk_inst<4, 24, 4, 7, 2>(a, sh, stream);
-        return sh.NL == 1 ? launch_blk_inst<4, 32, 4, 7, 1>(a, sh, stream) : launch_blk_inst<4, 32, 4, 7, 2>(a, sh, stream);
+        if (sh.S == 16) return sh.NL == 1 ? launch_blk_inst<4, 16, 4, 7, 1>(a, sh, alpha, stream) : launch_blk_inst<4, 16, 4, 7, 2>(a, sh, alpha, stream);
+        if (sh.S == 24) return sh.NL == 1 ? launch_blk_inst<4, 24, 4, 7, 1>(a, sh, alpha, stream) : launch_blk_inst<4, 24, 4, 7, 2>(a, sh, alpha, stream);
+        return sh.NL == 1 ? launch_blk_inst<4, 32, 4, 7, 1>(a, sh, alpha, stream) : launch_blk_inst<4, 32, 4, 7, 2>(a, sh, alpha, stream);
     }
     if (sh.G == 4 && sh.NL < 4) {
-        if (sh.S == 16) return sh.NL == 1 ? launch_blk_inst<4, 16, 4, 8, 1>(a, sh, stream) : launch_blk_inst<4, 16, 4, 8, 2>(a, sh, stream);
-        if (sh.S == 24) return sh.NL == 1 ? launch_blk_inst<4, 24, 4, 8, 1>(a, sh, stream) : launch_blk_inst<4, 24, 4, 8, 2>(a, sh, stream);
+        if (sh.S == 16) return sh.NL == 1 ? launch_blk_inst<4, 16, 4, 8, 1>(a, sh, alpha, stream) : launch_blk_inst<4, 16, 4, 8, 2>(a, sh, alpha, stream);
+        if (sh.S == 24) return sh.NL == 1 ? launch_blk_inst<4, 24, 4, 8, 1>(a, sh, alpha, stream) : launch_blk_inst<4, 24, 4, 8, 2>(a, sh, alpha, stream);
         // (eleven sweep wavefronts buy these shapes nothing: 4096 x 512 on 1024 samples 1.77 against 1.62 ms, 4096 x 2048 1.94 / 1.95 in round 4;
         //  measured again on round 5's kernels, one neuron per lane: 1.326 against 1.285 -- profiles/r05/cluster_form.txt)
-        return sh.NL == 1 ? launch_blk_inst<4, 32, 4, 8, 1>(a, sh, stream) : launch_blk_inst<4, 32, 4, 8, 2>(a, sh, stream);
+        return sh.NL == 1 ? launch_blk_inst<4, 32, 4, 8, 1>(a, sh, alpha, stream) : launch_blk_inst<4, 32, 4, 8, 2>(a, sh, alpha, stream);
     }
     if (sh.NL == 1) {                                              // one-neuron workgroups (layers of at most 128 neurons)
-        if (sh.B == 4) return sh.S == 4 ? launch_blk_inst<1, 4, 4, 4, 1>(a, sh, stream) : launch_blk_inst<1, 8, 4, 8, 1>(a, sh, stream);
-        if (sh.B == 2) return sh.S == 12 ? launch_blk_inst<1, 12, 2, 8, 1>(a, sh, stream) : launch_blk_inst<1, 16, 2, 8, 1>(a, sh, stream);
-        if (sh.S == 24) return launch_blk_inst<1, 24, 1, 8, 1>(a, sh, stream);
-        return sh.S == 32 ? launch_blk_inst<1, 32, 1, 8, 1>(a, sh, stream) : launch_blk_inst<1, 40, 1, 8, 1>(a, sh, stream);
+        if (sh.B == 4) return sh.S == 4 ? launch_blk_inst<1, 4, 4, 4, 1>(a, sh, alpha, stream) : launch_blk_inst<1, 8, 4, 8, 1>(a, sh, alpha, stream);
+        if (sh.B == 2) return sh.S == 12 ? launch_blk_inst<1, 12, 2, 8, 1>(a, sh, alpha, stream) : launch_blk_inst<1, 16, 2, 8, 1>(a, sh, alpha, stream);
+        if (sh.S == 24) return launch_blk_inst<1, 24, 1, 8, 1>(a, sh, alpha, stream);
+        return sh.S == 32 ? launch_blk_inst<1, 32, 1, 8, 1>(a, sh, alpha, stream) : launch_blk_inst<1, 40, 1, 8, 1>(a, sh, alpha, stream);
     }
     if (sh.NL == 2) {                                              // two-neuron workgroups (layers of at most 512 neurons)
-        if (sh.B == 4) return sh.S == 4 ? launch_blk_inst<1, 4, 4, 4, 2>(a, sh, stream) : launch_blk_inst<1, 8, 4, 8, 2>(a, sh, stream);
-        if (sh.B == 2) return sh.S == 12 ? launch_blk_inst<1, 12, 2, 8, 2>(a, sh, stream) : launch_blk_inst<1, 16, 2, 8, 2>(a, sh, stream);
-        if (sh.S == 24) return launch_blk_inst<1, 24, 1, 8, 2>(a, sh, stream);
-        return sh.S == 32 ? launch_blk_inst<1, 32, 1, 8, 2>(a, sh, stream) : launch_blk_inst<1, 40, 1, 8, 2>(a, sh, stream);
+        if (sh.B == 4) return sh.S == 4 ? launch_blk_inst<1, 4, 4, 4, 2>(a, sh, alpha, stream) : launch_blk_inst<1, 8, 4, 8, 2>(a, sh, alpha, stream);
+        if (sh.B == 2) return sh.S == 12 ? launch_blk_inst<1, 12, 2, 8, 2>(a, sh, alpha, stream) : launch_blk_inst<1, 16, 2, 8, 2>(a, sh, alpha, stream);
+        if (sh.S == 24) return launch_blk_inst<1, 24, 1, 8, 2>(a, sh, alpha, stream);
+        return sh.S == 32 ? launch_blk_inst<1, 32, 1, 8, 2>(a, sh, alpha, stream) : launch_blk_inst<1, 40, 1, 8, 2>(a, sh, alpha, stream);
     }
-    if (sh.B == 1 && sh.S == 40) return launch_blk_inst<1, 40, 1>(a, sh, stream);
+    if (sh.B == 1 && sh.S == 40) return launch_blk_inst<1, 40, 1>(a, sh, alpha, stream);
     if (sh.B == 1) {
-        if (sh.G == 2) return sh.S == 64 ? launch_blk_inst<2, 64, 1, 11>(a, sh, stream) : launch_blk_inst<2, 48, 1, 11>(a, sh, stream);
-        return sh.S == 32 ? launch_blk_inst<1, 32, 1>(a, sh, stream) : launch_blk_inst<1, 24, 1>(a, sh, stream);
+        if (sh.G == 2) return sh.S == 64 ? launch_blk_inst<2, 64, 1, 11>(a, sh, alpha, stream) : launch_blk_inst<2, 48, 1, 11>(a, sh, alpha, stream);
+        return sh.S == 32 ? launch_blk_inst<1, 32, 1>(a, sh, alpha, stream) : launch_blk_inst<1, 24, 1>(a, sh, alpha, stream);
     }
-    if (sh.G == 4 && sh.S == 64) return launch_blk_inst<4, 64, 2, 11>(a, sh, stream);
-    if (sh.G == 4 && sh.S == 48) return launch_blk_inst<4, 48, 2, 11>(a, sh, stream);
+    if (sh.G == 4 && sh.S == 64) return launch_blk_inst<4, 64, 2, 11>(a, sh, alpha, stream);
+    if (sh.G == 4 && sh.S == 48) return launch_blk_inst<4, 48, 2, 11>(a, sh, alpha, stream);
     if (sh.G == 4 && sh.NW == 11) {
-        if (sh.S == 16) return launch_blk_inst<4, 16, 4, 11>(a, sh, stream);
-        if (sh.S == 24) return launch_blk_inst<4, 24, 4, 11>(a, sh, stream);
-        return launch_blk_inst<4, 32, 4, 11>(a, sh, stream);
+        if (sh.S == 16) return launch_blk_inst<4, 16, 4, 11>(a, sh, alpha, stream);
+        if (sh.S == 24) return launch_blk_inst<4, 24, 4, 11>(a, sh, alpha, stream);
+        return launch_blk_inst<4, 32, 4, 11>(a, sh, alpha, stream);
     }
     if (sh.G == 4) {
-        if (sh.S == 16) return launch_blk_inst<4, 16, 4>(a, sh, stream);
-        if (sh.S == 24) return launch_blk_inst<4, 24, 4>(a, sh, stream);
-        return launch_blk_inst<4, 32, 4>(a, sh, stream);
+        if (sh.S == 16) return launch_blk_inst<4, 16, 4>(a, sh, alpha, stream);
+        if (sh.S == 24) return launch_blk_inst<4, 24, 4>(a, sh, alpha, stream);
+        return launch_blk_inst<4, 32, 4>(a, sh, alpha, stream);
     }
     if (sh.G == 1) {
-        if (sh.S == 8) return launch_blk_inst<1, 8, 4>(a, sh, stream);
-        if (sh.S == 12) return launch_blk_inst<1, 12, 2>(a, sh, stream);
-        return launch_blk_inst<1, 16, 2>(a, sh, stream);
+        if (sh.S == 8) return launch_blk_inst<1, 8, 4>(a, sh, alpha, stream);
+        if (sh.S == 12) return launch_blk_inst<1, 12, 2>(a, sh, alpha, stream);
+        return launch_blk_inst<1, 16, 2>(a, sh, alpha, stream);
     }
-    if (sh.B == 4) return launch_blk_inst<2, 16, 4>(a, sh, stream);
-    if (sh.S == 24) return launch_blk_inst<2, 24, 2>(a, sh, stream);
-    return launch_blk_inst<2, 32, 2>(a, sh, stream);
+    if (sh.B == 4) return launch_blk_inst<2, 16, 4>(a, sh, alpha, stream);
+    if (sh.S == 24) return launch_blk_inst<2, 24, 2>(a, sh, alpha, stream);
+    return launch_blk_inst<2, 32, 2>(a, sh, alpha, stream);
 }
 
 }  // namespace gpfq

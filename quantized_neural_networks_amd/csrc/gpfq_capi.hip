@@ -98,7 +98,7 @@ hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes)
 
 extern "C" {
 
-int gpfq_version(void) { return 304; }   // 304: options blk_cluster / blk_cluster_nl / blk_cluster_map, larger workspaces for long rows (round 5); 303: gpfq_set_main_kernel_events (round 4); hip.load() checks it
+int gpfq_version(void) { return 305; }   // 305: device-resident layer alphabet, gpfq_quantize_dense_layer, gpfq_call_status, the block kernel's workspace grew by its alphabet block (round 6); 304: options blk_cluster / blk_cluster_nl / blk_cluster_map, larger workspaces for long rows (round 5); 303: gpfq_set_main_kernel_events (round 4); hip.load() checks it
 
 const char *gpfq_last_dense_kernel(void) { return g_dense_kernel; }
 
@@ -192,6 +192,7 @@ static std::atomic<int> g_conv_fused{1};       // conv channel loop: 3x3/stride-
 static std::atomic<int> g_conv_planes_free{1}; // 7x7 / 2 layers read the NHWC activations themselves (gpfq_quantize_conv_channels_nhwc; 0: channel planes first)
 static std::atomic<int> g_conv_nhwc{1};        // 3x3 / stride 1 / SAME layers straight from the NHWC activations (no channel-major copy)
 static std::atomic<int> g_conv_strip{0};
+static std::atomic<int> g_sync_errors{0};      // 1: gpfq_quantize_neurons / gpfq_quantize_dense_layer wait for their launches and return the call's status words as an error code
 static std::atomic<int> g_conv_shift{1};    // fused 3x3 conv kernel with SAME padding: the shift form (0 = the per-output-position form)       // fused conv kernel: forced strip length (0 = heuristic)
 
 int gpfq_set_option(const char *key, int value)
@@ -218,6 +219,13 @@ int gpfq_set_option(const char *key, int value)
     if (!std::strcmp(key, "blk_single_groups")) { gpfq::blk_set_single_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_quad_groups")) { gpfq::blk_set_quad_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_cluster_map")) { gpfq::blk_set_cluster_map(value); return GPFQ_OK; }
+    if (!std::strcmp(key, "blk_chip_ok")) { gpfq::blk_set_chip_ok(value); return GPFQ_OK; }
+    if (!std::strcmp(key, "blk_cluster_fault")) { gpfq::blk_set_cluster_fault(value); return GPFQ_OK; }
+    if (!std::strcmp(key, "blk_cluster_timeout_ms")) {
+        if (value < 1 || value > 60000) return fail(GPFQ_ERR_INVALID_ARG, "blk_cluster_timeout_ms must be in [1, 60000]");
+        gpfq::blk_set_cluster_timeout_ms(value); return GPFQ_OK;
+    }
+    if (!std::strcmp(key, "sync_errors")) { g_sync_errors = value ? 1 : 0; return GPFQ_OK; }
     if (!std::strcmp(key, "blk_cluster_nl")) { gpfq::blk_set_cluster_nl(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_cluster")) {
         if (value < 0 || (value > 1 && value < 1024)) return fail(GPFQ_ERR_INVALID_ARG, "blk_cluster must be 0 (off), 1 (default: by row length and width) or a row length >= 1024");
@@ -258,6 +266,23 @@ int gpfq_set_option(const char *key, int value)
         g_lpn = value; return GPFQ_OK;
     }
     return fail(GPFQ_ERR_INVALID_ARG, "unknown option '%s'", key);
+}
+
+int gpfq_call_status(const void *workspace, void *stream)
+{
+    if (!workspace) return fail(GPFQ_ERR_INVALID_ARG, "workspace is NULL");
+    int32_t w[4] = {0, 0, 0, 0};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemcpyAsync(w, workspace, sizeof(w), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hip_fail(e, "gpfq_call_status");
+    if (w[2] != 0)
+        return fail(GPFQ_ERR_CLUSTER_TIMEOUT, "an exchange between the workgroups of the block kernel's cluster form timed out (a slice never arrived): "
+                                              "the outputs of this call are invalid; rerun it with gpfq_set_option(\"blk_cluster\", 0)");
+    if (w[3] != 0)
+        return fail(GPFQ_ERR_ALPHABET, "the device-resident alphabet is not a strictly ascending arithmetic progression (radius zero, infinite or NaN): "
+                                       "nothing was computed; rerun the layer through gpfq_quantize_neurons with a host alphabet");
+    return GPFQ_OK;
 }
 
 int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const float *nrm32,
@@ -364,7 +389,8 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
                 pa.fallback_count = static_cast<unsigned long long *>(workspace);
                 gpfq::note_dense_kernel("gpfq_blk_kernel (4 to 11 sweep wavefronts + 1 decision wavefront per workgroup, blocks of steps per slot)");
                 hipError_t e = gpfq::launch_blk(pa, s);
-                return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_neurons(block-pipelined)");
+                if (e != hipSuccess) return hip_fail(e, "gpfq_quantize_neurons(block-pipelined)");
+                return g_sync_errors ? gpfq_call_status(workspace, stream) : GPFQ_OK;
             }
             if (want && N > 0 && m > 0 && gpfq::pipe_supported(pa) && workspace && (uintptr_t)workspace % 16 == 0 &&
                 workspace_bytes >= onchip_workspace_bytes(N, m, C)) {
@@ -399,6 +425,125 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
     gpfq::note_dense_kernel("gpfq_stream_step_kernel + gpfq_stream_decide_kernel (residual in HBM)");
     hipError_t e = gpfq::launch_stream(a, s);
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_neurons(stream)");
+}
+
+
+// ---- the Dense layer driver as one call, alphabet in device memory (round 6) ----------------------------------------------------------
+static int unit_alphabet_arg(const double *unit_alphabet, int M, HostAlphabet *H)
+{
+    if (!unit_alphabet) return fail(GPFQ_ERR_INVALID_ARG, "unit_alphabet is NULL");
+    int zero_idx = -1;
+    for (int k = 0; k < M && k < GPFQ_MAX_ALPHABET; ++k)
+        if (unit_alphabet[k] == 0.0) zero_idx = k;
+    return make_alphabet(unit_alphabet, M, zero_idx, H);
+}
+
+int gpfq_layer_alphabet_device(const float *median32, double alphabet_scalar, const double *unit_alphabet, int M,
+                               void *dev_alphabet, void *stream)
+{
+    HostAlphabet H;
+    int rc = unit_alphabet_arg(unit_alphabet, M, &H);
+    if (rc != GPFQ_OK) return rc;
+    if (H.is_big) return fail(GPFQ_ERR_UNSUPPORTED, "device-resident alphabets hold up to 64 members (got %d)", M);
+    if (!median32 || !dev_alphabet) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    if ((uintptr_t)dev_alphabet % 16 != 0) return fail(GPFQ_ERR_INVALID_ARG, "dev_alphabet must be 16-byte aligned");
+    hipError_t e = gpfq::launch_alphabet_device(median32, alphabet_scalar, H.A, dev_alphabet, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_layer_alphabet_device");
+}
+
+static gpfq::PipeArgs dense_layer_probe(int64_t N, int64_t m, int64_t C, const HostAlphabet &H)
+{
+    gpfq::PipeArgs pa{};
+    pa.A = H.A; pa.N = N; pa.m = m; pa.C = C;
+    return pa;
+}
+
+int gpfq_dense_layer_supported(int64_t N, int64_t m, int64_t C, const double *unit_alphabet, int M)
+{
+    if (N < 1 || m < 1 || C < 1 || !unit_alphabet || M < 1 || M > 64) return 0;
+    HostAlphabet H;
+    if (unit_alphabet_arg(unit_alphabet, M, &H) != GPFQ_OK) return 0;
+    // exactly the rows and alphabets gpfq_quantize_neurons gives the block-pipelined kernel by default
+    const bool forced_old = g_lpn != 0 || g_wpn != 0 || g_onchip_mode != 1 || g_pipe == 0 || g_pipe == 1;
+    if (forced_old || !(m > 256 && m <= GPFQ_ONCHIP_MAX_M)) return 0;
+    return gpfq::blk_supported(dense_layer_probe(N, m, C, H)) ? 1 : 0;
+}
+
+size_t gpfq_dense_layer_workspace_bytes(int64_t N, int64_t m, int64_t C)
+{
+    if (N < 0 || m < 0 || C < 0) return 0;
+    return onchip_workspace_bytes(N, m, C) + al256((size_t)N * sizeof(float));      // (+ the row norms when the caller passes none)
+}
+
+int gpfq_quantize_dense_layer(const float *X, const float *Xq, int64_t ld, const float *nrm32,
+                              const float *W, int64_t ldc, int64_t c_lo, int64_t C,
+                              const void *dev_alphabet, const double *unit_alphabet, int M,
+                              int64_t N, int64_t m,
+                              int8_t *qidx, float *Q, int out_layout, int64_t ldo, double *resid,
+                              void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (N < 1 || m < 1 || C < 0 || c_lo < 0)
+        return fail(GPFQ_ERR_INVALID_ARG, "bad size N=%lld m=%lld C=%lld c_lo=%lld", (long long)N, (long long)m, (long long)C, (long long)c_lo);
+    HostAlphabet H;
+    int rc = unit_alphabet_arg(unit_alphabet, M, &H);
+    if (rc != GPFQ_OK) return rc;
+    if (C == 0) return GPFQ_OK;
+    if (!X || !Xq || !W || !dev_alphabet) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    if (ld < m) return fail(GPFQ_ERR_INVALID_ARG, "row pitch ld=%lld < m=%lld", (long long)ld, (long long)m);
+    if (ldc < c_lo + C) return fail(GPFQ_ERR_INVALID_ARG, "kernel pitch ldc=%lld < c_lo + C=%lld", (long long)ldc, (long long)(c_lo + C));
+    if (out_layout != GPFQ_LAYOUT_NEURON_MAJOR && out_layout != GPFQ_LAYOUT_KERAS) return fail(GPFQ_ERR_INVALID_ARG, "unknown output layout %d", out_layout);
+    if (out_layout == GPFQ_LAYOUT_KERAS && ldo < c_lo + C) return fail(GPFQ_ERR_INVALID_ARG, "output pitch ldo=%lld < c_lo + C=%lld", (long long)ldo, (long long)(c_lo + C));
+    if (!gpfq_dense_layer_supported(N, m, C, unit_alphabet, M))
+        return fail(GPFQ_ERR_UNSUPPORTED, "no block-pipelined kernel for N=%lld m=%lld C=%lld M=%d (gpfq_dense_layer_supported): use gpfq_quantize_neurons with a host alphabet",
+                    (long long)N, (long long)m, (long long)C, M);
+    if (!workspace || (uintptr_t)workspace % 16 != 0 || workspace_bytes < gpfq_dense_layer_workspace_bytes(N, m, C))
+        return fail(GPFQ_ERR_WORKSPACE, "gpfq_quantize_dense_layer needs %zu aligned workspace bytes", gpfq_dense_layer_workspace_bytes(N, m, C));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(workspace, 0, 64, s);           // the call's counter block: exact fallbacks, cluster timeout, alphabet word
+    if (e != hipSuccess) return hip_fail(e, "gpfq_quantize_dense_layer(workspace)");
+    if (!nrm32) {
+        float *n32 = reinterpret_cast<float *>(static_cast<char *>(workspace) + onchip_workspace_bytes(N, m, C));
+        e = gpfq::launch_row_norms(Xq, N, m, ld, n32, s);
+        if (e != hipSuccess) return hip_fail(e, "gpfq_quantize_dense_layer(row norms)");
+        nrm32 = n32;
+    }
+    gpfq::PipeArgs pa{};
+    pa.X = X; pa.Xq = Xq; pa.ld = ld; pa.nrm32 = nrm32;
+    pa.Wt = W + c_lo; pa.ldw = 1; pa.ldt = ldc;                   // the Keras kernel itself: neuron j's weight of step t is W[t][c_lo + j]
+    pa.A = H.A; pa.N = N; pa.m = m; pa.C = C;
+    pa.resid = resid; pa.u_out = nullptr;
+    pa.ts_override = g_tile_steps; pa.variant = g_variant >> 4;
+    if (out_layout == GPFQ_LAYOUT_KERAS) {
+        pa.qidx = qidx ? qidx + c_lo : nullptr; pa.Qt = Q ? Q + c_lo : nullptr;
+        pa.o_sj = 1; pa.o_st = ldo;
+        if (ldo == 1) { pa.o_sj = N; pa.o_st = 1; }               // (a one-neuron layer: the two layouts coincide)
+    } else {
+        pa.qidx = qidx; pa.Qt = Q;
+    }
+    pa.dev_alpha = static_cast<const gpfq::DevAlphabet *>(dev_alphabet);
+    pa.workspace = static_cast<char *>(workspace) + onchip_stats_bytes(N);
+    pa.fallback_count = static_cast<unsigned long long *>(workspace);
+    gpfq::note_dense_kernel("gpfq_blk_kernel (4 to 11 sweep wavefronts + 1 decision wavefront per workgroup, blocks of steps per slot)");
+    e = gpfq::launch_blk(pa, s);
+    if (e != hipSuccess) return hip_fail(e, "gpfq_quantize_dense_layer");
+    return g_sync_errors ? gpfq_call_status(workspace, stream) : GPFQ_OK;
+}
+
+int gpfq_assemble_kernel_device(const void *qidx, int bits, const void *dev_alphabet, int M, int64_t N, int64_t C,
+                                float *Q, void *qidx_t, void *stream)
+{
+    if (N < 0 || C < 0) return fail(GPFQ_ERR_INVALID_ARG, "negative size");
+    if (bits != 2 && bits != 4 && bits != 8) return fail(GPFQ_ERR_INVALID_ARG, "bits must be 2, 4 or 8 (device-resident alphabets hold up to 64 members)");
+    if (M < 1 || M > 64) return fail(GPFQ_ERR_UNSUPPORTED, "device-resident alphabets hold 1..64 members (got %d)", M);
+    if (bits < 8 && M + 1 > (1 << bits)) return fail(GPFQ_ERR_INVALID_ARG, "%d-bit codes cannot hold an alphabet of %d", bits, M);
+    if (N == 0 || C == 0) return GPFQ_OK;
+    if (!qidx || !dev_alphabet) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    if (N > 2147483647LL * 32) return fail(GPFQ_ERR_UNSUPPORTED, "kernel too large to assemble in one call");
+    gpfq::AlphabetArg A{};
+    A.M = M;
+    hipError_t e = gpfq::launch_assemble(static_cast<const int8_t *>(qidx), A, N, C, bits, Q, static_cast<int8_t *>(qidx_t),
+                                         static_cast<hipStream_t>(stream), nullptr, static_cast<const gpfq::DevAlphabet *>(dev_alphabet));
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_assemble_kernel_device");
 }
 
 size_t gpfq_gram_workspace_bytes(int64_t N, int64_t m, int64_t C)

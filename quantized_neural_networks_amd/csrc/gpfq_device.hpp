@@ -212,6 +212,30 @@ struct AlphabetT {
 using AlphabetArg = AlphabetT<64>;     // by-value kernel argument of every kernel family (bits <= 6)
 using AlphabetBig = AlphabetT<256>;    // GPFQ_MAX_ALPHABET: the kernels that take 65..256 members (bits 7, 8) write int16 indices
 
+// The layer alphabet IN DEVICE MEMORY (round 6; include/gpfq.h: GPFQ_DEVICE_ALPHABET_BYTES, gpfq_layer_alphabet_device): everything a
+// launch of the block-pipelined dense kernel needs of `rad * linspace(-1, 1, M)` (scripts/quantized_network.py:544-545), formed on the
+// device from the float32 median of |W| -- or stored from a host alphabet -- by gpfq_alphabet_setup_kernel (gpfq_blk.hip), so that no
+// launch waits for the radius to cross to the host.  `ok` = 0: not a strictly ascending arithmetic progression the chain of decisions
+// can index by arithmetic (rad = 0, infinite or NaN: the median of a kernel that is mostly zeros): the kernel then writes nothing and
+// raises the call's alphabet word (workspace bytes 12..15), and the caller reruns the layer with a host alphabet.
+struct DevAlphabet {
+    double rad;                          // float64(alphabet_scalar) * float64(float32 median): the reference's legacy-NumPy product (:544); NaN when stored from a host alphabet
+    double a0, step, inv, c0;            // member k = a0 + k step; inv = 1 / step, c0 = -a0 / step (blk_uniform, gpfq_blk.hip)
+    unsigned long long plus, minus;      // bit k: float32(a[k]) is the float32 above / below float32(fma(k, step, a0))
+    float sym_a;                         // float32(a[M - 1]) of an exactly symmetric {-a, 0, a} / {-a, a}, else 0
+    int M, zero_idx, ok;
+    double amax;                         // max |member|
+    double pad[6];
+    double a[64];                        // the members (float64), a[k] = rad * unit[k]
+};
+static_assert(sizeof(DevAlphabet) == 128 + 64 * 8, "DevAlphabet layout (include/gpfq.h documents the offsets of rad and a[])");
+
+// an alphabet by reference (members in device memory): the kernels templated on their alphabet argument index it like AlphabetT
+struct AlphabetRef {
+    const double *a;
+    int M;
+};
+
 __device__ __forceinline__ double alphabet_lane(const AlphabetArg &A, int lane)
 {
     return lane < A.M ? A.a[lane] : __longlong_as_double(0x7ff8000000000000LL);

@@ -75,8 +75,18 @@ struct PipeArgs {
     unsigned long long *fallback_count = nullptr;
     int ts_override = 0;                   // tuning hook (bench/tests); 0 = heuristic
     int variant = 0;                       // tuning / timing experiments (PipeK::flags)
+    // Block form only (round 6, gpfq_quantize_dense_layer): the weights and the outputs in the layer's own (Keras) layout, the alphabet in
+    // device memory.  Weight of neuron j at step t: Wt[j ldw + t ldt]; output element (j, t) at j o_sj + t o_st (o_st == 1: neuron-major
+    // [C][N] whatever o_sj says).  dev_alpha != NULL: a DevAlphabet formed on the device (launch_alphabet_device) -- A then holds the UNIT
+    // alphabet linspace(-1, 1, M), from which the host takes M, zero_idx and the choice of the symmetric form.
+    int64_t ldt = 1;
+    int64_t o_sj = 0, o_st = 1;
+    const DevAlphabet *dev_alpha = nullptr;
 };
 // Block form (gpfq_blk.hip): B steps per slot; same arguments.
+// The layer alphabet formed on the device from the float32 median of |W| (device scalar): rad = alphabet_scalar * median, members
+// rad * unit[k]; dev_alphabet: GPFQ_DEVICE_ALPHABET_BYTES of device memory (a DevAlphabet).
+hipError_t launch_alphabet_device(const float *median32, double alphabet_scalar, const AlphabetArg &unit, void *dev_alphabet, hipStream_t stream);
 bool blk_supported(const PipeArgs &a);
 size_t blk_workspace_bytes(int64_t N, int64_t m, int64_t C);   // (C: the cluster form's exchange buffers are per 16 neurons)
 hipError_t launch_blk(const PipeArgs &a, hipStream_t stream);
@@ -89,6 +99,9 @@ void blk_set_quad_waves(int nw);    // sweep wavefronts of the four-group narrow
 void blk_set_cluster_nl(int v);     // cluster form: neurons per lane of a workgroup, 0 (default) = by width, 1 / 2 / 4 force it (speed only)
 void blk_set_cluster_map(int v);    // cluster form: workgroup id -> (cluster, slice): -1 (default) by the slice count, 0 = a cluster inside one XCD, 1 = consecutive ids (speed only)
 void blk_set_cluster(int v);        // cluster form (rows cut into 1024-sample slices over several workgroups, up to 16384 samples): 1 (default) = by shape, 0 = off, v >= 1024 = every row beyond v samples (speed only)
+void blk_set_chip_ok(int v);        // -1 (default): the cluster form asks the device whether it is the whole 8 x 32-CU chip; 0 / 1: forced (tests)
+void blk_set_cluster_timeout_ms(int v);  // cluster form: how long an exchange waits for a missing slice (default 3000 ms)
+void blk_set_cluster_fault(int v);  // tests: 1 = one slice never publishes (forces the timeout and the caller's fallback)
 void blk_set_sweep_waves(int nw);   // sweep wavefronts of the 16-neuron four-step shapes: 0 (default) = by shape (eleven for rows of 769..1024 samples, eight below), 8 or 11 force it (speed only)
 bool pipe_supported(const PipeArgs &a);
 size_t pipe_workspace_bytes(int64_t N, int64_t m);
@@ -258,7 +271,8 @@ hipError_t launch_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, f
 hipError_t launch_msq(const float *W, int64_t n, const AlphabetArg &A, float *Q, int8_t *qidx, hipStream_t stream,
                       const AlphabetBig *big = nullptr, const int32_t *dead = nullptr, int64_t row_len = 1, int zero_idx = -1);
 hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, int64_t C, int bits, float *Q, int8_t *idxT,
-                           hipStream_t stream, const AlphabetBig *big = nullptr);
+                           hipStream_t stream, const AlphabetBig *big = nullptr, const DevAlphabet *dev = nullptr);
+// dev != NULL: the members are read from a DevAlphabet in device memory (A: its size only)
 hipError_t launch_pack(const int8_t *qidx, int64_t N, int64_t C, int bits, uint8_t *packed, hipStream_t stream);
 size_t median_workspace_bytes();
 size_t channel_sumsq_workspace_bytes(int64_t Cin);

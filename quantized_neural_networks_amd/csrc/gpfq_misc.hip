@@ -515,8 +515,9 @@ gpfq_assemble_kernel(const Idx *__restrict__ qidx, Alph A, int64_t N, int64_t C,
 
 // The common case -- one int8 index per weight, N and C multiples of four -- in 64 x 64 tiles with 4-byte index reads and
 // 16-byte value writes (the 32 x 32 form reads single bytes: 43 -> 27 us for 4096 x 4096).
+template <class Alph>
 __global__ void __launch_bounds__(256)
-gpfq_assemble64_kernel(const int8_t *__restrict__ qidx, AlphabetArg A, int64_t N, int64_t C, float *__restrict__ Q, int8_t *__restrict__ idxT,
+gpfq_assemble64_kernel(const int8_t *__restrict__ qidx, Alph A, int64_t N, int64_t C, float *__restrict__ Q, int8_t *__restrict__ idxT,
                        int64_t jtile0)
 {
     __shared__ int8_t tile[64][68];                               // [neuron][step], rows 4-byte aligned
@@ -551,9 +552,10 @@ gpfq_assemble64_kernel(const int8_t *__restrict__ qidx, AlphabetArg A, int64_t N
 }
 
 hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, int64_t C, int bits, float *Q, int8_t *idxT,
-                           hipStream_t stream, const AlphabetBig *big)
+                           hipStream_t stream, const AlphabetBig *big, const DevAlphabet *dev)
 {
     if (N == 0 || C == 0) return hipSuccess;
+    const AlphabetRef R{dev ? dev->a : nullptr, A.M};             // (dev: the members stay in device memory -- only the address is taken here)
     // the neuron tiles ride on grid.y (at most 65535): kernels of more rows -- a multi-GPU 1 x 1 conv layer has Cin * F of them,
     // 2^21 for ResNet50's conv5_block1_0_conv -- take several launches, each told its first tile
     constexpr int64_t kMaxY = 65535;
@@ -561,8 +563,8 @@ hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, 
         const int64_t tiles = (C + 63) / 64;
         for (int64_t j = 0; j < tiles; j += kMaxY) {
             const int64_t ny = tiles - j < kMaxY ? tiles - j : kMaxY;
-            hipLaunchKernelGGL(gpfq_assemble64_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)ny), dim3(256), 0, stream,
-                               qidx, A, N, C, Q, idxT, j);
+            if (dev) hipLaunchKernelGGL(gpfq_assemble64_kernel<AlphabetRef>, dim3((unsigned)((N + 63) / 64), (unsigned)ny), dim3(256), 0, stream, qidx, R, N, C, Q, idxT, j);
+            else hipLaunchKernelGGL(gpfq_assemble64_kernel<AlphabetArg>, dim3((unsigned)((N + 63) / 64), (unsigned)ny), dim3(256), 0, stream, qidx, A, N, C, Q, idxT, j);
         }
         return hipGetLastError();
     }
@@ -573,6 +575,8 @@ hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, 
         if (big)
             hipLaunchKernelGGL((gpfq_assemble_kernel<AlphabetBig, int16_t>), grid, dim3(256), 0, stream,
                                reinterpret_cast<const int16_t *>(qidx), *big, N, C, bits, Q, reinterpret_cast<int16_t *>(idxT), j);
+        else if (dev)
+            hipLaunchKernelGGL((gpfq_assemble_kernel<AlphabetRef, int8_t>), grid, dim3(256), 0, stream, qidx, R, N, C, bits, Q, idxT, j);
         else
             hipLaunchKernelGGL((gpfq_assemble_kernel<AlphabetArg, int8_t>), grid, dim3(256), 0, stream, qidx, A, N, C, bits, Q, idxT, j);
     }

@@ -18,6 +18,9 @@ GPFQ_GRAM_MAX_N = 1024             # longest walk the Gram path takes (include/g
 GPFQ_MAX_ALPHABET = 256       # more than 64 members: int16 indices (index_dtype)
 GPFQ_ONCHIP_MAX_M = 28672          # longest row whose residual stays in registers (include/gpfq.h)
 GPFQ_GRAM_MIN_M = 16384
+GPFQ_DEVICE_ALPHABET_BYTES = 1024
+GPFQ_LAYOUT_NEURON_MAJOR, GPFQ_LAYOUT_KERAS = 0, 1
+GPFQ_ERR_CLUSTER_TIMEOUT, GPFQ_ERR_ALPHABET = -6, -7
 
 # every symbol include/gpfq.h declares: (restype, argtypes)
 _i64, _int, _vp, _sz = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
@@ -33,6 +36,13 @@ SYMBOLS = {
     "gpfq_set_option": (_int, [ctypes.c_char_p, _int]),
     "gpfq_quantize_neurons": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _dp, _int, _int, _i64, _i64, _i64,
                                      _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp]),
+    "gpfq_call_status": (_int, [_vp, _vp]),
+    "gpfq_layer_alphabet_device": (_int, [_vp, ctypes.c_double, _dp, _int, _vp, _vp]),
+    "gpfq_dense_layer_supported": (_int, [_i64, _i64, _i64, _dp, _int]),
+    "gpfq_dense_layer_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "gpfq_quantize_dense_layer": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _dp, _int, _i64, _i64,
+                                         _vp, _vp, _int, _i64, _vp, _vp, _sz, _vp]),
+    "gpfq_assemble_kernel_device": (_int, [_vp, _int, _vp, _int, _i64, _i64, _vp, _vp, _vp]),
     "gpfq_gram_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "gpfq_quantize_neurons_gram": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _i64, _dp, _int, _int, _i64, _i64, _i64,
                                           _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -83,7 +93,7 @@ def lib_path():
     return _build.LIB
 
 
-ABI_VERSION = 304                  # gpfq_version() of the library this binding was written against
+ABI_VERSION = 305                  # gpfq_version() of the library this binding was written against
 
 
 def load():
@@ -543,6 +553,122 @@ def conv_channels_from_records(records, negflags, act_w_cm, act_q_cm, Wt_all, al
     _check(rc, "gpfq_quantize_conv_channels_from_records")
 
 
+class DeviceAlphabet:
+    """The layer alphabet rad * unit (scripts/quantized_network.py:544-545) held in DEVICE memory (gpfq_layer_alphabet_device): formed by
+    one single-thread kernel from the float32 device scalar median(|W|), so that no launch of the layer waits for the radius to cross to
+    the host.  `buf`: the GPFQ_DEVICE_ALPHABET_BYTES block the kernels read; `unit`: linspace(-1, 1, M) on the host (M, the zero member
+    and the symmetric form are decided from it).  rad() / values() read the radius back (one sync: logging, the reference's return value)."""
+
+    def __init__(self, buf, unit, alphabet_scalar):
+        import numpy as np
+        self.buf, self.unit, self.alphabet_scalar = buf, np.asarray(unit, dtype=np.float64), float(alphabet_scalar)
+        self._rad = None
+
+    def __len__(self):
+        return len(self.unit)
+
+    def rad(self):
+        import numpy as np
+        if self._rad is None:
+            self._rad = np.float64(self.buf[:8].view(torch.float64).cpu().item())
+        return self._rad
+
+    def values(self):
+        """rad * unit as float64: the host alphabet of the same layer (bit-identical to the device's members: the same float64 products)."""
+        return self.rad() * self.unit
+
+
+def layer_alphabet_device(median32, unit_alphabet, alphabet_scalar):
+    """DeviceAlphabet of a layer from the float32 DEVICE scalar median32 = median(|W|) (median_abs(..., on_device=True)).  No sync."""
+    import numpy as np
+    _dev(median32, torch.float32, "median32")
+    unit = np.asarray(unit_alphabet, dtype=np.float64)
+    if not 1 <= len(unit) <= 64:
+        raise GpfqError(f"device-resident alphabets hold 1..64 members, got {len(unit)}")
+    arr = (ctypes.c_double * len(unit))(*[float(v) for v in unit])
+    buf = torch.empty(GPFQ_DEVICE_ALPHABET_BYTES, dtype=torch.uint8, device=median32.device)
+    with torch.cuda.device(median32.device):
+        _check(load().gpfq_layer_alphabet_device(median32.data_ptr(), float(alphabet_scalar), arr, len(unit), buf.data_ptr(), _stream()),
+               "gpfq_layer_alphabet_device")
+    return DeviceAlphabet(buf, unit, alphabet_scalar)
+
+
+def dense_layer_supported(N, m, C, unit_alphabet):
+    """Whether quantize_dense_layer (device-resident alphabet, the block-pipelined kernel) takes this shape and unit alphabet."""
+    arr = (ctypes.c_double * len(unit_alphabet))(*[float(v) for v in unit_alphabet])
+    return bool(load().gpfq_dense_layer_supported(int(N), int(m), int(C), arr, len(unit_alphabet)))
+
+
+def quantize_dense_layer(X, Xq, W, dalpha, lo=0, hi=None, nrm32=None, keras_out=True, want_values=True, want_idx=True, want_resid=True):
+    """Neurons [lo, hi) of a Dense layer in one library call (gpfq_quantize_dense_layer): W f32 [N][C] is the Keras kernel itself, the
+    alphabet a DeviceAlphabet.  keras_out: Q f32 / idx i8 are whole-layer [N][C] tensors of which columns lo..hi are written (the layout
+    set_weights takes, scripts/quantized_network.py:562, :570); else this shard's neuron-major [hi - lo][N].
+    Returns dict(Q, idx, resid f64 [hi - lo], workspace); call_status(result) is the deferred error check.  No sync."""
+    _dev(X, torch.float32, "X"); _dev(Xq, torch.float32, "Xq"); _dev(W, torch.float32, "W")
+    xp, N, m, ld = _rows(X, "X")
+    xqp, N2, m2, ld2 = _rows(Xq, "Xq")
+    if W.dim() != 2 or not W.is_contiguous() or W.shape[0] != N or (N2, m2) != (N, m) or ld2 != ld:
+        raise GpfqError(f"shape mismatch: X {tuple(X.shape)}, Xq {tuple(Xq.shape)}, W {tuple(W.shape)} (contiguous [N][C] kernel, one row pitch)")
+    Ctot = W.shape[1]
+    hi = Ctot if hi is None else hi
+    C = hi - lo
+    if not 0 <= lo <= hi <= Ctot:
+        raise GpfqError(f"neuron range [{lo}, {hi}) outside the layer's {Ctot}")
+    M = len(dalpha)
+    arr = (ctypes.c_double * M)(*[float(v) for v in dalpha.unit])
+    dev = X.device
+    shape = (N, Ctot) if keras_out else (C, N)
+    idx = torch.empty(shape, dtype=torch.int8, device=dev) if want_idx else None
+    Q = torch.empty(shape, dtype=torch.float32, device=dev) if want_values else None
+    resid = torch.empty(C, dtype=torch.float64, device=dev) if want_resid is not False else None
+    lib = load()
+    if C == 0:                                            # (an empty shard: nothing launched, a clean status block)
+        return dict(idx=idx, Q=Q, resid=resid, u=None, workspace=torch.zeros(16, dtype=torch.uint8, device=dev))
+    nbytes = lib.gpfq_dense_layer_workspace_bytes(N, m, C)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    if nrm32 is not None:
+        _dev(nrm32, torch.float32, "nrm32")
+    with torch.cuda.device(dev):
+        rc = lib.gpfq_quantize_dense_layer(xp, xqp, ld, nrm32.data_ptr() if nrm32 is not None else None,
+                                           W.data_ptr(), Ctot, lo, C, dalpha.buf.data_ptr(), arr, M, N, m,
+                                           idx.data_ptr() if idx is not None else None, Q.data_ptr() if Q is not None else None,
+                                           GPFQ_LAYOUT_KERAS if keras_out else GPFQ_LAYOUT_NEURON_MAJOR, Ctot,
+                                           resid.data_ptr() if resid is not None else None, ws.data_ptr(), nbytes, _stream())
+    _check(rc, "gpfq_quantize_dense_layer")
+    return dict(idx=idx, Q=Q, resid=resid, u=None, workspace=ws)
+
+
+def call_status(result):
+    """Deferred errors of an asynchronous dense call (gpfq_call_status; forces a device sync): 0, GPFQ_ERR_CLUSTER_TIMEOUT (an exchange
+    of the block kernel's cluster form timed out: the outputs are invalid) or GPFQ_ERR_ALPHABET (a device-resident alphabet whose radius
+    was 0 / infinite / NaN: nothing was computed).  The layer drivers check it before a layer's result is used (layer.quantize_dense)."""
+    ws = result.get("workspace") if isinstance(result, dict) else result
+    if ws is None or ws.numel() < 16:
+        return 0
+    with torch.cuda.device(ws.device):
+        return int(load().gpfq_call_status(ws.data_ptr(), _stream()))
+
+
+def assemble_kernel_device(qidx, dalpha, want_idx=True, bits=8, N=None):
+    """assemble_kernel with the members read from a DeviceAlphabet (gpfq_assemble_kernel_device): [C][N] int8 indices or rows packed by
+    pack_indices (bits = 2 / 4, pass N) -> (Q f32 [N][C] in Keras layout, idx i8 [N][C])."""
+    _dev(qidx, torch.int8 if bits == 8 else torch.uint8, "qidx")
+    if qidx.dim() != 2 or not qidx.is_contiguous():
+        raise GpfqError("qidx must be a contiguous 2-D tensor")
+    C = qidx.shape[0]
+    if bits >= 8:
+        N = qidx.shape[1]
+    elif N is None or qidx.shape[1] != (N * bits + 7) // 8:
+        raise GpfqError("packed indices need N, with ceil(N*bits/8) bytes per row")
+    Q = torch.empty((N, C), dtype=torch.float32, device=qidx.device)
+    idx_t = torch.empty((N, C), dtype=torch.int8, device=qidx.device) if want_idx else None
+    with torch.cuda.device(qidx.device):
+        _check(load().gpfq_assemble_kernel_device(qidx.data_ptr(), bits, dalpha.buf.data_ptr(), len(dalpha), N, C, Q.data_ptr(),
+                                                  idx_t.data_ptr() if idx_t is not None else None, _stream()),
+               "gpfq_assemble_kernel_device")
+    return Q, idx_t
+
+
 def last_dense_kernel():
     """Name of the dense kernel family the last quantize_neurons() call dispatched (diagnostics)."""
     return load().gpfq_last_dense_kernel().decode()
@@ -577,8 +703,33 @@ def cluster_timeouts(result):
     return 0 if ws is None or ws.numel() < 16 else int(ws[8:12].view(torch.int32).item())
 
 
+_OPTION_DEFAULTS = {"blk_cluster": 1, "blk_cluster_nl": 0, "blk_cluster_map": -1, "blk_chip_ok": -1, "blk_cluster_timeout_ms": 3000,
+                    "blk_cluster_fault": 0, "sync_errors": 0}
+_options = {}
+
+
 def set_option(key, value):
     _check(load().gpfq_set_option(key.encode(), int(value)), f"gpfq_set_option({key})")
+    _options[key] = int(value)
+
+
+class option:
+    """`with hip.option(key, value):` -- a process-wide library option for the duration of a block, then back to what this binding last
+    set it to (or the library's default).  Results never depend on options, only which kernel runs."""
+
+    def __init__(self, key, value):
+        self.key, self.value = key, int(value)
+
+    def __enter__(self):
+        self.prev = _options.get(self.key, _OPTION_DEFAULTS.get(self.key))
+        if self.prev is None:
+            raise GpfqError(f"hip.option: no known default for '{self.key}'")
+        set_option(self.key, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.key, self.prev)
+        return False
 
 
 def msq_round(W, alphabet):
@@ -688,7 +839,7 @@ def medians_to_host(scalars):
 GPFQ_MEDIAN_HIST_OFFSET, GPFQ_MEDIAN_HIST_WORDS = 64, 4096
 
 
-def median_abs_sharded(W_local, n_total, all_reduce_sum, meanwhile=None):
+def median_abs_sharded(W_local, n_total, all_reduce_sum, meanwhile=None, on_device=False):
     """The same median when every rank counts one slice of the layer's n_total weights (W_local: this rank's
     contiguous float32 slice; slices partition the flattened kernel).  `all_reduce_sum(t)` must sum the int32
     tensor t in place over the ranks (dist.all_reduce): three 16 KiB all-reduces per median."""
@@ -707,6 +858,8 @@ def median_abs_sharded(W_local, n_total, all_reduce_sum, meanwhile=None):
             all_reduce_sum(hist)
             _check(lib.gpfq_median_abs_pick(n_total, p, ws.data_ptr(), _stream()), "gpfq_median_abs_pick")
         _check(lib.gpfq_median_abs_end(n_total, ws.data_ptr(), out.data_ptr(), _stream()), "gpfq_median_abs_end")
+        if on_device:
+            return out
         return _read_scalar(out, meanwhile)
 
 

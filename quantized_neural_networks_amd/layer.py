@@ -41,6 +41,25 @@ def median_abs(W, group=None, meanwhile=None):
     return hip.median_abs_sharded(flat[lo:hi], n, lambda t: dist.all_reduce(t, group=group), meanwhile)
 
 
+def layer_alphabet_device(W, alphabet, alphabet_scalar, group=None):
+    """The layer alphabet of :544-545 formed and kept ON THE DEVICE (hip.DeviceAlphabet): the median of |W| stays a device scalar and one
+    single-thread kernel forms rad = float64(alphabet_scalar) * float64(median) and rad * alphabet -- nothing waits for the host.
+    quantize_dense() takes it in place of the host alphabet wherever the block-pipelined kernel runs (hip.dense_layer_supported)."""
+    flat = W.detach().reshape(-1)
+    n = flat.numel()
+    if n == 0:
+        raise hip.GpfqError("layer_alphabet_device: empty kernel")
+    world, rank = _group_info(group)
+    if world == 1 or n < _SHARDED_MEDIAN_MIN:
+        med = hip.median_abs(flat, on_device=True)
+    else:
+        import torch.distributed as dist
+        per = -(-n // (4 * world)) * 4
+        lo, hi = min(rank * per, n), min((rank + 1) * per, n)
+        med = hip.median_abs_sharded(flat[lo:hi], n, lambda t: dist.all_reduce(t, group=group), on_device=True)
+    return hip.layer_alphabet_device(med, alphabet, alphabet_scalar)
+
+
 def layer_alphabet(W, alphabet, alphabet_scalar, group=None, meanwhile=None):
     """(rad * alphabet, rad) with the reference's legacy-NumPy typing (:544-545): the python
     scalar times the float32 median is a float64 product.  `meanwhile()` may queue GPU work that does not need the
@@ -112,29 +131,87 @@ def all_gather_units(local, n_units, group=None):
 # ------------------------------------------------------------------------------------------
 # Dense layer
 # ------------------------------------------------------------------------------------------
-def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True):
+def _log_failure(log, msg):
+    import warnings
+    warnings.warn(msg, RuntimeWarning, stacklevel=3)
+    if log is not None:
+        log(msg)
+
+
+def quantize_neurons_checked(X, Xq, Wt, alphabet, log=None, **kw):
+    """hip.quantize_neurons with the block kernel's deferred failure handled at the reference's granularity (the reference logs the
+    failing unit and re-raises at once, scripts/quantized_network.py:563-565): when the call went through the CLUSTER FORM -- several
+    workgroups per group of neurons that exchange partial dot products, which rests on their being co-resident -- its status word is read
+    (one host wait) BEFORE the result is used; a timed-out exchange is logged and the same neurons are rerun at once through the classic
+    kernels (option blk_cluster = 0), and only a failure of that run raises.  Every other kernel family has no deferred failure and no wait."""
+    r = hip.quantize_neurons(X, Xq, Wt, alphabet, **kw)
+    if "cluster form" not in hip.last_dense_kernel():
+        return r
+    st = hip.call_status(r)
+    if st == 0:
+        return r
+    _log_failure(log, f"quantize_neurons: the cluster form's exchange timed out on {Wt.shape[0]} neurons x {X.shape[1]} samples "
+                      f"(status {st}); rerunning them through the classic kernels")
+    with hip.option("blk_cluster", 0):
+        r = hip.quantize_neurons(X, Xq, Wt, alphabet, **kw)
+        st = hip.call_status(r)
+    if st != 0:
+        raise hip.GpfqError(f"quantize_neurons failed again without the cluster form (status {st})")
+    r["cluster_fallback"] = True
+    return r
+
+
+def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True, log=None, check=True):
     """Quantize every neuron (column) of a Dense kernel.
 
     W        f32 [N][C]  Keras kernel layout (row = input feature), on the GPU
     X, Xq    f32 [N][m]  feature-major analog / quantized activations (the transposed wX, qX)
-    alphabet f64 [M]     the layer alphabet rad * linspace(-1, 1, M)
+    alphabet f64 [M]     the layer alphabet rad * linspace(-1, 1, M) -- or a hip.DeviceAlphabet (layer_alphabet_device): the radius then
+                         never crosses to the host, the kernel reads W in its Keras layout and, on one GPU, writes Q and the indices
+                         in it (no neuron-major copy, no assembly pass); shapes the block-pipelined kernel does not take fall back
+                         to the host alphabet (one read-back)
 
     Returns dict(Q f32 [N][C], idx i8 [N][C], resid f64 [C]) on every rank.  want_resid=None: residual norms only
     where the kernel holds the residual anyway (NaN from the Gram path, which would replay it in an extra pass).
+    check=False (device alphabets; benchmarks): the deferred status of the launch is NOT read here -- no host wait at all; the result
+    carries "workspace" and the caller owes hip.call_status(result) before it trusts Q.
     """
     N, C = W.shape
     world, rank = _group_info(group)
     lo, hi = shard_bounds(C, world, rank)
-    Wt = hip.neuron_major(W.contiguous(), lo, hi)            # neuron-major shard [C_local][N]
-    flag = None
+    dalpha = alphabet if isinstance(alphabet, hip.DeviceAlphabet) else None
+    if dalpha is not None and not (X.shape[1] > 0 and hip.dense_layer_supported(N, X.shape[1], max(hi - lo, 1), dalpha.unit)):
+        alphabet, dalpha = dalpha.values(), None                   # (no block-pipelined kernel for this shape: the host alphabet's paths)
+    Wc = W.contiguous()
+    if dalpha is not None:
+        r = hip.quantize_dense_layer(X, Xq, Wc, dalpha, lo, hi, keras_out=(world == 1), want_values=(world == 1), want_resid=want_resid)
+        st = hip.call_status(r) if check else 0
+        if st == hip.GPFQ_ERR_CLUSTER_TIMEOUT:
+            _log_failure(log, f"Dense layer {N} x {C}: the cluster form's exchange timed out; rerunning the layer through the classic kernels")
+            with hip.option("blk_cluster", 0):
+                r = hip.quantize_dense_layer(X, Xq, Wc, dalpha, lo, hi, keras_out=(world == 1), want_values=(world == 1), want_resid=want_resid)
+                st = hip.call_status(r)
+        if st == hip.GPFQ_ERR_ALPHABET:
+            # radius 0 / infinite / NaN (the median of a kernel that is mostly zeros): only the host alphabet's kernels take such a one
+            alphabet, dalpha = dalpha.values(), None
+        elif st != 0:
+            raise hip.GpfqError(f"quantize_dense: status {st} after the fallback")
+    if dalpha is not None:
+        if world == 1:
+            out = dict(Q=r["Q"], idx=r["idx"], workspace=r["workspace"], cluster_err=torch.zeros(1, dtype=torch.int32, device=W.device))
+            if want_resid is not False:
+                out["resid"] = r["resid"]
+            return out
+        packed, bits = hip.pack_indices(r["idx"], len(dalpha))
+        Q, idx = hip.assemble_kernel_device(all_gather_units(packed, C, group).contiguous(), dalpha, bits=bits, N=N)
+        out = dict(Q=Q, idx=idx, workspace=r["workspace"], cluster_err=torch.zeros(1, dtype=torch.int32, device=W.device))
+        if want_resid is not False:
+            out["resid"] = all_gather_units(r["resid"], C, group)
+        return out
+    Wt = hip.neuron_major(Wc, lo, hi)                            # neuron-major shard [C_local][N]
     if hi > lo:
-        r = hip.quantize_neurons(X, Xq, Wt, alphabet, want_values=False, want_resid=want_resid)
+        r = quantize_neurons_checked(X, Xq, Wt, alphabet, log=log, want_values=False, want_resid=want_resid)
         i_loc, res_loc = r["idx"], r["resid"]
-        ws = r.get("workspace")
-        if ws is not None and ws.numel() >= 16:
-            # the block kernel's cluster form raises this word when an exchange between its workgroups timed out (hip.cluster_timeouts):
-            # a copy of it travels with the result, checked by the class surface at the end of quantize_network()
-            flag = ws[8:12].view(torch.int32).clone()
     else:
         i_loc = torch.empty((0, N), dtype=hip.index_dtype(len(alphabet)), device=W.device)
         res_loc = torch.empty((0,), dtype=torch.float64, device=W.device)
@@ -145,7 +222,8 @@ def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True):
         Q, idx = hip.assemble_kernel(all_gather_units(packed, C, group).contiguous(), alphabet, bits=bits, N=N)
     else:
         Q, idx = hip.assemble_kernel(i_loc, alphabet)
-    out = dict(Q=Q, idx=idx, cluster_err=flag if flag is not None else torch.zeros(1, dtype=torch.int32, device=W.device))
+    # (cluster_err: kept for callers of round 5's interface -- a timed-out exchange no longer leaves this function, see quantize_neurons_checked)
+    out = dict(Q=Q, idx=idx, cluster_err=torch.zeros(1, dtype=torch.int32, device=W.device))
     if want_resid is not False:
         out["resid"] = all_gather_units(res_loc, C, group)
     return out
@@ -247,7 +325,7 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
             patches(c)
             fsel = torch.tensor(fs, dtype=torch.long, device=dev)
             path = hip.GPFQ_PATH_ONCHIP if Pw.shape[1] <= hip.GPFQ_ONCHIP_MAX_M else hip.GPFQ_PATH_STREAM
-            r = hip.quantize_neurons(Pw, Pq, Wt_all[c].index_select(0, fsel).contiguous(), alphabet, path=path)
+            r = quantize_neurons_checked(Pw, Pq, Wt_all[c].index_select(0, fsel).contiguous(), alphabet, path=path)     # (rows of up to 28672 samples: possibly the cluster form)
             Qc[c, fsel], Ic[c, fsel] = r["Q"], r["idx"]
             if with_resid:
                 Rc[c, fsel] = r["resid"]
@@ -319,7 +397,7 @@ def quantize_conv2d(W, act_w, act_q, alphabet, strides, padding, rate, group=Non
     else:
         for c in range(c_lo, c_hi):
             patches(c)
-            r = hip.quantize_neurons(Pw, Pq, Wt_all[c, f_lo:f_hi], alphabet)
+            r = quantize_neurons_checked(Pw, Pq, Wt_all[c, f_lo:f_hi], alphabet)
             Qc[c, f_lo:f_hi] = r["Q"]
             Ic[c, f_lo:f_hi] = r["idx"]
             Rc[c, f_lo:f_hi] = r["resid"]

@@ -609,7 +609,10 @@ class QuantizedNeuralNetwork:
         tic = time()
         try:
             # residual norms are diagnostics (last_layer_stats): kept where the kernel holds the residual anyway
-            out = _layer.quantize_dense(Wd, wX, qX, layer_alphabet, group=self.process_group, want_resid=None)
+            # (a deferred failure of the kernel -- the cluster form's exchange timing out -- is noticed, logged and repaired INSIDE this
+            #  call, before Q exists: nothing unchecked reaches set_weights, as nothing does in the reference, :563-565)
+            out = _layer.quantize_dense(Wd, wX, qX, layer_alphabet, group=self.process_group, want_resid=None,
+                                        log=lambda msg: self._log(f"\t\tLayer {layer_idx}: {msg}"))
             Q = out["Q"]
         except Exception as exc:
             self._log(f"\t\tLayer {layer_idx} generated an exception: {exc}")
@@ -618,17 +621,6 @@ class QuantizedNeuralNetwork:
         self._update_weights(layer_idx, Q)
         self._log(f"\tdone. {time()-tic:.2f} seconds.")
         self.last_layer_stats[layer_idx] = _LazyStats(rad=rad, alphabet=layer_alphabet, resid=out["resid"], idx=out["idx"])
-        if out.get("cluster_err") is not None:
-            self._cluster_flags = getattr(self, "_cluster_flags", []) + [(layer_idx, out["cluster_err"])]
-
-    def _check_cluster_flags(self):
-        """One look, at the end of quantize_network(), at the words the block kernel's cluster form raises when an exchange between its
-        workgroups timed out (a slice of a cluster never became resident: the layer's results would be garbage).  Cannot happen on a
-        whole MI355X; fails loudly if it ever does."""
-        flags, self._cluster_flags = getattr(self, "_cluster_flags", []), []
-        if flags and bool(torch.stack([f.reshape(()) for _, f in flags]).any().item()):
-            bad = [k for k, f in flags if int(f.item())]
-            raise hip.GpfqError(f"layers {bad}: the block kernel's cluster exchange timed out; results are invalid (set_option('blk_cluster', 0) avoids that kernel)")
 
     # The reference logs one record per neuron / filter as its futures complete (:567, :716).  Here all of a layer's units complete
     # together; the records still go out ONE PER UNIT (handlers and formatters that count or prefix records see what they saw), unless
@@ -657,7 +649,6 @@ class QuantizedNeuralNetwork:
                 self._log(f"Quantizing layer {layer_idx} (in parallel) of {num_layers}...")
                 self._quantize_layer_parallel(layer_idx)
                 self._log(f"Layer {layer_idx} of {num_layers} quantized successfully in {time() - tic:.2f} seconds.")
-        self._check_cluster_flags()
 
 
 class QuantizedCNN(QuantizedNeuralNetwork):
@@ -735,4 +726,3 @@ class QuantizedCNN(QuantizedNeuralNetwork):
                 tic = time()
                 self._quantize_conv2D_layer_parallel_jit(layer_idx)
                 self._log(f"done. {time() - tic:.2f} seconds.")
-        self._check_cluster_flags()

@@ -28,7 +28,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_errors_without_gpu(lib):
-    assert lib.gpfq_version() == 304
+    assert lib.gpfq_version() == 305
     # argument validation happens before any launch: safe without a device
     a = (ctypes.c_double * 3)(-1.0, 0.0, 1.0)
     rc = lib.gpfq_quantize_neurons(None, None, 4, None, None, 4, a, 3, 1, 4, 8, 2, None, None, None, None, None, 0, 0, None)
@@ -47,6 +47,21 @@ def test_version_and_errors_without_gpu(lib):
     assert lib.gpfq_workspace_bytes(9, 1024, 8, 0) == 512 + (9 + 17) * (128 + 16 * 1024)
     assert lib.gpfq_workspace_bytes(9, 100000, 8, 0) >= 8 * 100000 * 8
     assert lib.gpfq_workspace_bytes(9, 1024, 8, 2) > 0
+    # an empty calibration set sizes a workspace without dividing by its slice count (SIGFPE in blk_shape)
+    for path in (0, 1, 2):
+        assert lib.gpfq_workspace_bytes(4, 0, 4, path) >= 0
+    assert lib.gpfq_dense_layer_workspace_bytes(4, 0, 4) >= 0
+    # round 6: the device-resident layer alphabet's entry points validate before they launch
+    unit = (ctypes.c_double * 3)(-1.0, 0.0, 1.0)
+    assert lib.gpfq_dense_layer_supported(64, 1024, 32, unit, 3) == 1
+    assert lib.gpfq_dense_layer_supported(64, 200, 32, unit, 3) == 0        # rows of at most 256 samples: no block-pipelined kernel
+    assert lib.gpfq_dense_layer_supported(64, 0, 32, unit, 3) == 0
+    crooked = (ctypes.c_double * 3)(-1.0, 0.3, 1.0)
+    assert lib.gpfq_dense_layer_supported(64, 1024, 32, crooked, 3) == 0    # not an arithmetic progression
+    assert lib.gpfq_dense_layer_workspace_bytes(64, 1024, 32) > lib.gpfq_workspace_bytes(64, 1024, 32, 1)
+    assert lib.gpfq_layer_alphabet_device(None, 3.0, unit, 3, None, None) == -1
+    assert lib.gpfq_quantize_dense_layer(None, None, 1024, None, None, 32, 0, 32, None, unit, 3, 64, 1024, None, None, 1, 32, None, None, 0, None) == -1
+    assert lib.gpfq_call_status(None, None) == -1
 
 
 def test_patch_out_dim(lib):

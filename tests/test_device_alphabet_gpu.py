@@ -1,0 +1,283 @@
+"""Round 6: the Dense layer driver with nothing crossing to the host -- the layer alphabet rad * linspace(-1, 1, M)
+(scripts/quantized_network.py:544-545) formed and kept in DEVICE memory (gpfq_layer_alphabet_device), the kernel reading the Keras
+kernel itself and writing Q / the indices in the layout set_weights takes (:562, :570) -- and the fail-safe handling of the block
+kernel's deferred failures (a cluster exchange that times out; a degenerate radius): noticed BEFORE the result is used, logged, and the
+layer rerun through the classic kernels, as the reference logs and re-raises at once (:563-565).  Everything against the oracle, bit for bit."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RESID_RTOL = 1e-5      # north star: 1e-5 relative on the float residual norms (observed ~1e-15)
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from quantized_neural_networks_amd import hip as h
+    h.load()
+    return h
+
+
+@pytest.fixture(scope="module")
+def layer():
+    from quantized_neural_networks_amd import layer as l
+    return l
+
+
+def _synthetic(N, m, C, seed=0):
+    W = (np.random.default_rng(seed).standard_normal((N, C)) / np.sqrt(N)).astype(np.float32)
+    G = np.random.default_rng(seed + 1).standard_normal((N, m))
+    X = np.maximum(G, 0).astype(np.float32)
+    Xq = np.maximum(G + 0.1 * np.random.default_rng(seed + 2).standard_normal((N, m)), 0).astype(np.float32)
+    return W, X, Xq
+
+
+@pytest.mark.parametrize("levels,scalar", [(3, 3), (2, 1.5), (4, 2), (16, 5), (15, 4), (64, 7)])
+def test_device_alphabet_is_the_reference_product(hip, layer, oracle_mod, levels, scalar):
+    """rad and every member: the float64 products of :544-545, bit for bit, without the median leaving the device."""
+    W = (np.random.default_rng(levels).standard_normal((301, 77)) / 17).astype(np.float32)
+    unit = np.linspace(-1, 1, levels)
+    want_alphabet, want_rad = oracle_mod.layer_alphabet(W, unit, scalar)
+    d = layer.layer_alphabet_device(_dev(W), unit, scalar)
+    raw = d.buf.cpu().numpy()
+    rad = raw[:8].view(np.float64)[0]
+    members = raw[128:128 + 8 * levels].view(np.float64)
+    assert rad == want_rad and d.rad() == want_rad
+    assert np.array_equal(members, want_alphabet)
+    assert np.array_equal(d.values(), want_alphabet)
+    host_alphabet, host_rad = layer.layer_alphabet(_dev(W), unit, scalar)
+    assert host_rad == want_rad and np.array_equal(host_alphabet, want_alphabet)
+
+
+# (N, C, m, levels): widths that are no multiple of the 8- / 16-neuron output groups, every neurons-per-workgroup class, rows on either side
+# of the shape thresholds, the cluster form (1537+ samples in a narrow layer, 3073+ anywhere)
+SHAPES = [(61, 70, 512, 3), (40, 33, 1000, 16), (37, 16, 300, 4), (29, 5, 700, 3), (23, 1, 900, 2), (33, 130, 1024, 3), (21, 600, 768, 3),
+          (19, 1100, 1024, 15), (17, 2100, 1024, 3), (26, 40, 1500, 3), (22, 200, 2048, 16), (18, 24, 2100, 3), (15, 70, 3100, 4), (13, 9, 5008, 8)]
+
+
+@pytest.mark.parametrize("N,C,m,levels", SHAPES)
+def test_dense_layer_device_alphabet_vs_oracle(hip, layer, oracle_mod, N, C, m, levels):
+    W, X, Xq = _synthetic(N, m, C, seed=N + C)
+    Xq[N - 2] = 0                                                 # a dead row: rule (i), the literal 0
+    unit = np.linspace(-1, 1, levels)
+    alphabet, rad = oracle_mod.layer_alphabet(W, unit, 3)
+    Q, idx, resid = oracle_mod.layer(W, X, Xq, alphabet)
+    Wd, Xd, Xqd = _dev(W), _dev(X), _dev(Xq)
+    assert hip.dense_layer_supported(N, m, C, unit)
+    d = layer.layer_alphabet_device(Wd, unit, 3)
+    out = layer.quantize_dense(Wd, Xd, Xqd, d)
+    assert "gpfq_blk_kernel" in hip.last_dense_kernel()
+    assert hip.call_status(out) == 0
+    assert out["Q"].shape == (N, C) and out["idx"].shape == (N, C) and out["idx"].dtype == torch.int8
+    assert np.array_equal(out["idx"].cpu().numpy(), idx.T)       # Keras layout [N][C], written by the kernel's own flush
+    assert np.array_equal(out["Q"].cpu().numpy(), Q.T.astype(np.float32))
+    np.testing.assert_allclose(out["resid"].cpu().numpy(), resid, rtol=RESID_RTOL)
+    # ... and the host alphabet's path (neuron-major copy, kernel, assembly pass) gives the same tensors
+    ref = layer.quantize_dense(Wd, Xd, Xqd, alphabet)
+    assert torch.equal(ref["Q"], out["Q"]) and torch.equal(ref["idx"], out["idx"]) and torch.equal(ref["resid"], out["resid"])
+    assert d.rad() == rad
+
+
+def test_dense_layer_shard_of_a_layer_neuron_major(hip, layer, oracle_mod):
+    """Neurons [lo, hi) of a wider layer (what one rank of a process group quantizes), neuron-major indices for the all-gather, then the
+    device-alphabet assembly: equal to the whole layer's columns."""
+    N, C, m = 45, 150, 800
+    W, X, Xq = _synthetic(N, m, C, seed=3)
+    unit = np.linspace(-1, 1, 3)
+    alphabet, _ = oracle_mod.layer_alphabet(W, unit, 2)
+    Q, idx, resid = oracle_mod.layer(W, X, Xq, alphabet)
+    Wd, Xd, Xqd = _dev(W), _dev(X), _dev(Xq)
+    d = layer.layer_alphabet_device(Wd, unit, 2)
+    shards = []
+    for lo, hi in ((0, 64), (64, 128), (128, 150)):
+        r = hip.quantize_dense_layer(Xd, Xqd, Wd, d, lo, hi, keras_out=False, want_values=False)
+        assert hip.call_status(r) == 0
+        assert np.array_equal(r["idx"].cpu().numpy(), idx[lo:hi])
+        np.testing.assert_allclose(r["resid"].cpu().numpy(), resid[lo:hi], rtol=RESID_RTOL)
+        shards.append(r["idx"])
+    for bits in (8, 2):
+        gathered = torch.cat(shards)
+        if bits == 2:
+            gathered, b = hip.pack_indices(gathered, 3)
+            assert b == 2
+        Qk, Ik = hip.assemble_kernel_device(gathered.contiguous(), d, bits=bits, N=N)
+        assert np.array_equal(Ik.cpu().numpy(), idx.T) and np.array_equal(Qk.cpu().numpy(), Q.T.astype(np.float32))
+    # a shard written straight into the whole layer's Keras-layout tensors leaves the other columns alone
+    r = hip.quantize_dense_layer(Xd, Xqd, Wd, d, 64, 128)
+    assert np.array_equal(r["idx"][:, 64:128].cpu().numpy(), idx[64:128].T)
+    assert np.array_equal(r["Q"][:, 64:128].cpu().numpy(), Q[64:128].T.astype(np.float32))
+
+
+def test_degenerate_radius_is_caught_on_the_device_and_the_layer_rerun(hip, layer, oracle_mod):
+    """More than half of the kernel is zero: median(|W|) = 0, the alphabet is {-0, 0, 0} (:544-545) -- no arithmetic progression.  The
+    host cannot know (the median never left the device): the kernel writes nothing and raises the call's alphabet word, and the layer
+    driver reruns the layer with the host alphabet; the reference's result for such a layer (q = first member = -0.0) comes out."""
+    N, C, m = 31, 20, 600
+    W, X, Xq = _synthetic(N, m, C, seed=9)
+    W[np.random.default_rng(1).random(W.shape) < 0.6] = 0
+    unit = np.linspace(-1, 1, 3)
+    alphabet, rad = oracle_mod.layer_alphabet(W, unit, 3)
+    assert rad == 0
+    Q, idx, resid = oracle_mod.layer(W, X, Xq, alphabet)
+    Wd, Xd, Xqd = _dev(W), _dev(X), _dev(Xq)
+    d = layer.layer_alphabet_device(Wd, unit, 3)
+    raw = hip.quantize_dense_layer(Xd, Xqd, Wd, d)
+    assert hip.call_status(raw) == hip.GPFQ_ERR_ALPHABET
+    assert "radius" in hip.load().gpfq_last_error().decode()
+    out = layer.quantize_dense(Wd, Xd, Xqd, d)
+    assert np.array_equal(out["idx"].cpu().numpy(), idx.T)
+    assert np.array_equal(out["Q"].cpu().numpy(), Q.T.astype(np.float32))
+    np.testing.assert_allclose(out["resid"].cpu().numpy(), resid, rtol=RESID_RTOL)
+
+
+def test_shapes_without_a_block_kernel_fall_back_to_the_host_alphabet(hip, layer, oracle_mod):
+    N, C, m = 25, 12, 200                                          # rows of at most 256 samples: the row-group kernels
+    W, X, Xq = _synthetic(N, m, C, seed=4)
+    unit = np.linspace(-1, 1, 4)
+    alphabet, _ = oracle_mod.layer_alphabet(W, unit, 2)
+    _, idx, _ = oracle_mod.layer(W, X, Xq, alphabet)
+    assert not hip.dense_layer_supported(N, m, C, unit)
+    d = layer.layer_alphabet_device(_dev(W), unit, 2)
+    out = layer.quantize_dense(_dev(W), _dev(X), _dev(Xq), d)
+    assert np.array_equal(out["idx"].cpu().numpy(), idx.T)
+    with pytest.raises(hip.GpfqError):
+        hip.quantize_dense_layer(_dev(X), _dev(Xq), _dev(W), d)
+
+
+# ---- the cluster form's fail-safe -------------------------------------------------------------------------------
+@pytest.fixture
+def faulty_cluster(hip):
+    """One slice of the first cluster never publishes: every exchange of that cluster times out (after 40 ms instead of 3 s)."""
+    hip.set_option("blk_cluster_fault", 1)
+    hip.set_option("blk_cluster_timeout_ms", 40)
+    yield
+    hip.set_option("blk_cluster_fault", 0)
+    hip.set_option("blk_cluster_timeout_ms", 3000)
+    hip.set_option("sync_errors", 0)
+
+
+def test_forced_exchange_timeout_is_reported_by_the_c_abi(hip, oracle_mod, faulty_cluster):
+    N, C, m = 14, 24, 3500                                         # four slices
+    W, X, Xq = _synthetic(N, m, C, seed=2)
+    alphabet, _ = oracle_mod.layer_alphabet(W, np.linspace(-1, 1, 3), 3)
+    r = hip.quantize_neurons(_dev(X), _dev(Xq), _dev(W.T), alphabet, path=1)
+    assert "cluster form" in hip.last_dense_kernel()
+    assert hip.call_status(r) == hip.GPFQ_ERR_CLUSTER_TIMEOUT and hip.cluster_timeouts(r) != 0
+    # synchronous error reporting: the call itself returns the code
+    hip.set_option("sync_errors", 1)
+    with pytest.raises(hip.GpfqError, match="timed out"):
+        hip.quantize_neurons(_dev(X), _dev(Xq), _dev(W.T), alphabet, path=1)
+    hip.set_option("sync_errors", 0)
+    # without the fault the same call is clean
+    hip.set_option("blk_cluster_fault", 0)
+    r = hip.quantize_neurons(_dev(X), _dev(Xq), _dev(W.T), alphabet, path=1)
+    assert hip.call_status(r) == 0
+    _, idx, _ = oracle_mod.layer(W, X, Xq, alphabet)
+    assert np.array_equal(r["idx"].cpu().numpy(), idx)
+
+
+@pytest.mark.parametrize("device_alphabet", [False, True])
+def test_forced_exchange_timeout_falls_back_to_the_classic_kernels(hip, layer, oracle_mod, faulty_cluster, device_alphabet):
+    """The layer driver reads the status BEFORE anything uses Q, logs the layer and reruns it with blk_cluster = 0: the result is the
+    oracle's, and the option is back to its default afterwards."""
+    N, C, m = 14, 40, 3500
+    W, X, Xq = _synthetic(N, m, C, seed=6)
+    unit = np.linspace(-1, 1, 3)
+    alphabet, _ = oracle_mod.layer_alphabet(W, unit, 3)
+    Q, idx, resid = oracle_mod.layer(W, X, Xq, alphabet)
+    Wd, Xd, Xqd = _dev(W), _dev(X), _dev(Xq)
+    a = layer.layer_alphabet_device(Wd, unit, 3) if device_alphabet else alphabet
+    logged = []
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        out = layer.quantize_dense(Wd, Xd, Xqd, a, log=logged.append)
+    assert any("timed out" in str(w.message) for w in caught) and any("timed out" in msg for msg in logged)
+    assert "cluster form" not in hip.last_dense_kernel()
+    assert np.array_equal(out["idx"].cpu().numpy(), idx.T)
+    assert np.array_equal(out["Q"].cpu().numpy(), Q.T.astype(np.float32))
+    np.testing.assert_allclose(out["resid"].cpu().numpy(), resid, rtol=RESID_RTOL)
+    # the next (healthy) layer takes the cluster form again
+    hip.set_option("blk_cluster_fault", 0)
+    out = layer.quantize_dense(Wd, Xd, Xqd, a)
+    assert "cluster form" in hip.last_dense_kernel()
+    assert np.array_equal(out["idx"].cpu().numpy(), idx.T)
+
+
+def test_class_surface_survives_a_timed_out_exchange(hip, oracle_mod, faulty_cluster):
+    """quantize_network() on a two-layer MLP whose first layer takes the cluster form: the fault is logged with the layer's index and the
+    network that comes out equals the one of a healthy run -- no garbage reaches set_weights or the next layer's activations."""
+    from quantized_neural_networks_amd import keras_shim as ks
+    from quantized_neural_networks_amd import quantized_network as qn
+
+    class ListLogger:
+        def __init__(self):
+            self.lines = []
+
+        def info(self, msg):
+            self.lines.append(msg)
+
+    n, d0, d1, d2 = 3300, 12, 24, 5                                # 3300 samples: four slices
+    x = np.random.default_rng(0).standard_normal((n, d0)).astype(np.float32)
+
+    def run():
+        net = ks.Sequential([ks.Dense(d1, activation="relu", input_shape=(d0,)), ks.Dense(d2)], seed=3)
+        logger = ListLogger()
+        q = qn.QuantizedNeuralNetwork(network=net, batch_size=n, get_data=qn.MNISTSequence(x, np.zeros((n, 1)), n),
+                                      logger=logger, bits=np.log2(3), alphabet_scalar=2)
+        q.quantize_network()
+        return [np.asarray(w.cpu() if isinstance(w, torch.Tensor) else w).copy() for w in q.quantized_net.get_weights()], logger.lines
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        faulty, lines = run()
+    assert any("timed out" in line and "Layer 0" in line for line in lines), [l for l in lines if "Layer" in l][:5]
+    hip.set_option("blk_cluster_fault", 0)
+    healthy, lines = run()
+    assert not any("timed out" in line for line in lines)
+    for a, b in zip(faulty, healthy):
+        assert np.array_equal(a, b)
+
+
+def test_partitioned_chip_keeps_the_classic_shapes(hip, oracle_mod):
+    """blk_chip_ok = 0 (what the library answers itself when the device is not the whole 8 x 32-CU chip): no cluster form anywhere."""
+    N, C, m = 12, 9, 6000
+    W, X, Xq = _synthetic(N, m, C, seed=8)
+    alphabet, _ = oracle_mod.layer_alphabet(W, np.linspace(-1, 1, 3), 3)
+    _, idx, _ = oracle_mod.layer(W, X, Xq, alphabet)
+    try:
+        hip.set_option("blk_chip_ok", 0)
+        r = hip.quantize_neurons(_dev(X), _dev(Xq), _dev(W.T), alphabet, path=1)
+        assert "cluster form" not in hip.last_dense_kernel()
+        assert np.array_equal(r["idx"].cpu().numpy(), idx)
+    finally:
+        hip.set_option("blk_chip_ok", -1)
+    r = hip.quantize_neurons(_dev(X), _dev(Xq), _dev(W.T), alphabet, path=1)
+    assert "cluster form" in hip.last_dense_kernel()
+    assert np.array_equal(r["idx"].cpu().numpy(), idx)
+
+
+def test_two_streams_of_cluster_launches_are_serialised_and_correct(hip, oracle_mod):
+    """Cluster-form launches on two streams at once: the library orders them (one in flight per device); both results are the oracle's."""
+    N, C, m = 10, 300, 4100
+    W, X, Xq = _synthetic(N, m, C, seed=12)
+    alphabet, _ = oracle_mod.layer_alphabet(W, np.linspace(-1, 1, 3), 3)
+    _, idx, _ = oracle_mod.layer(W, X, Xq, alphabet)
+    Xd, Xqd, Wt = _dev(X), _dev(Xq), _dev(W.T)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    results = []
+    for rep in range(3):
+        for s in streams:
+            with torch.cuda.stream(s):
+                results.append(hip.quantize_neurons(Xd, Xqd, Wt, alphabet, path=1))
+    torch.cuda.synchronize()
+    for r in results:
+        assert hip.cluster_timeouts(r) == 0
+        assert np.array_equal(r["idx"].cpu().numpy(), idx)
