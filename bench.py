@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=512, help="neurons timed on the host cores (0 = skip)")
     ap.add_argument("--long-rows", type=int, default=8192,
                     help="also time the same layer on this many calibration samples (a secondary record: the block kernel's cluster form); 0 = skip")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false",
+                    help="one stream: median, alphabet, row norms, record pre-pass, kernel in sequence (default: the pre-pass on a second stream beside the median)")
     ap.add_argument("--numpy-sample", type=int, default=-1,
                     help="neurons of the NumPy process-pool baseline (the reference-shaped one); -1 = 2 x host cores, 0 = skip")
     args = ap.parse_args()
@@ -142,13 +144,26 @@ def main():
         lo, hi = layer.shard_bounds(C_total, world, rank)
         if not device_path:
             return step_host(i_timed, C_total, Wd, lo, hi)
+        # The layer's two independent halves on two HIP streams (layer.quantize_dense_layer): row norms + record pre-pass (activations only)
+        # on the side stream, median of |W| + alphabet (kernel only) on this one; the recurrence follows both.  --no-overlap: one stream.
         # (st["alphabet_pre"], secondary figure only: the alphabet formed before the loop, as _prefetch_medians does for a network)
+        ws = None
+        if args.overlap:
+            main, side = torch.cuda.current_stream(dev), layer._side_stream(dev)
+            ws = hip.dense_layer_workspace(N, m, hi - lo, dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                hip.dense_layer_prepare(Xd, Xqd, unit_alphabet, hi - lo, ws)
         dalpha = st.get("alphabet_pre") or layer.layer_alphabet_device(Wd, unit_alphabet, args.alphabet_scalar, group)   # N > 1: counting sharded over ranks
-        nrm = hip.row_norms(Xqd)
+        nrm = None
+        if args.overlap:
+            main.wait_stream(side)
+        else:
+            nrm = hip.row_norms(Xqd)
         if i_timed is not None:
             hip.set_main_kernel_events(*ev_k[i_timed])
             ev[i_timed][0].record()          # same stream the kernel is launched on (torch current stream)
-        r = hip.quantize_dense_layer(Xd, Xqd, Wd, dalpha, lo, hi, nrm32=nrm, keras_out=(world == 1), want_values=(world == 1))
+        r = hip.quantize_dense_layer(Xd, Xqd, Wd, dalpha, lo, hi, nrm32=nrm, keras_out=(world == 1), want_values=(world == 1), prepared=ws)
         if i_timed is not None:
             ev[i_timed][1].record()
             hip.set_main_kernel_events(None, None)
@@ -301,8 +316,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_medians_prefetched": ms_prefetched, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "step": ("device-resident alphabet: median(|W|) -> rad * alphabet on the device, row norms, record pre-pass, the block-pipelined kernel "
-                     "reading the Keras kernel and writing Q / indices in the Keras layout; no host wait inside a step" if device_path else
+            "step": ("device-resident alphabet: median(|W|) -> rad * alphabet on the device" + (" while a second HIP stream forms the row norms and the record pre-pass" if args.overlap else ", row norms, record pre-pass")
+                     + ", then the block-pipelined kernel reading the Keras kernel and writing Q / indices in the Keras layout; no host wait inside a step" if device_path else
                      "host alphabet (one host wait per step), neuron-major copy, row norms, record pre-pass, kernel, assembly pass"),
             "deferred_status_nonzero_steps": bad_status,
             "config": {
@@ -322,7 +337,9 @@ def main():
                 "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS,
                 "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
                 "kernel_ms_avg": k_avg_s * 1e3, "kernel_ms_min": float(np.min(kernel_ms)),
-                "call_ms_avg": float(np.mean(call_ms)),     # the whole gpfq_quantize_neurons call: record pre-pass + this kernel
+                # events around the library call that launches the kernel: with the overlapped step (default) the alphabet-dependent half
+                # (one in-place pass over the records for the symmetric alphabet + this kernel); --no-overlap: record pre-pass + this kernel
+                "call_ms_avg": float(np.mean(call_ms)),
                 # the same fraction on the bracket rounds 1-3 quoted (events around the whole call): comparable across rounds
                 "frac_call": alg_flops / (float(np.mean(call_ms)) / 1e3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                 "algorithmic_flops_per_launch": alg_flops,
@@ -338,7 +355,7 @@ def main():
                 "note": "skinny dot products with the residual on chip: the binding resource is FP64-rate vector issue "
                         "(per weight and sample one f64 fma, one f32->f64 convert, one f64 add, three f32 ops on two samples each -- two for the symmetric ternary alphabet), not HBM; "
                         "flops per launch = 6 m N C_local (SURVEY 8d); duration = HIP events recorded by the library immediately around this "
-                        "kernel's launch on its stream (gpfq_set_main_kernel_events; call_ms_avg also holds the record pre-pass)",
+                        "kernel's launch on its stream (gpfq_set_main_kernel_events; call_ms_avg: the events around the library call that launches it)",
             },
         }
         if collective is not None:

@@ -170,6 +170,9 @@ int gpfq_set_main_kernel_events(void *start_event, void *stop_event);
  */
 int gpfq_set_option(const char *key, int value);
 /* Round 6 additions to the option list above:
+ *   "blk_prep_run"  1 (default): the block kernel's record pre-pass takes runs of eight records per workgroup (each row read three times
+ *                  instead of eighteen) for walks of 2048+ steps; 0: one record per workgroup (the same records); 4 / 8: runs of that many
+ *                  records whatever the walk's length (tests)
  *   "blk_chip_ok"   -1 (default): the cluster form asks the device whether it is the whole chip its workgroup maps assume (256 compute
  *                  units = 8 XCDs x 32, no compute-unit mask in the environment) and is not used otherwise; 0 / 1 force the answer (tests)
  *   "blk_cluster_timeout_ms"  how long an exchange of the cluster form waits for a slice that does not arrive (default 3000)
@@ -250,6 +253,10 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
 int gpfq_layer_alphabet_device(const float *median32, double alphabet_scalar, const double *unit_alphabet, int M,
                                void *dev_alphabet, void *stream);
 int gpfq_dense_layer_supported(int64_t N, int64_t m, int64_t C, const double *unit_alphabet, int M);
+/* ... and whether the kernel of that shape writes GPFQ_LAYOUT_KERAS outputs itself (the 16-neuron four-step shapes: layers wider than 2048
+ * neurons on rows of up to 1024 samples -- the decision wavefront has the slack there); elsewhere gpfq_quantize_dense_layer takes
+ * GPFQ_LAYOUT_NEURON_MAJOR only (GPFQ_ERR_UNSUPPORTED otherwise) and gpfq_assemble_kernel_device lays the result out in one pass */
+int gpfq_dense_layer_keras_out_supported(int64_t N, int64_t m, int64_t C, const double *unit_alphabet, int M);
 size_t gpfq_dense_layer_workspace_bytes(int64_t N, int64_t m, int64_t C);
 int gpfq_quantize_dense_layer(const float *X, const float *Xq, int64_t ld, const float *nrm32,
                               const float *W, int64_t ldc, int64_t c_lo, int64_t C,
@@ -257,6 +264,22 @@ int gpfq_quantize_dense_layer(const float *X, const float *Xq, int64_t ld, const
                               int64_t N, int64_t m,
                               int8_t *qidx, float *Q, int out_layout, int64_t ldo, double *resid,
                               void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * gpfq_quantize_dense_layer in two halves, for callers that overlap them: the median of |W| and the alphabet depend on the kernel alone, the
+ * row norms and the record pre-pass on the activations alone.  gpfq_dense_layer_prepare (status block, row norms when nrm32 is NULL, record
+ * pre-pass) may run on one stream while gpfq_median_abs + gpfq_layer_alphabet_device run on another; gpfq_dense_layer_run (for symmetric
+ * alphabets one in-place pass over the records, then the kernel) follows once both are done, on the same workspace.  Same results as the
+ * one-call form, bit for bit (quantized_neural_networks_amd/layer.py: quantize_dense_layer).
+ */
+int gpfq_dense_layer_prepare(const float *X, const float *Xq, int64_t ld, const float *nrm32, const double *unit_alphabet, int M,
+                             int64_t N, int64_t m, int64_t C, void *workspace, size_t workspace_bytes, void *stream);
+int gpfq_dense_layer_run(const float *X, const float *Xq, int64_t ld,
+                         const float *W, int64_t ldc, int64_t c_lo, int64_t C,
+                         const void *dev_alphabet, const double *unit_alphabet, int M,
+                         int64_t N, int64_t m,
+                         int8_t *qidx, float *Q, int out_layout, int64_t ldo, double *resid,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * The same recurrence for SHORT walks over LONG rows (conv: N = kh*kw steps against patch matrices of
@@ -323,6 +346,9 @@ int gpfq_assemble_kernel_device(const void *qidx, int bits, const void *dev_alph
  *   W [device] f32 [n]; median_out [device] f32 [1]; workspace [device] >= gpfq_median_abs_workspace_bytes().
  */
 size_t gpfq_median_abs_workspace_bytes(void);
+/* ... or, with room for the candidate list that lets the third pass read a few per cent of the data instead of all of it (round 6; the
+ * call uses whatever the workspace holds beyond the minimum): */
+size_t gpfq_median_abs_workspace_bytes_for(int64_t n);
 int gpfq_median_abs(const float *W, int64_t n, float *median_out, void *workspace, size_t workspace_bytes,
                     void *stream);
 

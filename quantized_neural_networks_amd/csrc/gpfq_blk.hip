@@ -228,6 +228,148 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
     }
 }
 
+// The same pre-pass for a RUN of consecutive records per workgroup (round 6; classic form, 16-byte aligned rows): row t of X and Xq is
+// an operand of records t .. t + ND (the band) and of records t + B, t - B (the operand rows), so one workgroup per record pulls every
+// row out of the L2s about 2 ND + 4 = 18 times -- 295 MB through the L2s for the headline layer's 32 MB, which with the one-pass-per-
+// workgroup latency is the launch's 49 us.  Here a workgroup keeps the band's rows of its 4 samples per thread in registers as a sliding
+// window and steps through RUN records: three row reads per record (t of both matrices, t + B of Xq), the wavefronts' partial sums of
+// every record parked in LDS and ONE workgroup reduction for the whole run.  Same records, bit for bit, for rows of up to 1024 padded
+// samples (one chunk per thread: the same order of additions); longer rows add their chunks' wavefront sums in chunk order.
+template <int B, bool R64, int RUN>
+__global__ void __launch_bounds__(256)
+gpfq_blk_prep_run_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t N, int m, int mp, int64_t nrec,
+                         const float *__restrict__ nrm32, char *__restrict__ recs, char *__restrict__ hdrs,
+                         const DevAlphabet *__restrict__ alpha, int sym)
+{
+    constexpr int GREC = R64 ? 2 : 1;
+    constexpr int ND = blk_band(B), NV = 3 + 4 * ND, NP = (NV + 3) & ~3;
+    constexpr int hdr = blk_hdr_bytes(B);
+    __shared__ double sm[RUN][4][NP + 1];
+    const float sym_a = sym ? alpha->sym_a : 0.f;
+    const int64_t t0 = (int64_t)blockIdx.x * RUN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double up = 1.0 + 0x1p-20;
+    for (int k = threadIdx.x; k < RUN * 4 * (NP + 1); k += 256) (&sm[0][0][0])[k] = 0.0;
+    __syncthreads();
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t rbytes = blk_rec_bytes(mp, B, GREC);
+    for (int i = 4 * threadIdx.x; i < mp; i += 1024) {
+        auto row = [&](const float *base, int64_t r) -> float4 {
+            if (r < 0 || r >= N || i >= m) return z4;
+            float4 w = *reinterpret_cast<const float4 *>(base + r * ld + i);
+            if (i + 3 >= m) { w.y = i + 1 < m ? w.y : 0.f; w.z = i + 2 < m ? w.z : 0.f; w.w = 0.f; }   // (m % 4 != 0: the row's tail)
+            return w;
+        };
+        float4 wx[ND], wq[ND];                                    // the window: rows t - 1 .. t - ND of the record in hand
+#pragma unroll
+        for (int d = 1; d <= ND; ++d) { wx[d - 1] = row(X, t0 - d); wq[d - 1] = row(Xq, t0 - d); }
+        float4 xc = row(X, t0), qc4 = row(Xq, t0), qn = row(Xq, t0 + B);
+#pragma unroll
+        for (int r = 0; r < RUN; ++r) {
+            const int64_t t = t0 + r;
+            // (the next record's three rows: requested before this record's arithmetic)
+            const float4 xc1 = r + 1 < RUN ? row(X, t + 1) : z4, qc1 = r + 1 < RUN ? row(Xq, t + 1) : z4, qn1 = r + 1 < RUN ? row(Xq, t + 1 + B) : z4;
+            if (t < nrec) {
+                char *rb = recs + t * rbytes;
+                float *ox = reinterpret_cast<float *>(rb + hdr), *oq = ox + mp;
+                const float4 xp = wx[B - 1], qp = wq[B - 1];      // rows t - B
+                *reinterpret_cast<float4 *>(ox + i) = xp;
+                *reinterpret_cast<float4 *>(oq + i) = sym_a != 0.f ? make_float4(__fmul_rn(sym_a, qp.x), __fmul_rn(sym_a, qp.y), __fmul_rn(sym_a, qp.z), __fmul_rn(sym_a, qp.w)) : qp;
+                if constexpr (R64) {
+                    double *od = reinterpret_cast<double *>(rb + hdr + 8 * (int64_t)mp);
+                    *reinterpret_cast<double2 *>(od + i) = make_double2((double)qn.x, (double)qn.y);
+                    *reinterpret_cast<double2 *>(od + i + 2) = make_double2((double)qn.z, (double)qn.w);
+                } else {
+                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(rb + hdr + 8 * (int64_t)mp) + i) = qn;
+                }
+            }
+            double v[NP];                                         // G, sum|Xq X|, sum|Xq|, then (H1, H2, sum|.|, sum|.|) per distance
+#pragma unroll
+            for (int k = 0; k < NP; ++k) v[k] = 0.0;
+            auto one = [&](float xcs, float qcs, const float (&bx)[ND], const float (&bq)[ND]) {
+                const double q = (double)qcs, pr = q * (double)xcs;
+                v[0] += pr; v[1] += fabs(pr); v[2] += fabs(q);
+#pragma unroll
+                for (int d = 1; d <= ND; ++d) {
+                    const double p1 = q * (double)bx[d - 1], p2 = q * (double)bq[d - 1];
+                    v[3 + 4 * (d - 1) + 0] += p1;       v[3 + 4 * (d - 1) + 1] += p2;
+                    v[3 + 4 * (d - 1) + 2] += fabs(p1); v[3 + 4 * (d - 1) + 3] += fabs(p2);
+                }
+            };
+            float b1[ND], b2[ND];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) { b1[d] = wx[d].x; b2[d] = wq[d].x; }
+            one(xc.x, qc4.x, b1, b2);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) { b1[d] = wx[d].y; b2[d] = wq[d].y; }
+            one(xc.y, qc4.y, b1, b2);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) { b1[d] = wx[d].z; b2[d] = wq[d].z; }
+            one(xc.z, qc4.z, b1, b2);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) { b1[d] = wx[d].w; b2[d] = wq[d].w; }
+            one(xc.w, qc4.w, b1, b2);
+#pragma unroll
+            for (int g = 0; g < NP / 4; ++g) {
+                double x = fold16(fold32(v[4 * g], v[4 * g + 2]), fold32(v[4 * g + 1], v[4 * g + 3]));
+                x = ror_add<8>(x); x = ror_add<4>(x); x = ror_add<2>(x); x = ror_add<1>(x);
+                if ((lane & 15) == 0) sm[r][wave][4 * g + (lane >> 4)] += x;     // (this thread's slot in every chunk)
+            }
+            // slide the window
+#pragma unroll
+            for (int d = ND - 1; d >= 1; --d) { wx[d] = wx[d - 1]; wq[d] = wq[d - 1]; }
+            wx[0] = xc; wq[0] = qc4;
+            xc = xc1; qc4 = qc1; qn = qn1;
+        }
+    }
+    __syncthreads();
+    // the run's headers: thread (r, e) -- e = 0 the statistics, e = d the band entry at distance d
+    for (int w = threadIdx.x; w < RUN * (ND + 1); w += 256) {
+        const int r = w / (ND + 1), e = w - r * (ND + 1);
+        const int64_t t = t0 + r;
+        if (t >= nrec) continue;
+        auto total = [&](int k) { return (sm[r][0][k] + sm[r][1][k]) + (sm[r][2][k] + sm[r][3][k]); };
+        char *rb = recs + t * rbytes;
+        if (e == 0) {
+            BlkStats st{};
+            const double nrm = t < N ? (double)nrm32[t] : 0.0;
+            const double s1 = total(1), s2 = total(2);
+            st.nrm = nrm;
+            st.rden = nrm < 1e-16 ? 0.0 : 1.0 / (nrm * nrm);
+            st.G = total(0);
+            st.cb = 0x1p-23 * s1 * st.rden * up;
+            st.ca = 0x1p-149 * s2 * st.rden * up;
+            st.Ea = 0x1p-149 * s2 * up;
+            double e1 = 0.0, e2 = 0.0;
+#pragma unroll
+            for (int d = 1; d <= ND; ++d) { e1 += total(5 + 4 * (d - 1)); e2 += total(6 + 4 * (d - 1)); }
+            st.sE1 = 0x1p-23 * e1 * up * up; st.sE2 = 0x1p-23 * e2 * up * up;
+            *reinterpret_cast<BlkStats *>(rb) = st;
+            *reinterpret_cast<BlkStats *>(hdrs + t * hdr) = st;
+        } else {
+            const int d = e;
+            BandEntry be;
+            be.H1 = total(3 + 4 * (d - 1)); be.H2 = total(4 + 4 * (d - 1));
+            be.E1 = 0x1p-23 * total(5 + 4 * (d - 1)) * up; be.E2 = 0x1p-23 * total(6 + 4 * (d - 1)) * up;
+            *reinterpret_cast<BandEntry *>(rb + 64 + 32 * (d - 1)) = be;
+            *reinterpret_cast<BandEntry *>(hdrs + t * hdr + 64 + 32 * (d - 1)) = be;
+        }
+    }
+}
+
+// Symmetric form, two-phase calls (gpfq_dense_layer_prepare / _run): the pre-pass ran before the alphabet existed and left Xq_{t-B} as it
+// is; this pass multiplies those rows by a32 in place (the same single float32 product the fused pre-pass forms).  grid (records, slices).
+__global__ void __launch_bounds__(256)
+gpfq_blk_scale_kernel(char *__restrict__ recs, int64_t rec_bytes, int hdr, int mps, int64_t slice_bytes, const DevAlphabet *__restrict__ alpha)
+{
+    const float a = alpha->sym_a;
+    float4 *row = reinterpret_cast<float4 *>(recs + (int64_t)blockIdx.y * slice_bytes + (int64_t)blockIdx.x * rec_bytes + hdr + 4 * (int64_t)mps);
+    for (int i = threadIdx.x; i < mps / 4; i += 256) {
+        const float4 v = row[i];
+        row[i] = make_float4(__fmul_rn(a, v.x), __fmul_rn(a, v.y), __fmul_rn(a, v.z), __fmul_rn(a, v.w));
+    }
+}
+
 // Who writes a block's outputs from the LDS ring to memory (round 5).  The sweep wavefronts, block b - 1 at the top of slot b, one wavefront per
 // slot in turn, wherever the decision wavefront IS the slot -- the four-group shapes with one neuron per lane: its own flush (eight slots'
 // worth at a time, 64-bit address arithmetic on operands hipcc spills at three wavefronts per SIMD) cost those shapes 9-12 % while the sweeps
@@ -688,8 +830,8 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             const int64_t t = (int64_t)(b - 1) * B + sidx, jn = jbase + nn;
             if (t < N && jn < K.C) {
                 const int2 v = lds_ld<int2>(lds, L.off_out + (nn * kOutSteps + (int)(t % kOutSteps)) * 8);
-                if (K.qidx) K.qidx[jn * K.o_sj + t * K.o_st] = (int8_t)v.x;
-                if (K.Qt) K.Qt[jn * K.o_sj + t * K.o_st] = __int_as_float(v.y);
+                if (K.qidx) K.qidx[jn * N + t] = (int8_t)v.x;
+                if (K.Qt) K.Qt[jn * N + t] = __int_as_float(v.y);
             }
         }
         if (b + 1 < nslots) load_weights(b + 1);                  // the block's weights: one piece
@@ -1115,7 +1257,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 }
 
 // ---- decision wavefront ------------------------------------------------------------------------------
-template <int G, int MP, int B, int NSW, bool SYM, int NL, int CLM>
+template <int G, int MP, int B, int NSW, bool SYM, int NL, int CLM, bool KOUT = false>
 __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_generic, const BlkLds &L, int lane, ClState &cs)
 {
     constexpr bool CL = CLM != 0;
@@ -1142,6 +1284,10 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     // alphabet members r, r + R, ... of this sub-lane (NaN beyond M: never counted); larger alphabets loop over LDS
     const bool in_regs = M <= 4 * R;
 
+    // the alphabet's progression (DevAlphabet): read ONCE, here -- inside the slot loop these would be loads from memory on the chain of
+    // decisions (the stores of the loop may alias them for all the compiler knows), 10-25 % of a narrow layer's time
+    const double al_a0 = K.alpha->a0, al_step = K.alpha->step, al_inv = K.alpha->inv, al_c0 = K.alpha->c0;
+    const unsigned long long al_plus = K.alpha->plus, al_minus = K.alpha->minus;
     const double sym_top = SYM ? lds_ld<double>(lds, L.off_e + 8 * (2 + M - 1)) : 0.0;      // a;  a / 2 (0 for {-a, a})
     const double sym_hb = (SYM && M == 3) ? 0.5 * sym_top : 0.0;
     float wprev[B], qprev[B];                                     // block b-1 (final), this neuron
@@ -1163,7 +1309,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     // of one neuron (32-byte runs of indices, 128-byte runs of values per neuron)
     constexpr bool kOwnFlush = !blk_sweep_flush<G, NL, CL>();
     auto flush = [&](int64_t t0, int64_t t1) {
-        if (K.o_st != 1) {
+        if constexpr (KOUT) {
             // Keras layout [N][ldo] (round 6: the layer's outputs as set_weights takes them, scripts/quantized_network.py:562, :570 -- no
             // transposing pass behind the kernel): a lane takes NJ consecutive NEURONS of one step -- NJ indices in one store, NJ values
             // in NJ / 4; the lanes of the wavefront are consecutive steps, so the reads of the LDS ring do not conflict
@@ -1417,9 +1563,9 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             const double2 o67 = lds_ld<double2>(lds, rbm + 48);   // (sE1, sE2): the quick certification's bound (below)
             STAMP(dta);
             // ---- (2) the chain
-            const double u_a0 = K.alpha->a0, u_step = K.alpha->step, u_inv = K.alpha->inv, u_c0 = K.alpha->c0, u_kmax = (double)(M - 1);
+            const double u_a0 = al_a0, u_step = al_step, u_inv = al_inv, u_c0 = al_c0, u_kmax = (double)(M - 1);
             const double u_amax = fmax(fabs(u_a0), fabs(fma(u_kmax, u_step, u_a0))) * (1.0 + 0x1p-20);   // >= every |member| (and its float32 rounding)
-            const unsigned long long u_plus = K.alpha->plus, u_minus = K.alpha->minus;
+            const unsigned long long u_plus = al_plus, u_minus = al_minus;
             const int u_zero = K.zero_idx;
             const float sym_a32 = (float)sym_top;
             auto pick = [&](double tt, double &kd) -> float {     // nearest member of the uniform alphabet, by arithmetic
@@ -1848,7 +1994,10 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
 // XCDs round-robin by id): id = ((cluster / 8) nsl + slice) 8 + cluster % 8.  Workgroups are dispatched in id order, so whenever a
 // slice is resident every slice before it in the queue is resident or done -- the oldest cluster with work left is always complete on
 // the chip (nsl <= 28 <= the 32 CUs of an XCD) and the exchange cannot deadlock, whatever the mapping of ids to XCDs really is.
-template <int G, int S, int B, int NSW, bool SYM, int NL, int CLM = 0>
+// KOUT: the outputs in the Keras layout [N][ldo] (BlkK::o_st), written by the decision wavefront's flush -- instantiated for the 16-neuron
+// four-step shapes only (blk_kout_shape): there that wavefront has the slack; in every other shape the extra code cost registers the
+// hot loops do not have (SGPR and VGPR spills, 4-6 % on the narrow shapes), and their outputs stay neuron-major (one assembly pass follows).
+template <int G, int S, int B, int NSW, bool SYM, int NL, int CLM = 0, bool KOUT = false>
 __global__ void __launch_bounds__(64 * (NSW + 1))
 gpfq_blk_kernel(BlkK K)
 {
@@ -1905,7 +2054,7 @@ gpfq_blk_kernel(BlkK K)
         GPFQ_BLK_ROLE(1) GPFQ_BLK_ROLE(2) GPFQ_BLK_ROLE(3) GPFQ_BLK_ROLE(4) GPFQ_BLK_ROLE(5) GPFQ_BLK_ROLE(6)
 #undef GPFQ_BLK_ROLE
     } else {
-        blk_decision_role<G, MP, B, NSW, SYM, NL, CLM>(K, lds, L, lane, cs);
+        blk_decision_role<G, MP, B, NSW, SYM, NL, CLM, KOUT>(K, lds, L, lane, cs);
     }
 }
 
@@ -1936,6 +2085,8 @@ void blk_set_pair_groups(int on) { g_blk_pairs.store(on ? 1 : 0, std::memory_ord
 // from 1024 up = every row beyond that many samples (tests, A/B).
 static std::atomic<int> g_blk_cluster_nl{0};      // cluster form: neurons per lane, 0 = by width; 1 / 2 / 4 force it (option blk_cluster_nl)
 void blk_set_cluster_nl(int v) { g_blk_cluster_nl.store(v == 1 || v == 2 || v == 4 ? v : 0, std::memory_order_relaxed); }
+static std::atomic<int> g_blk_prep_run{1};         // 1 (default): the record pre-pass takes runs of eight records per workgroup for walks of 2048+ steps; 0: one record per workgroup; 4 / 8: runs of that many at any length (option blk_prep_run: A/B, tests)
+void blk_set_prep_run(int v) { g_blk_prep_run.store(v == 4 || v == 8 ? v : (v ? 1 : 0), std::memory_order_relaxed); }
 static std::atomic<int> g_blk_chip{-1};            // -1: ask the device; 0 / 1 force the answer of blk_chip_ok (option blk_chip_ok: tests)
 void blk_set_chip_ok(int v) { g_blk_chip.store(v < 0 ? -1 : (v ? 1 : 0), std::memory_order_relaxed); }
 static std::atomic<int> g_blk_cl_timeout_ms{3000};  // how long an exchange of the cluster form waits for a slice before it gives up (option blk_cluster_timeout_ms)
@@ -2178,6 +2329,13 @@ static size_t blk_hdrs_bytes(int64_t nblk, int B, bool CL = false) { return (siz
 static size_t blk_hdrs_off(int64_t nblk, const BlkShape &sh) { return blk_recs_bytes(nblk, sh) * (size_t)(sh.NS ? sh.NS : 1); }     // compact headers: behind the last record stream
 static size_t blk_mbox_off(int64_t nblk, const BlkShape &sh) { return blk_hdrs_off(nblk, sh) + ((blk_hdrs_bytes(nblk, sh.B, sh.NS != 0) + 255) & ~(size_t)255); }
 
+// Whether the kernel itself writes Keras-layout outputs for this shape (the 16-neuron four-step shapes: blk_kout_shape)
+bool blk_keras_out_supported(int64_t m, int64_t C)
+{
+    const BlkShape sh = blk_shape(m, C);
+    return sh.G == 4 && sh.B == 4 && sh.NL == 4 && sh.NS == 0;
+}
+
 bool blk_supported(const PipeArgs &a)
 {
     const BlkShape sh = blk_shape(a.m, a.C);
@@ -2217,14 +2375,20 @@ static float blk_sym_a(const PipeArgs &a)
     return blk_sym_of(a.A.a, a.A.M);
 }
 
-template <int G, int S, int B, int NSW, bool SYM, int NL, int CLM = 0>
+constexpr bool blk_kout_shape(int G, int B, int NL, int CLM) { return G == 4 && B == 4 && NL == 4 && CLM == 0; }
+
+template <int G, int S, int B, int NSW, bool SYM, int NL, int CLM = 0, bool KOUT = false>
 static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, const DevAlphabet *alpha, hipStream_t stream)
 {
     constexpr bool CL = CLM != 0;
+    if constexpr (!KOUT && blk_kout_shape(G, B, NL, CLM)) {
+        if (a.o_st != 1) return launch_blk_sym<G, S, B, NSW, SYM, NL, CLM, true>(a, sh, alpha, stream);
+    }
+    if (!KOUT && a.o_st != 1) return hipErrorInvalidValue;        // (Keras-layout outputs: blk_keras_out_supported said no)
     constexpr int NB = NL * G;
     const BlkLds L = blk_lds(sh.mp, NB, B, NSW, G, CL);
     const unsigned grid = CL ? (unsigned)(blk_clusters(a.C, sh) * sh.NS) : (unsigned)((a.C + NB - 1) / NB);
-    auto *kern = gpfq_blk_kernel<G, S, B, NSW, SYM, NL, CLM>;
+    auto *kern = gpfq_blk_kernel<G, S, B, NSW, SYM, NL, CLM, KOUT>;
     hipError_t e = ensure_dynamic_lds((const void *)kern, (size_t)L.total);
     if (e != hipSuccess) return e;
     BlkK K;
@@ -2348,18 +2512,33 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     const int64_t nblk = (a.N + sh.B - 1) / sh.B;
     const int64_t nrec = (nblk + 1) * sh.B + 1;
     const bool r64 = blk_row64(sh.G, sh.B);
+    // a.phase: 0 = the whole call; 1 = the alphabet-independent half (the record pre-pass, rows unscaled); 2 = the rest (symmetric form: the
+    // records' Xq rows scaled in place, then the kernel) -- gpfq_dense_layer_prepare / _run, which a caller runs on two streams
+    const bool do_prep = a.phase != 2, do_run = a.phase != 1;
     const DevAlphabet *alpha = nullptr;
-    hipError_t e = blk_alphabet(a, &alpha, stream);
+    hipError_t e = do_run ? blk_alphabet(a, &alpha, stream) : hipSuccess;
     if (e != hipSuccess) return e;
     char *const wbase = static_cast<char *>(a.workspace) + kAlphaBlock;
-    if (sh.NS) {                                                   // cluster form: NS slices of the headline shape
-        note_dense_kernel("gpfq_blk_kernel, cluster form (rows cut into 1024-sample slices: one workgroup of 8 or 11 sweep wavefronts + 1 decision wavefront per slice, partial dot products exchanged once per slot)");
-        const int sym = blk_sym_a(a) != 0.f ? 1 : 0;
-        hipLaunchKernelGGL((gpfq_blk_prep_kernel<4, true, true>), dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp * sh.NS,
-                           a.nrm32, wbase, wbase + blk_hdrs_off(nblk, sh), alpha, sym,
-                           sh.NS, (int64_t)blk_recs_bytes(nblk, sh));
+    const int sym_shape = (sh.NS || blk_has_sym(sh.S, sh.NW)) && blk_sym_a(a) != 0.f ? 1 : 0;
+    const int sym_prep = a.phase == 0 ? sym_shape : 0;            // (two-phase calls: the scaling follows in phase 2)
+    if (a.phase == 2 && sym_shape) {
+        const int mps = sh.mp;
+        hipLaunchKernelGGL(gpfq_blk_scale_kernel, dim3((unsigned)nrec, (unsigned)(sh.NS ? sh.NS : 1)), dim3(256), 0, stream, wbase,
+                           (int64_t)blk_rec_bytes(mps, sh.B, sh.G, sh.NS != 0), blk_hdr_bytes(sh.B, sh.NS != 0), mps, sh.NS ? (int64_t)blk_recs_bytes(nblk, sh) : (int64_t)0, alpha);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
+    }
+    if (sh.NS) {                                                   // cluster form: NS slices of the headline shape
+        note_dense_kernel("gpfq_blk_kernel, cluster form (rows cut into 1024-sample slices: one workgroup of 8 or 11 sweep wavefronts + 1 decision wavefront per slice, partial dot products exchanged once per slot)");
+        const int sym = sym_shape;
+        if (do_prep) {
+            hipLaunchKernelGGL((gpfq_blk_prep_kernel<4, true, true>), dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp * sh.NS,
+                               a.nrm32, wbase, wbase + blk_hdrs_off(nblk, sh), alpha, sym_prep,
+                               sh.NS, (int64_t)blk_recs_bytes(nblk, sh));
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+        if (!do_run) return hipSuccess;
         ClusterLaunchGuard one_at_a_time(stream);
         if (one_at_a_time.err != hipSuccess) return one_at_a_time.err;
 #define GPFQ_BLK_CL(NSW_, NL_, M_) (sym ? launch_blk_sym<4, 32, 4, NSW_, true, NL_, M_>(a, sh, alpha, stream) : launch_blk_sym<4, 32, 4, NSW_, false, NL_, M_>(a, sh, alpha, stream))
@@ -2369,11 +2548,26 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     }
     auto *prep = sh.B == 4 ? (r64 ? gpfq_blk_prep_kernel<4, true> : gpfq_blk_prep_kernel<4, false>)
                            : (sh.B == 2 ? (r64 ? gpfq_blk_prep_kernel<2, true> : gpfq_blk_prep_kernel<2, false>) : gpfq_blk_prep_kernel<1, false>);
-    const int sym = (blk_has_sym(sh.S, sh.NW) && blk_sym_a(a) != 0.f) ? 1 : 0;   // (exactly the launches launch_blk_inst gives the symmetric form)
-    hipLaunchKernelGGL(prep, dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp,
-                       a.nrm32, wbase, wbase + blk_recs_bytes(nblk, sh), alpha, sym, 1, (int64_t)0);
+    const int sym = sym_prep;   // (exactly the launches launch_blk_inst gives the symmetric form)
+    const bool vec = (a.ld % 4 == 0) && (((uintptr_t)a.X | (uintptr_t)a.Xq) % 16 == 0);
+    if (!do_prep) {
+    } else if (vec && (g_blk_prep_run.load(std::memory_order_relaxed) > 1 || (g_blk_prep_run.load(std::memory_order_relaxed) == 1 && nrec >= 2048))) {
+        // (walks of fewer than 2048 steps: runs of records would be fewer workgroups than the chip has compute units, each a chain of eight
+        //  records -- a Dense(128 -> 10) layer's pre-pass 0.08 ms longer; those keep one record per workgroup)
+        // runs of eight (option value 4: four) records per workgroup (gpfq_blk_prep_run_kernel); the one-record form keeps the rows it cannot read 16 bytes at a time
+        const int run = g_blk_prep_run.load(std::memory_order_relaxed) == 4 ? 4 : 8;
+#define GPFQ_PREP_RUN(RUN_) (sh.B == 4 ? (r64 ? gpfq_blk_prep_run_kernel<4, true, RUN_> : gpfq_blk_prep_run_kernel<4, false, RUN_>) \
+                                       : (sh.B == 2 ? (r64 ? gpfq_blk_prep_run_kernel<2, true, RUN_> : gpfq_blk_prep_run_kernel<2, false, RUN_>) : gpfq_blk_prep_run_kernel<1, false, RUN_>))
+        auto *prun = run == 4 ? GPFQ_PREP_RUN(4) : GPFQ_PREP_RUN(8);
+#undef GPFQ_PREP_RUN
+        hipLaunchKernelGGL(prun, dim3((unsigned)((nrec + run - 1) / run)), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp, nrec,
+                           a.nrm32, wbase, wbase + blk_recs_bytes(nblk, sh), alpha, sym);
+    } else {
+        hipLaunchKernelGGL(prep, dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp,
+                           a.nrm32, wbase, wbase + blk_recs_bytes(nblk, sh), alpha, sym, 1, (int64_t)0);
+    }
     e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || !do_run) return e;
     // (four neuron groups with one or two neurons per lane: the narrow forms of the fused matrix shape)
     if (sh.G == 4 && sh.NL < 4 && sh.NW == 7) {                    // (rows of at most 768 samples: blk_shape)
         if (sh.S == 16) return sh.NL == 1 ? launch_blk_inst<4, 16, 4, 7, 1>(a, sh, alpha, stream) : launch_blk_inst<4, 16, 4, 7, 2>(a, sh, alpha, stream);

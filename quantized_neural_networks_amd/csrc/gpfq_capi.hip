@@ -219,6 +219,8 @@ int gpfq_set_option(const char *key, int value)
     if (!std::strcmp(key, "blk_single_groups")) { gpfq::blk_set_single_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_quad_groups")) { gpfq::blk_set_quad_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_cluster_map")) { gpfq::blk_set_cluster_map(value); return GPFQ_OK; }
+    if (!std::strcmp(key, "blk_prep_run")) { gpfq::blk_set_prep_run(value); return GPFQ_OK; }
+    if (!std::strcmp(key, "blk_prep_run")) { gpfq::blk_set_prep_run(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_chip_ok")) { gpfq::blk_set_chip_ok(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_cluster_fault")) { gpfq::blk_set_cluster_fault(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_cluster_timeout_ms")) {
@@ -469,18 +471,24 @@ int gpfq_dense_layer_supported(int64_t N, int64_t m, int64_t C, const double *un
     return gpfq::blk_supported(dense_layer_probe(N, m, C, H)) ? 1 : 0;
 }
 
+int gpfq_dense_layer_keras_out_supported(int64_t N, int64_t m, int64_t C, const double *unit_alphabet, int M)
+{
+    return gpfq_dense_layer_supported(N, m, C, unit_alphabet, M) && gpfq::blk_keras_out_supported(m, C) ? 1 : 0;
+}
+
 size_t gpfq_dense_layer_workspace_bytes(int64_t N, int64_t m, int64_t C)
 {
     if (N < 0 || m < 0 || C < 0) return 0;
     return onchip_workspace_bytes(N, m, C) + al256((size_t)N * sizeof(float));      // (+ the row norms when the caller passes none)
 }
 
-int gpfq_quantize_dense_layer(const float *X, const float *Xq, int64_t ld, const float *nrm32,
-                              const float *W, int64_t ldc, int64_t c_lo, int64_t C,
-                              const void *dev_alphabet, const double *unit_alphabet, int M,
-                              int64_t N, int64_t m,
-                              int8_t *qidx, float *Q, int out_layout, int64_t ldo, double *resid,
-                              void *workspace, size_t workspace_bytes, void *stream)
+// phase 0: the whole layer call; 1: the alphabet-independent half (status block, row norms, record pre-pass); 2: the alphabet-dependent half
+static int dense_layer_impl(int phase, const float *X, const float *Xq, int64_t ld, const float *nrm32,
+                            const float *W, int64_t ldc, int64_t c_lo, int64_t C,
+                            const void *dev_alphabet, const double *unit_alphabet, int M,
+                            int64_t N, int64_t m,
+                            int8_t *qidx, float *Q, int out_layout, int64_t ldo, double *resid,
+                            void *workspace, size_t workspace_bytes, void *stream, const char *what)
 {
     if (N < 1 || m < 1 || C < 0 || c_lo < 0)
         return fail(GPFQ_ERR_INVALID_ARG, "bad size N=%lld m=%lld C=%lld c_lo=%lld", (long long)N, (long long)m, (long long)C, (long long)c_lo);
@@ -488,28 +496,37 @@ int gpfq_quantize_dense_layer(const float *X, const float *Xq, int64_t ld, const
     int rc = unit_alphabet_arg(unit_alphabet, M, &H);
     if (rc != GPFQ_OK) return rc;
     if (C == 0) return GPFQ_OK;
-    if (!X || !Xq || !W || !dev_alphabet) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    if (!X || !Xq) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    if (phase != 1 && (!W || !dev_alphabet)) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
     if (ld < m) return fail(GPFQ_ERR_INVALID_ARG, "row pitch ld=%lld < m=%lld", (long long)ld, (long long)m);
-    if (ldc < c_lo + C) return fail(GPFQ_ERR_INVALID_ARG, "kernel pitch ldc=%lld < c_lo + C=%lld", (long long)ldc, (long long)(c_lo + C));
-    if (out_layout != GPFQ_LAYOUT_NEURON_MAJOR && out_layout != GPFQ_LAYOUT_KERAS) return fail(GPFQ_ERR_INVALID_ARG, "unknown output layout %d", out_layout);
-    if (out_layout == GPFQ_LAYOUT_KERAS && ldo < c_lo + C) return fail(GPFQ_ERR_INVALID_ARG, "output pitch ldo=%lld < c_lo + C=%lld", (long long)ldo, (long long)(c_lo + C));
+    if (phase != 1) {
+        if (ldc < c_lo + C) return fail(GPFQ_ERR_INVALID_ARG, "kernel pitch ldc=%lld < c_lo + C=%lld", (long long)ldc, (long long)(c_lo + C));
+        if (out_layout != GPFQ_LAYOUT_NEURON_MAJOR && out_layout != GPFQ_LAYOUT_KERAS) return fail(GPFQ_ERR_INVALID_ARG, "unknown output layout %d", out_layout);
+        if (out_layout == GPFQ_LAYOUT_KERAS && ldo < c_lo + C) return fail(GPFQ_ERR_INVALID_ARG, "output pitch ldo=%lld < c_lo + C=%lld", (long long)ldo, (long long)(c_lo + C));
+        if (out_layout == GPFQ_LAYOUT_KERAS && ldo != 1 && !gpfq::blk_keras_out_supported(m, C))
+            return fail(GPFQ_ERR_UNSUPPORTED, "the kernel of this shape (m=%lld, C=%lld) writes neuron-major outputs only (gpfq_dense_layer_keras_out_supported): "
+                                              "ask for GPFQ_LAYOUT_NEURON_MAJOR and lay them out with gpfq_assemble_kernel_device", (long long)m, (long long)C);
+    }
     if (!gpfq_dense_layer_supported(N, m, C, unit_alphabet, M))
         return fail(GPFQ_ERR_UNSUPPORTED, "no block-pipelined kernel for N=%lld m=%lld C=%lld M=%d (gpfq_dense_layer_supported): use gpfq_quantize_neurons with a host alphabet",
                     (long long)N, (long long)m, (long long)C, M);
     if (!workspace || (uintptr_t)workspace % 16 != 0 || workspace_bytes < gpfq_dense_layer_workspace_bytes(N, m, C))
-        return fail(GPFQ_ERR_WORKSPACE, "gpfq_quantize_dense_layer needs %zu aligned workspace bytes", gpfq_dense_layer_workspace_bytes(N, m, C));
+        return fail(GPFQ_ERR_WORKSPACE, "%s needs %zu aligned workspace bytes", what, gpfq_dense_layer_workspace_bytes(N, m, C));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(workspace, 0, 64, s);           // the call's counter block: exact fallbacks, cluster timeout, alphabet word
-    if (e != hipSuccess) return hip_fail(e, "gpfq_quantize_dense_layer(workspace)");
-    if (!nrm32) {
-        float *n32 = reinterpret_cast<float *>(static_cast<char *>(workspace) + onchip_workspace_bytes(N, m, C));
-        e = gpfq::launch_row_norms(Xq, N, m, ld, n32, s);
-        if (e != hipSuccess) return hip_fail(e, "gpfq_quantize_dense_layer(row norms)");
-        nrm32 = n32;
+    hipError_t e = hipSuccess;
+    if (phase != 2) {
+        e = hipMemsetAsync(workspace, 0, 64, s);                   // the call's counter block: exact fallbacks, cluster timeout, alphabet word
+        if (e != hipSuccess) return hip_fail(e, what);
+        if (!nrm32) {
+            float *n32 = reinterpret_cast<float *>(static_cast<char *>(workspace) + onchip_workspace_bytes(N, m, C));
+            e = gpfq::launch_row_norms(Xq, N, m, ld, n32, s);
+            if (e != hipSuccess) return hip_fail(e, what);
+            nrm32 = n32;
+        }
     }
     gpfq::PipeArgs pa{};
     pa.X = X; pa.Xq = Xq; pa.ld = ld; pa.nrm32 = nrm32;
-    pa.Wt = W + c_lo; pa.ldw = 1; pa.ldt = ldc;                   // the Keras kernel itself: neuron j's weight of step t is W[t][c_lo + j]
+    pa.Wt = W ? W + c_lo : nullptr; pa.ldw = 1; pa.ldt = ldc;     // the Keras kernel itself: neuron j's weight of step t is W[t][c_lo + j]
     pa.A = H.A; pa.N = N; pa.m = m; pa.C = C;
     pa.resid = resid; pa.u_out = nullptr;
     pa.ts_override = g_tile_steps; pa.variant = g_variant >> 4;
@@ -521,12 +538,42 @@ int gpfq_quantize_dense_layer(const float *X, const float *Xq, int64_t ld, const
         pa.qidx = qidx; pa.Qt = Q;
     }
     pa.dev_alpha = static_cast<const gpfq::DevAlphabet *>(dev_alphabet);
+    pa.phase = phase;
     pa.workspace = static_cast<char *>(workspace) + onchip_stats_bytes(N);
     pa.fallback_count = static_cast<unsigned long long *>(workspace);
-    gpfq::note_dense_kernel("gpfq_blk_kernel (4 to 11 sweep wavefronts + 1 decision wavefront per workgroup, blocks of steps per slot)");
+    if (phase != 1) gpfq::note_dense_kernel("gpfq_blk_kernel (4 to 11 sweep wavefronts + 1 decision wavefront per workgroup, blocks of steps per slot)");
     e = gpfq::launch_blk(pa, s);
-    if (e != hipSuccess) return hip_fail(e, "gpfq_quantize_dense_layer");
-    return g_sync_errors ? gpfq_call_status(workspace, stream) : GPFQ_OK;
+    if (e != hipSuccess) return hip_fail(e, what);
+    return (g_sync_errors && phase != 1) ? gpfq_call_status(workspace, stream) : GPFQ_OK;
+}
+
+int gpfq_quantize_dense_layer(const float *X, const float *Xq, int64_t ld, const float *nrm32,
+                              const float *W, int64_t ldc, int64_t c_lo, int64_t C,
+                              const void *dev_alphabet, const double *unit_alphabet, int M,
+                              int64_t N, int64_t m,
+                              int8_t *qidx, float *Q, int out_layout, int64_t ldo, double *resid,
+                              void *workspace, size_t workspace_bytes, void *stream)
+{
+    return dense_layer_impl(0, X, Xq, ld, nrm32, W, ldc, c_lo, C, dev_alphabet, unit_alphabet, M, N, m, qidx, Q, out_layout, ldo, resid,
+                            workspace, workspace_bytes, stream, "gpfq_quantize_dense_layer");
+}
+
+int gpfq_dense_layer_prepare(const float *X, const float *Xq, int64_t ld, const float *nrm32, const double *unit_alphabet, int M,
+                             int64_t N, int64_t m, int64_t C, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return dense_layer_impl(1, X, Xq, ld, nrm32, nullptr, 0, 0, C, nullptr, unit_alphabet, M, N, m, nullptr, nullptr, GPFQ_LAYOUT_KERAS, 0, nullptr,
+                            workspace, workspace_bytes, stream, "gpfq_dense_layer_prepare");
+}
+
+int gpfq_dense_layer_run(const float *X, const float *Xq, int64_t ld,
+                         const float *W, int64_t ldc, int64_t c_lo, int64_t C,
+                         const void *dev_alphabet, const double *unit_alphabet, int M,
+                         int64_t N, int64_t m,
+                         int8_t *qidx, float *Q, int out_layout, int64_t ldo, double *resid,
+                         void *workspace, size_t workspace_bytes, void *stream)
+{
+    return dense_layer_impl(2, X, Xq, ld, nullptr, W, ldc, c_lo, C, dev_alphabet, unit_alphabet, M, N, m, qidx, Q, out_layout, ldo, resid,
+                            workspace, workspace_bytes, stream, "gpfq_dense_layer_run");
 }
 
 int gpfq_assemble_kernel_device(const void *qidx, int bits, const void *dev_alphabet, int M, int64_t N, int64_t C,
@@ -633,15 +680,16 @@ int gpfq_assemble_kernel(const void *qidx, int bits, const double *alphabet, int
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_assemble_kernel");
 }
 
-size_t gpfq_median_abs_workspace_bytes(void) { return gpfq::median_workspace_bytes(); }
+size_t gpfq_median_abs_workspace_bytes(void) { return gpfq::median_workspace_bytes() + 64; }
+size_t gpfq_median_abs_workspace_bytes_for(int64_t n) { return n > 0 ? gpfq::median_workspace_bytes_fast(n) : gpfq::median_workspace_bytes() + 64; }
 
 int gpfq_median_abs(const float *W, int64_t n, float *median_out, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (n <= 0) return fail(GPFQ_ERR_INVALID_ARG, "median of %lld elements", (long long)n);
     if (!W || !median_out) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
-    if (!workspace || workspace_bytes < gpfq::median_workspace_bytes() || (uintptr_t)workspace % 16 != 0)
-        return fail(GPFQ_ERR_WORKSPACE, "median needs %zu aligned workspace bytes", gpfq::median_workspace_bytes());
-    hipError_t e = gpfq::launch_median_abs(W, n, median_out, workspace, static_cast<hipStream_t>(stream));
+    if (!workspace || workspace_bytes < gpfq_median_abs_workspace_bytes() || (uintptr_t)workspace % 16 != 0)
+        return fail(GPFQ_ERR_WORKSPACE, "median needs %zu aligned workspace bytes", gpfq_median_abs_workspace_bytes());
+    hipError_t e = gpfq::launch_median_abs(W, n, median_out, workspace, static_cast<hipStream_t>(stream), workspace_bytes);
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_median_abs");
 }
 

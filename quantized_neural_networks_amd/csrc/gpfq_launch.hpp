@@ -82,12 +82,14 @@ struct PipeArgs {
     int64_t ldt = 1;
     int64_t o_sj = 0, o_st = 1;
     const DevAlphabet *dev_alpha = nullptr;
+    int phase = 0;                         // 0: the whole call; 1: the alphabet-independent half (record pre-pass); 2: the rest (launch_blk)
 };
 // Block form (gpfq_blk.hip): B steps per slot; same arguments.
 // The layer alphabet formed on the device from the float32 median of |W| (device scalar): rad = alphabet_scalar * median, members
 // rad * unit[k]; dev_alphabet: GPFQ_DEVICE_ALPHABET_BYTES of device memory (a DevAlphabet).
 hipError_t launch_alphabet_device(const float *median32, double alphabet_scalar, const AlphabetArg &unit, void *dev_alphabet, hipStream_t stream);
 bool blk_supported(const PipeArgs &a);
+bool blk_keras_out_supported(int64_t m, int64_t C);   // PipeArgs::o_st != 1 is taken (the 16-neuron four-step shapes; elsewhere neuron-major + one assembly pass)
 size_t blk_workspace_bytes(int64_t N, int64_t m, int64_t C);   // (C: the cluster form's exchange buffers are per 16 neurons)
 hipError_t launch_blk(const PipeArgs &a, hipStream_t stream);
 void blk_set_four_groups(int on);   // 4-neuron workgroups for layers of at most 1024 neurons (speed only)
@@ -99,6 +101,7 @@ void blk_set_quad_waves(int nw);    // sweep wavefronts of the four-group narrow
 void blk_set_cluster_nl(int v);     // cluster form: neurons per lane of a workgroup, 0 (default) = by width, 1 / 2 / 4 force it (speed only)
 void blk_set_cluster_map(int v);    // cluster form: workgroup id -> (cluster, slice): -1 (default) by the slice count, 0 = a cluster inside one XCD, 1 = consecutive ids (speed only)
 void blk_set_cluster(int v);        // cluster form (rows cut into 1024-sample slices over several workgroups, up to 16384 samples): 1 (default) = by shape, 0 = off, v >= 1024 = every row beyond v samples (speed only)
+void blk_set_prep_run(int v);       // 1 (default): the record pre-pass in runs of eight records per workgroup; 0: one record per workgroup (same records)
 void blk_set_chip_ok(int v);        // -1 (default): the cluster form asks the device whether it is the whole 8 x 32-CU chip; 0 / 1: forced (tests)
 void blk_set_cluster_timeout_ms(int v);  // cluster form: how long an exchange waits for a missing slice (default 3000 ms)
 void blk_set_cluster_fault(int v);  // tests: 1 = one slice never publishes (forces the timeout and the caller's fallback)
@@ -275,13 +278,14 @@ hipError_t launch_assemble(const int8_t *qidx, const AlphabetArg &A, int64_t N, 
 // dev != NULL: the members are read from a DevAlphabet in device memory (A: its size only)
 hipError_t launch_pack(const int8_t *qidx, int64_t N, int64_t C, int bits, uint8_t *packed, hipStream_t stream);
 size_t median_workspace_bytes();
+size_t median_workspace_bytes_fast(int64_t n);   // ... with room for the one-GPU form's candidate list (gpfq_median_abs_workspace_bytes_for)
 size_t channel_sumsq_workspace_bytes(int64_t Cin);
 hipError_t launch_channel_sumsq(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int sh, int sw, double *out,
                                 void *workspace, hipStream_t stream);
 size_t channel_dead_workspace_bytes(int64_t Cin);
 hipError_t launch_channel_dead(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int sh, int sw, int32_t *dead,
                                void *workspace, int64_t prefix_positions, hipStream_t stream);
-hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream);
+hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream, size_t workspace_bytes);
 hipError_t launch_median_begin(int64_t n_total, void *workspace, hipStream_t stream);
 hipError_t launch_median_count(const float *W_local, int64_t n_local, int64_t n_total, int pass, void *workspace, hipStream_t stream);
 hipError_t launch_median_pick(int64_t n_total, int pass, void *workspace, hipStream_t stream);

@@ -786,14 +786,181 @@ hipError_t launch_median_end(int64_t n_total, void *workspace, float *out, hipSt
     return hipGetLastError();
 }
 
-hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream)
+// ---- one-GPU form (round 6): two passes over the data, two launches ----------------------------------------------------------
+// The same exact select with the 31 key bits cut 15 + 16 instead of 11 + 11 + 10: a workgroup's histogram is 128 KiB of this chip's
+// 160 KiB LDS -- 32768 counters in pass A; 65536 SIXTEEN-bit counters, two to a word, in pass B, where a workgroup takes at most 65535
+// elements so that no counter can carry into its neighbour -- and each pass's pick is done by the LAST workgroup of the pass's own launch
+// to arrive (a ticket behind the histogram merges, which are agent-scope atomics), not by a launch of its own.  4096 x 4096 weights: seven
+// launches and three reads of the data (68 us) -> memset + two launches, two reads (profiles/r06).  The sharded protocol above keeps its
+// three 16 KiB histograms: those cross the ranks.
+struct Sel2Ctl {
+    unsigned done, pad0, pad1, pad2;
+};
+constexpr int kSel2A = 1 << 15, kSel2B = 1 << 16;
+// workspace: [SelState x 2, 64 B][ctl 64 B][histA 2 x 32768 u32][histB 2 x 65536 u32]
+static Sel2Ctl *sel2_ctl(void *ws) { return reinterpret_cast<Sel2Ctl *>(static_cast<char *>(ws) + 64); }
+static unsigned *sel2_hist_a(void *ws) { return reinterpret_cast<unsigned *>(static_cast<char *>(ws) + 128); }
+static unsigned *sel2_hist_b(void *ws) { return sel2_hist_a(ws) + 2 * kSel2A; }
+size_t median_workspace_bytes_fast(int64_t) { return 128 + (size_t)(2 * kSel2A + 2 * kSel2B) * sizeof(unsigned); }
+
+// PASS 0: bins = key >> 16 of every element; PASS 1: bins = key & 0xffff of the elements whose high bits are the class(es) pass 0 picked.
+template <int PASS>
+__global__ void __launch_bounds__(kSelThreads)
+gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, SelState *__restrict__ st, unsigned *hist,
+                    Sel2Ctl *__restrict__ ctl, int nsel, unsigned long long k0, unsigned long long k1, float *__restrict__ out)
 {
-    hipError_t e = launch_median_begin(n, workspace, stream);
-    for (int p = 0; p < 3 && e == hipSuccess; ++p) {
-        e = launch_median_count(W, n, n, p, workspace, stream);
-        if (e == hipSuccess) e = median_pick(n, p, workspace, p == 2 ? out : nullptr, stream);
+    extern __shared__ unsigned h[];                               // PASS 0: [32768] counters; PASS 1: [32768] words of two 16-bit counters (128 KiB either way)
+    __shared__ unsigned long long part[16];
+    __shared__ int found_bin, is_last;
+    __shared__ unsigned long long found_rank;
+    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int WORDS = kSel2A;                                 // per histogram, either pass
+    const unsigned p0 = PASS == 0 ? 0u : st[0].prefix, p1 = (PASS == 0 || nsel < 2) ? p0 : st[1].prefix;
+    const bool split = p1 != p0;
+    const int nh = split ? 2 : 1;                                 // (the two middle values of an even count in different classes -- rare: the range is read once per class)
+    unsigned pcur = p0;
+    auto count = [&](float w) {
+        const unsigned key = __float_as_uint(w) & 0x7fffffffu;
+        if (PASS == 0) atomicAdd(&h[key >> 16], 1u);
+        else {
+            const unsigned cls = key & 0xffff0000u, lo = key & 0xffffu;
+            if (cls == pcur) atomicAdd(&h[lo >> 1], 1u << (16 * (lo & 1u)));
+        }
+    };
+    // a contiguous range of per_block elements per workgroup, 16-byte reads where the range allows.  Pass 1 takes its range in chunks of at
+    // most 65532 elements and merges its histogram after each: a 16-bit counter then cannot carry into its neighbour.
+    const int64_t lo_e = (int64_t)blockIdx.x * per_block, hi_e = lo_e + per_block < n ? lo_e + per_block : n;
+    const int64_t span = hi_e > lo_e ? hi_e - lo_e : 0;
+    const int64_t nchunks = PASS == 0 ? 1 : (span + 65531) / 65532;
+    const int64_t chunk = nchunks > 0 ? (((span + nchunks - 1) / nchunks) + 3) & ~(int64_t)3 : 0;
+    const bool vec = ((uintptr_t)W % 16 == 0) && (per_block % 4 == 0);
+    for (int64_t cc = 0; cc < nh * (nchunks > 0 ? nchunks : 1); ++cc) {
+        const int hs = (int)(cc / (nchunks > 0 ? nchunks : 1));   // which class's histogram
+        const int64_t c = cc - hs * (nchunks > 0 ? nchunks : 1);
+        pcur = hs ? p1 : p0;
+        const int64_t c_lo = lo_e + c * chunk, c_hi = c_lo + chunk < hi_e ? c_lo + chunk : hi_e;
+        for (int b = tid; b < WORDS; b += kSelThreads) h[b] = 0;
+        __syncthreads();
+        if (vec && c_hi > c_lo) {
+            const float4 *W4 = reinterpret_cast<const float4 *>(W + c_lo);
+            const int64_t n4 = (c_hi - c_lo) / 4;
+            for (int64_t i = tid; i < n4; i += kSelThreads) {
+                const float4 v = W4[i];
+                count(v.x); count(v.y); count(v.z); count(v.w);
+            }
+            for (int64_t i = c_lo + n4 * 4 + tid; i < c_hi; i += kSelThreads) count(W[i]);
+        } else {
+            for (int64_t i = c_lo + tid; i < c_hi; i += kSelThreads) count(W[i]);
+        }
+        __syncthreads();
+        if (PASS == 0) {
+            for (int b = tid; b < WORDS; b += kSelThreads) {
+                const unsigned cnt = h[b];
+                if (cnt) atomicAdd(&hist[b], cnt);
+            }
+        } else {
+            for (int b = tid; b < WORDS; b += kSelThreads) {
+                const unsigned cnt = h[b];
+                if (cnt & 0xffffu) atomicAdd(&hist[hs * kSel2B + 2 * b], cnt & 0xffffu);
+                if (cnt >> 16) atomicAdd(&hist[hs * kSel2B + 2 * b + 1], cnt >> 16);
+            }
+        }
+        __syncthreads();
     }
-    return e;
+    // ---- the last workgroup to get here picks (each wavefront waits for its own merges -- agent-scope atomics -- to be acknowledged: a
+    // workgroup-scope release, no cache maintenance; an agent-scope fence per thread writes the L2 back thousands of times per pass) ----
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) is_last = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!is_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (PASS == 0 && tid == 0) {
+        st[0].prefix = 0; st[0].pad = 0; st[0].k = k0;
+        st[1].prefix = 0; st[1].pad = 0; st[1].k = k1;
+    }
+    __syncthreads();
+    constexpr int BINS = PASS == 0 ? kSel2A : kSel2B, PER = BINS / kSelThreads;      // 32 / 64 bins per thread
+    for (int sel = 0; sel < nsel; ++sel) {
+        const unsigned *src = hist + ((PASS == 1 && sel && split) ? kSel2B : 0);
+        if (tid == 0) { found_bin = BINS - 1; found_rank = 0; }
+        // (plain 16-byte loads: the acquire fence above has dropped this workgroup's stale lines, and every merge was acknowledged before
+        //  its workgroup took a ticket -- PER single agent-scope loads in sequence cost 50-90 us per pick)
+        unsigned long long mine = 0;
+        {
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(src + tid * PER);
+#pragma unroll
+            for (int b = 0; b < PER / 4; ++b) { const uint4 v = s4[b]; mine += (unsigned long long)v.x + v.y + v.z + v.w; }
+        }
+        unsigned long long incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        __syncthreads();
+        if (lane == 63) part[tid >> 6] = incl;
+        __syncthreads();
+        unsigned long long before = incl - mine;
+        for (int w = 0; w < (tid >> 6); ++w) before += part[w];
+        const unsigned long long k = st[sel].k;
+        if (before <= k && k < before + mine) {                   // exactly one thread (or none if k is out of range)
+            unsigned long long acc = before;
+            int b = tid * PER;
+            for (; b < tid * PER + PER - 1; ++b) {
+                const unsigned c = src[b];
+                if (acc + c > k) break;
+                acc += c;
+            }
+            found_bin = b;
+            found_rank = k - acc;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            st[sel].k = found_rank;
+            st[sel].prefix = st[sel].prefix | ((unsigned)found_bin << (PASS == 0 ? 16 : 0));
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        ctl->done = 0;
+        if (PASS == 1 && out) {
+            const float a = __uint_as_float(st[0].prefix);
+            *out = nsel > 1 ? __fdiv_rn(__fadd_rn(a, __uint_as_float(st[1].prefix)), 2.0f) : a;   // float32 mean of the two middle values
+        }
+    }
+}
+
+hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream, size_t workspace_bytes)
+{
+    if (workspace_bytes < median_workspace_bytes_fast(n)) {
+        // the minimal workspace of rounds 1-5 (gpfq_median_abs_workspace_bytes()): the three-pass sequence
+        hipError_t e = launch_median_begin(n, workspace, stream);
+        for (int p = 0; p < 3 && e == hipSuccess; ++p) {
+            e = launch_median_count(W, n, n, p, workspace, stream);
+            if (e == hipSuccess) e = median_pick(n, p, workspace, p == 2 ? out : nullptr, stream);
+        }
+        return e;
+    }
+    hipError_t e = hipMemsetAsync(workspace, 0, median_workspace_bytes_fast(n), stream);    // state, control words, both histograms
+    if (e != hipSuccess) return e;
+    const bool even = (n % 2) == 0;
+    const unsigned long long k0 = even ? (unsigned long long)(n / 2 - 1) : (unsigned long long)(n / 2), k1 = (unsigned long long)(n / 2);
+    // contiguous ranges of a multiple of four elements, one workgroup per compute unit for a layer-sized kernel (a histogram is most of a
+    // compute unit's LDS: a 257th workgroup would wait for a whole round)
+    int64_t per = (n + 255) / 256;
+    per = (per + 3) & ~(int64_t)3;
+    if (per < 4096) per = 4096;
+    const unsigned grid = (unsigned)((n + per - 1) / per);
+    const size_t lds = (size_t)kSel2A * sizeof(unsigned);         // one 128 KiB histogram per workgroup, either pass
+    e = ensure_dynamic_lds((const void *)gpfq_median2_kernel<0>, kSel2A * sizeof(unsigned));
+    if (e == hipSuccess) e = ensure_dynamic_lds((const void *)gpfq_median2_kernel<1>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gpfq_median2_kernel<0>, dim3(grid), dim3(kSelThreads), kSel2A * sizeof(unsigned), stream, W, n, per, sel_state(workspace),
+                       sel2_hist_a(workspace), sel2_ctl(workspace), sel_count(n), k0, k1, (float *)nullptr);
+    hipLaunchKernelGGL(gpfq_median2_kernel<1>, dim3(grid), dim3(kSelThreads), lds, stream, W, n, per, sel_state(workspace),
+                       sel2_hist_b(workspace), sel2_ctl(workspace), sel_count(n), k0, k1, out);
+    return hipGetLastError();
 }
 
 }  // namespace gpfq

@@ -39,9 +39,13 @@ SYMBOLS = {
     "gpfq_call_status": (_int, [_vp, _vp]),
     "gpfq_layer_alphabet_device": (_int, [_vp, ctypes.c_double, _dp, _int, _vp, _vp]),
     "gpfq_dense_layer_supported": (_int, [_i64, _i64, _i64, _dp, _int]),
+    "gpfq_dense_layer_keras_out_supported": (_int, [_i64, _i64, _i64, _dp, _int]),
     "gpfq_dense_layer_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "gpfq_quantize_dense_layer": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _dp, _int, _i64, _i64,
                                          _vp, _vp, _int, _i64, _vp, _vp, _sz, _vp]),
+    "gpfq_dense_layer_prepare": (_int, [_vp, _vp, _i64, _vp, _dp, _int, _i64, _i64, _i64, _vp, _sz, _vp]),
+    "gpfq_dense_layer_run": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _dp, _int, _i64, _i64,
+                                    _vp, _vp, _int, _i64, _vp, _vp, _sz, _vp]),
     "gpfq_assemble_kernel_device": (_int, [_vp, _int, _vp, _int, _i64, _i64, _vp, _vp, _vp]),
     "gpfq_gram_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "gpfq_quantize_neurons_gram": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _i64, _dp, _int, _int, _i64, _i64, _i64,
@@ -72,6 +76,7 @@ SYMBOLS = {
     "gpfq_pack_indices": (_int, [_vp, _i64, _i64, _int, _vp, _vp]),
     "gpfq_assemble_kernel": (_int, [_vp, _int, _dp, _int, _i64, _i64, _vp, _vp, _vp]),
     "gpfq_median_abs_workspace_bytes": (_sz, []),
+    "gpfq_median_abs_workspace_bytes_for": (_sz, [_i64]),
     "gpfq_median_abs": (_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
     "gpfq_median_abs_begin": (_int, [_i64, _vp, _sz, _vp]),
     "gpfq_median_abs_count": (_int, [_vp, _i64, _i64, _int, _vp, _vp]),
@@ -599,42 +604,93 @@ def dense_layer_supported(N, m, C, unit_alphabet):
     return bool(load().gpfq_dense_layer_supported(int(N), int(m), int(C), arr, len(unit_alphabet)))
 
 
-def quantize_dense_layer(X, Xq, W, dalpha, lo=0, hi=None, nrm32=None, keras_out=True, want_values=True, want_idx=True, want_resid=True):
+def _dense_layer_args(X, Xq, W, unit, lo, hi):
+    _dev(X, torch.float32, "X"); _dev(Xq, torch.float32, "Xq")
+    xp, N, m, ld = _rows(X, "X")
+    xqp, N2, m2, ld2 = _rows(Xq, "Xq")
+    if (N2, m2) != (N, m) or ld2 != ld:
+        raise GpfqError(f"shape mismatch: X {tuple(X.shape)}, Xq {tuple(Xq.shape)} (one row pitch)")
+    Ctot = None
+    if W is not None:
+        _dev(W, torch.float32, "W")
+        if W.dim() != 2 or not W.is_contiguous() or W.shape[0] != N:
+            raise GpfqError(f"W {tuple(W.shape)} must be the contiguous [N][C] Keras kernel of X's {N} input features")
+        Ctot = W.shape[1]
+        hi = Ctot if hi is None else hi
+        if not 0 <= lo <= hi <= Ctot:
+            raise GpfqError(f"neuron range [{lo}, {hi}) outside the layer's {Ctot}")
+    arr = (ctypes.c_double * len(unit))(*[float(v) for v in unit])
+    return xp, xqp, ld, N, m, Ctot, hi, arr
+
+
+def dense_layer_workspace(N, m, C, device):
+    """The workspace of a quantize_dense_layer / dense_layer_prepare + dense_layer_run call (status words in its first 16 bytes)."""
+    nbytes = load().gpfq_dense_layer_workspace_bytes(int(N), int(m), int(C))
+    return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+
+
+def dense_layer_prepare(X, Xq, unit_alphabet, C, ws, nrm32=None):
+    """The alphabet-independent half of quantize_dense_layer (gpfq_dense_layer_prepare): status block, row norms, record pre-pass, on the
+    current stream, into `ws` (dense_layer_workspace).  Needs neither the kernel nor the alphabet: a caller overlaps it with the median."""
+    xp, xqp, ld, N, m, _, _, arr = _dense_layer_args(X, Xq, None, unit_alphabet, 0, None)
+    if nrm32 is not None:
+        _dev(nrm32, torch.float32, "nrm32")
+    with torch.cuda.device(X.device):
+        rc = load().gpfq_dense_layer_prepare(xp, xqp, ld, nrm32.data_ptr() if nrm32 is not None else None, arr, len(unit_alphabet), N, m, int(C),
+                                             ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "gpfq_dense_layer_prepare")
+
+
+def quantize_dense_layer(X, Xq, W, dalpha, lo=0, hi=None, nrm32=None, keras_out=True, want_values=True, want_idx=True, want_resid=True,
+                         prepared=None):
     """Neurons [lo, hi) of a Dense layer in one library call (gpfq_quantize_dense_layer): W f32 [N][C] is the Keras kernel itself, the
     alphabet a DeviceAlphabet.  keras_out: Q f32 / idx i8 are whole-layer [N][C] tensors of which columns lo..hi are written (the layout
     set_weights takes, scripts/quantized_network.py:562, :570); else this shard's neuron-major [hi - lo][N].
+    prepared: the workspace a dense_layer_prepare call for the same X, Xq and hi - lo neurons has filled (the call is then
+    gpfq_dense_layer_run: the alphabet-dependent half only).
     Returns dict(Q, idx, resid f64 [hi - lo], workspace); call_status(result) is the deferred error check.  No sync."""
-    _dev(X, torch.float32, "X"); _dev(Xq, torch.float32, "Xq"); _dev(W, torch.float32, "W")
-    xp, N, m, ld = _rows(X, "X")
-    xqp, N2, m2, ld2 = _rows(Xq, "Xq")
-    if W.dim() != 2 or not W.is_contiguous() or W.shape[0] != N or (N2, m2) != (N, m) or ld2 != ld:
-        raise GpfqError(f"shape mismatch: X {tuple(X.shape)}, Xq {tuple(Xq.shape)}, W {tuple(W.shape)} (contiguous [N][C] kernel, one row pitch)")
-    Ctot = W.shape[1]
-    hi = Ctot if hi is None else hi
+    xp, xqp, ld, N, m, Ctot, hi, arr = _dense_layer_args(X, Xq, W, dalpha.unit, lo, hi)
     C = hi - lo
-    if not 0 <= lo <= hi <= Ctot:
-        raise GpfqError(f"neuron range [{lo}, {hi}) outside the layer's {Ctot}")
     M = len(dalpha)
-    arr = (ctypes.c_double * M)(*[float(v) for v in dalpha.unit])
     dev = X.device
-    shape = (N, Ctot) if keras_out else (C, N)
-    idx = torch.empty(shape, dtype=torch.int8, device=dev) if want_idx else None
-    Q = torch.empty(shape, dtype=torch.float32, device=dev) if want_values else None
-    resid = torch.empty(C, dtype=torch.float64, device=dev) if want_resid is not False else None
     lib = load()
+    # The kernel writes the Keras layout itself in the 16-neuron four-step shapes; elsewhere its outputs are neuron-major and one assembly
+    # pass (members from the device alphabet) lays them out
+    direct = keras_out and C > 0 and bool(lib.gpfq_dense_layer_keras_out_supported(N, m, C, arr, M))
+    via_assembly = keras_out and not direct
+    shape = (N, Ctot) if direct else (C, N)
+    idx = torch.empty(shape, dtype=torch.int8, device=dev) if (want_idx or via_assembly) else None
+    Q = torch.empty(shape, dtype=torch.float32, device=dev) if (want_values and not via_assembly) else None
+    resid = torch.empty(C, dtype=torch.float64, device=dev) if want_resid is not False else None
     if C == 0:                                            # (an empty shard: nothing launched, a clean status block)
+        if keras_out:
+            idx = torch.empty((N, Ctot), dtype=torch.int8, device=dev) if want_idx else None
+            Q = torch.empty((N, Ctot), dtype=torch.float32, device=dev) if want_values else None
         return dict(idx=idx, Q=Q, resid=resid, u=None, workspace=torch.zeros(16, dtype=torch.uint8, device=dev))
-    nbytes = lib.gpfq_dense_layer_workspace_bytes(N, m, C)
-    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
-    if nrm32 is not None:
-        _dev(nrm32, torch.float32, "nrm32")
+    ws = prepared if prepared is not None else dense_layer_workspace(N, m, C, dev)
     with torch.cuda.device(dev):
-        rc = lib.gpfq_quantize_dense_layer(xp, xqp, ld, nrm32.data_ptr() if nrm32 is not None else None,
-                                           W.data_ptr(), Ctot, lo, C, dalpha.buf.data_ptr(), arr, M, N, m,
-                                           idx.data_ptr() if idx is not None else None, Q.data_ptr() if Q is not None else None,
-                                           GPFQ_LAYOUT_KERAS if keras_out else GPFQ_LAYOUT_NEURON_MAJOR, Ctot,
-                                           resid.data_ptr() if resid is not None else None, ws.data_ptr(), nbytes, _stream())
-    _check(rc, "gpfq_quantize_dense_layer")
+        out_args = (idx.data_ptr() if idx is not None else None, Q.data_ptr() if Q is not None else None,
+                    GPFQ_LAYOUT_KERAS if direct else GPFQ_LAYOUT_NEURON_MAJOR, Ctot if direct else N, resid.data_ptr() if resid is not None else None,
+                    ws.data_ptr(), ws.numel(), _stream())
+        if prepared is not None:
+            rc = lib.gpfq_dense_layer_run(xp, xqp, ld, W.data_ptr(), Ctot, lo, C, dalpha.buf.data_ptr(), arr, M, N, m, *out_args)
+        else:
+            if nrm32 is not None:
+                _dev(nrm32, torch.float32, "nrm32")
+            rc = lib.gpfq_quantize_dense_layer(xp, xqp, ld, nrm32.data_ptr() if nrm32 is not None else None,
+                                               W.data_ptr(), Ctot, lo, C, dalpha.buf.data_ptr(), arr, M, N, m, *out_args)
+    _check(rc, "gpfq_dense_layer_run" if prepared is not None else "gpfq_quantize_dense_layer")
+    if via_assembly:
+        Qk, Ik = assemble_kernel_device(idx, dalpha, want_idx=want_idx)
+        if (lo, hi) != (0, Ctot):                         # a shard of a wider layer: its columns of whole-layer tensors, as the direct form writes them
+            Qf = torch.empty((N, Ctot), dtype=torch.float32, device=dev) if want_values else None
+            If = torch.empty((N, Ctot), dtype=torch.int8, device=dev) if want_idx else None
+            if Qf is not None:
+                Qf[:, lo:hi] = Qk
+            if If is not None:
+                If[:, lo:hi] = Ik
+            Qk, Ik = Qf, If
+        return dict(idx=Ik, Q=Qk if want_values else None, resid=resid, u=None, workspace=ws)
     return dict(idx=idx, Q=Q, resid=resid, u=None, workspace=ws)
 
 
@@ -816,7 +872,7 @@ def median_abs(W, meanwhile=None, on_device=False):
     _dev(W, torch.float32, "W")
     Wc = W.contiguous()
     lib = load()
-    nbytes = lib.gpfq_median_abs_workspace_bytes()
+    nbytes = lib.gpfq_median_abs_workspace_bytes_for(Wc.numel())
     ws = torch.empty(nbytes, dtype=torch.uint8, device=W.device)
     out = torch.empty(1, dtype=torch.float32, device=W.device)
     with torch.cuda.device(W.device):

@@ -161,7 +161,45 @@ def quantize_neurons_checked(X, Xq, Wt, alphabet, log=None, **kw):
     return r
 
 
-def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True, log=None, check=True):
+_side_streams = {}
+
+
+def _side_stream(device):
+    st = _side_streams.get(device.index)
+    if st is None:
+        st = _side_streams[device.index] = torch.cuda.Stream(device=device)
+    return st
+
+
+def quantize_dense_layer(W, X, Xq, unit_alphabet, alphabet_scalar, group=None, want_resid=True, log=None, check=True, overlap=True):
+    """The body of _quantize_layer_parallel (scripts/quantized_network.py:523-574) from "the activations are there" to the tensors
+    set_weights takes, with nothing crossing to the host and its two independent halves OVERLAPPED on two HIP streams: the median of |W|
+    and the alphabet (:544-545) depend on the kernel alone, the row norms and the record pre-pass on the activations alone
+    (gpfq_dense_layer_prepare on a side stream); the recurrence (gpfq_dense_layer_run) follows both.  Same tensors as
+    quantize_dense(W, X, Xq, rad * unit_alphabet), bit for bit.  Returns its dict + "alphabet" (the hip.DeviceAlphabet: rad() / values())."""
+    N, C = W.shape
+    world, rank = _group_info(group)
+    lo, hi = shard_bounds(C, world, rank)
+    m = X.shape[1]
+    if not (overlap and W.numel() and m > 0 and hi > lo and hip.dense_layer_supported(N, m, hi - lo, unit_alphabet)):
+        dalpha = layer_alphabet_device(W, unit_alphabet, alphabet_scalar, group)
+        out = quantize_dense(W, X, Xq, dalpha, group=group, want_resid=want_resid, log=log, check=check)
+        out["alphabet"] = dalpha
+        return out
+    main = torch.cuda.current_stream(W.device)
+    side = _side_stream(W.device)
+    ws = hip.dense_layer_workspace(N, m, hi - lo, W.device)
+    side.wait_stream(main)                                        # (the activations and the workspace's previous owner are done)
+    with torch.cuda.stream(side):
+        hip.dense_layer_prepare(X, Xq, unit_alphabet, hi - lo, ws)
+    dalpha = layer_alphabet_device(W, unit_alphabet, alphabet_scalar, group)
+    main.wait_stream(side)
+    out = quantize_dense(W, X, Xq, dalpha, group=group, want_resid=want_resid, log=log, check=check, prepared=ws)
+    out["alphabet"] = dalpha
+    return out
+
+
+def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True, log=None, check=True, prepared=None):
     """Quantize every neuron (column) of a Dense kernel.
 
     W        f32 [N][C]  Keras kernel layout (row = input feature), on the GPU
@@ -184,7 +222,8 @@ def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True, log=None, ch
         alphabet, dalpha = dalpha.values(), None                   # (no block-pipelined kernel for this shape: the host alphabet's paths)
     Wc = W.contiguous()
     if dalpha is not None:
-        r = hip.quantize_dense_layer(X, Xq, Wc, dalpha, lo, hi, keras_out=(world == 1), want_values=(world == 1), want_resid=want_resid)
+        r = hip.quantize_dense_layer(X, Xq, Wc, dalpha, lo, hi, keras_out=(world == 1), want_values=(world == 1), want_resid=want_resid,
+                                     prepared=prepared)           # (prepared: quantize_dense_layer's side stream has run the pre-pass into this workspace)
         st = hip.call_status(r) if check else 0
         if st == hip.GPFQ_ERR_CLUSTER_TIMEOUT:
             _log_failure(log, f"Dense layer {N} x {C}: the cluster form's exchange timed out; rerunning the layer through the classic kernels")
@@ -209,8 +248,17 @@ def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True, log=None, ch
             out["resid"] = all_gather_units(r["resid"], C, group)
         return out
     Wt = hip.neuron_major(Wc, lo, hi)                            # neuron-major shard [C_local][N]
+    deferred = None
     if hi > lo:
-        r = quantize_neurons_checked(X, Xq, Wt, alphabet, log=log, want_values=False, want_resid=want_resid)
+        if world > 1:
+            # (a rank whose exchange timed out repairs its shard BEFORE the all-gather: the other ranks never see garbage and nobody
+            #  has to agree on anything)
+            r = quantize_neurons_checked(X, Xq, Wt, alphabet, log=log, want_values=False, want_resid=want_resid)
+        else:
+            # one GPU: the assembly pass is queued behind the kernel first and the status read after it -- the host's wait then costs no
+            # bubble between the two (cfg4's Dense(128 -> 10): 0.06 ms of a 0.15 ms layer); nothing is RETURNED unchecked
+            r = hip.quantize_neurons(X, Xq, Wt, alphabet, want_values=False, want_resid=want_resid)
+            deferred = r if "cluster form" in hip.last_dense_kernel() else None
         i_loc, res_loc = r["idx"], r["resid"]
     else:
         i_loc = torch.empty((0, N), dtype=hip.index_dtype(len(alphabet)), device=W.device)
@@ -222,6 +270,14 @@ def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True, log=None, ch
         Q, idx = hip.assemble_kernel(all_gather_units(packed, C, group).contiguous(), alphabet, bits=bits, N=N)
     else:
         Q, idx = hip.assemble_kernel(i_loc, alphabet)
+        if deferred is not None and hip.call_status(deferred) != 0:
+            _log_failure(log, f"Dense layer {N} x {C}: the cluster form's exchange timed out; rerunning the layer through the classic kernels")
+            with hip.option("blk_cluster", 0):
+                r = hip.quantize_neurons(X, Xq, Wt, alphabet, want_values=False, want_resid=want_resid)
+                if hip.call_status(r) != 0:
+                    raise hip.GpfqError("quantize_dense failed again without the cluster form")
+            res_loc = r["resid"]
+            Q, idx = hip.assemble_kernel(r["idx"], alphabet)
     # (cluster_err: kept for callers of round 5's interface -- a timed-out exchange no longer leaves this function, see quantize_neurons_checked)
     out = dict(Q=Q, idx=idx, cluster_err=torch.zeros(1, dtype=torch.int32, device=W.device))
     if want_resid is not False:

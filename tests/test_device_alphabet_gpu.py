@@ -281,3 +281,50 @@ def test_two_streams_of_cluster_launches_are_serialised_and_correct(hip, oracle_
     for r in results:
         assert hip.cluster_timeouts(r) == 0
         assert np.array_equal(r["idx"].cpu().numpy(), idx)
+
+
+@pytest.mark.parametrize("N,C,m,levels", [(3, 20, 512, 3), (37, 70, 1000, 16), (64, 600, 1024, 3), (41, 33, 2048, 4), (19, 10, 3000, 3), (13, 9, 5008, 8),
+                                          (29, 2100, 768, 3), (45, 24, 1536, 2)])
+def test_record_prepass_in_runs_equals_one_record_per_workgroup(hip, oracle_mod, N, C, m, levels):
+    """Round 6: the block kernel's record pre-pass takes eight consecutive records per workgroup (every row read three times instead of
+    eighteen).  Same layer through both forms (option blk_prep_run): indices, values, residual vectors and the count of exact-fallback
+    decisions are equal, and equal to the oracle's."""
+    W, X, Xq = _synthetic(N, m, C, seed=N * m)
+    alphabet, _ = oracle_mod.layer_alphabet(W, np.linspace(-1, 1, levels), 3)
+    Q, idx, resid = oracle_mod.layer(W, X, Xq, alphabet)
+    outs = []
+    try:
+        for run in (0, 8, 4):                                      # (8 / 4: runs of records whatever the walk's length; 1, the default, only from 2048 steps)
+            hip.set_option("blk_prep_run", run)
+            with hip.option("blk_cluster", 0):
+                r = hip.quantize_neurons(_dev(X), _dev(Xq), _dev(W.T), alphabet, want_u=True, path=1)
+            assert "gpfq_blk_kernel" in hip.last_dense_kernel()
+            outs.append((r["idx"].cpu().numpy(), r["Q"].cpu().numpy(), r["u"].cpu().numpy(), r["resid"].cpu().numpy(), hip.exact_fallbacks(r)))
+    finally:
+        hip.set_option("blk_prep_run", 1)
+    for other in outs[1:]:
+        for a, b in zip(outs[0][:3], other[:3]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(other[0], idx) and np.array_equal(other[1], Q.astype(np.float32))
+        np.testing.assert_allclose(other[3], resid, rtol=RESID_RTOL)
+        if m <= 1024:
+            assert outs[0][4] == other[4]                          # one chunk per thread: the same order of additions, the same records bit for bit
+
+
+@pytest.mark.parametrize("N,C,m,levels", [(61, 70, 512, 3), (40, 33, 1000, 16), (33, 600, 1024, 2), (18, 24, 2100, 3), (15, 70, 3100, 3), (29, 5, 200, 3)])
+def test_overlapped_layer_driver_equals_the_one_stream_form(hip, layer, oracle_mod, N, C, m, levels):
+    """layer.quantize_dense_layer: the row norms and the record pre-pass on a second stream beside the median (gpfq_dense_layer_prepare /
+    _run; for symmetric alphabets the records are scaled in place once the alphabet exists).  Same tensors as the one-stream call and as the
+    oracle, also for a shape without a block-pipelined kernel (200 samples: the fallback inside)."""
+    W, X, Xq = _synthetic(N, m, C, seed=N + m)
+    Xq[1] = 0
+    unit = np.linspace(-1, 1, levels)
+    alphabet, rad = oracle_mod.layer_alphabet(W, unit, 3)
+    Q, idx, resid = oracle_mod.layer(W, X, Xq, alphabet)
+    Wd, Xd, Xqd = _dev(W), _dev(X), _dev(Xq)
+    outs = [layer.quantize_dense_layer(Wd, Xd, Xqd, unit, 3, overlap=ov) for ov in (True, False, True)]
+    for out in outs:
+        assert np.array_equal(out["idx"].cpu().numpy(), idx.T) and np.array_equal(out["Q"].cpu().numpy(), Q.T.astype(np.float32))
+        np.testing.assert_allclose(out["resid"].cpu().numpy(), resid, rtol=RESID_RTOL)
+        assert out["alphabet"].rad() == rad
+    assert torch.equal(outs[0]["resid"], outs[1]["resid"])
