@@ -22,7 +22,7 @@ STAMP = LIB + ".sha"
 OBJDIR = os.path.join(CSRC, "build")
 SOURCES = ["gpfq_capi.hip", "gpfq_onchip.hip", "gpfq_rows.hip", "gpfq_pipe.hip", "gpfq_blk.hip", "gpfq_wide.hip", "gpfq_stream.hip",
            "gpfq_gram.hip", "gpfq_gram_image.hip", "gpfq_gram_conv.hip", "gpfq_gram_s2.hip", "gpfq_gram_mfma.hip", "gpfq_misc.hip"]
-HEADERS = ["gpfq_device.hpp", "gpfq_launch.hpp", "gpfq_gram_tile.hpp", "gpfq_roles.hpp", os.path.join("..", "..", "include", "gpfq.h")]
+HEADERS = ["gpfq_device.hpp", "gpfq_launch.hpp", "gpfq_gram_tile.hpp", "gpfq_roles.hpp", "gpfq_blk_diag.hpp", os.path.join("..", "..", "include", "gpfq.h")]
 
 # -ffp-contract=off: the float32 products/subtraction of the residual update must round
 # separately (reference numerics); float64 accumulations use explicit fma().
@@ -40,6 +40,9 @@ DIAG_SOURCES = ("gpfq_blk.hip", "gpfq_wide.hip", "gpfq_gram_s2.hip", "gpfq_gram_
 if os.environ.get("GPFQ_DIAG"):
     for _src in DIAG_SOURCES:
         EXTRA_FLAGS[_src] = EXTRA_FLAGS.get(_src, []) + os.environ["GPFQ_DIAG"].split()
+    # (gpfq_blk.hip's switches live in gpfq_blk_diag.hpp, which only a -DGPFQ_BLK_DIAG build includes: the shipped unit compiles without them)
+    if any(f.startswith("-DGPFQ_BLK_") for f in os.environ["GPFQ_DIAG"].split()) and "-DGPFQ_BLK_DIAG" not in EXTRA_FLAGS["gpfq_blk.hip"]:
+        EXTRA_FLAGS["gpfq_blk.hip"] = EXTRA_FLAGS["gpfq_blk.hip"] + ["-DGPFQ_BLK_DIAG"]
     _tag = hashlib.sha256(" ".join(os.environ["GPFQ_DIAG"].split()).encode()).hexdigest()[:10]
     DIAG_DIR = os.path.join(CSRC, "diag_" + _tag)
     LIB = os.path.join(DIAG_DIR, "libgpfq_hip.so")
@@ -124,9 +127,13 @@ def build(force=False, verbose=False):
         os.makedirs(OBJDIR, exist_ok=True)
         if DIAG_DIR:
             os.makedirs(DIAG_DIR, exist_ok=True)
-        if force and not DIAG_DIR:
-            for f in os.listdir(OBJDIR):
-                os.remove(os.path.join(OBJDIR, f))
+        if force:
+            # a forced build starts from no objects: the shipped build's, or -- a diagnostic build -- the diagnostic directory's own
+            # (the objects it shares with the shipped build stay: they are checked against their content stamps like any other)
+            for d in ([DIAG_DIR] if DIAG_DIR else [OBJDIR]):
+                for f in os.listdir(d):
+                    if f.endswith(".o") or f.endswith(".o.sha"):
+                        os.remove(os.path.join(d, f))
         with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
             objs = list(ex.map(lambda s: _compile(hipcc, s, verbose), SOURCES))
         tmp_lib = LIB + ".tmp.%d" % os.getpid()

@@ -374,14 +374,8 @@ gpfq_blk_scale_kernel(char *__restrict__ recs, int64_t rec_bytes, int hdr, int m
 // slot in turn, wherever the decision wavefront IS the slot -- the four-group shapes with one neuron per lane: its own flush (eight slots'
 // worth at a time, 64-bit address arithmetic on operands hipcc spills at three wavefronts per SIMD) cost those shapes 9-12 % while the sweeps
 // idle at the barrier.  Everywhere else the decision wavefront, which has the slack there (profiles/r05/sweep_side_flush*.txt).
-#if defined(GPFQ_BLK_SWEEP_FLUSH_ALL)          // diagnostic builds: every shape one way or the other
-template <int G, int NL, bool CL = false> constexpr bool blk_sweep_flush() { return true; }
-#elif defined(GPFQ_BLK_SWEEP_FLUSH_NONE)
-template <int G, int NL, bool CL = false> constexpr bool blk_sweep_flush() { return CL; }
-#else
 // (and the cluster form: its decision wavefront has no register to spare for the flush's addresses)
 template <int G, int NL, bool CL = false> constexpr bool blk_sweep_flush() { return (G == 4 && NL == 1) || CL; }
-#endif
 
 // LDS carve-up (byte offsets), shared by host and device.
 struct BlkLds {
@@ -463,22 +457,14 @@ struct BlkK {
     int cl_fault;               // tests (option blk_cluster_fault): slice 1 of cluster 0 never publishes
 };
 
-#ifdef GPFQ_BLK_NO_MFMA            // diagnostic build: phase D on the vector unit everywhere (A/B timing of round 4's matrix form)
-constexpr bool kNoMfmaD = true;
+// Diagnostic builds only (GPFQ_DIAG="-DGPFQ_BLK_DIAG -DGPFQ_BLK_STAMPS ...", quantized_neural_networks_amd/build.py): gpfq_blk_diag.hpp holds
+// the in-kernel phase stamps and the two A/B switches of round 4's matrix form.  The shipped translation unit compiles without it.
+#ifdef GPFQ_BLK_DIAG
+#include "gpfq_blk_diag.hpp"
 #else
-constexpr bool kNoMfmaD = false;
-#endif
-
-#ifdef GPFQ_BLK_NO_FUSED           // diagnostic build: matrix-unit phase D as a phase of its own, after the updates (round 4's first form)
-constexpr bool kNoFused = true;
-#else
-constexpr bool kNoFused = false;
-#endif
-
-#ifdef GPFQ_BLK_STAMPS
-#define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
+constexpr bool kNoMfmaD = false, kNoFused = false;
 #define STAMP(var) do { } while (0)
+#define STAMP_DO(...)
 #endif
 
 // ---- cluster form: the exchange between the decision wavefronts of a cluster's slices (CL instantiations) ----
@@ -616,16 +602,6 @@ template <int G, int S, int NSW, int NL> constexpr const int *blk_split()
 
 template <int G, int S, int NSW, int NL> constexpr bool blk_split_has(int k)
 {
-#ifdef GPFQ_BLK_SPLIT_ENV
-    // diagnostic build: the split of the 8-wavefront shapes comes from the environment (GPFQ_BLK_SPLIT="2,2,2,2,2,2,2,2"), every pair
-    // count up to one more than an even split is instantiated
-    if (NSW == 8 && k <= (S + NSW - 1) / NSW + 1) return true;
-    if (NSW == 11) {                                               // every count from two below the shape's largest up to it
-        int mx = 0;
-        for (int w = 0; w < NSW; ++w) mx = blk_split<G, S, NSW, NL>()[w] > mx ? blk_split<G, S, NSW, NL>()[w] : mx;
-        if (k >= 1 && k >= mx - 2 && k <= mx) return true;
-    }
-#endif
     for (int w = 0; w < NSW; ++w)
         if (blk_split<G, S, NSW, NL>()[w] == k) return true;
     return false;
@@ -651,11 +627,9 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     const int nslots = K.nblk + 1;
     const int o_x  = HDR + 8 * (pbase + kq);                      // float2 x   [pair]  (row t - B of record t)
     int o_q = o_x + 4 * MP;                                       // float2 xq  [pair]
-#ifndef GPFQ_BLK_MERGED_READS
     // (opaque to the compiler: it would fuse the x and xq reads of a pair -- 4 MP bytes apart -- into ONE ds_read2st64_b64, which the
     //  LDS serves as two 32-bank accesses in 8 cycles; two ds_read_b64 take 2 cycles each: MI355X_MICROARCH.md, LDS)
     asm volatile("" : "+v"(o_q));
-#endif
     constexpr int DB = blk_row64(G, B) ? 16 : 8;                  // bytes of a sample pair of row t + B
     const int o_d  = HDR + 8 * MP + DB * (pbase + kq);           // double2 (float2) xqd[pair]  (row t + B)
     using DRaw = std::conditional_t<blk_row64(G, B), double2, float2>;   // as it sits in the record; converted where it is consumed
@@ -685,10 +659,6 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     const unsigned lane16 = (unsigned)lane * 16u;
     auto issue_piece = [&](int b1, int k) {
         const int pc = wave + NSW * k;
-#ifdef GPFQ_BLK_X_DMA2                 // timing experiment (same results): every piece of the record stream twice
-        glds16_s(K.recs + (int64_t)b1 * L.tile_bytes + ((int64_t)pc << 10), lane16,
-                 ldsT_addr + (unsigned)(b1 & 1) * (unsigned)L.tile_pitch + ((unsigned)pc << 10));
-#endif
         glds16_s(K.recs + (CL ? cs.rec_off : (int64_t)0) + (int64_t)b1 * L.tile_bytes + ((int64_t)pc << 10), lane16,
                  ldsT_addr + (unsigned)(b1 & 1) * (unsigned)L.tile_pitch + ((unsigned)pc << 10));
     };
@@ -820,9 +790,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     };
     for (int b = 0; b < nslots; ++b) {
         STAMP(st0);
-#ifdef GPFQ_BLK_STAMPS
-        if (b) acc_t += st0 - st5;                                // from the barrier to the top of the next slot: control word, next operands
-#endif
+        STAMP_DO(if (b) acc_t += st0 - st5;)   // from the barrier to the top of the next slot: control word, next operands
         // (blk_sweep_flush shapes) block b - 1's outputs -- final since the barrier, slow path included -- go from the LDS ring to memory
         // here, by one sweep wavefront per slot in turn: lane = (neuron, step), a byte and a float each
         if (blk_sweep_flush<G, NL, CL>() && b >= 1 && wave == b % NSW && lane < NB * B && (!CL || cs.slice == 0)) {
@@ -907,20 +875,8 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             double acc[NL];
 #pragma unroll
             for (int n = 0; n < NL; ++n) acc[n] = 0.0;
-#ifdef GPFQ_BLK_X_MFMA2
-            double xdummy[NL] = {0.0, 0.0, 0.0, 0.0};
-#endif
-#ifdef GPFQ_BLK_X_VALU2
-            double xu[NL][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
-#endif
-#ifdef GPFQ_BLK_X_LDS2
-            float2 xl[2];
-#endif
             auto mfma_pair = [&](int pp, int i, const double2 &dd) {      // matrix instruction i = 0 .. 2 NL - 1 of pair pp
                 const int n = i % NL, e = i / NL;
-#ifdef GPFQ_BLK_X_MFMA2                // timing experiment (same results): every matrix instruction twice, the copy into a dummy accumulator
-                xdummy[n] = __builtin_amdgcn_mfma_f64_4x4x4f64(u[n][2 * pp + e], e ? dd.x : dd.y, xdummy[n], 0, 0, 0);
-#endif
                 acc[n] = __builtin_amdgcn_mfma_f64_4x4x4f64(u[n][2 * pp + e], e ? dd.y : dd.x, acc[n], 0, 0, 0);
             };
 #pragma unroll
@@ -959,26 +915,6 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
 #pragma unroll
                     for (int n = 0; n < NL; ++n) { wv[n] = fwq[st][n].x; qv[n] = fwq[st][n].y; }
                     update_pair(p, x2, q2, wv, qv);
-#ifdef GPFQ_BLK_X_VALU2                // timing experiment (same results): the pair's arithmetic twice, the copy into dummy registers
-                    {
-                        const pk2 xv = {x2.x, x2.y}, qx = {q2.x, q2.y};
-#pragma unroll
-                        for (int n = 0; n < NL; ++n) {
-                            pk2 pr = pk2{wv[n], wv[n]} * xv;
-                            asm volatile("" : "+v"(pr));
-                            pk2 dd = SYM ? __builtin_elementwise_fma(pk2{qv[n], qv[n]}, qx, pr) : pr - pk2{qv[n], qv[n]} * qx;
-                            asm volatile("" : "+v"(dd));
-                            xu[n][0] += (double)dd.x; xu[n][1] += (double)dd.y;
-                        }
-                    }
-#endif
-#ifdef GPFQ_BLK_X_LDS2                 // timing experiment (same results): the pair's operand reads twice
-                    if (pn < PW) {
-                        xl[0] = lds_ld<float2>(lds, tbase + sn * RB + o_x + 8 * pn * KQ);
-                        xl[1] = lds_ld<float2>(lds, tbase + sn * RB + o_q + 8 * pn * KQ);
-                        asm volatile("" :: "v"(xl[0]), "v"(xl[1]));
-                    }
-#endif
                     if (p > 0) {                                   // the previous pair's 2 NL matrix instructions, spread over this pair's B steps
 #pragma unroll
                         for (int i = 0; i < 2 * NL; ++i)
@@ -994,12 +930,6 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
             for (int i = 0; i < 2 * NL; ++i) mfma_pair(PW - 1, i, dprev);
 #pragma unroll
             for (int n = 0; n < NL; ++n) { acc[n] = ror_add<8>(acc[n]); acc[n] = ror_add<4>(acc[n]); }   // blocks: lane bits 2, 3
-#ifdef GPFQ_BLK_X_MFMA2
-            asm volatile("" :: "v"(xdummy[0]), "v"(xdummy[1]), "v"(xdummy[2]), "v"(xdummy[3]));
-#endif
-#ifdef GPFQ_BLK_X_VALU2
-            asm volatile("" :: "v"(xu[0][0]), "v"(xu[0][1]), "v"(xu[1][0]), "v"(xu[1][1]), "v"(xu[2][0]), "v"(xu[2][1]), "v"(xu[3][0]), "v"(xu[3][1]));
-#endif
             if (b + 1 < nslots && (lane & 12) == 0) {             // one lane per (step, neuron group)
                 const int od = L.off_d + ((((((b + 1) & 1) * NW + wave) * B) + (lane & 3)) * NB + NL * (lane >> 4)) * 8;
                 if constexpr (NL == 4) {
@@ -1187,20 +1117,13 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         STAMP(st3);
         dma_wait();                                               // this wavefront's share of the next tile has landed
         STAMP(st4);
-#ifndef GPFQ_BLK_X_NOBAR               // timing experiment (WRONG results): no barrier between the slots, no slow path -- what free-running wavefronts could reach
         slot_barrier();
-#endif
         STAMP(st5);
-#ifdef GPFQ_BLK_STAMPS
-        acc_dma += st1 - st0; acc_u += st2 - st1; acc_d += st3 - st2; acc_w += st4 - st3; acc_b += st5 - st4;
-#endif
+        STAMP_DO(acc_dma += st1 - st0; acc_u += st2 - st1; acc_d += st3 - st2; acc_w += st4 - st3; acc_b += st5 - st4;)
 
         // ---- slow path: neurons of block b stopped at an uncertifiable step (rare) ----
         {
         int ctl = lds_ld<int>(lds, L.off_ctl + 4 * (b & 1));      // (requested first: it is waited for alone)
-#ifdef GPFQ_BLK_X_NOBAR
-        ctl = -1;
-#endif
         if constexpr (kHoist) {
             if (b + 1 < nslots) { preload_wq(b + 1); preload_rows(b + 1); }
         }
@@ -1213,14 +1136,14 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
         }
     }
 
-#ifdef GPFQ_BLK_STAMPS
+    STAMP_DO(
     if (K.stamps && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7)) {
         unsigned long long *o = K.stamps + (wave == 0 ? 0 : 8);
         o[0] = acc_dma; o[1] = acc_u; o[2] = acc_d; o[3] = acc_w; o[4] = acc_b; o[5] = (unsigned long long)nslots; o[6] = acc_t;
     }
     if (K.stamps && blockIdx.x == 0 && lane == 0) K.stamps[32 + wave] = acc_dma + acc_u + acc_d + acc_w;   // slot top -> arrival at the barrier, every sweep wavefront
 
-#endif
+    )
     // ---- epilogue: residual norms through the same partial-sum path, residual vectors straight to memory ----
     if (K.resid) {
         double ss[NL];
@@ -1432,9 +1355,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     (void)dt0; (void)dt1; (void)dt2; (void)dta; (void)dtb; (void)dacc_work; (void)dacc_bar; (void)dacc_pro; (void)dacc_chain; (void)dacc_tail;
     for (int b = 0; b < nslots; ++b) {
         STAMP(dt0);
-#ifdef GPFQ_BLK_STAMPS
-        if (b) dacc_tail += dt0 - dt2;                            // after the barrier
-#endif
+        STAMP_DO(if (b) dacc_tail += dt0 - dt2;)   // after the barrier
         const int tbase = (b & 1) * L.tile_pitch;
         const int cbq = (b & 1) * NB * B * 8;
         float  wc[B], qc[B];                                      // this block: weights, decisions (as float32 values)
@@ -1569,7 +1490,6 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
             const int u_zero = K.zero_idx;
             const float sym_a32 = (float)sym_top;
             auto pick = [&](double tt, double &kd) -> float {     // nearest member of the uniform alphabet, by arithmetic
-#ifndef GPFQ_BLK_NO_SYMPICK
                 if constexpr (SYM && NB <= 8) {
                     // {-a, 0, a} / {-a, a}, exactly symmetric (blk_sym_a): two comparisons with the boundaries -a/2, a/2 (or 0) instead of
                     // the progression's arithmetic -- ~10 instructions fewer per decision on the wavefront whose chain is the floor of the
@@ -1581,7 +1501,6 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
                     kd = up ? u_kmax : (mid ? 1.0 : 0.0);
                     return up ? sym_a32 : (mid ? 0.f : -sym_a32);
                 }
-#endif
                 kd = fmin(fmax(rint(fma(tt, u_inv, u_c0)), 0.0), u_kmax);
                 const int ki = (int)kd;
                 const int adj = (int)((unsigned)(u_plus >> ki) & 1u) - (int)((unsigned)(u_minus >> ki) & 1u);
@@ -1868,16 +1787,10 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
         using F_ = std::false_type;
         hnext = hnext == 2 ? 0 : hnext + 1;
         STAMP(dt1);
-#ifdef GPFQ_BLK_X_NOBAR
-        ctl_now = -1;
-#else
         if (kHdrChain || b >= K.nblk) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the last slot's only store; chain-prefetch shapes: the stores)
         asm volatile("s_barrier" ::: "memory");
-#endif
         STAMP(dt2);
-#ifdef GPFQ_BLK_STAMPS
-        dacc_work += dt1 - dt0; dacc_bar += dt2 - dt1; dacc_pro += dta - dt0; dacc_chain += dtb - dta;
-#endif
+        STAMP_DO(dacc_work += dt1 - dt0; dacc_bar += dt2 - dt1; dacc_pro += dta - dt0; dacc_chain += dtb - dta;)
 
         // ---- slow path: exact decision of the stopped step, then the chain resumes ----
         for (;;) {
@@ -1966,9 +1879,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     }
 
     if (K.fallback_count && n_fallback && (!CL || cs.slice == 0)) atomicAdd(K.fallback_count, n_fallback);   // rare
-#ifdef GPFQ_BLK_STAMPS
-    if (K.stamps && blockIdx.x == 0 && lane == 0) { K.stamps[16] = dacc_work; K.stamps[17] = dacc_bar; K.stamps[18] = dacc_pro; K.stamps[19] = dacc_chain; K.stamps[20] = dacc_tail; }
-#endif
+    STAMP_DO(if (K.stamps && blockIdx.x == 0 && lane == 0) { K.stamps[16] = dacc_work; K.stamps[17] = dacc_bar; K.stamps[18] = dacc_pro; K.stamps[19] = dacc_chain; K.stamps[20] = dacc_tail; })
     slot_barrier();                                               // residual-norm partials published
     if (K.resid) {
         double tot = 0.0;
@@ -2417,17 +2328,6 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, const De
     {
         const int *pw = blk_split<G, S, NSW, NL>();
         for (int w = 0; w < 12; ++w) K.pw[w] = (unsigned char)(w < NSW ? pw[w] : 0);
-#ifdef GPFQ_BLK_SPLIT_ENV
-        // (eleven sweep wavefronts, GPFQ_BLK_SPLIT11: counts from two below the shape's largest up to it)
-        if (const char *env = NSW == 8 ? getenv("GPFQ_BLK_SPLIT") : (NSW == 11 ? getenv("GPFQ_BLK_SPLIT11") : nullptr)) {
-            int v[12], n = 0, sum = 0;
-            for (const char *c = env; *c && n < NSW; ++c)
-                if (*c >= '0' && *c <= '9') { v[n] = *c - '0'; sum += v[n]; ++n; }
-            bool ok = n == NSW && sum == S;
-            for (int w = 0; ok && w < NSW; ++w) ok = v[w] >= 1 && blk_split_has<G, S, NSW, NL>(v[w]);
-            if (ok) for (int w = 0; w < NSW; ++w) K.pw[w] = (unsigned char)v[w];
-        }
-#endif
     }
     {
         MainKernelEvents ev(stream);       // (a benchmark's events around this launch alone, when it asked for them)

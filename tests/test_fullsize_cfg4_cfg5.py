@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_fullsize_configs import _conv_inputs, _conv_sample, _conv_slack_ab, _dense_inputs, _dense_oracle_sample
+from test_fullsize_configs import _conv_inputs, _conv_sample, _conv_slack_ab, _conv_whole_tensor, _dense_inputs, _dense_oracle_sample
 
 pytestmark = pytest.mark.gpu
 
@@ -47,6 +47,45 @@ def test_cfg4_conv_layer_full_size(hip, oracle_mod, cin, cout, hw):
     _conv_slack_ab(hip, layer, W, act_w, act_q, alphabet, out, kw)
     pairs = [(0, [0, cout - 1]), (cin - 1, [1, cout // 2])] if cin > 1 else [(0, [0, 1, cout // 2, cout - 1])]
     _conv_sample(hip, oracle_mod, act_w, act_q, W, alphabet, out, 3, 1, "SAME", pairs, host_gib_needed=4)
+
+
+@pytest.mark.parametrize("cin,cout,hw", CFG4_CONV)
+def test_cfg4_conv_layer_whole_tensor(hip, oracle_mod, cin, cout, hw):
+    """Round 6: every (channel, filter) pair of each cfg4 conv layer (96 ... 16 384 walks over 0.3 ... 5.1 M columns) -- the Gram path's
+    index tensor against the verbatim streaming kernel, channel by channel; 64+ pairs per layer against the C oracle."""
+    from quantized_neural_networks_amd import layer
+    dev = torch.device("cuda")
+    act_w, act_q, W = _conv_inputs(5008, hw, hw, cin, cout, 3, dev, 400 + cin + cout + hw)
+    if cin == 3:
+        act_q = act_w
+    alphabet, _ = layer.layer_alphabet(W, np.linspace(-1, 1, 8), 4)
+    out = layer.quantize_conv2d(W, act_w, act_q, alphabet, strides=(1, 1), padding="SAME", rate=(1, 1), want_resid=False)
+    chans = set(range(cin)) if cin == 3 else {0, cin // 3, cin // 2, cin - 1}
+    n = _conv_whole_tensor(hip, oracle_mod, act_w, act_q, W, alphabet, out, 3, 1, "SAME", chans, 22 if cin == 3 else 16)
+    assert n == cin * cout
+
+
+@pytest.mark.parametrize("ch,hw", [(64, 56), (128, 28), (256, 14), (512, 7)])
+def test_cfg5_resnet50_conv3x3_whole_tensor(hip, oracle_mod, ch, hw):
+    """Round 6: all 4 096 / 16 384 / 65 536 / 262 144 (channel, filter) walks of ResNet50's four 3x3 layer shapes at 4096 images (12.8 M ...
+    0.2 M columns) against the streaming kernel; 64 pairs against the oracle."""
+    from quantized_neural_networks_amd import layer
+    dev = torch.device("cuda")
+    act_w, act_q, W = _conv_inputs(4096, hw, hw, ch, ch, 3, dev, 500 + ch)
+    alphabet, _ = layer.layer_alphabet(W, np.linspace(-1, 1, 3), 3)
+    out = layer.quantize_conv2d(W, act_w, act_q, alphabet, strides=(1, 1), padding="SAME", rate=(1, 1), want_resid=False)
+    _conv_whole_tensor(hip, oracle_mod, act_w, act_q, W, alphabet, out, 3, 1, "SAME", {0, ch // 3, ch // 2, ch - 1}, 16)
+
+
+def test_cfg5_resnet50_conv1_whole_tensor(hip, oracle_mod):
+    """Round 6: all 192 (channel, filter) walks of ResNet50's conv1 (7x7 / 2 VALID on the padded 230 x 230 input, 49 steps over 51.4 M columns
+    each) against the streaming kernel on the GPU-built 10 GB patch matrices."""
+    from quantized_neural_networks_amd import layer
+    dev = torch.device("cuda")
+    act_w, act_q, W = _conv_inputs(4096, 230, 230, 3, 64, 7, dev, 51)
+    alphabet, _ = layer.layer_alphabet(W, np.linspace(-1, 1, 3), 3)
+    out = layer.quantize_conv2d(W, act_w, act_q, alphabet, strides=(2, 2), padding="VALID", rate=(1, 1), want_resid=False)
+    _conv_whole_tensor(hip, oracle_mod, act_w, act_q, W, alphabet, out, 7, 2, "VALID", set(), 0)
 
 
 @pytest.mark.parametrize("N,C", [(2048, 128), (128, 10)])
