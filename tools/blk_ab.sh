@@ -6,9 +6,9 @@
 #   waves ["N C m bits scalar oracle" ...]   8 against 11 sweep wavefronts, symmetric and general forms (rounds 3-4: sweep_waves_ab.sh, mfma_ab.sh)
 #   stamps ["shape" ...]                     the same with the in-kernel phase stamps (diagnostic build, rebuilt on the box; diag_stamps*.sh)
 #   flags "<hipcc flags>" ...                kernel time of the headline shape under diagnostic builds ("" = shipped): -DGPFQ_BLK_NO_MFMA (dot products
-#                                            on the vector unit), -DGPFQ_BLK_NO_FUSED (matrix-unit dot products as a phase of their own), and the marginal-cost
-#                                            switches -DGPFQ_BLK_X_MFMA2 / _VALU2 / _LDS2 / _DMA2 (a part of the slot issued twice, same results);
-#                                            add -DGPFQ_BLK_STAMPS for the stamps (rounds 3-4: diag_x.sh, diag_flags.sh)
+#                                            on the vector unit), -DGPFQ_BLK_NO_FUSED (matrix-unit dot products as a phase of their own), -DGPFQ_BLK_STAMPS
+#                                            (the in-kernel stamps): csrc/gpfq_blk_diag.hpp.  (The marginal-cost switches of rounds 4-5 -- a part of
+#                                            the slot issued twice, the barrier removed -- were removed in round 6: profiles/r04, profiles/r05 hold their numbers.)
 mode=$1; shift
 G='old kernel|pipe mode|oracle|cycles per slot|decision wave|slot top|rror'
 probe() { timeout 900 python tools/pipe_probe.py $1 2>&1 | grep -E "$G" | cut -c1-250; }
