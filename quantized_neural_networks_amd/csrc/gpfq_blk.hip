@@ -2203,9 +2203,10 @@ __host__ __device__ inline float blk_sym_of(const double *a, int M)
 }
 
 // A host alphabet's DevAlphabet, computed on the host (launch_blk), stored into the call's workspace.
-__global__ void gpfq_alphabet_store_kernel(DevAlphabet *out, DevAlphabet D)
+__global__ void gpfq_alphabet_store_kernel(DevAlphabet *out, DevAlphabet D, unsigned *counters)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) *out = D;
+    if (counters && threadIdx.x < 16) counters[threadIdx.x] = 0u;     // (the call's counter block, in the same launch: no memset of its own)
 }
 
 // The layer alphabet formed ON the device (gpfq_layer_alphabet_device): rad = float64(alphabet_scalar) * float64(float32 median) -- the
@@ -2382,7 +2383,10 @@ struct ClusterLaunchGuard {
 // with its progression computed here and stored in front of the records by one single-thread kernel.
 static hipError_t blk_alphabet(const PipeArgs &a, const DevAlphabet **alpha, hipStream_t stream)
 {
-    if (a.dev_alpha) { *alpha = a.dev_alpha; return hipSuccess; }
+    if (a.dev_alpha) {
+        *alpha = a.dev_alpha;
+        return a.zero_counters && a.fallback_count ? hipMemsetAsync(a.fallback_count, 0, 64, stream) : hipSuccess;
+    }
     DevAlphabet D{};
     D.M = a.A.M; D.zero_idx = a.A.zero_idx;
     D.rad = std::nan("");
@@ -2391,7 +2395,8 @@ static hipError_t blk_alphabet(const PipeArgs &a, const DevAlphabet **alpha, hip
     D.sym_a = blk_sym_a(a);
     D.ok = 1;
     DevAlphabet *dst = static_cast<DevAlphabet *>(a.workspace);
-    hipLaunchKernelGGL(gpfq_alphabet_store_kernel, dim3(1), dim3(64), 0, stream, dst, D);
+    hipLaunchKernelGGL(gpfq_alphabet_store_kernel, dim3(1), dim3(64), 0, stream, dst, D,
+                       a.zero_counters ? reinterpret_cast<unsigned *>(a.fallback_count) : (unsigned *)nullptr);
     *alpha = dst;
     return hipGetLastError();
 }

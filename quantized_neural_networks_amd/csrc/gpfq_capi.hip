@@ -360,10 +360,12 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
         a.variant = g_variant;
         // certified mode needs the per-row statistics in the workspace; without one, run the exact flow
         const bool have_ws = workspace && workspace_bytes >= onchip_stats_bytes(N) && (uintptr_t)workspace % 16 == 0;
-        if (have_ws) {
-            hipError_t e0 = hipMemsetAsync(workspace, 0, 64, s);       // exact-fallback counter
-            if (e0 != hipSuccess) return hip_fail(e0, "gpfq_quantize_neurons(workspace)");
-        }
+        bool counters_zeroed = false;
+        auto zero_counters = [&]() -> hipError_t {             // the call's counter block: exact fallbacks, cluster timeout, alphabet word
+            if (!have_ws || counters_zeroed) return hipSuccess;
+            counters_zeroed = true;
+            return hipMemsetAsync(workspace, 0, 64, s);
+        };
         // the pipelined kernel (gpfq_pipe.hip): rows of up to 2048 samples in layers wide enough to fill the chip
         // with 16 neurons per workgroup; narrow layers keep the latency-oriented kernels below
         if (!H.is_big) {
@@ -389,6 +391,7 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
                 (uintptr_t)workspace % 16 == 0 && workspace_bytes >= onchip_workspace_bytes(N, m, C)) {
                 pa.workspace = static_cast<char *>(workspace) + onchip_stats_bytes(N);
                 pa.fallback_count = static_cast<unsigned long long *>(workspace);
+                pa.zero_counters = 1;                              // (the kernel that stores the alphabet zeroes the counter block as well: one launch, no memset)
                 gpfq::note_dense_kernel("gpfq_blk_kernel (4 to 11 sweep wavefronts + 1 decision wavefront per workgroup, blocks of steps per slot)");
                 hipError_t e = gpfq::launch_blk(pa, s);
                 if (e != hipSuccess) return hip_fail(e, "gpfq_quantize_neurons(block-pipelined)");
@@ -396,12 +399,18 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
             }
             if (want && N > 0 && m > 0 && gpfq::pipe_supported(pa) && workspace && (uintptr_t)workspace % 16 == 0 &&
                 workspace_bytes >= onchip_workspace_bytes(N, m, C)) {
+                hipError_t ez = zero_counters();
+                if (ez != hipSuccess) return hip_fail(ez, "gpfq_quantize_neurons(workspace)");
                 pa.workspace = static_cast<char *>(workspace) + onchip_stats_bytes(N);
                 pa.fallback_count = static_cast<unsigned long long *>(workspace);
                 gpfq::note_dense_kernel("gpfq_pipe_kernel (8 sweep wavefronts over the sample axis + 1 decision wavefront per workgroup)");
                 hipError_t e = gpfq::launch_pipe(pa, s);
                 return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_quantize_neurons(pipelined)");
             }
+        }
+        {
+            hipError_t ez = zero_counters();
+            if (ez != hipSuccess) return hip_fail(ez, "gpfq_quantize_neurons(workspace)");
         }
         if (a.mode == 1 && N > 0 && have_ws) {
             auto *stats = reinterpret_cast<gpfq::RowStats *>(static_cast<char *>(workspace) + 64);

@@ -82,6 +82,7 @@ struct PipeArgs {
     int64_t ldt = 1;
     int64_t o_sj = 0, o_st = 1;
     const DevAlphabet *dev_alpha = nullptr;
+    int zero_counters = 0;                 // 1: launch_blk zeroes the call's 64-byte counter block (fallback_count) itself, with the alphabet's store
     int phase = 0;                         // 0: the whole call; 1: the alphabet-independent half (record pre-pass); 2: the rest (launch_blk)
 };
 // Block form (gpfq_blk.hip): B steps per slot; same arguments.

@@ -6,6 +6,9 @@
 #   bash tools/pmc.sh gpfq_blk_kernel tools/pmc_probe.py 3 1 0 0 0          (the headline kernel; rounds 1-3: pmc_run.sh / prof_r0N.sh)
 #   bash tools/pmc.sh gpfq_gram_s2 tools/conv1_probe.py                      (ResNet50 conv1; round 3: pmc_conv1.sh)
 #   bash tools/pmc.sh gpfq_gram_shift_nhwc tools/conv3x3_probe.py 4096 56 56 64 64      (round 3: pmc_nhwc.sh)
+# Round 6 added the groups VERDICT r05 asked for (instruction fetch / instruction cache, issue cycles of the memory instruction classes and
+# their in-flight levels, LDS address conflicts / unaligned stalls / FIFO-full cycles and the load / store split, the scalar data cache).
+#   PMC_LAYER=1 bash tools/pmc.sh gpfq_blk_kernel tools/pmc_probe.py 3 1 0 0 0        (the headline kernel as bench.py's step launches it)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 export PYTHONPATH=$ROOT
 KS=$1; shift
@@ -18,6 +21,11 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_LDS_DATA_FIFO_FULL SQ_INSTS_VMEM_RD SQ_WAVES" \
            "SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum" \
+           "SQ_IFETCH SQ_IFETCH_LEVEL SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_ICACHE_BUSY_CYCLES" \
+           "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_SMEM" \
+           "SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_CMD_FIFO_FULL SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_INSTS_LDS_LOAD_BANDWIDTH SQ_INSTS_LDS_STORE_BANDWIDTH" \
+           "SQ_ACTIVE_INST_VALU2 SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_THREAD_CYCLES_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_LEVEL_WAVES SQ_CYCLES" \
+           "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_TC_STALL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INSTS_SMEM_NORM" \
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   d=$OUT/p$i
