@@ -827,30 +827,33 @@ gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, S
             if (cls == pcur) atomicAdd(&h[lo >> 1], 1u << (16 * (lo & 1u)));
         }
     };
-    // a contiguous range of per_block elements per workgroup, 16-byte reads where the range allows.  Pass 1 takes its range in chunks of at
-    // most 65532 elements and merges its histogram after each: a 16-bit counter then cannot carry into its neighbour.
-    const int64_t lo_e = (int64_t)blockIdx.x * per_block, hi_e = lo_e + per_block < n ? lo_e + per_block : n;
-    const int64_t span = hi_e > lo_e ? hi_e - lo_e : 0;
-    const int64_t nchunks = PASS == 0 ? 1 : (span + 65531) / 65532;
-    const int64_t chunk = nchunks > 0 ? (((span + nchunks - 1) / nchunks) + 3) & ~(int64_t)3 : 0;
-    const bool vec = ((uintptr_t)W % 16 == 0) && (per_block % 4 == 0);
-    for (int64_t cc = 0; cc < nh * (nchunks > 0 ? nchunks : 1); ++cc) {
-        const int hs = (int)(cc / (nchunks > 0 ? nchunks : 1));   // which class's histogram
-        const int64_t c = cc - hs * (nchunks > 0 ? nchunks : 1);
+    // Grid-stride over 16-byte reads, at most 16 per thread (65536 elements per workgroup): consecutive workgroups read consecutive
+    // 16 KiB.  Pass 1's 16-bit counters must not carry into their neighbours: a workgroup counts at most 65532 elements in LDS -- thread 0's
+    // first read and the tail that is no whole read go straight to the global histogram.
+    const int64_t n4 = n / 4;                                     // (W is 16-byte aligned: launch_median_abs)
+    const float4 *W4 = reinterpret_cast<const float4 *>(W);
+    const int64_t stride4 = (int64_t)gridDim.x * kSelThreads;
+    auto count_global = [&](float w, int hs) {                    // (pass 1 only)
+        const unsigned key = __float_as_uint(w) & 0x7fffffffu, cls = key & 0xffff0000u, lo = key & 0xffffu;
+        if (cls == (hs ? p1 : p0)) atomicAdd(&hist[hs * kSel2B + lo], 1u);
+    };
+    for (int hs = 0; hs < nh; ++hs) {
         pcur = hs ? p1 : p0;
-        const int64_t c_lo = lo_e + c * chunk, c_hi = c_lo + chunk < hi_e ? c_lo + chunk : hi_e;
         for (int b = tid; b < WORDS; b += kSelThreads) h[b] = 0;
         __syncthreads();
-        if (vec && c_hi > c_lo) {
-            const float4 *W4 = reinterpret_cast<const float4 *>(W + c_lo);
-            const int64_t n4 = (c_hi - c_lo) / 4;
-            for (int64_t i = tid; i < n4; i += kSelThreads) {
-                const float4 v = W4[i];
-                count(v.x); count(v.y); count(v.z); count(v.w);
-            }
-            for (int64_t i = c_lo + n4 * 4 + tid; i < c_hi; i += kSelThreads) count(W[i]);
-        } else {
-            for (int64_t i = c_lo + tid; i < c_hi; i += kSelThreads) count(W[i]);
+        int64_t i = (int64_t)blockIdx.x * kSelThreads + tid;
+        if (PASS == 1 && tid == 0 && i < n4) {
+            const float4 v = W4[i];
+            count_global(v.x, hs); count_global(v.y, hs); count_global(v.z, hs); count_global(v.w, hs);
+            i += stride4;
+        }
+        for (; i < n4; i += stride4) {
+            const float4 v = W4[i];
+            count(v.x); count(v.y); count(v.z); count(v.w);
+        }
+        for (int64_t j = n4 * 4 + (int64_t)blockIdx.x * kSelThreads + tid; j < n; j += stride4) {      // (at most three elements)
+            if (PASS == 1) count_global(W[j], hs);
+            else atomicAdd(&hist[(__float_as_uint(W[j]) & 0x7fffffffu) >> 16], 1u);
         }
         __syncthreads();
         if (PASS == 0) {
@@ -933,8 +936,8 @@ gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, S
 
 hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream, size_t workspace_bytes)
 {
-    if (workspace_bytes < median_workspace_bytes_fast(n)) {
-        // the minimal workspace of rounds 1-5 (gpfq_median_abs_workspace_bytes()): the three-pass sequence
+    if (workspace_bytes < median_workspace_bytes_fast(n) || (uintptr_t)W % 16 != 0) {
+        // the minimal workspace of rounds 1-5 (gpfq_median_abs_workspace_bytes()), or a kernel that cannot be read 16 bytes at a time: the three-pass sequence
         hipError_t e = launch_median_begin(n, workspace, stream);
         for (int p = 0; p < 3 && e == hipSuccess; ++p) {
             e = launch_median_count(W, n, n, p, workspace, stream);
@@ -949,8 +952,9 @@ hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *worksp
     // contiguous ranges of a multiple of four elements, one workgroup per compute unit for a layer-sized kernel (a histogram is most of a
     // compute unit's LDS: a 257th workgroup would wait for a whole round)
     int64_t per = (n + 255) / 256;
-    per = (per + 3) & ~(int64_t)3;
+    per = (per + 4095) & ~(int64_t)4095;                          // whole rounds of a workgroup's 1024 16-byte reads, at most 16 of them (pass 1's 16-bit counters)
     if (per < 4096) per = 4096;
+    if (per > 65536) per = 65536;
     const unsigned grid = (unsigned)((n + per - 1) / per);
     const size_t lds = (size_t)kSel2A * sizeof(unsigned);         // one 128 KiB histogram per workgroup, either pass
     e = ensure_dynamic_lds((const void *)gpfq_median2_kernel<0>, kSel2A * sizeof(unsigned));
