@@ -811,8 +811,8 @@ gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, S
 {
     extern __shared__ unsigned h[];                               // PASS 0: [32768] counters; PASS 1: [32768] words of two 16-bit counters (128 KiB either way)
     __shared__ unsigned long long part[16];
-    __shared__ int found_bin, is_last;
-    __shared__ unsigned long long found_rank;
+    __shared__ int found_bin, is_last, found_thread;
+    __shared__ unsigned long long found_rank, found_before;
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr int WORDS = kSel2A;                                 // per histogram, either pass
     const unsigned p0 = PASS == 0 ? 0u : st[0].prefix, p1 = (PASS == 0 || nsel < 2) ? p0 : st[1].prefix;
@@ -907,16 +907,23 @@ gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, S
         unsigned long long before = incl - mine;
         for (int w = 0; w < (tid >> 6); ++w) before += part[w];
         const unsigned long long k = st[sel].k;
-        if (before <= k && k < before + mine) {                   // exactly one thread (or none if k is out of range)
-            unsigned long long acc = before;
-            int b = tid * PER;
-            for (; b < tid * PER + PER - 1; ++b) {
-                const unsigned c = src[b];
-                if (acc + c > k) break;
-                acc += c;
+        if (tid == 0) { found_thread = -1; found_before = 0; }
+        __syncthreads();
+        if (before <= k && k < before + mine) { found_thread = tid; found_before = before; }   // exactly one thread (or none if k is out of range)
+        __syncthreads();
+        // the bin inside that thread's PER (<= 64) bins: ONE parallel read by the first wavefront and a scan over its lanes (the thread
+        // walking its own bins one dependent load at a time cost 11-24 us of a 29-40 us pass)
+        if (tid < 64) {
+            const int T = found_thread;
+            const unsigned c = (T >= 0 && lane < PER) ? src[T * PER + lane] : 0u;
+            unsigned long long inc = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned long long up = __shfl_up(inc, off);
+                if (lane >= off) inc += up;
             }
-            found_bin = b;
-            found_rank = k - acc;
+            const unsigned long long kk = k - found_before, excl = inc - c;
+            if (T >= 0 && excl <= kk && kk < inc) { found_bin = T * PER + lane; found_rank = kk - excl; }
         }
         __syncthreads();
         if (tid == 0) {

@@ -82,6 +82,23 @@ while time.time() < t_end:
         n_dense += 1
         if not ok:
             bad.append(("dense", N, m, C, M, scalar, kind, path, opts, hip.last_dense_kernel()))
+        # round 6: the same layer through the layer driver with the alphabet formed and kept on the device (median -> rad * alphabet on the
+        # device, the Keras kernel read in place, the record pre-pass in runs of records / on a second stream), every shape -- the ones
+        # without a block-pipelined kernel fall back to the host alphabet inside
+        if M <= 64 and rng.random() < 0.6:
+            popts = dict(blk_prep_run=int(rng.choice([1, 1, 0, 4, 8])), blk_cluster=int(rng.choice([1, 1, 0, 1024])))
+            try:
+                for k, v in popts.items():
+                    hip.set_option(k, v)
+                out = layer.quantize_dense_layer(torch.from_numpy(W).to(dev), torch.from_numpy(X).to(dev), torch.from_numpy(Xq).to(dev),
+                                                 np.linspace(-1, 1, M), scalar, overlap=bool(rng.random() < 0.5))
+            finally:
+                hip.set_option("blk_prep_run", 1); hip.set_option("blk_cluster", 1)
+            ok = (np.array_equal(out["idx"].cpu().numpy(), io.T) and np.array_equal(out["Q"].cpu().numpy(), Qo.T.astype(np.float32))
+                  and np.allclose(out["resid"].cpu().numpy(), ro, rtol=1e-5, atol=0) and hip.call_status(out) == 0)
+            n_dense += 1
+            if not ok:
+                bad.append(("dense layer driver, device alphabet", N, m, C, M, scalar, kind, popts, hip.last_dense_kernel()))
     else:
         # ---- conv ---------------------------------------------------------------------------
         kh = int(rng.choice([1, 2, 3, 3, 3, 4, 5, 6, 7, 8])); kw = kh if rng.random() < 0.7 else int(rng.choice([1, 2, 3, 5, 7, 11, 17]))

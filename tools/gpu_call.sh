@@ -34,6 +34,8 @@ is_step() { case "$1" in suite|bench|ab|guard|configs|fuzz|trace|pmc|step|--) re
 while [ $# -gt 0 ]; do
   step=$1; shift
   args=()
+  # (the tag of `trace` / the kernel substring of `pmc` is taken as it comes, whatever it is called)
+  if [ "$step" == "trace" ] || [ "$step" == "pmc" ]; then args+=("$1"); shift; fi
   while [ $# -gt 0 ] && ! is_step "$1"; do args+=("$1"); shift; done
   [ "$1" == "--" ] && shift
   echo "=== $step ${args[*]}"
@@ -42,7 +44,7 @@ while [ $# -gt 0 ]; do
       if [ ${#args[@]} -gt 0 ]; then timeout 3000 python -m pytest tests -x -q -m gpu -k "${args[*]}" 2>&1 | tail -12 | tee $OUT/gpu_suite.txt
       else timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -12 | tee $OUT/gpu_suite.txt; fi ;;
     bench)
-      timeout 900 python bench.py "${args[@]}" > $OUT/bench.json 2> $OUT/bench.err; tail -2 $OUT/bench.err; show $OUT/bench.json ;;
+      timeout 900 python bench.py "${args[@]}" > $OUT/bench.json.tmp 2> $OUT/bench.err && mv $OUT/bench.json.tmp $OUT/bench.json; tail -2 $OUT/bench.err; show $OUT/bench.json ;;
     ab)
       for rep in 1 2; do
         (cd _base_r05 && timeout 600 python bench.py --steps 20 --warmup 3 --numpy-sample 0 --long-rows 0) > $OUT/bench_base_$rep.json 2> $OUT/bench_base_$rep.err
@@ -57,6 +59,7 @@ while [ $# -gt 0 ]; do
       timeout 1500 python tools/fuzz_parity.py ${args[0]:-300} 2>&1 | tail -6 | tee $OUT/fuzz.txt ;;
     trace)
       tag=${args[0]}
+      if [ ${#args[@]} -lt 2 ]; then echo "trace: <tag> <script> [args]"; continue; fi
       timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$tag -o t -- python3 "${args[@]:1}" > $OUT/trace_$tag.log 2>&1
       find $OUT/trace_$tag -name "t_kernel_stats.csv" -exec cp {} $OUT/trace_${tag}_kernel_stats.csv \;
       find $OUT/trace_$tag -name "t_kernel_trace.csv" -exec cp {} $OUT/trace_${tag}_kernel_trace.csv \;
