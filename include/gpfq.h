@@ -140,9 +140,9 @@ int gpfq_set_main_kernel_events(void *start_event, void *stop_event);
  *                  length >= 1024: every row beyond it (tests)
  *   "blk_cluster_nl"    that form's neurons per workgroup: 0 (default) 8 where the layer is then one round, else 16; 1 / 2 / 4 force 4 / 8 / 16
  *   "blk_cluster_map"   its workgroup id -> (cluster, slice) map: 0 a cluster's slices side by side in one XCD's queue, 1 consecutive ids
- *                  (the slices go round the XCDs), -1 (default) 1 where the slice count divides 8 or is a multiple of it -- an XCD then
- *                  streams one or two slices' records instead of all of them --, else the map under which the launch is fewer rounds
- *                  of whole clusters; same bits
+ *                  (the slices go round the XCDs), -1 (default) = 1: the chip holds 256 / slices whole clusters per round under map 1 and
+ *                  8 x (32 / slices) under map 0, never more (and where the slice count divides 8 an XCD streams one slice's records
+ *                  instead of all of them); map 0 only when forced (tests, A/B); same bits
  *   "blk_four_groups"   1 (default): layers of at most 1024 neurons on rows of 769..2048 samples take 4 neurons per workgroup; 0: 8
  *   "blk_wide_groups"   1 (default): rows of 1025..2048 samples in layers of more than 2048 neurons take 16 neurons per workgroup
  *                  (eleven sweep wavefronts, one round of workgroups); 0: 8 neurons per workgroup as narrower layers do

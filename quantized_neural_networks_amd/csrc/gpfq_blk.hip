@@ -2046,13 +2046,13 @@ static int blk_cluster_map(int nsl, int64_t clusters)
     // traffic is the headline's per slice (FETCH_SIZE at 4096 x 4096 on 8192 samples: 44.4 GB under map 0) -- so map 1 there.
     if (nsl > 0 && (8 % nsl == 0 || nsl % 8 == 0)) return 1;
     // Other slice counts: whole clusters per round -- an XCD's 32 CUs hold 32 / nsl of them under map 0 (the rest of its CUs wait a round
-    // for their mates), the chip's 256 hold 256 / nsl under map 1.  The map with fewer rounds, map 1 on a tie.  (At 256 clusters the two
-    // tie for 3, 5, 6 and 7 slices -- which is why they measured equal there; 20 slices: 32 rounds against 22, 122.0 against 83.9 ms at
-    // 4096 x 4096 on 20000 samples; 28 slices of 64 clusters tie at 8 rounds, 40.3 against 37.3 ms: profiles/r05/cluster_form.txt.)
-    if (nsl <= 0 || nsl > 32) return 0;
-    const int64_t per0 = 32 / nsl, per1 = 256 / nsl;
-    const int64_t r0 = ((clusters + 7) / 8 + per0 - 1) / per0, r1 = (clusters + per1 - 1) / per1;
-    return r1 <= r0 ? 1 : 0;
+    // for their mates), the chip's 256 hold 256 / nsl under map 1.  256 / nsl >= 8 (32 / nsl) for every nsl, so map 1 never needs more
+    // rounds than map 0 (the comparison this function used to make always came out the same way): the default is map 1 at
+    // every slice count; map 0 -- and its per-XCD deadlock-freedom argument -- runs only when the option forces it (tests, A/B).
+    // (Measured, profiles/r05/cluster_form.txt: the two tie at 3, 5, 6, 7 slices of 256 clusters; 20 slices: 32 rounds against 22,
+    //  122.0 against 83.9 ms at 4096 x 4096 on 20000 samples; 28 slices of 64 clusters: 40.3 against 37.3 ms.)
+    (void)clusters;
+    return 1;
 }
 
 static BlkShape blk_shape(int64_t m, int64_t C)

@@ -24,8 +24,8 @@ def _free_port():
 
 def _inputs(case, dev):
     g = torch.Generator(device=dev).manual_seed(11)
-    if case in ("dense", "dense_8bit", "dense_long"):
-        N, m, C = (120, 3100, 70) if case == "dense_long" else (300, 1024, 70)   # 70 neurons: uneven shards; dense_long: rows of the block kernel's cluster form (four slices per rank's launch)
+    if case in ("dense", "dense_8bit", "dense_long", "dense_device", "dense_device_long", "dense_device_wide"):
+        N, m, C = (120, 3100, 70) if case in ("dense_long", "dense_device_long") else ((40, 1024, 4500) if case == "dense_device_wide" else (300, 1024, 70))   # 70 neurons: uneven shards; dense_long: rows of the block kernel's cluster form (four slices per rank's launch)
         W = torch.randn((N, C), device=dev, generator=g) / np.sqrt(N)
         G = torch.randn((N, m), device=dev, generator=g)
         return dict(W=W, X=torch.relu(G), Xq=torch.relu(G + 0.1 * torch.randn((N, m), device=dev, generator=g)),
@@ -145,6 +145,19 @@ def _run(case, dev, group):
         return _run_network(name, dev, group, {"": None, "la0": False, "la1": True}[la])
     d = _inputs(case, dev)
     unit = np.linspace(-1, 1, int(round(2 ** d["bits"])))
+    if case.startswith("dense_device"):
+        # round 6: the layer driver with the alphabet formed and kept on the device (median -> rad * alphabet -> shard's kernel reading the
+        # Keras kernel -> all-gather of packed indices -> assembly from the device alphabet), the pre-pass on a second stream; _wide: shards
+        # of the 16-neuron shape at world size 2 (the Keras-layout flush on one GPU, neuron-major shards under a group)
+        out = layer.quantize_dense_layer(d["W"], d["X"], d["Xq"], unit, 3, group=group)
+        res = {k: v.cpu().numpy() for k, v in out.items() if k in ("Q", "idx", "resid")}
+        res["rad"] = np.float64(out["alphabet"].rad())
+        ref_alphabet, ref_rad = layer.layer_alphabet(d["W"], unit, 3, group)
+        assert res["rad"] == ref_rad
+        if group is None:                                        # ... equals the host alphabet's layer driver
+            ref = layer.quantize_dense(d["W"], d["X"], d["Xq"], ref_alphabet)
+            assert torch.equal(ref["Q"], out["Q"]) and torch.equal(ref["idx"], out["idx"]) and torch.equal(ref["resid"], out["resid"])
+        return res
     alphabet, rad = layer.layer_alphabet(d["W"], unit, 3, group)
     if case.startswith("dense"):
         W = d["W"][:, :d["neurons"]].contiguous() if "neurons" in d else d["W"]
@@ -171,6 +184,7 @@ def _worker(rank, world, port, case, result_dir):
 
 
 @pytest.mark.parametrize("case,world", [("dense", 2), ("dense", 3), ("dense_long", 2), ("dense_big_median", 2), ("conv3x3", 2), ("conv5x5", 3),
+                                        ("dense_device", 2), ("dense_device", 8), ("dense_device_long", 2), ("dense_device_wide", 2),
                                         ("dense_8bit", 3), ("conv3x3_8bit", 2), ("conv_filters_8bit", 2),
                                         ("network_mlp", 2), ("network_cnn", 2), ("network_cnn", 3), ("network_mlp_grid", 2),
                                         ("conv_filters", 2), ("conv_columns7", 3),    # fewer channels than ranks: image shards

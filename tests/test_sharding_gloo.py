@@ -55,12 +55,46 @@ def _standin_neuron_major(W, lo=0, hi=None):
     return W[:, lo:hi].t().contiguous()
 
 
+# ---- round 6: the device-resident alphabet's entry points (layer.quantize_dense_layer under a process group) ----
+def _standin_median(W, meanwhile=None, on_device=False):
+    return torch.from_numpy(np.array([np.median(np.abs(W.numpy()))], dtype=np.float32))
+
+
+def _standin_layer_alphabet_device(median32, unit_alphabet, alphabet_scalar):
+    from quantized_neural_networks_amd import hip
+    buf = torch.zeros(hip.GPFQ_DEVICE_ALPHABET_BYTES, dtype=torch.uint8)
+    buf[:8] = torch.from_numpy(np.array([np.float64(alphabet_scalar) * np.float64(median32.numpy()[0])]).view(np.uint8))   # the legacy-NumPy product (:544)
+    return hip.DeviceAlphabet(buf, unit_alphabet, alphabet_scalar)
+
+
+def _standin_dense_layer(X, Xq, W, dalpha, lo=0, hi=None, nrm32=None, keras_out=True, want_values=True, want_idx=True, want_resid=True, prepared=None):
+    import oracle
+    hi = W.shape[1] if hi is None else hi
+    Wn = np.ascontiguousarray(W.numpy()[:, lo:hi])
+    if hi > lo:
+        Q, idx, resid = oracle.layer(Wn, X.numpy(), Xq.numpy(), dalpha.values())
+    else:
+        Q, idx, resid = np.zeros((0, W.shape[0])), np.zeros((0, W.shape[0]), np.int8), np.zeros(0)
+    out = dict(idx=torch.from_numpy(idx.astype(np.int8)), Q=torch.from_numpy(Q.astype(np.float32)), resid=torch.from_numpy(resid), u=None,
+               workspace=torch.zeros(16, dtype=torch.uint8))
+    if keras_out:
+        out["idx"], out["Q"] = out["idx"].t().contiguous(), out["Q"].t().contiguous()
+    return out
+
+
+def _standin_assemble_device(qidx, dalpha, want_idx=True, bits=8, N=None):
+    return _standin_assemble(qidx, dalpha.values(), want_idx, bits, N)
+
+
 def _install_standins():
     """Swap the binding's entry points for CPU stand-ins in THIS process; returns the originals."""
     sys.path.insert(0, ROOT)
     from quantized_neural_networks_amd import hip
     names = dict(quantize_neurons=_standin_quantize, extract_patches=_standin_patches, assemble_kernel=_standin_assemble,
-                 pack_indices=_standin_pack, channel_planes=_standin_planes, neuron_major=_standin_neuron_major)
+                 pack_indices=_standin_pack, channel_planes=_standin_planes, neuron_major=_standin_neuron_major,
+                 median_abs=_standin_median, layer_alphabet_device=_standin_layer_alphabet_device,
+                 dense_layer_supported=lambda N, m, C, unit: True, quantize_dense_layer=_standin_dense_layer,
+                 assemble_kernel_device=_standin_assemble_device, call_status=lambda result: 0, last_dense_kernel=lambda: "stand-in")
     keep = {k: getattr(hip, k) for k in names}
     for k, v in names.items():
         setattr(hip, k, v)
@@ -84,7 +118,14 @@ def _worker(rank, world, port, case, result_dir):
         X = np.maximum(G, 0).astype(np.float32)
         Xq = np.maximum(G + 0.1 * r.standard_normal((N, m)), 0).astype(np.float32)
         alphabet = 0.3 * np.linspace(-1, 1, _dense_members(case))
-        out = layer.quantize_dense(torch.from_numpy(W), torch.from_numpy(X), torch.from_numpy(Xq), alphabet, group=group)
+        if case == "dense_device":
+            # round 6: median -> device alphabet -> shard -> all-gather of the indices -> assembly from the device alphabet (one stream:
+            # the second stream of the GPU form has no CPU counterpart)
+            out = layer.quantize_dense_layer(torch.from_numpy(W), torch.from_numpy(X), torch.from_numpy(Xq), np.linspace(-1, 1, 4), 2.0,
+                                             group=group, overlap=False)
+            out = {k: v for k, v in out.items() if k in ("Q", "idx", "resid")}
+        else:
+            out = layer.quantize_dense(torch.from_numpy(W), torch.from_numpy(X), torch.from_numpy(Xq), alphabet, group=group)
     else:
         Cin = 3 if case == "conv_channels" else 1            # Cin < world -> filters are sharded instead
         act = r.random((4, 6, 6, Cin)).astype(np.float32)
@@ -102,7 +143,7 @@ def _dense_members(case):
     return 200 if case == "dense_int16" else 4              # 200 members: int16 indices, gathered as bytes
 
 
-@pytest.mark.parametrize("case,world", [("dense", 2), ("dense_int16", 2), ("conv_channels", 2), ("conv_filters", 2),
+@pytest.mark.parametrize("case,world", [("dense", 2), ("dense_int16", 2), ("dense_device", 2), ("dense_device", 8), ("conv_channels", 2), ("conv_filters", 2),
                                         # the north-star's world size: 7 neurons / 3 channels / 5 filters over EIGHT ranks -- empty
                                         # shards, `per`-padded gathers, fewer channels than ranks (filters are sharded instead)
                                         ("dense", 8), ("dense_int16", 8), ("conv_channels", 8), ("conv_filters", 8)])
@@ -125,8 +166,16 @@ def test_sharded_equals_unsharded(case, world, tmp_path, oracle_mod):
             G = r.standard_normal((N, m))
             X = np.maximum(G, 0).astype(np.float32)
             Xq = np.maximum(G + 0.1 * r.standard_normal((N, m)), 0).astype(np.float32)
-            out = layer.quantize_dense(torch.from_numpy(W), torch.from_numpy(X), torch.from_numpy(Xq),
-                                       0.3 * np.linspace(-1, 1, _dense_members(case)))
+            if case == "dense_device":
+                out = layer.quantize_dense_layer(torch.from_numpy(W), torch.from_numpy(X), torch.from_numpy(Xq), np.linspace(-1, 1, 4), 2.0, overlap=False)
+                # ... which is the host alphabet's result for rad = 2 * median(|W|)
+                ref = layer.quantize_dense(torch.from_numpy(W), torch.from_numpy(X), torch.from_numpy(Xq),
+                                           np.float64(2.0) * np.float64(np.median(np.abs(W))) * np.linspace(-1, 1, 4))
+                assert torch.equal(ref["Q"], out["Q"]) and torch.equal(ref["idx"], out["idx"])
+                out = {k: v for k, v in out.items() if k in ("Q", "idx", "resid")}
+            else:
+                out = layer.quantize_dense(torch.from_numpy(W), torch.from_numpy(X), torch.from_numpy(Xq),
+                                           0.3 * np.linspace(-1, 1, _dense_members(case)))
         else:
             Cin = 3 if case == "conv_channels" else 1
             act = r.random((4, 6, 6, Cin)).astype(np.float32)
