@@ -621,7 +621,7 @@ __device__ __forceinline__ void blk_sweep_role(const BlkK &K, char *lds_generic,
     const bool writer = (lane & 15 & ~(G - 1)) == 0 && (row & ((1 << RSH) - 1)) == 0;   // one lane per (neuron, ng) publishes the folded sums
     const int nloc = NL * ng;                                     // first of this lane's NL neurons
     const int nrow = row >> RSH;                                  // the neuron (of the lane's NL) whose folded sums this row holds
-    const int64_t jbase = (CL ? cs.cl : (int64_t)blockIdx.x) * NB;
+    const int64_t jbase = cs.cl * NB;                             // (classic form: the workgroup's neuron block, see gpfq_blk_kernel)
     const unsigned ldsT_addr = lds_addr(lds_generic), ldsW_addr = lds_addr(lds_generic + L.off_w);
     const int64_t N = K.N;
     const int nslots = K.nblk + 1;
@@ -1191,7 +1191,7 @@ __device__ __forceinline__ void blk_decision_role(const BlkK &K, char *lds_gener
     // same decisions, same stores to the same addresses) and is left out of the counters
     const bool shadow = lane / R >= NB;
     const int n = shadow ? NB - 1 : lane / R, r = lane % R;
-    const int64_t wg = CL ? cs.cl : (int64_t)blockIdx.x;          // the workgroup's neurons: wg NB .. (cluster form: the cluster's)
+    const int64_t wg = cs.cl;                                     // the workgroup's neurons: wg NB .. (cluster form: the cluster's; classic form: its neuron block)
     const int64_t jn = wg * NB + n;
     const bool active = jn < K.C;
     const int64_t N = K.N;
@@ -1935,6 +1935,15 @@ gpfq_blk_kernel(BlkK K)
         cs.rec_off = (int64_t)cs.slice * K.slice_bytes;
         const int left = K.m - cs.slice * MP;
         cs.m_sl = left < 0 ? 0 : (left > MP ? MP : left);
+    }
+    if constexpr (!CL) {
+        // Classic form: workgroup id -> neuron block, XCD-aware (round 6).  Workgroups go to the eight XCDs round-robin by id, so with the
+        // identity map the two workgroups that share a 128-byte line of the Keras kernel's row (32 neurons) -- and of the Keras-layout
+        // outputs -- sit on DIFFERENT XCDs: every line of W crosses into two L2s and every output line is written back in halves.  Giving
+        // XCD x the x-th eighth of the neuron blocks keeps neighbours in one L2.  (Launches whose workgroup count is no multiple of 8 keep
+        // the identity.)
+        const unsigned nb = gridDim.x, b = blockIdx.x;
+        cs.cl = (nb & 7u) == 0u ? (int64_t)((b & 7u) * (nb >> 3) + (b >> 3)) : (int64_t)b;
     }
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const BlkLds L = blk_lds(MP, NB, B, NSW, G, CL);
