@@ -17,7 +17,11 @@ from . import hip
 # ------------------------------------------------------------------------------------------
 # alphabet radius
 # ------------------------------------------------------------------------------------------
-_SHARDED_MEDIAN_MIN = 1 << 22      # below this many weights one GPU counts faster than three all-reduces take
+# Below this many weights one GPU selects the median faster than three dependent all-reduces take.  Round 6: the one-GPU select is two reads
+# of the data in two launches (70 us at 16.8 M weights), the sharded protocol three reads of a 1 / world share + three all-reduces of 16 KiB
+# (tens of microseconds EACH over RCCL, and every one waits for the slowest rank): the break-even moved from 4 M to about 32 M weights --
+# the north-star layer (16.8 M) selects locally on every rank, VGG16's fc1 (102.8 M) shards its counting.
+_SHARDED_MEDIAN_MIN = 1 << 25
 
 
 def median_abs(W, group=None, meanwhile=None):

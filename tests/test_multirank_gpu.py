@@ -145,6 +145,8 @@ def _run(case, dev, group):
         return _run_network(name, dev, group, {"": None, "la0": False, "la1": True}[la])
     d = _inputs(case, dev)
     unit = np.linspace(-1, 1, int(round(2 ** d["bits"])))
+    if case == "dense_big_median":
+        layer._SHARDED_MEDIAN_MIN = 1 << 22                      # (the sharded counting protocol at a test's size: the default threshold is 32 M weights since round 6)
     if case.startswith("dense_device"):
         # round 6: the layer driver with the alphabet formed and kept on the device (median -> rad * alphabet -> shard's kernel reading the
         # Keras kernel -> all-gather of packed indices -> assembly from the device alphabet), the pre-pass on a second stream; _wide: shards
