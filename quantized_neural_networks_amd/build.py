@@ -36,7 +36,7 @@ EXTRA_FLAGS = {"gpfq_pipe.hip": ["-fno-slp-vectorize"], "gpfq_blk.hip": ["-fno-s
 # A diagnostic build lives beside the shipped library, in csrc/diag_<hash of the flags>/ (round 5): several variants can be built in the
 # CPU container, travel to the GPU box together and be timed there without a compiler run (the box's minutes are the scarce resource);
 # objects of sources that take no diagnostic flag are shared with the shipped build.
-DIAG_SOURCES = ("gpfq_blk.hip", "gpfq_wide.hip", "gpfq_gram_s2.hip", "gpfq_gram_image.hip")
+DIAG_SOURCES = ("gpfq_blk.hip", "gpfq_wide.hip", "gpfq_gram_s2.hip", "gpfq_gram_image.hip", "gpfq_misc.hip")
 if os.environ.get("GPFQ_DIAG"):
     for _src in DIAG_SOURCES:
         EXTRA_FLAGS[_src] = EXTRA_FLAGS.get(_src, []) + os.environ["GPFQ_DIAG"].split()

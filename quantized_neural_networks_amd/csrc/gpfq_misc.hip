@@ -811,10 +811,13 @@ gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, S
 {
     extern __shared__ unsigned h[];                               // PASS 0: [32768] counters; PASS 1: [32768] words of two 16-bit counters (128 KiB either way)
     __shared__ unsigned long long part[16];
-    __shared__ int found_bin, is_last, found_thread;
-    __shared__ unsigned long long found_rank, found_before;
+    __shared__ int is_last;
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr int WORDS = kSel2A;                                 // per histogram, either pass
+#ifdef GPFQ_MEDIAN_STAMPS
+    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(ctl) + 2 + PASS * 3;      // diagnostic build: [pass][3] in the control block's spare words
+    const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const unsigned p0 = PASS == 0 ? 0u : st[0].prefix, p1 = (PASS == 0 || nsel < 2) ? p0 : st[1].prefix;
     const bool split = p1 != p0;
     const int nh = split ? 2 : 1;                                 // (the two middle values of an even count in different classes -- rare: the range is read once per class)
@@ -870,6 +873,9 @@ gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, S
         }
         __syncthreads();
     }
+#ifdef GPFQ_MEDIAN_STAMPS
+    if (blockIdx.x == 0 && tid == 0) stamps[0] = __builtin_amdgcn_s_memrealtime() - ts0;          // workgroup 0: zeroing + reads + merge
+#endif
     // ---- the last workgroup to get here picks (each wavefront waits for its own merges -- agent-scope atomics -- to be acknowledged: a
     // workgroup-scope release, no cache maintenance; an agent-scope fence per thread writes the L2 back thousands of times per pass) ----
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -877,6 +883,10 @@ gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, S
     if (tid == 0) is_last = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
     __syncthreads();
     if (!is_last) return;
+#ifdef GPFQ_MEDIAN_STAMPS
+    const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) stamps[1] = ts1 - ts0;                                                         // the last workgroup: from its start to its ticket
+#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (PASS == 0 && tid == 0) {
         st[0].prefix = 0; st[0].pad = 0; st[0].k = k0;
@@ -884,9 +894,17 @@ gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, S
     }
     __syncthreads();
     constexpr int BINS = PASS == 0 ? kSel2A : kSel2B, PER = BINS / kSelThreads;      // 32 / 64 bins per thread
-    for (int sel = 0; sel < nsel; ++sel) {
-        const unsigned *src = hist + ((PASS == 1 && sel && split) ? kSel2B : 0);
-        if (tid == 0) { found_bin = BINS - 1; found_rank = 0; }
+    // One scan of the histogram serves BOTH order statistics while they share their class (always in pass 0, nearly always in pass 1:
+    // the two middle ranks of an even count are adjacent); when they have parted, the second class's histogram is scanned for the second.
+    // (Two scans for two ranks in one histogram made the pick 12 / 20 us of a 26 / 36 us pass: `tools/median_probe.py`.)
+    __shared__ int f_thread[2];
+    __shared__ unsigned long long f_before[2];
+    unsigned long long rank_of[2];
+    rank_of[0] = st[0].k; rank_of[1] = nsel > 1 ? st[1].k : 0;
+    for (int scan = 0; scan < (nsel > 1 && split ? 2 : 1); ++scan) {
+        const unsigned *src = hist + (scan ? kSel2B : 0);
+        const int s_lo = scan, s_hi = (nsel > 1 && !split) ? 2 : scan + 1;       // the order statistics this scan serves
+        if (tid < 2) { f_thread[tid] = -1; f_before[tid] = 0; }
         // (plain 16-byte loads: the acquire fence above has dropped this workgroup's stale lines, and every merge was acknowledged before
         //  its workgroup took a ticket -- PER single agent-scope loads in sequence cost 50-90 us per pick)
         unsigned long long mine = 0;
@@ -906,15 +924,13 @@ gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, S
         __syncthreads();
         unsigned long long before = incl - mine;
         for (int w = 0; w < (tid >> 6); ++w) before += part[w];
-        const unsigned long long k = st[sel].k;
-        if (tid == 0) { found_thread = -1; found_before = 0; }
+        for (int sel = s_lo; sel < s_hi; ++sel)
+            if (before <= rank_of[sel] && rank_of[sel] < before + mine) { f_thread[sel] = tid; f_before[sel] = before; }   // one thread per rank (none if it is out of range)
         __syncthreads();
-        if (before <= k && k < before + mine) { found_thread = tid; found_before = before; }   // exactly one thread (or none if k is out of range)
-        __syncthreads();
-        // the bin inside that thread's PER (<= 64) bins: ONE parallel read by the first wavefront and a scan over its lanes (the thread
-        // walking its own bins one dependent load at a time cost 11-24 us of a 29-40 us pass)
-        if (tid < 64) {
-            const int T = found_thread;
+        // the bin inside that thread's PER (<= 64) bins: one parallel read and a scan over the lanes of a wavefront per order statistic
+        const int wsel = s_lo + (tid >> 6);
+        if (wsel < s_hi) {
+            const int T = f_thread[wsel];
             const unsigned c = (T >= 0 && lane < PER) ? src[T * PER + lane] : 0u;
             unsigned long long inc = c;
 #pragma unroll
@@ -922,16 +938,20 @@ gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, S
                 const unsigned long long up = __shfl_up(inc, off);
                 if (lane >= off) inc += up;
             }
-            const unsigned long long kk = k - found_before, excl = inc - c;
-            if (T >= 0 && excl <= kk && kk < inc) { found_bin = T * PER + lane; found_rank = kk - excl; }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            st[sel].k = found_rank;
-            st[sel].prefix = st[sel].prefix | ((unsigned)found_bin << (PASS == 0 ? 16 : 0));
+            const unsigned long long kk = rank_of[wsel] - f_before[wsel], excl = inc - c;
+            const bool hit = T >= 0 && excl <= kk && kk < inc;
+            const unsigned long long any = __ballot(hit);
+            if (hit || (any == 0ull && lane == 0)) {              // (a rank beyond the data -- cannot happen -- keeps the last bin, rank 0)
+                const int fb = hit ? T * PER + lane : BINS - 1;
+                st[wsel].k = hit ? kk - excl : 0ull;
+                st[wsel].prefix = st[wsel].prefix | ((unsigned)fb << (PASS == 0 ? 16 : 0));
+            }
         }
         __syncthreads();
     }
+#ifdef GPFQ_MEDIAN_STAMPS
+    if (tid == 0) stamps[2] = __builtin_amdgcn_s_memrealtime() - ts1;                            // the pick
+#endif
     if (tid == 0) {
         ctl->done = 0;
         if (PASS == 1 && out) {
