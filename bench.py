@@ -73,8 +73,12 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=512, help="neurons timed on the host cores (0 = skip)")
     ap.add_argument("--long-rows", type=int, default=8192,
                     help="also time the same layer on this many calibration samples (a secondary record: the block kernel's cluster form); 0 = skip")
-    ap.add_argument("--no-overlap", dest="overlap", action="store_false",
-                    help="one stream: median, alphabet, row norms, record pre-pass, kernel in sequence (default: the pre-pass on a second stream beside the median)")
+    ap.add_argument("--overlap", dest="overlap", action="store_true",
+                    help="row norms + record pre-pass on a second HIP stream beside the median (gpfq_dense_layer_prepare / _run).  Off by default: measured on "
+                         "this chip the two cross-stream waits idle the GPU ~17 + 22 us and the overlap hides ~50 us -- 3.034-3.049 ms per step with it, "
+                         "3.033-3.050 without, and slower with it once the medians are prefetched (profiles/r06/README.md)")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="(the default) one stream: median, alphabet, row norms, record pre-pass, kernel in sequence")
+    ap.set_defaults(overlap=False)
     ap.add_argument("--numpy-sample", type=int, default=-1,
                     help="neurons of the NumPy process-pool baseline (the reference-shaped one); -1 = 2 x host cores, 0 = skip")
     args = ap.parse_args()
@@ -144,8 +148,9 @@ def main():
         lo, hi = layer.shard_bounds(C_total, world, rank)
         if not device_path:
             return step_host(i_timed, C_total, Wd, lo, hi)
-        # The layer's two independent halves on two HIP streams (layer.quantize_dense_layer): row norms + record pre-pass (activations only)
-        # on the side stream, median of |W| + alphabet (kernel only) on this one; the recurrence follows both.  --no-overlap: one stream.
+        # --overlap: the layer's two independent halves on two HIP streams (layer.quantize_dense_layer(overlap=True)): row norms + record
+        # pre-pass (activations only) on the side stream, median of |W| + alphabet (kernel only) on this one; the recurrence follows both.
+        # Default: one stream.
         # (st["alphabet_pre"], secondary figure only: the alphabet formed before the loop, as _prefetch_medians does for a network)
         ws = None
         if args.overlap:
@@ -155,11 +160,9 @@ def main():
             with torch.cuda.stream(side):
                 hip.dense_layer_prepare(Xd, Xqd, unit_alphabet, hi - lo, ws)
         dalpha = st.get("alphabet_pre") or layer.layer_alphabet_device(Wd, unit_alphabet, args.alphabet_scalar, group)   # N > 1: counting sharded over ranks
-        nrm = None
+        nrm = None                            # (the row norms are formed inside the layer call: its launch also zeroes the call's counter block)
         if args.overlap:
             main.wait_stream(side)
-        else:
-            nrm = hip.row_norms(Xqd)
         if i_timed is not None:
             hip.set_main_kernel_events(*ev_k[i_timed])
             ev[i_timed][0].record()          # same stream the kernel is launched on (torch current stream)
@@ -337,8 +340,8 @@ def main():
                 "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS,
                 "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
                 "kernel_ms_avg": k_avg_s * 1e3, "kernel_ms_min": float(np.min(kernel_ms)),
-                # events around the library call that launches the kernel: with the overlapped step (default) the alphabet-dependent half
-                # (one in-place pass over the records for the symmetric alphabet + this kernel); --no-overlap: record pre-pass + this kernel
+                # events around the library call that launches the kernel: record pre-pass + this kernel (--overlap: the alphabet-dependent
+                # half only -- one in-place pass over the records for the symmetric alphabet + this kernel)
                 "call_ms_avg": float(np.mean(call_ms)),
                 # the same fraction on the bracket rounds 1-3 quoted (events around the whole call): comparable across rounds
                 "frac_call": alg_flops / (float(np.mean(call_ms)) / 1e3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,

@@ -170,9 +170,9 @@ int gpfq_set_main_kernel_events(void *start_event, void *stop_event);
  */
 int gpfq_set_option(const char *key, int value);
 /* Round 6 additions to the option list above:
- *   "blk_prep_run"  1 (default): the block kernel's record pre-pass takes runs of eight records per workgroup (each row read three times
- *                  instead of eighteen) for walks of 2048+ steps; 0: one record per workgroup (the same records); 4 / 8: runs of that many
- *                  records whatever the walk's length (tests)
+ *   "blk_prep_run"  1 (default): the block kernel's record pre-pass takes runs of 4 .. 16 records per workgroup (each row read about four
+ *                  times instead of eighteen) for walks of 2048+ steps, the run length by the number of records; 0: one record per
+ *                  workgroup (the same records); 4 .. 16: runs of that many records whatever the walk's length (tests, A/B)
  *   "blk_chip_ok"   -1 (default): the cluster form asks the device whether it is the whole chip its workgroup maps assume (256 compute
  *                  units = 8 XCDs x 32, no compute-unit mask in the environment) and is not used otherwise; 0 / 1 force the answer (tests)
  *   "blk_cluster_timeout_ms"  how long an exchange of the cluster form waits for a slice that does not arrive (default 3000)
@@ -252,6 +252,11 @@ int gpfq_quantize_neurons(const float *X, const float *Xq, int64_t ld, const flo
 #define GPFQ_LAYOUT_KERAS        1
 int gpfq_layer_alphabet_device(const float *median32, double alphabet_scalar, const double *unit_alphabet, int M,
                                void *dev_alphabet, void *stream);
+/* ... or both steps of :544-545 in one call: median(|W|) and, by the last workgroup of the median's second pass, the alphabet -- no launch
+ * between the two.  W [device] f32 [n], 16-byte aligned; median_out [device] f32 [1] (may be NULL); workspace >=
+ * gpfq_median_abs_workspace_bytes_for(n). */
+int gpfq_layer_alphabet_from_kernel(const float *W, int64_t n, double alphabet_scalar, const double *unit_alphabet, int M,
+                                    void *dev_alphabet, float *median_out, void *workspace, size_t workspace_bytes, void *stream);
 int gpfq_dense_layer_supported(int64_t N, int64_t m, int64_t C, const double *unit_alphabet, int M);
 /* ... and whether the kernel of that shape writes GPFQ_LAYOUT_KERAS outputs itself (the 16-neuron four-step shapes: layers wider than 2048
  * neurons on rows of up to 1024 samples -- the decision wavefront has the slack there); elsewhere gpfq_quantize_dense_layer takes

@@ -228,28 +228,29 @@ gpfq_blk_prep_kernel(const float *__restrict__ X, const float *__restrict__ Xq, 
     }
 }
 
-// The same pre-pass for a RUN of consecutive records per workgroup (round 6; classic form, 16-byte aligned rows): row t of X and Xq is
+// The same pre-pass for a RUN of 8 .. 16 consecutive records per workgroup (round 6; classic form, 16-byte aligned rows): row t of X and Xq is
 // an operand of records t .. t + ND (the band) and of records t + B, t - B (the operand rows), so one workgroup per record pulls every
 // row out of the L2s about 2 ND + 4 = 18 times -- 295 MB through the L2s for the headline layer's 32 MB, which with the one-pass-per-
 // workgroup latency is the launch's 49 us.  Here a workgroup keeps the band's rows of its 4 samples per thread in registers as a sliding
 // window and steps through RUN records: three row reads per record (t of both matrices, t + B of Xq), the wavefronts' partial sums of
 // every record parked in LDS and ONE workgroup reduction for the whole run.  Same records, bit for bit, for rows of up to 1024 padded
 // samples (one chunk per thread: the same order of additions); longer rows add their chunks' wavefront sums in chunk order.
-template <int B, bool R64, int RUN>
+constexpr int kPrepRunMax = 16;               // records per workgroup: 4 .. 16, chosen per launch (launch_blk)
+template <int B, bool R64>
 __global__ void __launch_bounds__(256)
-gpfq_blk_prep_run_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t N, int m, int mp, int64_t nrec,
+gpfq_blk_prep_run_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t N, int m, int mp, int64_t nrec, int RUN,
                          const float *__restrict__ nrm32, char *__restrict__ recs, char *__restrict__ hdrs,
                          const DevAlphabet *__restrict__ alpha, int sym)
 {
     constexpr int GREC = R64 ? 2 : 1;
     constexpr int ND = blk_band(B), NV = 3 + 4 * ND, NP = (NV + 3) & ~3;
     constexpr int hdr = blk_hdr_bytes(B);
-    __shared__ double sm[RUN][4][NP + 1];
+    __shared__ double sm[kPrepRunMax][4][NP + 1];
     const float sym_a = sym ? alpha->sym_a : 0.f;
     const int64_t t0 = (int64_t)blockIdx.x * RUN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double up = 1.0 + 0x1p-20;
-    for (int k = threadIdx.x; k < RUN * 4 * (NP + 1); k += 256) (&sm[0][0][0])[k] = 0.0;
+    for (int k = threadIdx.x; k < RUN * 4 * (NP + 1); k += 256) (&sm[0][0][0])[k] = 0.0;     // (RUN: a launch parameter, <= kPrepRunMax)
     __syncthreads();
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t rbytes = blk_rec_bytes(mp, B, GREC);
@@ -264,7 +265,9 @@ gpfq_blk_prep_run_kernel(const float *__restrict__ X, const float *__restrict__ 
 #pragma unroll
         for (int d = 1; d <= ND; ++d) { wx[d - 1] = row(X, t0 - d); wq[d - 1] = row(Xq, t0 - d); }
         float4 xc = row(X, t0), qc4 = row(Xq, t0), qn = row(Xq, t0 + B);
-#pragma unroll
+        // (a run-time trip count: the window slides by register moves -- 56 of them per record, next to ~330 arithmetic instructions in a
+        //  launch that waits for memory)
+#pragma unroll 1
         for (int r = 0; r < RUN; ++r) {
             const int64_t t = t0 + r;
             // (the next record's three rows: requested before this record's arithmetic)
@@ -2005,8 +2008,8 @@ void blk_set_pair_groups(int on) { g_blk_pairs.store(on ? 1 : 0, std::memory_ord
 // from 1024 up = every row beyond that many samples (tests, A/B).
 static std::atomic<int> g_blk_cluster_nl{0};      // cluster form: neurons per lane, 0 = by width; 1 / 2 / 4 force it (option blk_cluster_nl)
 void blk_set_cluster_nl(int v) { g_blk_cluster_nl.store(v == 1 || v == 2 || v == 4 ? v : 0, std::memory_order_relaxed); }
-static std::atomic<int> g_blk_prep_run{1};         // 1 (default): the record pre-pass takes runs of eight records per workgroup for walks of 2048+ steps; 0: one record per workgroup; 4 / 8: runs of that many at any length (option blk_prep_run: A/B, tests)
-void blk_set_prep_run(int v) { g_blk_prep_run.store(v == 4 || v == 8 ? v : (v ? 1 : 0), std::memory_order_relaxed); }
+static std::atomic<int> g_blk_prep_run{1};         // 1 (default): the record pre-pass takes runs of 4 .. 16 records per workgroup for walks of 2048+ steps; 0: one record per workgroup; 4 .. 16: runs of that many at any length (option blk_prep_run: A/B, tests)
+void blk_set_prep_run(int v) { g_blk_prep_run.store(v >= 4 && v <= 16 ? v : (v ? 1 : 0), std::memory_order_relaxed); }
 static std::atomic<int> g_blk_chip{-1};            // -1: ask the device; 0 / 1 force the answer of blk_chip_ok (option blk_chip_ok: tests)
 void blk_set_chip_ok(int v) { g_blk_chip.store(v < 0 ? -1 : (v ? 1 : 0), std::memory_order_relaxed); }
 static std::atomic<int> g_blk_cl_timeout_ms{3000};  // how long an exchange of the cluster form waits for a slice before it gives up (option blk_cluster_timeout_ms)
@@ -2162,54 +2165,7 @@ static BlkShape blk_shape(int64_t m, int64_t C)
     return {0, 0, 0, 0, 0, 0};
 }
 
-// The alphabet as an arithmetic progression, if it is one in the sense the chain of decisions needs: strictly ascending and
-// float32(fma(k, step, a0)) == float32(alphabet[k]) for every k (up to the one-ulp corrections of D.plus / D.minus), with
-// step = (a[M-1] - a[0]) / (M - 1) -- the same fused operation the kernel performs.  Everything the reference builds
-// (rad * linspace(-1, 1, M), scripts/quantized_network.py:396, :545) is, for a finite rad > 0.  Host and device (round 6: the device forms
-// the alphabet itself from the layer's median, gpfq_alphabet_device_kernel): fills D's progression fields from D.a[0..M), true if it is one.
-__host__ __device__ inline bool blk_fin(double x) { return fabs(x) <= 1.7976931348623157e308; }     // finite (false for NaN)
-__host__ __device__ inline bool blk_uniform(DevAlphabet &D)
-{
-    const int M = D.M;
-    const double *a = D.a;
-    D.plus = D.minus = 0ull;
-    D.a0 = D.step = D.inv = D.c0 = 0.0;
-    if (M < 1 || M > 64 || !blk_fin(a[0]) || !blk_fin(a[M - 1])) return false;
-    D.a0 = a[0];
-    D.amax = fmax(fabs(a[0]), fabs(a[M - 1]));
-    if (M == 1) return true;
-    D.step = (a[M - 1] - a[0]) / (double)(M - 1);
-    if (!(D.step > 0.0) || !blk_fin(D.step)) return false;
-    D.inv = 1.0 / D.step;
-    D.c0 = -D.a0 * D.inv;
-    if (!blk_fin(D.inv) || !blk_fin(D.c0)) return false;
-    for (int k = 0; k < M; ++k) {
-        if (k > 0 && !(a[k - 1] < a[k])) return false;
-        if (a[k] == 0.0) {                                     // (the member 0 is returned as such, BlkK::zero_idx, if the progression passes through it)
-            if (!(fabs(fma((double)k, D.step, D.a0)) <= 0x1p-40 * D.amax)) return false;
-        } else {
-            const float want = (float)a[k], have = (float)fma((double)k, D.step, D.a0);
-            const int64_t d = (int64_t)__builtin_bit_cast(int32_t, want) - (int64_t)__builtin_bit_cast(int32_t, have);
-            if (d == 1) D.plus |= 1ull << k;
-            else if (d == -1) D.minus |= 1ull << k;
-            else if (d != 0) return false;
-        }
-        // and the index arithmetic finds a member from its own value (monotone rounding does the rest)
-        if (rint(fma(a[k], D.inv, D.c0)) != (double)k) return false;
-    }
-    return true;
-}
-
-// a32 of an exactly symmetric alphabet {-a, 0, a} or {-a, a} (DevAlphabet::sym_a; the SYM instantiations), else 0
-__host__ __device__ inline float blk_sym_of(const double *a, int M)
-{
-    if (M != 2 && M != 3) return 0.f;
-    // (exactly symmetric as float64 too: the decisions' nearest-member search takes its boundaries as -a/2 and a/2)
-    if (a[0] != -a[M - 1] || (M == 3 && a[1] != 0.0)) return 0.f;
-    const float hi = (float)a[M - 1];
-    if (!(hi > 0.f) || !blk_fin((double)hi)) return 0.f;
-    return hi;
-}
+// (blk_uniform, blk_sym_of, form_device_alphabet: gpfq_device.hpp -- shared with the median's last workgroup, which forms the alphabet itself)
 
 // A host alphabet's DevAlphabet, computed on the host (launch_blk), stored into the call's workspace.
 __global__ void gpfq_alphabet_store_kernel(DevAlphabet *out, DevAlphabet D, unsigned *counters)
@@ -2225,17 +2181,7 @@ __global__ void gpfq_alphabet_store_kernel(DevAlphabet *out, DevAlphabet D, unsi
 __global__ void gpfq_alphabet_device_kernel(DevAlphabet *out, const float *__restrict__ median32, double alphabet_scalar, AlphabetArg unit, int want_sym)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    DevAlphabet D{};
-    D.M = unit.M; D.zero_idx = unit.zero_idx;
-    D.rad = alphabet_scalar * (double)median32[0];
-    for (int k = 0; k < unit.M && k < 64; ++k) D.a[k] = D.rad * unit.a[k];
-    bool ok = blk_fin(D.rad) && blk_uniform(D);
-    D.sym_a = blk_sym_of(D.a, D.M);
-    if (want_sym && D.sym_a == 0.f) ok = false;
-    // (the literal zero of rule (i) and the member 0: the caller's zero_idx is the unit alphabet's -- rad * 0 = 0 for every finite rad)
-    if (ok && D.zero_idx >= 0 && D.a[D.zero_idx] != 0.0) ok = false;
-    D.ok = ok ? 1 : 0;
-    *out = D;
+    form_device_alphabet(out, median32[0], alphabet_scalar, unit, want_sym);
 }
 
 // workspace: [records of slots 0..nblk, + one record of DMA over-read][compact headers of the same records, + 2 KiB of over-read]
@@ -2410,6 +2356,13 @@ static hipError_t blk_alphabet(const PipeArgs &a, const DevAlphabet **alpha, hip
     return hipGetLastError();
 }
 
+bool blk_unit_wants_sym(const AlphabetArg &unit)
+{
+    PipeArgs a{};
+    a.A = unit;
+    return blk_sym_a(a) != 0.f;
+}
+
 hipError_t launch_alphabet_device(const float *median32, double alphabet_scalar, const AlphabetArg &unit, void *dev_alphabet, hipStream_t stream)
 {
     PipeArgs a{};
@@ -2468,13 +2421,23 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     } else if (vec && (g_blk_prep_run.load(std::memory_order_relaxed) > 1 || (g_blk_prep_run.load(std::memory_order_relaxed) == 1 && nrec >= 2048))) {
         // (walks of fewer than 2048 steps: runs of records would be fewer workgroups than the chip has compute units, each a chain of eight
         //  records -- a Dense(128 -> 10) layer's pre-pass 0.08 ms longer; those keep one record per workgroup)
-        // runs of eight (option value 4: four) records per workgroup (gpfq_blk_prep_run_kernel); the one-record form keeps the rows it cannot read 16 bytes at a time
-        const int run = g_blk_prep_run.load(std::memory_order_relaxed) == 4 ? 4 : 8;
-#define GPFQ_PREP_RUN(RUN_) (sh.B == 4 ? (r64 ? gpfq_blk_prep_run_kernel<4, true, RUN_> : gpfq_blk_prep_run_kernel<4, false, RUN_>) \
-                                       : (sh.B == 2 ? (r64 ? gpfq_blk_prep_run_kernel<2, true, RUN_> : gpfq_blk_prep_run_kernel<2, false, RUN_>) : gpfq_blk_prep_run_kernel<1, false, RUN_>))
-        auto *prun = run == 4 ? GPFQ_PREP_RUN(4) : GPFQ_PREP_RUN(8);
-#undef GPFQ_PREP_RUN
-        hipLaunchKernelGGL(prun, dim3((unsigned)((nrec + run - 1) / run)), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp, nrec,
+        // runs of 4 .. 16 records per workgroup (gpfq_blk_prep_run_kernel); the one-record form keeps the rows it cannot read 16 bytes at a time.
+        // The kernel holds four workgroups per compute unit (116 registers): 1024 at a time.  A workgroup is a chain of 1 + run round trips to
+        // memory, so the run length is the one in 4 .. 16 under which the launch is the fewest rounds x (1 + run) -- the SHORTEST run that
+        // still fits one round where there is one (4101 records of the headline layer: runs of five, 821 workgroups).
+        const int opt = g_blk_prep_run.load(std::memory_order_relaxed);
+        int run = 8;
+        if (opt >= 4 && opt <= kPrepRunMax) run = opt;
+        else {
+            int64_t best = -1;
+            for (int rl = 4; rl <= kPrepRunMax; ++rl) {
+                const int64_t wgs = (nrec + rl - 1) / rl, cost = ((wgs + 1023) / 1024) * (1 + rl);
+                if (best < 0 || cost < best) { best = cost; run = rl; }
+            }
+        }
+        auto *prun = sh.B == 4 ? (r64 ? gpfq_blk_prep_run_kernel<4, true> : gpfq_blk_prep_run_kernel<4, false>)
+                               : (sh.B == 2 ? (r64 ? gpfq_blk_prep_run_kernel<2, true> : gpfq_blk_prep_run_kernel<2, false>) : gpfq_blk_prep_run_kernel<1, false>);
+        hipLaunchKernelGGL(prun, dim3((unsigned)((nrec + run - 1) / run)), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp, nrec, run,
                            a.nrm32, wbase, wbase + blk_recs_bytes(nblk, sh), alpha, sym);
     } else {
         hipLaunchKernelGGL(prep, dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp,

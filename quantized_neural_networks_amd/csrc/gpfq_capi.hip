@@ -467,6 +467,26 @@ int gpfq_layer_alphabet_device(const float *median32, double alphabet_scalar, co
     return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_layer_alphabet_device");
 }
 
+// median(|W|) and the layer alphabet in one go: the last workgroup of the median's second pass forms the alphabet (no launch of its
+// own between the two).  Needs the two-pass form: a 16-byte aligned kernel and gpfq_median_abs_workspace_bytes_for(n) of workspace.
+int gpfq_layer_alphabet_from_kernel(const float *W, int64_t n, double alphabet_scalar, const double *unit_alphabet, int M,
+                                    void *dev_alphabet, float *median_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (n <= 0) return fail(GPFQ_ERR_INVALID_ARG, "median of %lld elements", (long long)n);
+    HostAlphabet H;
+    int rc = unit_alphabet_arg(unit_alphabet, M, &H);
+    if (rc != GPFQ_OK) return rc;
+    if (H.is_big) return fail(GPFQ_ERR_UNSUPPORTED, "device-resident alphabets hold up to 64 members (got %d)", M);
+    if (!W || !dev_alphabet) return fail(GPFQ_ERR_INVALID_ARG, "NULL pointer");
+    if ((uintptr_t)dev_alphabet % 16 != 0) return fail(GPFQ_ERR_INVALID_ARG, "dev_alphabet must be 16-byte aligned");
+    if ((uintptr_t)W % 16 != 0) return fail(GPFQ_ERR_UNSUPPORTED, "a kernel that is not 16-byte aligned: gpfq_median_abs + gpfq_layer_alphabet_device");
+    if (!workspace || (uintptr_t)workspace % 16 != 0 || workspace_bytes < gpfq_median_abs_workspace_bytes_for(n))
+        return fail(GPFQ_ERR_WORKSPACE, "gpfq_layer_alphabet_from_kernel needs %zu aligned workspace bytes", gpfq_median_abs_workspace_bytes_for(n));
+    hipError_t e = gpfq::launch_median_abs(W, n, median_out, workspace, static_cast<hipStream_t>(stream), workspace_bytes,
+                                           dev_alphabet, alphabet_scalar, &H.A, gpfq::blk_unit_wants_sym(H.A) ? 1 : 0);
+    return e == hipSuccess ? GPFQ_OK : hip_fail(e, "gpfq_layer_alphabet_from_kernel");
+}
+
 static gpfq::PipeArgs dense_layer_probe(int64_t N, int64_t m, int64_t C, const HostAlphabet &H)
 {
     gpfq::PipeArgs pa{};
@@ -529,13 +549,15 @@ static int dense_layer_impl(int phase, const float *X, const float *Xq, int64_t 
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e = hipSuccess;
     if (phase != 2) {
-        e = hipMemsetAsync(workspace, 0, 64, s);                   // the call's counter block: exact fallbacks, cluster timeout, alphabet word
-        if (e != hipSuccess) return hip_fail(e, what);
+        // the call's counter block (exact fallbacks, cluster timeout, alphabet word) is zeroed by the row-norm launch when that runs here
         if (!nrm32) {
             float *n32 = reinterpret_cast<float *>(static_cast<char *>(workspace) + onchip_workspace_bytes(N, m, C));
-            e = gpfq::launch_row_norms(Xq, N, m, ld, n32, s);
+            e = gpfq::launch_row_norms(Xq, N, m, ld, n32, s, static_cast<unsigned *>(workspace));
             if (e != hipSuccess) return hip_fail(e, what);
             nrm32 = n32;
+        } else {
+            e = hipMemsetAsync(workspace, 0, 64, s);
+            if (e != hipSuccess) return hip_fail(e, what);
         }
     }
     gpfq::PipeArgs pa{};

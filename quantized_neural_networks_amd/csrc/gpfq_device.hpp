@@ -236,6 +236,76 @@ struct AlphabetRef {
     int M;
 };
 
+// The alphabet as an arithmetic progression, if it is one in the sense the chain of decisions needs: strictly ascending and
+// float32(fma(k, step, a0)) == float32(alphabet[k]) for every k (up to the one-ulp corrections of D.plus / D.minus), with
+// step = (a[M-1] - a[0]) / (M - 1) -- the same fused operation the kernel performs.  Everything the reference builds
+// (rad * linspace(-1, 1, M), scripts/quantized_network.py:396, :545) is, for a finite rad > 0.  Host and device (round 6: the device forms
+// the alphabet itself from the layer's median, gpfq_alphabet_device_kernel): fills D's progression fields from D.a[0..M), true if it is one.
+__host__ __device__ inline bool blk_fin(double x) { return fabs(x) <= 1.7976931348623157e308; }     // finite (false for NaN)
+__host__ __device__ inline bool blk_uniform(DevAlphabet &D)
+{
+    const int M = D.M;
+    const double *a = D.a;
+    D.plus = D.minus = 0ull;
+    D.a0 = D.step = D.inv = D.c0 = 0.0;
+    if (M < 1 || M > 64 || !blk_fin(a[0]) || !blk_fin(a[M - 1])) return false;
+    D.a0 = a[0];
+    D.amax = fmax(fabs(a[0]), fabs(a[M - 1]));
+    if (M == 1) return true;
+    D.step = (a[M - 1] - a[0]) / (double)(M - 1);
+    if (!(D.step > 0.0) || !blk_fin(D.step)) return false;
+    D.inv = 1.0 / D.step;
+    D.c0 = -D.a0 * D.inv;
+    if (!blk_fin(D.inv) || !blk_fin(D.c0)) return false;
+    for (int k = 0; k < M; ++k) {
+        if (k > 0 && !(a[k - 1] < a[k])) return false;
+        if (a[k] == 0.0) {                                     // (the member 0 is returned as such, BlkK::zero_idx, if the progression passes through it)
+            if (!(fabs(fma((double)k, D.step, D.a0)) <= 0x1p-40 * D.amax)) return false;
+        } else {
+            const float want = (float)a[k], have = (float)fma((double)k, D.step, D.a0);
+            const int64_t d = (int64_t)__builtin_bit_cast(int32_t, want) - (int64_t)__builtin_bit_cast(int32_t, have);
+            if (d == 1) D.plus |= 1ull << k;
+            else if (d == -1) D.minus |= 1ull << k;
+            else if (d != 0) return false;
+        }
+        // and the index arithmetic finds a member from its own value (monotone rounding does the rest)
+        if (rint(fma(a[k], D.inv, D.c0)) != (double)k) return false;
+    }
+    return true;
+}
+
+// a32 of an exactly symmetric alphabet {-a, 0, a} or {-a, a} (DevAlphabet::sym_a; the SYM instantiations), else 0
+__host__ __device__ inline float blk_sym_of(const double *a, int M)
+{
+    if (M != 2 && M != 3) return 0.f;
+    // (exactly symmetric as float64 too: the decisions' nearest-member search takes its boundaries as -a/2 and a/2)
+    if (a[0] != -a[M - 1] || (M == 3 && a[1] != 0.0)) return 0.f;
+    const float hi = (float)a[M - 1];
+    if (!(hi > 0.f) || !blk_fin((double)hi)) return 0.f;
+    return hi;
+}
+
+
+// The layer alphabet formed ON the device: rad = float64(alphabet_scalar) * float64(float32 median) -- the reference's legacy-NumPy
+// product (:544: python scalar times np.float32 is a float64 product) --, members rad * unit[k] (:545: float64 products), and the
+// progression the chain of decisions indexes.  `want_sym`: the caller will launch the symmetric-form instantiations (the unit alphabet is
+// {-1, 0, 1} / {-1, 1}): an alphabet that is then not exactly symmetric is not ok.  One thread (gpfq_alphabet_device_kernel; the last
+// workgroup of the one-GPU median, gpfq_median2_kernel).
+__device__ inline void form_device_alphabet(DevAlphabet *out, float median32, double alphabet_scalar, const AlphabetArg &unit, int want_sym)
+{
+    DevAlphabet D{};
+    D.M = unit.M; D.zero_idx = unit.zero_idx;
+    D.rad = alphabet_scalar * (double)median32;
+    for (int k = 0; k < unit.M && k < 64; ++k) D.a[k] = D.rad * unit.a[k];
+    bool ok = blk_fin(D.rad) && blk_uniform(D);
+    D.sym_a = blk_sym_of(D.a, D.M);
+    if (want_sym && D.sym_a == 0.f) ok = false;
+    // (the literal zero of rule (i) and the member 0: the caller's zero_idx is the unit alphabet's -- rad * 0 = 0 for every finite rad)
+    if (ok && D.zero_idx >= 0 && D.a[D.zero_idx] != 0.0) ok = false;
+    D.ok = ok ? 1 : 0;
+    *out = D;
+}
+
 __device__ __forceinline__ double alphabet_lane(const AlphabetArg &A, int lane)
 {
     return lane < A.M ? A.a[lane] : __longlong_as_double(0x7ff8000000000000LL);

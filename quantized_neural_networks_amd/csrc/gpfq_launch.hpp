@@ -269,7 +269,8 @@ hipError_t launch_gram_image_nhwc(const ImageGramArgs &a, hipStream_t stream);
 
 hipError_t launch_row_stats(const float *X, const float *Xq, int64_t N, int64_t m, int64_t ld, const float *nrm32,
                             RowStats *stats, hipStream_t stream);
-hipError_t launch_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, float *nrm32, hipStream_t stream);
+hipError_t launch_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, float *nrm32, hipStream_t stream, unsigned *zero16 = nullptr);
+// zero16 != NULL: the launch also zeroes those sixteen 32-bit words (a call's counter block)
 // big != NULL (65..256 members): A is unused, index arrays hold int16 elements (assemble: bits = 16)
 // dead / row_len / zero_idx: weights [rows][row_len]; rows with dead[row] != 0 take Q = 0, index zero_idx (a 1 x 1 conv layer's dead channels)
 hipError_t launch_msq(const float *W, int64_t n, const AlphabetArg &A, float *Q, int8_t *qidx, hipStream_t stream,
@@ -286,7 +287,11 @@ hipError_t launch_channel_sumsq(const float *act, int64_t n, int64_t H, int64_t 
 size_t channel_dead_workspace_bytes(int64_t Cin);
 hipError_t launch_channel_dead(const float *act, int64_t n, int64_t H, int64_t W, int64_t Cin, int sh, int sw, int32_t *dead,
                                void *workspace, int64_t prefix_positions, hipStream_t stream);
-hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream, size_t workspace_bytes);
+hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream, size_t workspace_bytes,
+                             void *alpha_out = nullptr, double alphabet_scalar = 0.0, const AlphabetArg *unit = nullptr, int want_sym = 0);
+// alpha_out != NULL (two-pass form only): the last workgroup of the second pass also forms the layer's DevAlphabet from the median
+// (unit: the unit alphabet, passed on by value; want_sym: the symmetric-form instantiations will be launched)
+bool blk_unit_wants_sym(const AlphabetArg &unit);   // gpfq_blk.hip: whether the symmetric form applies to rad * unit
 hipError_t launch_median_begin(int64_t n_total, void *workspace, hipStream_t stream);
 hipError_t launch_median_count(const float *W_local, int64_t n_local, int64_t n_total, int pass, void *workspace, hipStream_t stream);
 hipError_t launch_median_pick(int64_t n_total, int pass, void *workspace, hipStream_t stream);

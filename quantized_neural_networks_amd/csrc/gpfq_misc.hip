@@ -10,9 +10,10 @@ namespace gpfq {
 // (scripts/quantized_network.py:83, :89) = BLAS snrm2, a float32-rounded norm.
 // One workgroup per row; lanes stride the row with 16-B loads; fixed-order reduction.
 __global__ void __launch_bounds__(256)
-gpfq_row_norms_kernel(const float *__restrict__ Xq, int64_t m, int64_t ld, int vec, float *__restrict__ nrm32)
+gpfq_row_norms_kernel(const float *__restrict__ Xq, int64_t m, int64_t ld, int vec, float *__restrict__ nrm32, unsigned *__restrict__ zero16)
 {
     __shared__ double sm[4];
+    if (zero16 && blockIdx.x == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0u;     // (gpfq_quantize_dense_layer: the call's counter block, no memset of its own)
     const float *row = Xq + (int64_t)blockIdx.x * ld;
     double s = 0.0;
     if (vec) {
@@ -36,11 +37,11 @@ gpfq_row_norms_kernel(const float *__restrict__ Xq, int64_t m, int64_t ld, int v
     if (threadIdx.x == 0) nrm32[blockIdx.x] = (float)sqrt(sm[0] + sm[1] + sm[2] + sm[3]);
 }
 
-hipError_t launch_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, float *nrm32, hipStream_t stream)
+hipError_t launch_row_norms(const float *Xq, int64_t N, int64_t m, int64_t ld, float *nrm32, hipStream_t stream, unsigned *zero16)
 {
-    if (N == 0) return hipSuccess;
+    if (N == 0) return zero16 ? hipMemsetAsync(zero16, 0, 64, stream) : hipSuccess;
     const int vec = (ld % 4 == 0) && ((uintptr_t)Xq % 16 == 0);
-    hipLaunchKernelGGL(gpfq_row_norms_kernel, dim3((unsigned)N), dim3(256), 0, stream, Xq, m, ld, vec, nrm32);
+    hipLaunchKernelGGL(gpfq_row_norms_kernel, dim3((unsigned)N), dim3(256), 0, stream, Xq, m, ld, vec, nrm32, zero16);
     return hipGetLastError();
 }
 
@@ -807,7 +808,8 @@ size_t median_workspace_bytes_fast(int64_t) { return 128 + (size_t)(2 * kSel2A +
 template <int PASS>
 __global__ void __launch_bounds__(kSelThreads)
 gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, SelState *__restrict__ st, unsigned *hist,
-                    Sel2Ctl *__restrict__ ctl, int nsel, unsigned long long k0, unsigned long long k1, float *__restrict__ out)
+                    Sel2Ctl *__restrict__ ctl, int nsel, unsigned long long k0, unsigned long long k1, float *__restrict__ out,
+                    DevAlphabet *alpha_out, double alphabet_scalar, AlphabetArg unit, int want_sym)
 {
     extern __shared__ unsigned h[];                               // PASS 0: [32768] counters; PASS 1: [32768] words of two 16-bit counters (128 KiB either way)
     __shared__ unsigned long long part[16];
@@ -954,15 +956,20 @@ gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, S
 #endif
     if (tid == 0) {
         ctl->done = 0;
-        if (PASS == 1 && out) {
+        if (PASS == 1) {
             const float a = __uint_as_float(st[0].prefix);
-            *out = nsel > 1 ? __fdiv_rn(__fadd_rn(a, __uint_as_float(st[1].prefix)), 2.0f) : a;   // float32 mean of the two middle values
+            const float med = nsel > 1 ? __fdiv_rn(__fadd_rn(a, __uint_as_float(st[1].prefix)), 2.0f) : a;   // float32 mean of the two middle values
+            if (out) *out = med;
+            // (gpfq_layer_alphabet_from_kernel: the layer alphabet rad * unit, :544-545, formed right here -- no launch of its own)
+            if (alpha_out) form_device_alphabet(alpha_out, med, alphabet_scalar, unit, want_sym);
         }
     }
 }
 
-hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream, size_t workspace_bytes)
+hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *workspace, hipStream_t stream, size_t workspace_bytes,
+                             void *alpha_out, double alphabet_scalar, const AlphabetArg *unit, int want_sym)
 {
+    const AlphabetArg no_unit{};
     if (workspace_bytes < median_workspace_bytes_fast(n) || (uintptr_t)W % 16 != 0) {
         // the minimal workspace of rounds 1-5 (gpfq_median_abs_workspace_bytes()), or a kernel that cannot be read 16 bytes at a time: the three-pass sequence
         hipError_t e = launch_median_begin(n, workspace, stream);
@@ -970,7 +977,7 @@ hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *worksp
             e = launch_median_count(W, n, n, p, workspace, stream);
             if (e == hipSuccess) e = median_pick(n, p, workspace, p == 2 ? out : nullptr, stream);
         }
-        return e;
+        return (e == hipSuccess && alpha_out) ? hipErrorInvalidValue : e;      // (the fused alphabet needs the two-pass form: the caller checks first)
     }
     hipError_t e = hipMemsetAsync(workspace, 0, median_workspace_bytes_fast(n), stream);    // state, control words, both histograms
     if (e != hipSuccess) return e;
@@ -988,9 +995,11 @@ hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *worksp
     if (e == hipSuccess) e = ensure_dynamic_lds((const void *)gpfq_median2_kernel<1>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gpfq_median2_kernel<0>, dim3(grid), dim3(kSelThreads), kSel2A * sizeof(unsigned), stream, W, n, per, sel_state(workspace),
-                       sel2_hist_a(workspace), sel2_ctl(workspace), sel_count(n), k0, k1, (float *)nullptr);
+                       sel2_hist_a(workspace), sel2_ctl(workspace), sel_count(n), k0, k1, (float *)nullptr,
+                       (DevAlphabet *)nullptr, 0.0, no_unit, 0);
     hipLaunchKernelGGL(gpfq_median2_kernel<1>, dim3(grid), dim3(kSelThreads), lds, stream, W, n, per, sel_state(workspace),
-                       sel2_hist_b(workspace), sel2_ctl(workspace), sel_count(n), k0, k1, out);
+                       sel2_hist_b(workspace), sel2_ctl(workspace), sel_count(n), k0, k1, out,
+                       static_cast<DevAlphabet *>(alpha_out), alphabet_scalar, unit ? *unit : no_unit, want_sym);
     return hipGetLastError();
 }
 

@@ -38,6 +38,7 @@ SYMBOLS = {
                                      _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp]),
     "gpfq_call_status": (_int, [_vp, _vp]),
     "gpfq_layer_alphabet_device": (_int, [_vp, ctypes.c_double, _dp, _int, _vp, _vp]),
+    "gpfq_layer_alphabet_from_kernel": (_int, [_vp, _i64, ctypes.c_double, _dp, _int, _vp, _vp, _vp, _sz, _vp]),
     "gpfq_dense_layer_supported": (_int, [_i64, _i64, _i64, _dp, _int]),
     "gpfq_dense_layer_keras_out_supported": (_int, [_i64, _i64, _i64, _dp, _int]),
     "gpfq_dense_layer_workspace_bytes": (_sz, [_i64, _i64, _i64]),
@@ -595,6 +596,28 @@ def layer_alphabet_device(median32, unit_alphabet, alphabet_scalar):
     with torch.cuda.device(median32.device):
         _check(load().gpfq_layer_alphabet_device(median32.data_ptr(), float(alphabet_scalar), arr, len(unit), buf.data_ptr(), _stream()),
                "gpfq_layer_alphabet_device")
+    return DeviceAlphabet(buf, unit, alphabet_scalar)
+
+
+def layer_alphabet_from_kernel(W, unit_alphabet, alphabet_scalar):
+    """DeviceAlphabet of a layer straight from its float32 kernel W (any shape, contiguous): median(|W|) and the alphabet in one library
+    call, the alphabet formed by the last workgroup of the median's second pass (gpfq_layer_alphabet_from_kernel).  No sync."""
+    import numpy as np
+    _dev(W, torch.float32, "W")
+    Wc = W.contiguous()
+    unit = np.asarray(unit_alphabet, dtype=np.float64)
+    if not 1 <= len(unit) <= 64:
+        raise GpfqError(f"device-resident alphabets hold 1..64 members, got {len(unit)}")
+    if Wc.data_ptr() % 16 != 0:
+        return layer_alphabet_device(median_abs(Wc.reshape(-1), on_device=True), unit, alphabet_scalar)
+    arr = (ctypes.c_double * len(unit))(*[float(v) for v in unit])
+    lib = load()
+    nbytes = lib.gpfq_median_abs_workspace_bytes_for(Wc.numel())
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=W.device)
+    buf = torch.empty(GPFQ_DEVICE_ALPHABET_BYTES, dtype=torch.uint8, device=W.device)
+    with torch.cuda.device(W.device):
+        _check(lib.gpfq_layer_alphabet_from_kernel(Wc.data_ptr(), Wc.numel(), float(alphabet_scalar), arr, len(unit), buf.data_ptr(), None,
+                                                   ws.data_ptr(), nbytes, _stream()), "gpfq_layer_alphabet_from_kernel")
     return DeviceAlphabet(buf, unit, alphabet_scalar)
 
 

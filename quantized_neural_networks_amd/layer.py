@@ -55,7 +55,7 @@ def layer_alphabet_device(W, alphabet, alphabet_scalar, group=None):
         raise hip.GpfqError("layer_alphabet_device: empty kernel")
     world, rank = _group_info(group)
     if world == 1 or n < _SHARDED_MEDIAN_MIN:
-        med = hip.median_abs(flat, on_device=True)
+        return hip.layer_alphabet_from_kernel(flat, alphabet, alphabet_scalar)      # median + alphabet: one call, two launches
     else:
         import torch.distributed as dist
         per = -(-n // (4 * world)) * 4
@@ -175,11 +175,13 @@ def _side_stream(device):
     return st
 
 
-def quantize_dense_layer(W, X, Xq, unit_alphabet, alphabet_scalar, group=None, want_resid=True, log=None, check=True, overlap=True):
+def quantize_dense_layer(W, X, Xq, unit_alphabet, alphabet_scalar, group=None, want_resid=True, log=None, check=True, overlap=False):
     """The body of _quantize_layer_parallel (scripts/quantized_network.py:523-574) from "the activations are there" to the tensors
-    set_weights takes, with nothing crossing to the host and its two independent halves OVERLAPPED on two HIP streams: the median of |W|
-    and the alphabet (:544-545) depend on the kernel alone, the row norms and the record pre-pass on the activations alone
-    (gpfq_dense_layer_prepare on a side stream); the recurrence (gpfq_dense_layer_run) follows both.  Same tensors as
+    set_weights takes, with nothing crossing to the host: median of |W| -> rad * alphabet on the device (:544-545), row norms, record
+    pre-pass, the recurrence reading the Keras kernel in place.  overlap=True runs its two independent halves on two HIP streams -- the
+    median and the alphabet depend on the kernel alone, the row norms and the record pre-pass on the activations alone
+    (gpfq_dense_layer_prepare on a side stream; gpfq_dense_layer_run follows both) --, which pays where the median is long against the
+    two cross-stream waits it costs (~40 us of idle on this chip: at the north-star layer a wash, hence off by default).  Same tensors as
     quantize_dense(W, X, Xq, rad * unit_alphabet), bit for bit.  Returns its dict + "alphabet" (the hip.DeviceAlphabet: rad() / values())."""
     N, C = W.shape
     world, rank = _group_info(group)

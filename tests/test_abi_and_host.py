@@ -60,6 +60,7 @@ def test_version_and_errors_without_gpu(lib):
     assert lib.gpfq_dense_layer_supported(64, 1024, 32, crooked, 3) == 0    # not an arithmetic progression
     assert lib.gpfq_dense_layer_workspace_bytes(64, 1024, 32) > lib.gpfq_workspace_bytes(64, 1024, 32, 1)
     assert lib.gpfq_layer_alphabet_device(None, 3.0, unit, 3, None, None) == -1
+    assert lib.gpfq_layer_alphabet_from_kernel(None, 16, 3.0, unit, 3, None, None, None, 0, None) == -1
     assert lib.gpfq_quantize_dense_layer(None, None, 1024, None, None, 32, 0, 32, None, unit, 3, 64, 1024, None, None, 1, 32, None, None, 0, None) == -1
     assert lib.gpfq_call_status(None, None) == -1
 

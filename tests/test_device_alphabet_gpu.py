@@ -294,7 +294,7 @@ def test_record_prepass_in_runs_equals_one_record_per_workgroup(hip, oracle_mod,
     Q, idx, resid = oracle_mod.layer(W, X, Xq, alphabet)
     outs = []
     try:
-        for run in (0, 8, 4):                                      # (8 / 4: runs of records whatever the walk's length; 1, the default, only from 2048 steps)
+        for run in (0, 8, 4, 13):                                  # (4 .. 16: runs of that many records whatever the walk's length; 1, the default, only from 2048 steps)
             hip.set_option("blk_prep_run", run)
             with hip.option("blk_cluster", 0):
                 r = hip.quantize_neurons(_dev(X), _dev(Xq), _dev(W.T), alphabet, want_u=True, path=1)

@@ -151,7 +151,7 @@ def _run(case, dev, group):
         # round 6: the layer driver with the alphabet formed and kept on the device (median -> rad * alphabet -> shard's kernel reading the
         # Keras kernel -> all-gather of packed indices -> assembly from the device alphabet), the pre-pass on a second stream; _wide: shards
         # of the 16-neuron shape at world size 2 (the Keras-layout flush on one GPU, neuron-major shards under a group)
-        out = layer.quantize_dense_layer(d["W"], d["X"], d["Xq"], unit, 3, group=group)
+        out = layer.quantize_dense_layer(d["W"], d["X"], d["Xq"], unit, 3, group=group, overlap=(case != "dense_device_long"))
         res = {k: v.cpu().numpy() for k, v in out.items() if k in ("Q", "idx", "resid")}
         res["rad"] = np.float64(out["alphabet"].rad())
         ref_alphabet, ref_rad = layer.layer_alphabet(d["W"], unit, 3, group)

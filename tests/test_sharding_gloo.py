@@ -93,6 +93,7 @@ def _install_standins():
     names = dict(quantize_neurons=_standin_quantize, extract_patches=_standin_patches, assemble_kernel=_standin_assemble,
                  pack_indices=_standin_pack, channel_planes=_standin_planes, neuron_major=_standin_neuron_major,
                  median_abs=_standin_median, layer_alphabet_device=_standin_layer_alphabet_device,
+                 layer_alphabet_from_kernel=lambda W, unit, scalar: _standin_layer_alphabet_device(_standin_median(W), unit, scalar),
                  dense_layer_supported=lambda N, m, C, unit: True, quantize_dense_layer=_standin_dense_layer,
                  assemble_kernel_device=_standin_assemble_device, call_status=lambda result: 0, last_dense_kernel=lambda: "stand-in")
     keep = {k: getattr(hip, k) for k in names}

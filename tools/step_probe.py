@@ -39,7 +39,7 @@ timed("row_norms", lambda: hip.row_norms(Xq))
 d = layer.layer_alphabet_device(W, unit, 3.0)
 nrm = hip.row_norms(Xq)
 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-for run in (0, 4, 1):
+for run in (0, 4, 5, 6, 8, 9, 12, 16, 1):
     hip.set_option("blk_prep_run", run)
     ks, cs = [], []
     for _ in range(8):
