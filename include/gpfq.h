@@ -173,6 +173,9 @@ int gpfq_set_option(const char *key, int value);
  *   "blk_prep_run"  1 (default): the block kernel's record pre-pass takes runs of 4 .. 16 records per workgroup (each row read about four
  *                  times instead of eighteen) for walks of 2048+ steps, the run length by the number of records; 0: one record per
  *                  workgroup (the same records); 4 .. 16: runs of that many records whatever the walk's length (tests, A/B)
+ *   "blk_cluster768"  -1 (default): rows of 2049..3072 samples in layers wider than 2048 neurons run as FOUR 768-sample slices of the cluster
+ *                  form (64 clusters per round: whole rounds), eleven sweep wavefronts for symmetric alphabets, eight otherwise; 8 / 11 force
+ *                  the count; 0: the classic one-step shape of rounds 4-5
  *   "blk_chip_ok"   -1 (default): the cluster form asks the device whether it is the whole chip its workgroup maps assume (256 compute
  *                  units = 8 XCDs x 32, no compute-unit mask in the environment) and is not used otherwise; 0 / 1 force the answer (tests)
  *   "blk_cluster_timeout_ms"  how long an exchange of the cluster form waits for a slice that does not arrive (default 3000)

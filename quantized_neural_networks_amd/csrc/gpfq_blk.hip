@@ -2016,6 +2016,8 @@ static std::atomic<int> g_blk_cl_timeout_ms{3000};  // how long an exchange of t
 void blk_set_cluster_timeout_ms(int v) { g_blk_cl_timeout_ms.store(v < 1 ? 1 : v, std::memory_order_relaxed); }
 static std::atomic<int> g_blk_cl_fault{0};         // tests: 1 = slice 1 of cluster 0 never publishes (forces the exchange's timeout; option blk_cluster_fault)
 void blk_set_cluster_fault(int v) { g_blk_cl_fault.store(v ? 1 : 0, std::memory_order_relaxed); }
+static std::atomic<int> g_blk_cluster768{-1};      // rows of 2049..3072 samples in wide layers as four 768-sample slices: -1 (default) yes, 0 off, 8 / 11 force the sweep wavefronts (option blk_cluster768)
+void blk_set_cluster768(int v) { g_blk_cluster768.store(v == 0 ? 0 : (v == 8 ? 8 : (v == 11 ? 11 : -1)), std::memory_order_relaxed); }
 static std::atomic<int> g_blk_cluster{1};
 void blk_set_cluster(int v) { g_blk_cluster.store(v <= 0 ? 0 : (v < 1024 ? 1 : v), std::memory_order_relaxed); }
 constexpr int64_t kClusterMaxM = 28672;      // = GPFQ_ONCHIP_MAX_M: 28 slices, still inside one XCD's 32 CUs
@@ -2079,6 +2081,12 @@ static BlkShape blk_shape(int64_t m, int64_t C)
         const int ns_ = (int)((m + 1023) / 1024);
         const bool one_round = ns_ <= 32 && ((C + 15) / 16 + 7) / 8 <= 32 / ns_;      // with 16 neurons per workgroup
         const bool take = blk_chip_ok() && (clm == 1 ? (m > 3072 || (m > 1536 && one_round && (m > 2048 || C > 128))) : (clm > 1 && m > clm));   // (at most 128 neurons on rows of at most 2048 samples: the one-neuron workgroups stay ahead, 1.98 / 2.07 ms)
+        // Round 6: rows of 2049..3072 samples in layers wider than 2048 neurons -- three 1024-sample slices would be 85 clusters per round
+        // (four rounds for 3.01 rounds of work: 12.6 ms at 4096 x 4096 on 3000 samples, behind the classic one-step shape's 11.5) -- as FOUR
+        // slices of 768 samples: 64 clusters per round, four whole rounds of a shorter slot.  (Other ragged lengths gain nothing from
+        // shorter slices: a 768-sample slot takes 0.875 of a 1024-sample one)
+        if (clm == 1 && blk_chip_ok() && m > 2048 && m <= 3072 && C > 2048 && g_blk_cluster768.load(std::memory_order_relaxed) != 0)
+            return {4, 24, 4, 768, 11, 4, 4};                      // (eight or eleven sweep wavefronts: launch_blk, by the alphabet's form)
         if (take && m <= kClusterMaxM) {
             // neurons per workgroup: the fewest (4, 8, 16) with which the layer is still ONE round of the chip -- a slot of the 4- and
             // 8-neuron shapes is the decision wavefront's (with the exchange's flight exposed), a slot of the 16-neuron shape the sweeps'
@@ -2408,9 +2416,16 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
         if (!do_run) return hipSuccess;
         ClusterLaunchGuard one_at_a_time(stream);
         if (one_at_a_time.err != hipSuccess) return one_at_a_time.err;
-#define GPFQ_BLK_CL(NSW_, NL_, M_) (sym ? launch_blk_sym<4, 32, 4, NSW_, true, NL_, M_>(a, sh, alpha, stream) : launch_blk_sym<4, 32, 4, NSW_, false, NL_, M_>(a, sh, alpha, stream))
-        if (sh.NL == 4) return GPFQ_BLK_CL(11, 4, 1);
-        return sh.NL == 1 ? GPFQ_BLK_CL(8, 1, 1) : GPFQ_BLK_CL(8, 2, 1);
+#define GPFQ_BLK_CL(S_, NSW_, NL_, M_) (sym ? launch_blk_sym<4, S_, 4, NSW_, true, NL_, M_>(a, sh, alpha, stream) : launch_blk_sym<4, S_, 4, NSW_, false, NL_, M_>(a, sh, alpha, stream))
+        if (sh.S == 24) {
+            // four 768-sample slices (blk_shape).  Sweep wavefronts, measured at 4096 x 4096 on 3000 samples (tools/c768_probe.py): the symmetric
+            // form 10.29 ms with eleven against 10.68 with eight, the general form 11.02 with eight against 11.25 with eleven
+            const int forced = g_blk_cluster768.load(std::memory_order_relaxed);
+            const int nw = forced == 8 || forced == 11 ? forced : (sym ? 11 : 8);
+            return nw == 8 ? GPFQ_BLK_CL(24, 8, 4, 1) : GPFQ_BLK_CL(24, 11, 4, 1);
+        }
+        if (sh.NL == 4) return GPFQ_BLK_CL(32, 11, 4, 1);
+        return sh.NL == 1 ? GPFQ_BLK_CL(32, 8, 1, 1) : GPFQ_BLK_CL(32, 8, 2, 1);
 #undef GPFQ_BLK_CL
     }
     auto *prep = sh.B == 4 ? (r64 ? gpfq_blk_prep_kernel<4, true> : gpfq_blk_prep_kernel<4, false>)

@@ -219,7 +219,7 @@ int gpfq_set_option(const char *key, int value)
     if (!std::strcmp(key, "blk_single_groups")) { gpfq::blk_set_single_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_quad_groups")) { gpfq::blk_set_quad_groups(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_cluster_map")) { gpfq::blk_set_cluster_map(value); return GPFQ_OK; }
-    if (!std::strcmp(key, "blk_prep_run")) { gpfq::blk_set_prep_run(value); return GPFQ_OK; }
+    if (!std::strcmp(key, "blk_cluster768")) { gpfq::blk_set_cluster768(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_prep_run")) { gpfq::blk_set_prep_run(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_chip_ok")) { gpfq::blk_set_chip_ok(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_cluster_fault")) { gpfq::blk_set_cluster_fault(value); return GPFQ_OK; }

@@ -103,6 +103,7 @@ void blk_set_cluster_nl(int v);     // cluster form: neurons per lane of a workg
 void blk_set_cluster_map(int v);    // cluster form: workgroup id -> (cluster, slice): -1 (default) by the slice count, 0 = a cluster inside one XCD, 1 = consecutive ids (speed only)
 void blk_set_cluster(int v);        // cluster form (rows cut into 1024-sample slices over several workgroups, up to 16384 samples): 1 (default) = by shape, 0 = off, v >= 1024 = every row beyond v samples (speed only)
 void blk_set_prep_run(int v);       // 1 (default): the record pre-pass in runs of eight records per workgroup; 0: one record per workgroup (same records)
+void blk_set_cluster768(int v);     // rows of 2049..3072 samples in layers wider than 2048 neurons as four 768-sample slices: -1 (default) yes, 8 / 11 force the sweep wavefronts, 0 = the classic one-step shape (speed only)
 void blk_set_chip_ok(int v);        // -1 (default): the cluster form asks the device whether it is the whole 8 x 32-CU chip; 0 / 1: forced (tests)
 void blk_set_cluster_timeout_ms(int v);  // cluster form: how long an exchange waits for a missing slice (default 3000 ms)
 void blk_set_cluster_fault(int v);  // tests: 1 = one slice never publishes (forces the timeout and the caller's fallback)

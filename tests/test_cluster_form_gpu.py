@@ -146,3 +146,47 @@ def test_cluster_form_both_workgroup_maps(hip, oracle_mod, cmap, m):
         hip.set_option("blk_cluster_map", -1)
     assert np.array_equal(out["idx"], idx)
     np.testing.assert_allclose(out["resid"], resid, rtol=RESID_RTOL)
+
+
+@pytest.mark.parametrize("m", [2049, 2500, 3072])
+@pytest.mark.parametrize("levels,waves", [(3, -1), (3, 8), (16, -1), (16, 11), (2, 11)])
+def test_four_slices_of_768_samples_vs_oracle(hip, oracle_mod, m, levels, waves):
+    """Round 6: rows of 2049..3072 samples in layers wider than 2048 neurons run as FOUR 768-sample slices of the cluster form (64 clusters
+    per round instead of 85 three-slice clusters: whole rounds) -- `<4,24,4>` workgroups with eleven sweep wavefronts for symmetric
+    alphabets, eight otherwise (option blk_cluster768 forces either, 0 gives the classic one-step shape back).  Indices, values, residual
+    norms and residual VECTORS against the oracle; the classic shape gives the same tensors."""
+    N, C = 21, 2100
+    W, X, Xq = _synthetic(N, m, C, seed=m + levels)
+    Xq[N - 3] = 0                                                 # a dead row: rule (i)
+    alphabet, _ = oracle_mod.layer_alphabet(W, np.linspace(-1, 1, levels), 2)
+    Q, idx, resid = oracle_mod.layer(W, X, Xq, alphabet)
+    try:
+        hip.set_option("blk_cluster768", waves)
+        r, out = _run(hip, W, X, Xq, alphabet)
+        name = hip.last_dense_kernel()
+        hip.set_option("blk_cluster768", 0)
+        r0, out0 = _run(hip, W, X, Xq, alphabet, want_u=False)
+        name0 = hip.last_dense_kernel()
+    finally:
+        hip.set_option("blk_cluster768", -1)
+    assert "cluster form" in name and "cluster form" not in name0
+    assert np.array_equal(out["idx"], idx) and np.array_equal(out0["idx"], idx)
+    assert np.array_equal(out["Q"], Q.astype(np.float32))
+    np.testing.assert_allclose(out["resid"], resid, rtol=RESID_RTOL)
+    for j in (0, 1033, C - 1):
+        _, _, u = oracle_mod.neuron(W[:, j], X, Xq, alphabet)
+        assert np.array_equal(out["u"][j], u), j                 # the residual vector, bit for bit, across the four slices
+
+
+def test_four_slices_of_768_only_where_they_pay(hip, oracle_mod):
+    """... and only there: 2048 neurons or fewer, or rows of at most 2048 / more than 3072 samples, keep their shapes."""
+    for N, C, m, want in ((9, 2048, 2500, False), (9, 2100, 2048, False), (9, 2100, 3073, False), (9, 2100, 2500, True)):
+        W, X, Xq = _synthetic(N, m, C, seed=C + m)
+        alphabet, _ = oracle_mod.layer_alphabet(W, np.linspace(-1, 1, 3), 3)
+        _, idx, _ = oracle_mod.layer(W, X, Xq, alphabet)
+        r, out = _run(hip, W, X, Xq, alphabet, want_u=False)
+        ws = hip.load().gpfq_workspace_bytes(N, m, C, 1)
+        assert np.array_equal(out["idx"], idx)
+        # (four slices of 768 samples: 3072 padded samples per record row -- the workspace tells the shapes apart)
+        four = hip.load().gpfq_workspace_bytes(N, m, C, 1) == hip.load().gpfq_workspace_bytes(N, 2500, 2100, 1)
+        assert ws > 0 and (four or not want), (N, C, m)
