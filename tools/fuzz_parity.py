@@ -48,6 +48,8 @@ while time.time() < t_end:
             N = int(rng.integers(1, 60)); C = int(rng.choice([rng.integers(1, 60), rng.integers(100, 700), rng.integers(1000, 1400)])); m = int(rng.choice([rng.integers(2049, 5200), rng.integers(5121, 16385)]))
         if rng.random() < 0.12:                     # wide layers on long rows: 16 neurons per workgroup over eleven sweep wavefronts
             N = int(rng.integers(1, 40)); C = int(rng.integers(2049, 2400)); m = int(rng.integers(1025, 2049))
+        if rng.random() < 0.08:                     # round 6: rows of 2049..3072 samples in layers wider than 2048 neurons: four 768-sample slices of the cluster form
+            N = int(rng.integers(1, 30)); C = int(rng.integers(2049, 2300)); m = int(rng.integers(2049, 3073))
         kind = rng.choice(["relu", "sparse", "signed", "uniform"])
         X = activations((N, m), kind)
         Xq = X if rng.random() < 0.2 else (X + 0.1 * rng.standard_normal((N, m)).astype(np.float32) * (X != 0 if kind == "sparse" else 1)).astype(np.float32)
@@ -66,7 +68,8 @@ while time.time() < t_end:
             opts = dict(pipe=int(rng.choice([1, 2])), blk_sweep_waves=int(rng.choice([0, 8, 11])), blk_wide_groups=int(rng.choice([1, 1, 0])), blk_four_groups=int(rng.choice([1, 1, 0])),
                         blk_pair_groups=int(rng.choice([1, 1, 0])), blk_single_groups=int(rng.choice([1, 1, 0])), blk_quad_groups=int(rng.choice([2, 2, 0, 1])), blk_quad_waves=int(rng.choice([0, 0, 7, 8])),
                         variant=int(rng.choice([0, 0, 32])),
-                        blk_cluster=int(rng.choice([1, 1, 0, 1024, 2048])), blk_cluster_map=int(rng.choice([-1, 0, 1])), blk_cluster_nl=int(rng.choice([0, 0, 1, 2, 4])))   # cluster form (round 5): by shape, off, from 1025 / 2049 samples up; both workgroup maps
+                        blk_cluster=int(rng.choice([1, 1, 0, 1024, 2048])), blk_cluster_map=int(rng.choice([-1, 0, 1])), blk_cluster_nl=int(rng.choice([0, 0, 1, 2, 4])),
+                        blk_cluster768=int(rng.choice([-1, -1, 0, 8, 11])))   # cluster form (round 5): by shape, off, from 1025 / 2049 samples up; both workgroup maps
         elif path == 1:
             opts = dict(lanes_per_neuron=int(rng.choice([0, 1, 16, 32, 64])), waves_per_neuron=int(rng.choice([0, 0, 2, 4, 8, 16])),
                         onchip_mode=int(rng.integers(0, 2)))
@@ -77,7 +80,7 @@ while time.time() < t_end:
                                      alphabet, path=path)
         finally:
             for k in opts:
-                hip.set_option(k, {"onchip_mode": 1, "pipe": -1, "blk_sweep_waves": 0, "blk_quad_waves": 0, "blk_wide_groups": 1, "blk_four_groups": 1, "blk_pair_groups": 1, "blk_single_groups": 1, "blk_quad_groups": 2, "blk_cluster": 1, "blk_cluster_map": -1, "blk_cluster_nl": 0}.get(k, 0))
+                hip.set_option(k, {"onchip_mode": 1, "pipe": -1, "blk_sweep_waves": 0, "blk_quad_waves": 0, "blk_wide_groups": 1, "blk_four_groups": 1, "blk_pair_groups": 1, "blk_single_groups": 1, "blk_quad_groups": 2, "blk_cluster": 1, "blk_cluster_map": -1, "blk_cluster_nl": 0, "blk_cluster768": -1}.get(k, 0))
         ok = np.array_equal(r["idx"].cpu().numpy(), io) and np.allclose(r["resid"].cpu().numpy(), ro, rtol=1e-5, atol=0)
         n_dense += 1
         if not ok:
