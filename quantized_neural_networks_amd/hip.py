@@ -569,6 +569,8 @@ class DeviceAlphabet:
         import numpy as np
         self.buf, self.unit, self.alphabet_scalar = buf, np.asarray(unit, dtype=np.float64), float(alphabet_scalar)
         self._rad = None
+        self.radius_ok = False        # set by a caller that KNOWS the radius is finite and positive (it read the median): quantize_dense then
+                                      # has no deferred alphabet status to wait for
 
     def __len__(self):
         return len(self.unit)

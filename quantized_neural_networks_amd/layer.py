@@ -230,7 +230,10 @@ def quantize_dense(W, X, Xq, alphabet, group=None, want_resid=True, log=None, ch
     if dalpha is not None:
         r = hip.quantize_dense_layer(X, Xq, Wc, dalpha, lo, hi, keras_out=(world == 1), want_values=(world == 1), want_resid=want_resid,
                                      prepared=prepared)           # (prepared: quantize_dense_layer's side stream has run the pre-pass into this workspace)
-        st = hip.call_status(r) if check else 0
+        # (the status costs one host wait: skipped where nothing deferred can have happened -- the caller knows the radius is a finite
+        #  positive number, DeviceAlphabet.radius_ok, and the launch was not the cluster form)
+        need = check and not (getattr(dalpha, "radius_ok", False) and "cluster form" not in hip.last_dense_kernel())
+        st = hip.call_status(r) if need else 0
         if st == hip.GPFQ_ERR_CLUSTER_TIMEOUT:
             _log_failure(log, f"Dense layer {N} x {C}: the cluster form's exchange timed out; rerunning the layer through the classic kernels")
             with hip.option("blk_cluster", 0):

@@ -584,15 +584,28 @@ class QuantizedNeuralNetwork:
     def _prefetch_medians(self, layer_indices):
         """median(|W|) of the given layers' analog kernels, all queued before the first host wait (layers whose kernel is on the
         GPU and small enough for the one-GPU select; the others compute theirs when their turn comes)."""
-        self._medians = {}
+        self._medians, self._medians_dev = {}, {}
         todo = []
         for k in layer_indices:
             Wd = self._kernel_on_device(self.trained_net.layers[k])
             world, _ = _layer._group_info(self.process_group)
             if Wd.is_cuda and Wd.numel() > 0 and (world == 1 or Wd.numel() < _layer._SHARDED_MEDIAN_MIN):
                 todo.append((k, hip.median_abs(Wd.detach().reshape(-1), on_device=True)))
-        for (k, _), v in zip(todo, hip.medians_to_host([t for _, t in todo])):
+        for (k, t), v in zip(todo, hip.medians_to_host([t for _, t in todo])):
             self._medians[k] = v
+            self._medians_dev[k] = t
+
+    def _layer_alphabet_device(self, layer_idx, rad):
+        """The same alphabet resident on the device (hip.DeviceAlphabet), formed from the prefetched DEVICE median: the Dense layer then
+        runs as bench.py's step does -- the kernel reads the Keras kernel in place and writes Q and the indices in its layout, no
+        neuron-major copy and no assembly pass.  The host already holds rad (last_layer_stats, the log), so nothing waits for it."""
+        t = getattr(self, "_medians_dev", {}).pop(layer_idx, None)
+        if t is None or not 1 <= len(self.alphabet) <= 64:
+            return None
+        d = hip.layer_alphabet_device(t, self.alphabet, self.alphabet_scalar)
+        d._rad = np.float64(rad)
+        d.radius_ok = bool(np.isfinite(rad) and rad > 0)          # known good on the host: no deferred alphabet status to wait for
+        return d
 
     # -- Dense layer (reference :523-574) ---------------------------------------------------
     def _quantize_layer_parallel(self, layer_idx):
@@ -604,6 +617,7 @@ class QuantizedNeuralNetwork:
         self._log(f"\tdone. {time()-tic:2f} seconds.")
 
         layer_alphabet, rad = self._layer_alphabet(Wd, layer_idx)
+        dalpha = self._layer_alphabet_device(layer_idx, rad)
 
         self._log("\tQuantizing neurons (in parallel)...")
         tic = time()
@@ -611,7 +625,7 @@ class QuantizedNeuralNetwork:
             # residual norms are diagnostics (last_layer_stats): kept where the kernel holds the residual anyway
             # (a deferred failure of the kernel -- the cluster form's exchange timing out -- is noticed, logged and repaired INSIDE this
             #  call, before Q exists: nothing unchecked reaches set_weights, as nothing does in the reference, :563-565)
-            out = _layer.quantize_dense(Wd, wX, qX, layer_alphabet, group=self.process_group, want_resid=None,
+            out = _layer.quantize_dense(Wd, wX, qX, layer_alphabet if dalpha is None else dalpha, group=self.process_group, want_resid=None,
                                         log=lambda msg: self._log(f"\t\tLayer {layer_idx}: {msg}"))
             Q = out["Q"]
         except Exception as exc:

@@ -328,3 +328,44 @@ def test_overlapped_layer_driver_equals_the_one_stream_form(hip, layer, oracle_m
         np.testing.assert_allclose(out["resid"].cpu().numpy(), resid, rtol=RESID_RTOL)
         assert out["alphabet"].rad() == rad
     assert torch.equal(outs[0]["resid"], outs[1]["resid"])
+
+
+def test_class_surface_runs_dense_layers_on_the_device_path(hip, layer, monkeypatch):
+    """QuantizedNeuralNetwork.quantize_network() (scripts/quantized_network.py:576-590) takes its Dense layers through the same driver
+    as bench.py's step: device-resident alphabet from the prefetched median, the Keras kernel read in place, no assembly pass and -- the
+    host knowing the radius is good and the launch not being the cluster form -- no status wait.  The network, the radii and the residual
+    norms equal those of the host-alphabet path, bit for bit."""
+    from quantized_neural_networks_amd import keras_shim as ks
+    from quantized_neural_networks_amd import quantized_network as qn
+
+    n, d0, d1, d2 = 600, 40, 33, 7
+    x = np.random.default_rng(0).standard_normal((n, d0)).astype(np.float32)
+    calls = dict(device=0, assemble=0, status=0)
+    real_layer, real_asm, real_status = hip.quantize_dense_layer, hip.assemble_kernel, hip.call_status
+
+    def run(device_path):
+        net = ks.Sequential([ks.Dense(d1, activation="relu", input_shape=(d0,)), ks.Dense(d2)], seed=5)
+        q = qn.QuantizedNeuralNetwork(network=net, batch_size=n, get_data=qn.MNISTSequence(x, np.zeros((n, 1)), n),
+                                      bits=2, alphabet_scalar=2.5)
+        if not device_path:
+            q._layer_alphabet_device = lambda layer_idx, rad: None
+        q.quantize_network()
+        ws = [np.asarray(w.cpu() if isinstance(w, torch.Tensor) else w).copy() for w in q.quantized_net.get_weights()]
+        stats = {k: (float(v["rad"]), np.asarray(v["resid"]), np.asarray(v["idx"])) for k, v in q.last_layer_stats.items()}
+        return ws, stats
+
+    monkeypatch.setattr(hip, "quantize_dense_layer", lambda *a, **k: (calls.__setitem__("device", calls["device"] + 1), real_layer(*a, **k))[1])
+    monkeypatch.setattr(hip, "assemble_kernel", lambda *a, **k: (calls.__setitem__("assemble", calls["assemble"] + 1), real_asm(*a, **k))[1])
+    monkeypatch.setattr(hip, "call_status", lambda *a, **k: (calls.__setitem__("status", calls["status"] + 1), real_status(*a, **k))[1])
+    dev_ws, dev_stats = run(True)
+    assert calls == dict(device=2, assemble=0, status=0), calls
+    host_ws, host_stats = run(False)
+    assert calls["device"] == 2 and calls["assemble"] == 2
+    assert len(dev_ws) == len(host_ws)
+    for a, b in zip(dev_ws, host_ws):
+        assert np.array_equal(a, b)
+    assert dev_stats.keys() == host_stats.keys()
+    for k in dev_stats:
+        assert dev_stats[k][0] == host_stats[k][0]
+        np.testing.assert_allclose(dev_stats[k][1], host_stats[k][1], rtol=RESID_RTOL)
+        assert np.array_equal(dev_stats[k][2], host_stats[k][2])
