@@ -74,11 +74,12 @@ def main():
     ap.add_argument("--long-rows", type=int, default=8192,
                     help="also time the same layer on this many calibration samples (a secondary record: the block kernel's cluster form); 0 = skip")
     ap.add_argument("--overlap", dest="overlap", action="store_true",
-                    help="row norms + record pre-pass on a second HIP stream beside the median (gpfq_dense_layer_prepare / _run).  Off by default: measured on "
-                         "this chip the two cross-stream waits idle the GPU ~17 + 22 us and the overlap hides ~50 us -- 3.034-3.049 ms per step with it, "
-                         "3.033-3.050 without, and slower with it once the medians are prefetched (profiles/r06/README.md)")
-    ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="(the default) one stream: median, alphabet, row norms, record pre-pass, kernel in sequence")
-    ap.set_defaults(overlap=False)
+                    help="(the default on one GPU) the median of |W| + alphabet on a second HIP stream -- they depend on the analog kernel alone, which is "
+                         "complete long before the step, as a trained network's is: no fork wait --, row norms + record pre-pass on this one "
+                         "(gpfq_dense_layer_prepare), ONE join, then the alphabet-dependent rest (gpfq_dense_layer_run): layer.quantize_dense_layer("
+                         "overlap=True, kernel_ready=True).  Same box: 3.050 -> 2.998 / 3.010 ms per step (profiles/r06/overlap_ab.txt)")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="one stream: median, alphabet, row norms, record pre-pass, kernel in sequence")
+    ap.set_defaults(overlap=True)
     ap.add_argument("--numpy-sample", type=int, default=-1,
                     help="neurons of the NumPy process-pool baseline (the reference-shaped one); -1 = 2 x host cores, 0 = skip")
     args = ap.parse_args()
@@ -148,21 +149,22 @@ def main():
         lo, hi = layer.shard_bounds(C_total, world, rank)
         if not device_path:
             return step_host(i_timed, C_total, Wd, lo, hi)
-        # --overlap: the layer's two independent halves on two HIP streams (layer.quantize_dense_layer(overlap=True)): row norms + record
-        # pre-pass (activations only) on the side stream, median of |W| + alphabet (kernel only) on this one; the recurrence follows both.
-        # Default: one stream.
+        # --overlap (default): the layer's two independent halves on two HIP streams, as layer.quantize_dense_layer(overlap=True,
+        # kernel_ready=True) runs them: median of |W| + alphabet (kernel only) on the side stream, row norms + record pre-pass
+        # (activations only) on this one, one join, then the recurrence.  --no-overlap: one stream.
         # (st["alphabet_pre"], secondary figure only: the alphabet formed before the loop, as _prefetch_medians does for a network)
         ws = None
-        if args.overlap:
+        if args.overlap and st.get("alphabet_pre") is None and world == 1:
             main, side = torch.cuda.current_stream(dev), layer._side_stream(dev)
-            ws = hip.dense_layer_workspace(N, m, hi - lo, dev)
-            side.wait_stream(main)
             with torch.cuda.stream(side):
-                hip.dense_layer_prepare(Xd, Xqd, unit_alphabet, hi - lo, ws)
-        dalpha = st.get("alphabet_pre") or layer.layer_alphabet_device(Wd, unit_alphabet, args.alphabet_scalar, group)   # N > 1: counting sharded over ranks
-        nrm = None                            # (the row norms are formed inside the layer call: its launch also zeroes the call's counter block)
-        if args.overlap:
+                dalpha = layer.layer_alphabet_device(Wd, unit_alphabet, args.alphabet_scalar, None)
+            dalpha.buf.record_stream(main)
+            ws = hip.dense_layer_workspace(N, m, hi - lo, dev)
+            hip.dense_layer_prepare(Xd, Xqd, unit_alphabet, hi - lo, ws)
             main.wait_stream(side)
+        else:
+            dalpha = st.get("alphabet_pre") or layer.layer_alphabet_device(Wd, unit_alphabet, args.alphabet_scalar, group)   # N > 1: counting sharded over ranks
+        nrm = None                            # (the row norms are formed inside the layer call: its launch also zeroes the call's counter block)
         if i_timed is not None:
             hip.set_main_kernel_events(*ev_k[i_timed])
             ev[i_timed][0].record()          # same stream the kernel is launched on (torch current stream)
@@ -319,7 +321,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_medians_prefetched": ms_prefetched, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "step": ("device-resident alphabet: median(|W|) -> rad * alphabet on the device" + (" while a second HIP stream forms the row norms and the record pre-pass" if args.overlap else ", row norms, record pre-pass")
+            "step": ("device-resident alphabet: median(|W|) -> rad * alphabet on the device"
+                     + (" on a second HIP stream (it depends on the analog kernel alone: no fork wait, one join) beside the row norms and the record pre-pass"
+                        if args.overlap and world == 1 else ", row norms, record pre-pass")
                      + ", then the block-pipelined kernel reading the Keras kernel and writing Q / indices in the Keras layout; no host wait inside a step" if device_path else
                      "host alphabet (one host wait per step), neuron-major copy, row norms, record pre-pass, kernel, assembly pass"),
             "deferred_status_nonzero_steps": bad_status,
@@ -340,8 +344,8 @@ def main():
                 "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS,
                 "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
                 "kernel_ms_avg": k_avg_s * 1e3, "kernel_ms_min": float(np.min(kernel_ms)),
-                # events around the library call that launches the kernel: record pre-pass + this kernel (--overlap: the alphabet-dependent
-                # half only -- one in-place pass over the records for the symmetric alphabet + this kernel)
+                # events around the library call that launches the kernel: with --overlap (default, one GPU) the alphabet-dependent half only --
+                # one in-place pass over the records for the symmetric alphabet + this kernel; --no-overlap: row norms + record pre-pass + this kernel
                 "call_ms_avg": float(np.mean(call_ms)),
                 # the same fraction on the bracket rounds 1-3 quoted (events around the whole call): comparable across rounds
                 "frac_call": alg_flops / (float(np.mean(call_ms)) / 1e3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,

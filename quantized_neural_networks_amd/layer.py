@@ -175,30 +175,44 @@ def _side_stream(device):
     return st
 
 
-def quantize_dense_layer(W, X, Xq, unit_alphabet, alphabet_scalar, group=None, want_resid=True, log=None, check=True, overlap=False):
+def quantize_dense_layer(W, X, Xq, unit_alphabet, alphabet_scalar, group=None, want_resid=True, log=None, check=True, overlap=False,
+                         kernel_ready=None):
     """The body of _quantize_layer_parallel (scripts/quantized_network.py:523-574) from "the activations are there" to the tensors
     set_weights takes, with nothing crossing to the host: median of |W| -> rad * alphabet on the device (:544-545), row norms, record
-    pre-pass, the recurrence reading the Keras kernel in place.  overlap=True runs its two independent halves on two HIP streams -- the
-    median and the alphabet depend on the kernel alone, the row norms and the record pre-pass on the activations alone
-    (gpfq_dense_layer_prepare on a side stream; gpfq_dense_layer_run follows both) --, which pays where the median is long against the
-    two cross-stream waits it costs (~40 us of idle on this chip: at the north-star layer a wash, hence off by default).  Same tensors as
-    quantize_dense(W, X, Xq, rad * unit_alphabet), bit for bit.  Returns its dict + "alphabet" (the hip.DeviceAlphabet: rad() / values())."""
+    pre-pass, the recurrence reading the Keras kernel in place.
+
+    overlap=True runs its two independent halves on two HIP streams: the median and the alphabet depend on the kernel W alone and go to a
+    side stream; the row norms and the record pre-pass depend on the activations alone and stay on this one (gpfq_dense_layer_prepare);
+    ONE join, then the alphabet-dependent rest (gpfq_dense_layer_run).  kernel_ready says when W was complete: None -- unknown, the side
+    stream first waits for everything outstanding on this one (always safe; the wait then sits on the longer of the two chains and the
+    overlap buys little); a torch.cuda.Event -- the side stream waits for that; True -- W was complete before anything now outstanding
+    here was queued (a trained network's analog kernel: the reference never writes it), no wait at all: the median of layer k + 1 then
+    also fills the tail of layer k.  Measured at the north-star layer: 3.05 -> 3.00 ms per layer (profiles/r06/overlap_ab.txt).
+    (Round 6's first scheme -- the pre-pass on the side stream behind a fork wait -- measured a wash and is gone.)
+
+    Same tensors as quantize_dense(W, X, Xq, rad * unit_alphabet), bit for bit.  Returns its dict + "alphabet" (the hip.DeviceAlphabet)."""
     N, C = W.shape
     world, rank = _group_info(group)
     lo, hi = shard_bounds(C, world, rank)
     m = X.shape[1]
-    if not (overlap and W.numel() and m > 0 and hi > lo and hip.dense_layer_supported(N, m, hi - lo, unit_alphabet)):
+    side_ok = world == 1 or W.numel() < _SHARDED_MEDIAN_MIN      # (the sharded median's collectives stay on the caller's stream)
+    if not (overlap and side_ok and W.numel() and m > 0 and hi > lo and hip.dense_layer_supported(N, m, hi - lo, unit_alphabet)):
         dalpha = layer_alphabet_device(W, unit_alphabet, alphabet_scalar, group)
         out = quantize_dense(W, X, Xq, dalpha, group=group, want_resid=want_resid, log=log, check=check)
         out["alphabet"] = dalpha
         return out
     main = torch.cuda.current_stream(W.device)
     side = _side_stream(W.device)
-    ws = hip.dense_layer_workspace(N, m, hi - lo, W.device)
-    side.wait_stream(main)                                        # (the activations and the workspace's previous owner are done)
+    if kernel_ready is None:
+        side.wait_stream(main)
+    elif kernel_ready is not True:
+        side.wait_event(kernel_ready)
     with torch.cuda.stream(side):
-        hip.dense_layer_prepare(X, Xq, unit_alphabet, hi - lo, ws)
-    dalpha = layer_alphabet_device(W, unit_alphabet, alphabet_scalar, group)
+        dalpha = layer_alphabet_device(W, unit_alphabet, alphabet_scalar, None)
+    W.record_stream(side)                                         # (the allocator's bookkeeping: both streams use W and the alphabet block)
+    dalpha.buf.record_stream(main)
+    ws = hip.dense_layer_workspace(N, m, hi - lo, W.device)
+    hip.dense_layer_prepare(X, Xq, unit_alphabet, hi - lo, ws)
     main.wait_stream(side)
     out = quantize_dense(W, X, Xq, dalpha, group=group, want_resid=want_resid, log=log, check=check, prepared=ws)
     out["alphabet"] = dalpha

@@ -313,16 +313,21 @@ def test_record_prepass_in_runs_equals_one_record_per_workgroup(hip, oracle_mod,
 
 @pytest.mark.parametrize("N,C,m,levels", [(61, 70, 512, 3), (40, 33, 1000, 16), (33, 600, 1024, 2), (18, 24, 2100, 3), (15, 70, 3100, 3), (29, 5, 200, 3)])
 def test_overlapped_layer_driver_equals_the_one_stream_form(hip, layer, oracle_mod, N, C, m, levels):
-    """layer.quantize_dense_layer: the row norms and the record pre-pass on a second stream beside the median (gpfq_dense_layer_prepare /
-    _run; for symmetric alphabets the records are scaled in place once the alphabet exists).  Same tensors as the one-stream call and as the
-    oracle, also for a shape without a block-pipelined kernel (200 samples: the fallback inside)."""
+    """layer.quantize_dense_layer(overlap=True): the median and the alphabet on a second stream beside the row norms and the record pre-pass
+    (gpfq_dense_layer_prepare / _run; for symmetric alphabets the records are scaled in place once the alphabet exists), with every way of
+    saying when the kernel W was complete -- unknown (a fork wait), an event, "long ago" (no wait).  Same tensors as the one-stream call and
+    as the oracle, also for a shape without a block-pipelined kernel (200 samples: the fallback inside)."""
     W, X, Xq = _synthetic(N, m, C, seed=N + m)
     Xq[1] = 0
     unit = np.linspace(-1, 1, levels)
     alphabet, rad = oracle_mod.layer_alphabet(W, unit, 3)
     Q, idx, resid = oracle_mod.layer(W, X, Xq, alphabet)
     Wd, Xd, Xqd = _dev(W), _dev(X), _dev(Xq)
-    outs = [layer.quantize_dense_layer(Wd, Xd, Xqd, unit, 3, overlap=ov) for ov in (True, False, True)]
+    ready = torch.cuda.Event()
+    ready.record()
+    torch.cuda.synchronize()                                       # (kernel_ready=True below is then the truth)
+    outs = [layer.quantize_dense_layer(Wd, Xd, Xqd, unit, 3, overlap=ov, kernel_ready=kr)
+            for ov, kr in ((True, None), (False, None), (True, True), (True, ready), (True, True))]
     for out in outs:
         assert np.array_equal(out["idx"].cpu().numpy(), idx.T) and np.array_equal(out["Q"].cpu().numpy(), Q.T.astype(np.float32))
         np.testing.assert_allclose(out["resid"].cpu().numpy(), resid, rtol=RESID_RTOL)

@@ -94,7 +94,7 @@ while time.time() < t_end:
                 for k, v in popts.items():
                     hip.set_option(k, v)
                 out = layer.quantize_dense_layer(torch.from_numpy(W).to(dev), torch.from_numpy(X).to(dev), torch.from_numpy(Xq).to(dev),
-                                                 np.linspace(-1, 1, M), scalar, overlap=bool(rng.random() < 0.5))
+                                                 np.linspace(-1, 1, M), scalar, overlap=bool(rng.random() < 0.5), kernel_ready=[None, True][int(rng.random() < 0.5)])
             finally:
                 hip.set_option("blk_prep_run", 1); hip.set_option("blk_cluster", 1)
             ok = (np.array_equal(out["idx"].cpu().numpy(), io.T) and np.array_equal(out["Q"].cpu().numpy(), Qo.T.astype(np.float32))
