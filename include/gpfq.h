@@ -102,11 +102,12 @@ size_t gpfq_workspace_bytes(int64_t N, int64_t m, int64_t C, int path);
  * the first call); diagnostics for benchmarks and tests. */
 const char *gpfq_last_dense_kernel(void);
 
-/* Measurement hook: two hipEvent_t of the caller (NULL, NULL to clear; per calling thread), recorded on the launch stream
- * immediately before and after the launch of a dense layer's MAIN kernel -- the recurrence, without the pre-passes
- * that share the gpfq_quantize_neurons call -- so that a benchmark times exactly the kernel its roofline statement
- * names (bench.py).  Only the block-pipelined kernel family (gpfq_blk_kernel) records them; with any other family
- * the events are left as they were.  Results never depend on it. */
+/* Measurement hook: two hipEvent_t of the caller (NULL, NULL to clear; per calling thread; created with timing enabled) that take the
+ * start and the end of a dense layer's MAIN kernel -- the recurrence, without the pre-passes that share the call -- so that a
+ * benchmark times exactly the kernel its roofline statement names (bench.py): hipEventElapsedTime(start, stop) afterwards.  The
+ * kernel is launched WITH the events (hipExtLaunchKernelGGL: the dispatch's own timestamps, the figure rocprofv3 reports; no
+ * extra packet in the queue).  Only the block-pipelined kernel family (gpfq_blk_kernel) uses them; with any other family the
+ * events are left as they were.  Results never depend on it. */
 int gpfq_set_main_kernel_events(void *start_event, void *stop_event);
 
 /*

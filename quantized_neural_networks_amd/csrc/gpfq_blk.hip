@@ -50,6 +50,7 @@
 #include <cstdlib>
 #include <mutex>
 #include "gpfq_device.hpp"
+#include <hip/hip_ext.h>
 #include "gpfq_launch.hpp"
 #include "gpfq_roles.hpp"
 
@@ -2293,10 +2294,11 @@ static hipError_t launch_blk_sym(const PipeArgs &a, const BlkShape &sh, const De
         const int *pw = blk_split<G, S, NSW, NL>();
         for (int w = 0; w < 12; ++w) K.pw[w] = (unsigned char)(w < NSW ? pw[w] : 0);
     }
-    {
-        MainKernelEvents ev(stream);       // (a benchmark's events around this launch alone, when it asked for them)
+    hipEvent_t ev0, ev1;
+    if (main_kernel_events(&ev0, &ev1))    // (a benchmark's events on this launch alone, when it asked for them: the dispatch's own start and end)
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NSW + 1)), (unsigned)L.total, stream, ev0, ev1, 0, K);
+    else
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NSW + 1)), (size_t)L.total, stream, K);
-    }
     return hipGetLastError();
 }
 

@@ -75,8 +75,11 @@ int make_alphabet(const double *alphabet, int M, int zero_idx, HostAlphabet *H)
 
 namespace gpfq {
 void note_dense_kernel(const char *name) { g_dense_kernel = name; }
-MainKernelEvents::MainKernelEvents(hipStream_t s) : stream(s) { if (g_main_ev[0]) (void)hipEventRecord(g_main_ev[0], stream); }
-MainKernelEvents::~MainKernelEvents() { if (g_main_ev[1]) (void)hipEventRecord(g_main_ev[1], stream); }
+bool main_kernel_events(hipEvent_t *start, hipEvent_t *stop)
+{
+    *start = g_main_ev[0]; *stop = g_main_ev[1];
+    return g_main_ev[0] != nullptr && g_main_ev[1] != nullptr;
+}
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): it is raised when a launch needs more than
 // any launch before it on that device, not once per launch.

@@ -118,15 +118,12 @@ hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes);
 // Which dense kernel family the last gpfq_quantize_neurons call of this thread dispatched (diagnostics: gpfq_last_dense_kernel).
 void note_dense_kernel(const char *name);
 
-// Measurement hook (gpfq_set_main_kernel_events): two events of the calling thread, recorded on the launch stream immediately before and
-// after the launch of a dense layer's MAIN kernel -- the recurrence itself, without its pre-passes -- so that a benchmark can time
-// exactly the kernel its roofline statement names.  Recorded by the block-pipelined kernel (gpfq_blk.hip); other families leave
-// the events alone.
-struct MainKernelEvents {
-    explicit MainKernelEvents(hipStream_t stream);
-    ~MainKernelEvents();
-    hipStream_t stream;
-};
+// Measurement hook (gpfq_set_main_kernel_events): two events of the calling thread that take the start and the end of a dense layer's
+// MAIN kernel -- the recurrence itself, without its pre-passes -- so that a benchmark can time exactly the kernel its roofline statement
+// names.  The block-pipelined kernel (gpfq_blk.hip) is launched with them (hipExtLaunchKernelGGL: the dispatch's own timestamps, nothing
+// extra in the queue -- two hipEventRecord calls around the launch were two barrier packets, ~6 us of idle queue each, inside every timed
+// step); other families leave the events alone.  False: no events set.
+bool main_kernel_events(hipEvent_t *start, hipEvent_t *stop);
 
 hipError_t launch_onchip(const OnchipArgs &a, hipStream_t stream);
 bool rows_supported(const OnchipArgs &a, int lpn);

@@ -798,16 +798,18 @@ struct Sel2Ctl {
     unsigned done, pad0, pad1, pad2;
 };
 constexpr int kSel2A = 1 << 15, kSel2B = 1 << 16;
-// workspace: [SelState x 2, 64 B][ctl 64 B][histA 2 x 32768 u32][histB 2 x 65536 u32]
+// workspace: [SelState x 2, 64 B][ctl 64 B][histA 2 x 32768 u32][histB 2 x 65536 u32][coarseA 1024 u32][coarseB 2 x 1024 u32]
 static Sel2Ctl *sel2_ctl(void *ws) { return reinterpret_cast<Sel2Ctl *>(static_cast<char *>(ws) + 64); }
 static unsigned *sel2_hist_a(void *ws) { return reinterpret_cast<unsigned *>(static_cast<char *>(ws) + 128); }
 static unsigned *sel2_hist_b(void *ws) { return sel2_hist_a(ws) + 2 * kSel2A; }
-size_t median_workspace_bytes_fast(int64_t) { return 128 + (size_t)(2 * kSel2A + 2 * kSel2B) * sizeof(unsigned); }
+static unsigned *sel2_coarse_a(void *ws) { return sel2_hist_b(ws) + 2 * kSel2B; }
+static unsigned *sel2_coarse_b(void *ws) { return sel2_coarse_a(ws) + kSelThreads; }
+size_t median_workspace_bytes_fast(int64_t) { return 128 + (size_t)(2 * kSel2A + 2 * kSel2B + 3 * kSelThreads) * sizeof(unsigned); }
 
 // PASS 0: bins = key >> 16 of every element; PASS 1: bins = key & 0xffff of the elements whose high bits are the class(es) pass 0 picked.
 template <int PASS>
 __global__ void __launch_bounds__(kSelThreads)
-gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, SelState *__restrict__ st, unsigned *hist,
+gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, SelState *__restrict__ st, unsigned *hist, unsigned *coarse,
                     Sel2Ctl *__restrict__ ctl, int nsel, unsigned long long k0, unsigned long long k1, float *__restrict__ out,
                     DevAlphabet *alpha_out, double alphabet_scalar, AlphabetArg unit, int want_sym)
 {
@@ -815,7 +817,8 @@ gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, S
     __shared__ unsigned long long part[16];
     __shared__ int is_last;
     const int tid = threadIdx.x, lane = tid & 63;
-    constexpr int WORDS = kSel2A;                                 // per histogram, either pass
+    constexpr int WORDS = kSel2A;
+    constexpr int CSH = PASS == 0 ? 5 : 6;                        // fine bin >> CSH = its owner (32768 / 65536 bins over 1024 threads)                                 // per histogram, either pass
 #ifdef GPFQ_MEDIAN_STAMPS
     unsigned long long *stamps = reinterpret_cast<unsigned long long *>(ctl) + 2 + PASS * 3;      // diagnostic build: [pass][3] in the control block's spare words
     const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
@@ -840,7 +843,7 @@ gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, S
     const int64_t stride4 = (int64_t)gridDim.x * kSelThreads;
     auto count_global = [&](float w, int hs) {                    // (pass 1 only)
         const unsigned key = __float_as_uint(w) & 0x7fffffffu, cls = key & 0xffff0000u, lo = key & 0xffffu;
-        if (cls == (hs ? p1 : p0)) atomicAdd(&hist[hs * kSel2B + lo], 1u);
+        if (cls == (hs ? p1 : p0)) { atomicAdd(&hist[hs * kSel2B + lo], 1u); atomicAdd(&coarse[hs * kSelThreads + (lo >> CSH)], 1u); }
     };
     for (int hs = 0; hs < nh; ++hs) {
         pcur = hs ? p1 : p0;
@@ -858,9 +861,14 @@ gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, S
         }
         for (int64_t j = n4 * 4 + (int64_t)blockIdx.x * kSelThreads + tid; j < n; j += stride4) {      // (at most three elements)
             if (PASS == 1) count_global(W[j], hs);
-            else atomicAdd(&hist[(__float_as_uint(W[j]) & 0x7fffffffu) >> 16], 1u);
+            else {
+                const unsigned bin = (__float_as_uint(W[j]) & 0x7fffffffu) >> 16;
+                atomicAdd(&hist[bin], 1u); atomicAdd(&coarse[bin >> CSH], 1u);
+            }
         }
         __syncthreads();
+        // merge: the fine counts in rounds of 1024 consecutive words (a wavefront's atomics of a round fall into four lines: one owner's
+        // words per thread made every one of them 64 lines, 92 us of pass 0) ...
         if (PASS == 0) {
             for (int b = tid; b < WORDS; b += kSelThreads) {
                 const unsigned cnt = h[b];
@@ -872,6 +880,18 @@ gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, S
                 if (cnt & 0xffffu) atomicAdd(&hist[hs * kSel2B + 2 * b], cnt & 0xffffu);
                 if (cnt >> 16) atomicAdd(&hist[hs * kSel2B + 2 * b + 1], cnt >> 16);
             }
+        }
+        // ... and the coarse count of thread t's own bins -- the 32 words from 32 t: 32 bins of pass 0, 64 sixteen-bit bins of pass 1 -- as
+        // a sum in a register (the words of a wavefront's lanes taken rotated by the lane: 32 different banks per round)
+        {
+            constexpr int WPT = WORDS / kSelThreads;
+            unsigned tot = 0;
+#pragma unroll 8
+            for (int j = 0; j < WPT; ++j) {
+                const unsigned cnt = h[tid * WPT + ((j + lane) & (WPT - 1))];
+                tot += PASS == 0 ? cnt : (cnt & 0xffffu) + (cnt >> 16);
+            }
+            if (tot) atomicAdd(&coarse[hs * kSelThreads + tid], tot);
         }
         __syncthreads();
     }
@@ -904,17 +924,16 @@ gpfq_median2_kernel(const float *__restrict__ W, int64_t n, int64_t per_block, S
     unsigned long long rank_of[2];
     rank_of[0] = st[0].k; rank_of[1] = nsel > 1 ? st[1].k : 0;
     for (int scan = 0; scan < (nsel > 1 && split ? 2 : 1); ++scan) {
-        const unsigned *src = hist + (scan ? kSel2B : 0);
+        const unsigned *src = hist + (scan ? kSel2B : 0), *csrc = coarse + (scan ? kSelThreads : 0);
         const int s_lo = scan, s_hi = (nsel > 1 && !split) ? 2 : scan + 1;       // the order statistics this scan serves
         if (tid < 2) { f_thread[tid] = -1; f_before[tid] = 0; }
         // (plain 16-byte loads: the acquire fence above has dropped this workgroup's stale lines, and every merge was acknowledged before
         //  its workgroup took a ticket -- PER single agent-scope loads in sequence cost 50-90 us per pick)
-        unsigned long long mine = 0;
-        {
-            const uint4 *s4 = reinterpret_cast<const uint4 *>(src + tid * PER);
-#pragma unroll
-            for (int b = 0; b < PER / 4; ++b) { const uint4 v = s4[b]; mine += (unsigned long long)v.x + v.y + v.z + v.w; }
-        }
+        // Thread tid owns the PER consecutive bins from tid * PER; their sum is word tid of the pass's COARSE histogram, which every
+        // workgroup merged beside the fine one: one 4 KiB read instead of the whole 128 / 256 KiB histogram, whose lines -- last written by
+        // agent-scope atomics of all eight XCDs -- one compute unit pulled in at 20 GB/s (7 / 12.6 us of pick in a 22 / 30 us pass,
+        // whatever the access pattern: profiles/r06/median_probe.txt).
+        const unsigned long long mine = csrc[tid];
         unsigned long long incl = mine;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -995,10 +1014,10 @@ hipError_t launch_median_abs(const float *W, int64_t n, float *out, void *worksp
     if (e == hipSuccess) e = ensure_dynamic_lds((const void *)gpfq_median2_kernel<1>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gpfq_median2_kernel<0>, dim3(grid), dim3(kSelThreads), kSel2A * sizeof(unsigned), stream, W, n, per, sel_state(workspace),
-                       sel2_hist_a(workspace), sel2_ctl(workspace), sel_count(n), k0, k1, (float *)nullptr,
+                       sel2_hist_a(workspace), sel2_coarse_a(workspace), sel2_ctl(workspace), sel_count(n), k0, k1, (float *)nullptr,
                        (DevAlphabet *)nullptr, 0.0, no_unit, 0);
     hipLaunchKernelGGL(gpfq_median2_kernel<1>, dim3(grid), dim3(kSelThreads), lds, stream, W, n, per, sel_state(workspace),
-                       sel2_hist_b(workspace), sel2_ctl(workspace), sel_count(n), k0, k1, out,
+                       sel2_hist_b(workspace), sel2_coarse_b(workspace), sel2_ctl(workspace), sel_count(n), k0, k1, out,
                        static_cast<DevAlphabet *>(alpha_out), alphabet_scalar, unit ? *unit : no_unit, want_sym);
     return hipGetLastError();
 }

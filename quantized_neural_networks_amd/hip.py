@@ -756,9 +756,10 @@ def last_dense_kernel():
 
 
 def set_main_kernel_events(start=None, stop=None):
-    """Measurement hook (gpfq_set_main_kernel_events): two torch.cuda.Event(enable_timing=True) that the block-pipelined dense
-    kernel records around its own launch -- the recurrence without the pre-passes of the same quantize_neurons() call.  None, None
-    clears.  torch creates an event's handle at its first record(): the events are recorded once here so that the handle exists."""
+    """Measurement hook (gpfq_set_main_kernel_events): two torch.cuda.Event(enable_timing=True) that take the start and the end of the
+    block-pipelined dense kernel's own dispatch -- the recurrence without the pre-passes of the same call (the kernel is launched with
+    them: hipExtLaunchKernelGGL, no extra packet in the queue); start.elapsed_time(stop) afterwards.  None, None clears.  torch creates an
+    event's handle at its first record(): events that have none are recorded once here (a benchmark does that before its timed region)."""
     if start is None or stop is None:
         _check(load().gpfq_set_main_kernel_events(None, None), "gpfq_set_main_kernel_events")
         return
