@@ -48,7 +48,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
 
 @pytest.mark.gpu
 def test_main_kernel_events_bracket_the_recurrence_kernel_alone():
-    """gpfq_set_main_kernel_events: the block-pipelined kernel records the caller's two events around its own launch -- inside the
+    """gpfq_set_main_kernel_events: the block-pipelined kernel is launched with the caller's two events (its own start and end) -- inside the
     events around the gpfq_quantize_neurons call, which also holds the record pre-pass; cleared, nothing is recorded; a kernel
     family that does not take part leaves them alone."""
     import numpy as np
