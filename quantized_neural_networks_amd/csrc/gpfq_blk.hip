@@ -241,12 +241,17 @@ template <int B, bool R64>
 __global__ void __launch_bounds__(256)
 gpfq_blk_prep_run_kernel(const float *__restrict__ X, const float *__restrict__ Xq, int64_t ld, int64_t N, int m, int mp, int64_t nrec, int RUN,
                          const float *__restrict__ nrm32, char *__restrict__ recs, char *__restrict__ hdrs,
-                         const DevAlphabet *__restrict__ alpha, int sym)
+                         const DevAlphabet *__restrict__ alpha, int sym, unsigned *__restrict__ zero16)
 {
     constexpr int GREC = R64 ? 2 : 1;
     constexpr int ND = blk_band(B), NV = 3 + 4 * ND, NP = (NV + 3) & ~3;
     constexpr int hdr = blk_hdr_bytes(B);
     __shared__ double sm[kPrepRunMax][4][NP + 1];
+    // nrm32 == NULL (rows of ONE chunk per thread, m % 4 == 0: launch_blk): the row norms are formed here, as gpfq_row_norms_kernel forms
+    // them -- the same four products per thread in the same order, the same wavefront sum, the same sum of the four wavefronts -- bit for bit
+    __shared__ double nsm[kPrepRunMax][4];
+    const bool own_norms = nrm32 == nullptr;
+    if (zero16 && blockIdx.x == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0u;    // (the call's counter block: gpfq_quantize_dense_layer)
     const float sym_a = sym ? alpha->sym_a : 0.f;
     const int64_t t0 = (int64_t)blockIdx.x * RUN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -286,6 +291,15 @@ gpfq_blk_prep_run_kernel(const float *__restrict__ X, const float *__restrict__ 
                 } else {
                     *reinterpret_cast<float4 *>(reinterpret_cast<float *>(rb + hdr + 8 * (int64_t)mp) + i) = qn;
                 }
+            }
+            if (own_norms) {
+                double s = 0.0;
+                s = fma((double)qc4.x, (double)qc4.x, s);
+                s = fma((double)qc4.y, (double)qc4.y, s);
+                s = fma((double)qc4.z, (double)qc4.z, s);
+                s = fma((double)qc4.w, (double)qc4.w, s);
+                s = wave_sum(s);
+                if (lane == 0) nsm[r][wave] = s;
             }
             double v[NP];                                         // G, sum|Xq X|, sum|Xq|, then (H1, H2, sum|.|, sum|.|) per distance
 #pragma unroll
@@ -336,7 +350,7 @@ gpfq_blk_prep_run_kernel(const float *__restrict__ X, const float *__restrict__ 
         char *rb = recs + t * rbytes;
         if (e == 0) {
             BlkStats st{};
-            const double nrm = t < N ? (double)nrm32[t] : 0.0;
+            const double nrm = t < N ? (own_norms ? (double)(float)sqrt(nsm[r][0] + nsm[r][1] + nsm[r][2] + nsm[r][3]) : (double)nrm32[t]) : 0.0;
             const double s1 = total(1), s2 = total(2);
             st.nrm = nrm;
             st.rden = nrm < 1e-16 ? 0.0 : 1.0 / (nrm * nrm);
@@ -2011,6 +2025,8 @@ static std::atomic<int> g_blk_cluster_nl{0};      // cluster form: neurons per l
 void blk_set_cluster_nl(int v) { g_blk_cluster_nl.store(v == 1 || v == 2 || v == 4 ? v : 0, std::memory_order_relaxed); }
 static std::atomic<int> g_blk_prep_run{1};         // 1 (default): the record pre-pass takes runs of 4 .. 16 records per workgroup for walks of 2048+ steps; 0: one record per workgroup; 4 .. 16: runs of that many at any length (option blk_prep_run: A/B, tests)
 void blk_set_prep_run(int v) { g_blk_prep_run.store(v >= 4 && v <= 16 ? v : (v ? 1 : 0), std::memory_order_relaxed); }
+static std::atomic<int> g_blk_prep_norms{1};       // 1 (default): gpfq_quantize_dense_layer's row norms inside the record pre-pass where that is bit-identical; 0: always the row-norm kernel (option blk_prep_norms: A/B, tests)
+void blk_set_prep_norms(int v) { g_blk_prep_norms.store(v ? 1 : 0, std::memory_order_relaxed); }
 static std::atomic<int> g_blk_chip{-1};            // -1: ask the device; 0 / 1 force the answer of blk_chip_ok (option blk_chip_ok: tests)
 void blk_set_chip_ok(int v) { g_blk_chip.store(v < 0 ? -1 : (v ? 1 : 0), std::memory_order_relaxed); }
 static std::atomic<int> g_blk_cl_timeout_ms{3000};  // how long an exchange of the cluster form waits for a slice before it gives up (option blk_cluster_timeout_ms)
@@ -2405,12 +2421,26 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
+    const bool vec_rows = (a.ld % 4 == 0) && (((uintptr_t)a.X | (uintptr_t)a.Xq) % 16 == 0);
+    const bool run_form = !sh.NS && vec_rows && (g_blk_prep_run.load(std::memory_order_relaxed) > 1 || (g_blk_prep_run.load(std::memory_order_relaxed) == 1 && nrec >= 2048));
+    // (the row norms, when the caller left them to this call: inside the pre-pass where it forms the row-norm kernel's very sums, else by that kernel)
+    const float *nrm32 = a.nrm32;
+    unsigned *zero16 = nullptr;
+    if (do_prep && !nrm32 && a.nrm32_out) {
+        zero16 = reinterpret_cast<unsigned *>(a.fallback_count);
+        const bool fuse = run_form && sh.mp <= 1024 && a.m % 4 == 0 && g_blk_prep_norms.load(std::memory_order_relaxed) != 0;
+        if (!fuse) {
+            e = launch_row_norms(a.Xq, a.N, a.m, a.ld, a.nrm32_out, stream, zero16);
+            if (e != hipSuccess) return e;
+            nrm32 = a.nrm32_out; zero16 = nullptr;
+        }
+    }
     if (sh.NS) {                                                   // cluster form: NS slices of the headline shape
         note_dense_kernel("gpfq_blk_kernel, cluster form (rows cut into 1024-sample slices: one workgroup of 8 or 11 sweep wavefronts + 1 decision wavefront per slice, partial dot products exchanged once per slot)");
         const int sym = sym_shape;
         if (do_prep) {
             hipLaunchKernelGGL((gpfq_blk_prep_kernel<4, true, true>), dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp * sh.NS,
-                               a.nrm32, wbase, wbase + blk_hdrs_off(nblk, sh), alpha, sym_prep,
+                               nrm32, wbase, wbase + blk_hdrs_off(nblk, sh), alpha, sym_prep,
                                sh.NS, (int64_t)blk_recs_bytes(nblk, sh));
             e = hipGetLastError();
             if (e != hipSuccess) return e;
@@ -2455,10 +2485,10 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
         auto *prun = sh.B == 4 ? (r64 ? gpfq_blk_prep_run_kernel<4, true> : gpfq_blk_prep_run_kernel<4, false>)
                                : (sh.B == 2 ? (r64 ? gpfq_blk_prep_run_kernel<2, true> : gpfq_blk_prep_run_kernel<2, false>) : gpfq_blk_prep_run_kernel<1, false>);
         hipLaunchKernelGGL(prun, dim3((unsigned)((nrec + run - 1) / run)), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp, nrec, run,
-                           a.nrm32, wbase, wbase + blk_recs_bytes(nblk, sh), alpha, sym);
+                           nrm32, wbase, wbase + blk_recs_bytes(nblk, sh), alpha, sym, zero16);
     } else {
         hipLaunchKernelGGL(prep, dim3((unsigned)nrec), dim3(256), 0, stream, a.X, a.Xq, a.ld, a.N, (int)a.m, sh.mp,
-                           a.nrm32, wbase, wbase + blk_recs_bytes(nblk, sh), alpha, sym, 1, (int64_t)0);
+                           nrm32, wbase, wbase + blk_recs_bytes(nblk, sh), alpha, sym, 1, (int64_t)0);
     }
     e = hipGetLastError();
     if (e != hipSuccess || !do_run) return e;

@@ -224,6 +224,7 @@ int gpfq_set_option(const char *key, int value)
     if (!std::strcmp(key, "blk_cluster_map")) { gpfq::blk_set_cluster_map(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_cluster768")) { gpfq::blk_set_cluster768(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_prep_run")) { gpfq::blk_set_prep_run(value); return GPFQ_OK; }
+    if (!std::strcmp(key, "blk_prep_norms")) { gpfq::blk_set_prep_norms(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_chip_ok")) { gpfq::blk_set_chip_ok(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_cluster_fault")) { gpfq::blk_set_cluster_fault(value); return GPFQ_OK; }
     if (!std::strcmp(key, "blk_cluster_timeout_ms")) {
@@ -551,20 +552,19 @@ static int dense_layer_impl(int phase, const float *X, const float *Xq, int64_t 
         return fail(GPFQ_ERR_WORKSPACE, "%s needs %zu aligned workspace bytes", what, gpfq_dense_layer_workspace_bytes(N, m, C));
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e = hipSuccess;
+    float *n32_out = nullptr;
     if (phase != 2) {
-        // the call's counter block (exact fallbacks, cluster timeout, alphabet word) is zeroed by the row-norm launch when that runs here
+        // the call's counter block (exact fallbacks, cluster timeout, alphabet word) is zeroed with the row norms when they are formed here
+        // (launch_blk: inside the record pre-pass, or by the row-norm kernel in front of it)
         if (!nrm32) {
-            float *n32 = reinterpret_cast<float *>(static_cast<char *>(workspace) + onchip_workspace_bytes(N, m, C));
-            e = gpfq::launch_row_norms(Xq, N, m, ld, n32, s, static_cast<unsigned *>(workspace));
-            if (e != hipSuccess) return hip_fail(e, what);
-            nrm32 = n32;
+            n32_out = reinterpret_cast<float *>(static_cast<char *>(workspace) + onchip_workspace_bytes(N, m, C));
         } else {
             e = hipMemsetAsync(workspace, 0, 64, s);
             if (e != hipSuccess) return hip_fail(e, what);
         }
     }
     gpfq::PipeArgs pa{};
-    pa.X = X; pa.Xq = Xq; pa.ld = ld; pa.nrm32 = nrm32;
+    pa.X = X; pa.Xq = Xq; pa.ld = ld; pa.nrm32 = nrm32; pa.nrm32_out = n32_out;
     pa.Wt = W ? W + c_lo : nullptr; pa.ldw = 1; pa.ldt = ldc;     // the Keras kernel itself: neuron j's weight of step t is W[t][c_lo + j]
     pa.A = H.A; pa.N = N; pa.m = m; pa.C = C;
     pa.resid = resid; pa.u_out = nullptr;

@@ -84,6 +84,10 @@ struct PipeArgs {
     const DevAlphabet *dev_alpha = nullptr;
     int zero_counters = 0;                 // 1: launch_blk zeroes the call's 64-byte counter block (fallback_count) itself, with the alphabet's store
     int phase = 0;                         // 0: the whole call; 1: the alphabet-independent half (record pre-pass); 2: the rest (launch_blk)
+    // nrm32 == NULL with nrm32_out set (gpfq_quantize_dense_layer without the caller's norms): launch_blk forms the row norms itself -- inside the
+    // record pre-pass where that reproduces the row-norm kernel's sums bit for bit (runs of records, rows of one 1024-sample chunk, m % 4 == 0),
+    // else by that kernel into nrm32_out -- and zeroes the call's counter block (fallback_count) with them
+    float *nrm32_out = nullptr;
 };
 // Block form (gpfq_blk.hip): B steps per slot; same arguments.
 // The layer alphabet formed on the device from the float32 median of |W| (device scalar): rad = alphabet_scalar * median, members
@@ -102,6 +106,7 @@ void blk_set_quad_waves(int nw);    // sweep wavefronts of the four-group narrow
 void blk_set_cluster_nl(int v);     // cluster form: neurons per lane of a workgroup, 0 (default) = by width, 1 / 2 / 4 force it (speed only)
 void blk_set_cluster_map(int v);    // cluster form: workgroup id -> (cluster, slice): -1 (default) by the slice count, 0 = a cluster inside one XCD, 1 = consecutive ids (speed only)
 void blk_set_cluster(int v);        // cluster form (rows cut into 1024-sample slices over several workgroups, up to 16384 samples): 1 (default) = by shape, 0 = off, v >= 1024 = every row beyond v samples (speed only)
+void blk_set_prep_norms(int v);     // 1 (default): the dense-layer call's row norms formed inside the record pre-pass where bit-identical; 0: always by the row-norm kernel
 void blk_set_prep_run(int v);       // 1 (default): the record pre-pass in runs of eight records per workgroup; 0: one record per workgroup (same records)
 void blk_set_cluster768(int v);     // rows of 2049..3072 samples in layers wider than 2048 neurons as four 768-sample slices: -1 (default) yes, 8 / 11 force the sweep wavefronts, 0 = the classic one-step shape (speed only)
 void blk_set_chip_ok(int v);        // -1 (default): the cluster form asks the device whether it is the whole 8 x 32-CU chip; 0 / 1: forced (tests)

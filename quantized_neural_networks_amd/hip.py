@@ -785,7 +785,7 @@ def cluster_timeouts(result):
     return 0 if ws is None or ws.numel() < 16 else int(ws[8:12].view(torch.int32).item())
 
 
-_OPTION_DEFAULTS = {"blk_cluster768": -1, "blk_prep_run": 1, "blk_cluster": 1, "blk_cluster_nl": 0, "blk_cluster_map": -1, "blk_chip_ok": -1, "blk_cluster_timeout_ms": 3000,
+_OPTION_DEFAULTS = {"blk_cluster768": -1, "blk_prep_run": 1, "blk_prep_norms": 1, "blk_cluster": 1, "blk_cluster_nl": 0, "blk_cluster_map": -1, "blk_chip_ok": -1, "blk_cluster_timeout_ms": 3000,
                     "blk_cluster_fault": 0, "sync_errors": 0}
 _options = {}
 

@@ -374,3 +374,37 @@ def test_class_surface_runs_dense_layers_on_the_device_path(hip, layer, monkeypa
         assert dev_stats[k][0] == host_stats[k][0]
         np.testing.assert_allclose(dev_stats[k][1], host_stats[k][1], rtol=RESID_RTOL)
         assert np.array_equal(dev_stats[k][2], host_stats[k][2])
+
+
+@pytest.mark.parametrize("N,C,m,levels,run", [(37, 70, 1000, 16, 8), (64, 600, 1024, 3, 5), (2100, 40, 1024, 3, 1), (33, 20, 772, 4, 16), (21, 9, 1022, 3, 8),
+                                              (41, 33, 2048, 4, 8), (13, 9, 5008, 8, 8), (50, 17, 1024, 3, 0)])
+def test_row_norms_inside_the_record_prepass(hip, layer, oracle_mod, N, C, m, levels, run):
+    """gpfq_quantize_dense_layer without the caller's row norms forms them inside the record pre-pass where that reproduces the row-norm
+    kernel's sums bit for bit (runs of records, one 1024-sample chunk, m % 4 == 0: the first four cases) and by that kernel otherwise (a
+    ragged row, long rows, the cluster form, one record per workgroup).  Option blk_prep_norms = 0 always takes the kernel: same indices,
+    values, residual norms, the same count of exact-fallback decisions -- and the call's counter block is zeroed either way."""
+    W, X, Xq = _synthetic(N, m, C, seed=N + 3 * m)
+    Xq[N // 2] = 0                                                 # a zero row: norm 0, the reference's first rule
+    unit = np.linspace(-1, 1, levels)
+    alphabet, rad = oracle_mod.layer_alphabet(W, unit, 2.5)
+    Q, idx, resid = oracle_mod.layer(W, X, Xq, alphabet)
+    Wd, Xd, Xqd = _dev(W), _dev(X), _dev(Xq)
+    dalpha = layer.layer_alphabet_device(Wd, unit, 2.5)
+    outs = []
+    try:
+        hip.set_option("blk_prep_run", run)
+        for norms in (1, 0, 1):
+            hip.set_option("blk_prep_norms", norms)
+            r = hip.quantize_dense_layer(Xd, Xqd, Wd, dalpha, keras_out=False, want_values=True)
+            assert hip.call_status(r) == 0
+            outs.append((r["idx"].cpu().numpy(), r["Q"].cpu().numpy(), r["resid"].cpu().numpy(), hip.exact_fallbacks(r)))
+        # the caller's own norms (gpfq_row_norms): the third way to the same records
+        r = hip.quantize_dense_layer(Xd, Xqd, Wd, dalpha, nrm32=hip.row_norms(Xqd), keras_out=False, want_values=True)
+        outs.append((r["idx"].cpu().numpy(), r["Q"].cpu().numpy(), r["resid"].cpu().numpy(), hip.exact_fallbacks(r)))
+    finally:
+        hip.set_option("blk_prep_run", 1)
+        hip.set_option("blk_prep_norms", 1)
+    for o in outs:
+        assert np.array_equal(o[0], idx) and np.array_equal(o[1], Q.astype(np.float32))
+        np.testing.assert_allclose(o[2], resid, rtol=RESID_RTOL)
+        assert np.array_equal(o[2], outs[0][2]) and o[3] == outs[0][3]
