@@ -101,7 +101,7 @@ hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes)
 
 extern "C" {
 
-int gpfq_version(void) { return 305; }   // 305: device-resident layer alphabet, gpfq_quantize_dense_layer, gpfq_call_status, the block kernel's workspace grew by its alphabet block (round 6); 304: options blk_cluster / blk_cluster_nl / blk_cluster_map, larger workspaces for long rows (round 5); 303: gpfq_set_main_kernel_events (round 4); hip.load() checks it
+int gpfq_version(void) { return 306; }   // 306: the two-pass median's workspace grew by its coarse histograms (gpfq_median_abs_workspace_bytes_for), gpfq_set_main_kernel_events' events ride on the kernel's dispatch, option blk_prep_norms (round 6); 305: device-resident layer alphabet, gpfq_quantize_dense_layer, gpfq_call_status, the block kernel's workspace grew by its alphabet block (round 6); 304: options blk_cluster / blk_cluster_nl / blk_cluster_map, larger workspaces for long rows (round 5); 303: gpfq_set_main_kernel_events (round 4); hip.load() checks it
 
 const char *gpfq_last_dense_kernel(void) { return g_dense_kernel; }
 

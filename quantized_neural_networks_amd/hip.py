@@ -99,7 +99,7 @@ def lib_path():
     return _build.LIB
 
 
-ABI_VERSION = 305                  # gpfq_version() of the library this binding was written against
+ABI_VERSION = 306                  # gpfq_version() of the library this binding was written against
 
 
 def load():

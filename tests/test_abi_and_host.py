@@ -28,7 +28,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_errors_without_gpu(lib):
-    assert lib.gpfq_version() == 305
+    assert lib.gpfq_version() == 306
     # argument validation happens before any launch: safe without a device
     a = (ctypes.c_double * 3)(-1.0, 0.0, 1.0)
     rc = lib.gpfq_quantize_neurons(None, None, 4, None, None, 4, a, 3, 1, 4, 8, 2, None, None, None, None, None, 0, 0, None)
