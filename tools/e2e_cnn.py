@@ -1,14 +1,15 @@
 """End-to-end QuantizedCNN.quantize_network() on BASELINE cfg4: the CIFAR10 CNN of train_cifar10_cnn.py:63-86
 (random weights), 5000 synthetic calibration images in batches of 16 (=> 5008 columns with the partial-batch
 quirk), 3 bits, alphabet_scalar 4.  Prints where the wall time goes: activation capture vs quantization.
-usage: e2e_cnn.py [n_images] [batch]"""
+usage: e2e_cnn.py [n_images] [batch] [--bn] [--profile] [--host-alphabet]"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 from quantized_neural_networks_amd import keras_shim as ks, quantized_network as qn
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
-batch = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(_pos[0]) if len(_pos) > 0 else 5000
+batch = int(_pos[1]) if len(_pos) > 1 else 16
 
 
 class TimingLogger:
@@ -45,6 +46,8 @@ for it in range(4):
     net = build()
     log = TimingLogger()
     q = qn.QuantizedCNN(network=net, batch_size=batch, get_data=qn.CIFAR10Sequence(x, y, batch), logger=log, bits=3, alphabet_scalar=4)
+    if "--host-alphabet" in sys.argv:         # (A/B: round 5's Dense driver -- host alphabet, neuron-major copy, assembly pass)
+        q._layer_alphabet_device = lambda layer_idx, rad: None
     q.lookahead_capture = it >= 2            # runs 2, 3: with the analog look-ahead on the second stream (default on a single GPU: off)
     torch.cuda.synchronize(); t0 = time.time()
     if it == 1 and "--profile" in sys.argv:

@@ -1,7 +1,7 @@
 """End-to-end QuantizedNeuralNetwork.quantize_network() on the MNIST MLP of train_mnist_mlp.py:61-73
 (Flatten, Dense(relu)+BatchNormalization per hidden width, Dense(softmax); random weights) with one batch of
 `m` synthetic calibration samples as quantize_pretrained_mlp.py:73 feeds it.
-usage: e2e_mlp.py [m] [widths, comma separated] [bits] [--profile]"""
+usage: e2e_mlp.py [m] [widths, comma separated] [bits] [--profile] [--host-alphabet]"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -32,11 +32,13 @@ def build():
 r = np.random.default_rng(0)
 x = r.random((m, 28, 28)).astype(np.float32)
 y = np.zeros((m, 10), dtype=np.float32)
-for it in range(3):
+for it in range(6 if "--more" in sys.argv else 3):
     net = build()
     log = NullLogger()
     q = qn.QuantizedNeuralNetwork(network=net, batch_size=m, get_data=qn.MNISTSequence(x, y, m), logger=log, bits=bits,
                                   alphabet_scalar=5)
+    if "--host-alphabet" in sys.argv:                  # (A/B: round 5's Dense driver -- host alphabet, neuron-major copy, assembly pass)
+        q._layer_alphabet_device = lambda layer_idx, rad: None
     torch.cuda.synchronize(); t0 = time.time()
     if it == 2 and "--profile" in sys.argv:
         import cProfile, pstats
