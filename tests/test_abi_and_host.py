@@ -289,3 +289,19 @@ def test_cluster_form_options_and_workspace_sizing(lib):
         lib.gpfq_set_option(b"blk_cluster", 1)
         lib.gpfq_set_option(b"blk_cluster_nl", 0)
         lib.gpfq_set_option(b"blk_cluster_map", -1)
+
+
+def test_round6_options_and_median_workspace(lib):
+    """Host side of round 6's late additions (no launch): the options are known to gpfq_set_option, an unknown key is refused with its
+    name in the message, and the two-pass median's workspace holds its two fine histograms AND the three coarse ones the picks read."""
+    try:
+        for key, values in ((b"blk_prep_norms", (0, 1)), (b"blk_prep_run", (0, 1, 4, 16)), (b"blk_cluster768", (-1, 0, 8, 11)), (b"sync_errors", (0, 1))):
+            for v in values:
+                assert lib.gpfq_set_option(key, v) == 0, (key, v)
+        assert lib.gpfq_set_option(b"blk_prep_norm", 1) != 0 and b"blk_prep_norm" in lib.gpfq_last_error()
+    finally:
+        for key, v in ((b"blk_prep_norms", 1), (b"blk_prep_run", 1), (b"blk_cluster768", -1), (b"sync_errors", 0)):
+            lib.gpfq_set_option(key, v)
+    fine = 4 * (2 * (1 << 15) + 2 * (1 << 16))
+    assert int(lib.gpfq_median_abs_workspace_bytes_for(1 << 24)) == 128 + fine + 4 * 3 * 1024
+    assert int(lib.gpfq_median_abs_workspace_bytes_for(1 << 24)) == int(lib.gpfq_median_abs_workspace_bytes_for(1000))   # (any kernel: a function of nothing but the form)

@@ -23,6 +23,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]:
         assert key in out, key
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True
+    assert out["clock_warmup_steps"] == 10 and out["deferred_status_nonzero_steps"] == 0       # (untimed steps before the warm-up steps: the chip's clock ramp)
     assert out["value"] > 0 and out["ms_per_step"] > 0 and out["vs_baseline"] is None and "workload" in out["config"]
     roof = out["roofline"]
     for key in ["bound", "achieved", "peak", "unit", "frac", "traffic"]:
@@ -32,7 +33,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert 0 < roof["frac"] <= 1.0 and roof["unit"] in ("TFLOP/s", "GB/s") and roof["kernel"]
     assert roof["kernel_ms_avg"] > 0 and roof["algorithmic_flops_per_launch"] == 6.0 * 512 * 256 * 512
     assert roof["compulsory_bytes_per_launch"] == (2 * 256 * 512 + 2 * 256 * 512) * 4 and "hbm_equiv" in roof
-    # the kernel's own events (recorded by the library around its launch) lie inside the events around the whole call
+    # the kernel's own events (its dispatch's start and end) lie inside the events around the whole call (five extra steps after the timed region)
     assert 0 < roof["kernel_ms_min"] <= roof["kernel_ms_avg"] <= roof["call_ms_avg"]
     cpu = out["cpu_baseline"]
     for key in ["value", "unit", "cores", "kind", "sample"]:
