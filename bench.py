@@ -81,7 +81,7 @@ def main():
                     help="(the default on one GPU) the median of |W| + alphabet on a second HIP stream -- they depend on the analog kernel alone, which is "
                          "complete long before the step, as a trained network's is: no fork wait --, row norms + record pre-pass on this one "
                          "(gpfq_dense_layer_prepare), ONE join, then the alphabet-dependent rest (gpfq_dense_layer_run): layer.quantize_dense_layer("
-                         "overlap=True, kernel_ready=True).  Same box: 3.050 -> 2.998 / 3.010 ms per step (profiles/r06/overlap_ab.txt)")
+                         "overlap=True, kernel_ready=True).  Same box: 2.97 -> 2.94 ms per step, kernel + 0.10 -> kernel + 0.07 (profiles/r06/overlap_ab.txt)")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="one stream: median, alphabet, row norms, record pre-pass, kernel in sequence")
     ap.set_defaults(overlap=True)
     ap.add_argument("--numpy-sample", type=int, default=-1,
