@@ -175,7 +175,7 @@ int gpfq_set_option(const char *key, int value);
  *                  times instead of eighteen) for walks of 2048+ steps, the run length by the number of records; 0: one record per
  *                  workgroup (the same records); 4 .. 16: runs of that many records whatever the walk's length (tests, A/B)
  *   "blk_prep_norms"  1 (default): gpfq_quantize_dense_layer / _prepare called without the caller's row norms form them INSIDE the record
- *                  pre-pass where that reproduces gpfq_row_norms' sums bit for bit (runs of records, rows of at most 1024 padded samples,
+ *                  pre-pass where that reproduces gpfq_row_norms' sums bit for bit (runs of records, rows of 769 .. 1024 samples,
  *                  m a multiple of four) -- one launch less; 0: always by the row-norm kernel in front of the pre-pass (tests, A/B)
  *   "blk_cluster768"  -1 (default): rows of 2049..3072 samples in layers wider than 2048 neurons run as FOUR 768-sample slices of the cluster
  *                  form (64 clusters per round: whole rounds), eleven sweep wavefronts for symmetric alphabets, eight otherwise; 8 / 11 force

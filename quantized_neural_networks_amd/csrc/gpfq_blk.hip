@@ -247,7 +247,7 @@ gpfq_blk_prep_run_kernel(const float *__restrict__ X, const float *__restrict__ 
     constexpr int ND = blk_band(B), NV = 3 + 4 * ND, NP = (NV + 3) & ~3;
     constexpr int hdr = blk_hdr_bytes(B);
     __shared__ double sm[kPrepRunMax][4][NP + 1];
-    // nrm32 == NULL (rows of ONE chunk per thread, m % 4 == 0: launch_blk): the row norms are formed here, as gpfq_row_norms_kernel forms
+    // nrm32 == NULL (rows of exactly ONE 16-byte piece per thread -- 1024 padded samples --, m % 4 == 0: launch_blk): the row norms are formed here, as gpfq_row_norms_kernel forms
     // them -- the same four products per thread in the same order, the same wavefront sum, the same sum of the four wavefronts -- bit for bit
     __shared__ double nsm[kPrepRunMax][4];
     const bool own_norms = nrm32 == nullptr;
@@ -2428,7 +2428,9 @@ hipError_t launch_blk(const PipeArgs &a, hipStream_t stream)
     unsigned *zero16 = nullptr;
     if (do_prep && !nrm32 && a.nrm32_out) {
         zero16 = reinterpret_cast<unsigned *>(a.fallback_count);
-        const bool fuse = run_form && sh.mp <= 1024 && a.m % 4 == 0 && g_blk_prep_norms.load(std::memory_order_relaxed) != 0;
+        // (mp == 1024 exactly: every thread of the pre-pass's workgroups then holds one 16-byte piece of a row -- with fewer, whole wavefronts sit
+        //  the loop out and the wavefront sum would read lanes that never ran: tools/fuzz_parity.py found that at 292 samples)
+        const bool fuse = run_form && sh.mp == 1024 && a.m % 4 == 0 && g_blk_prep_norms.load(std::memory_order_relaxed) != 0;
         if (!fuse) {
             e = launch_row_norms(a.Xq, a.N, a.m, a.ld, a.nrm32_out, stream, zero16);
             if (e != hipSuccess) return e;

@@ -85,7 +85,7 @@ struct PipeArgs {
     int zero_counters = 0;                 // 1: launch_blk zeroes the call's 64-byte counter block (fallback_count) itself, with the alphabet's store
     int phase = 0;                         // 0: the whole call; 1: the alphabet-independent half (record pre-pass); 2: the rest (launch_blk)
     // nrm32 == NULL with nrm32_out set (gpfq_quantize_dense_layer without the caller's norms): launch_blk forms the row norms itself -- inside the
-    // record pre-pass where that reproduces the row-norm kernel's sums bit for bit (runs of records, rows of one 1024-sample chunk, m % 4 == 0),
+    // record pre-pass where that reproduces the row-norm kernel's sums bit for bit (runs of records, rows of 1024 padded samples, m % 4 == 0),
     // else by that kernel into nrm32_out -- and zeroes the call's counter block (fallback_count) with them
     float *nrm32_out = nullptr;
 };

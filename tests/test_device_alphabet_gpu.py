@@ -377,11 +377,13 @@ def test_class_surface_runs_dense_layers_on_the_device_path(hip, layer, monkeypa
 
 
 @pytest.mark.parametrize("N,C,m,levels,run", [(37, 70, 1000, 16, 8), (64, 600, 1024, 3, 5), (2100, 40, 1024, 3, 1), (33, 20, 772, 4, 16), (21, 9, 1022, 3, 8),
-                                              (41, 33, 2048, 4, 8), (13, 9, 5008, 8, 8), (50, 17, 1024, 3, 0)])
+                                              (41, 33, 2048, 4, 8), (13, 9, 5008, 8, 8), (50, 17, 1024, 3, 0),
+                                              (156, 2050, 292, 4, 8), (40, 33, 512, 3, 8), (25, 70, 768, 3, 4), (31, 18, 260, 2, 16)])
 def test_row_norms_inside_the_record_prepass(hip, layer, oracle_mod, N, C, m, levels, run):
     """gpfq_quantize_dense_layer without the caller's row norms forms them inside the record pre-pass where that reproduces the row-norm
-    kernel's sums bit for bit (runs of records, one 1024-sample chunk, m % 4 == 0: the first four cases) and by that kernel otherwise (a
-    ragged row, long rows, the cluster form, one record per workgroup).  Option blk_prep_norms = 0 always takes the kernel: same indices,
+    kernel's sums bit for bit (runs of records, rows padded to exactly 1024 samples, m % 4 == 0: the first four cases) and by that kernel
+    otherwise (a ragged row, long rows, the cluster form, one record per workgroup, rows of fewer than 769 samples -- whole wavefronts of the
+    pre-pass then sit the row out, which the fuzzer found at 292 samples).  Option blk_prep_norms = 0 always takes the kernel: same indices,
     values, residual norms, the same count of exact-fallback decisions -- and the call's counter block is zeroed either way."""
     W, X, Xq = _synthetic(N, m, C, seed=N + 3 * m)
     Xq[N // 2] = 0                                                 # a zero row: norm 0, the reference's first rule
