@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--long-rows", type=int, default=8192,
                     help="also time the same layer on this many calibration samples (a secondary record: the block kernel's cluster form); 0 = skip")
     ap.add_argument("--overlap", dest="overlap", action="store_true",
-                    help="(the default on one GPU) the median of |W| + alphabet on a second HIP stream -- they depend on the analog kernel alone, which is "
+                    help="(the default; N > 1: where the median is not sharded over the ranks) the median of |W| + alphabet on a second HIP stream -- they depend on the analog kernel alone, which is "
                          "complete long before the step, as a trained network's is: no fork wait --, row norms + record pre-pass on this one "
                          "(gpfq_dense_layer_prepare), ONE join, then the alphabet-dependent rest (gpfq_dense_layer_run): layer.quantize_dense_layer("
                          "overlap=True, kernel_ready=True).  Same box: 2.97 -> 2.94 ms per step, kernel + 0.10 -> kernel + 0.07 (profiles/r06/overlap_ab.txt)")
@@ -168,7 +168,9 @@ def main():
         # (activations only) on this one, one join, then the recurrence.  --no-overlap: one stream.
         # (st["alphabet_pre"], secondary figure only: the alphabet formed before the loop, as _prefetch_medians does for a network)
         ws = None
-        if args.overlap and st.get("alphabet_pre") is None and world == 1:
+        # (N > 1: wherever the median is not sharded over the ranks -- kernels below layer._SHARDED_MEDIAN_MIN elements, the north-star layer among them:
+        #  every rank selects it itself, no collective on the side stream)
+        if args.overlap and st.get("alphabet_pre") is None and (world == 1 or Wd.numel() < layer._SHARDED_MEDIAN_MIN):
             main, side = torch.cuda.current_stream(dev), layer._side_stream(dev)
             with torch.cuda.stream(side):
                 dalpha = layer.layer_alphabet_device(Wd, unit_alphabet, args.alphabet_scalar, None)
@@ -355,7 +357,7 @@ def main():
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "step": ("device-resident alphabet: median(|W|) -> rad * alphabet on the device"
                      + (" on a second HIP stream (it depends on the analog kernel alone: no fork wait, one join) beside the row norms and the record pre-pass"
-                        if args.overlap and world == 1 else ", row norms, record pre-pass")
+                        if args.overlap and (world == 1 or N * C_total < layer._SHARDED_MEDIAN_MIN) else ", row norms, record pre-pass")
                      + ", then the block-pipelined kernel reading the Keras kernel and writing Q / indices in the Keras layout; no host wait inside a step" if device_path else
                      "host alphabet (one host wait per step), neuron-major copy, row norms, record pre-pass, kernel, assembly pass"),
             "deferred_status_nonzero_steps": bad_status,
