@@ -395,8 +395,9 @@ def main():
                                    "no committed rocprofv3 --pmc pass for this kernel and shape (profiles/traffic.json)"),
                 "note": "skinny dot products with the residual on chip: the binding resource is FP64-rate vector issue "
                         "(per weight and sample one f64 fma, one f32->f64 convert, one f64 add, three f32 ops on two samples each -- two for the symmetric ternary alphabet), not HBM; "
-                        "flops per launch = 6 m N C_local (SURVEY 8d); duration = HIP events recorded by the library immediately around this "
-                        "kernel's launch on its stream (gpfq_set_main_kernel_events; call_ms_avg: the events around the library call that launches it)",
+                        "flops per launch = 6 m N C_local (SURVEY 8d); duration = the HIP events this kernel's launch carries on its stream -- its dispatch's own "
+                        "start and end (gpfq_set_main_kernel_events -> hipExtLaunchKernelGGL; call_ms_avg: events around the library call that launches it, "
+                        "recorded in five extra steps after the timed region)",
             },
         }
         if collective is not None:
