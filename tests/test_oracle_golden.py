@@ -110,3 +110,23 @@ def test_median_abs(oracle_mod):
     for n in (1, 2, 5, 6, 1001, 4096):
         W = r.standard_normal(n).astype(np.float32)
         assert oracle_mod.median_abs(W) == np.median(np.abs(W))
+
+
+def test_oracle_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """The C oracle (test infrastructure, CPU only -- the GPU pool offers no sanitizer) built with -fsanitize=address,undefined and driven over
+    ragged layers, zero rows, m = 0, partial neuron ranges and NULL outputs (oracle/sanitize_drive.c): no report."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    exe = tmp_path / "drive"
+    cmd = [gcc, "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-ffp-contract=off", "-fopenmp", "-o", str(exe),
+           os.path.join(root, "oracle", "sanitize_drive.c"), os.path.join(root, "oracle", "gpfq_oracle.c"), "-lm"]
+    built = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    if built.returncode != 0:
+        pytest.skip("this gcc has no sanitizer runtime: " + built.stderr[-300:])
+    ran = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="2"))
+    assert ran.returncode == 0 and "ok" in ran.stdout and "runtime error" not in ran.stderr and "AddressSanitizer" not in ran.stderr, ran.stderr[-2000:]
